@@ -1,0 +1,646 @@
+"""CPU oracle for the stylisation hot path of byungsook/neural-flow-style.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package may import this
+module: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and there only as the checker / timed baseline.
+
+What it is: a function-by-function restatement, in PyTorch-CPU tensor ops with
+autograd (float32 or float64), of the TensorFlow-1.15 graph the reference
+builds for this path.  Every function cites the reference ``file:line`` it
+follows (paths relative to the reference tree).
+
+Pinning status -- "parity unpinned" except for the warp kernel:
+  * The reference cannot be imported here (tensorflow==1.15 / tf.contrib.slim
+    are absent, there is no native code to compile), and its tree holds a
+    single known-answer vector: the 5x5 bilinear-warp docstring in
+    transform.py:1859-1885.  ``tests/test_oracle_kat.py`` pins
+    ``interpolate2d`` to it (and the 3-D twin to it by embedding).
+  * Everything else is pinned only to (a) the cited lines, (b) float64
+    ``torch.autograd.gradcheck`` of each operator, (c) closed-form adjoints
+    (render), (d) an independent NumPy loop restatement for the splat.
+  The arithmetic of the reference lives in TensorFlow 1.15 (un-vendored, pinned
+  by setup.bat:8 ``pip install tensorflow==1.15``); the TF1 op semantics that
+  differ from PyTorch defaults are restated explicitly below (ApplyAdam epsilon
+  placement, legacy image.resize coordinates, Maximum/ReduceMax gradient ties,
+  ScatterNd dropping out-of-range indices on GPU, VALID 2x2 avg-pool).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# A1  mgrid / batch_mgrid                                   transform.py:152-204
+# --------------------------------------------------------------------------
+
+def mgrid(*n, dtype=torch.float32, low=-1.0, high=1.0):
+    """linspace(low, high, n_k) per axis, meshgrid(indexing='ij'), stacked on a
+    leading axis -> [len(n), n0, n1, ...]   (transform.py:171-177)."""
+    axes = [torch.linspace(low, high, int(k), dtype=dtype) for k in n]
+    return torch.stack(torch.meshgrid(*axes, indexing="ij"))
+
+
+# --------------------------------------------------------------------------
+# A2  _interpolate2d / _interpolate3d                       transform.py:280-433
+# --------------------------------------------------------------------------
+
+def interpolate2d(imgs, x, y, out_shape):
+    """imgs [B,X,Y,C]; x,y flat normalised coords in [-1,1] (len B*X'*Y').
+
+    Follows transform.py:280-341: scale to index space (299-300), floor,
+    x1=x0+1, clip BOTH to [0,n-1] (308-311), weights from ``x - float(clipped
+    x0)`` (330-331) => exact border replication, 4 gathers + add_n (322-336).
+    """
+    B, X, Y, C = imgs.shape
+    nb, Xo, Yo = out_shape
+    x = (x + 1.0) * (X - 1.0) * 0.5
+    y = (y + 1.0) * (Y - 1.0) * 0.5
+    x0 = torch.floor(x).long(); x1 = x0 + 1
+    y0 = torch.floor(y).long(); y1 = y0 + 1
+    x0 = x0.clamp(0, X - 1); x1 = x1.clamp(0, X - 1)
+    y0 = y0.clamp(0, Y - 1); y1 = y1.clamp(0, Y - 1)
+    # transform.py:312 uses the OUTPUT dims for the batch offset
+    base = torch.arange(nb).repeat_interleave(Xo * Yo) * (Xo * Yo)
+    flat = imgs.reshape(-1, C)
+    i00 = flat[base + x0 * Y + y0]; i01 = flat[base + x0 * Y + y1]
+    i10 = flat[base + x1 * Y + y0]; i11 = flat[base + x1 * Y + y1]
+    dx = (x - x0.to(x.dtype)).unsqueeze(1)
+    dy = (y - y0.to(y.dtype)).unsqueeze(1)
+    out = ((1 - dx) * (1 - dy)) * i00 + ((1 - dx) * dy) * i01 \
+        + (dx * (1 - dy)) * i10 + (dx * dy) * i11
+    return out.reshape(nb, Xo, Yo, C)
+
+
+def interpolate3d(imgs, x, y, z, out_shape):
+    """imgs [B,X,Y,Z,C]; 3-D twin, transform.py:343-433 (8 gathers)."""
+    B, X, Y, Z, C = imgs.shape
+    nb, Xo, Yo, Zo = out_shape
+    x = (x + 1.0) * (X - 1.0) * 0.5
+    y = (y + 1.0) * (Y - 1.0) * 0.5
+    z = (z + 1.0) * (Z - 1.0) * 0.5
+    x0 = torch.floor(x).long(); x1 = x0 + 1
+    y0 = torch.floor(y).long(); y1 = y0 + 1
+    z0 = torch.floor(z).long(); z1 = z0 + 1
+    x0 = x0.clamp(0, X - 1); x1 = x1.clamp(0, X - 1)
+    y0 = y0.clamp(0, Y - 1); y1 = y1.clamp(0, Y - 1)
+    z0 = z0.clamp(0, Z - 1); z1 = z1.clamp(0, Z - 1)
+    base = torch.arange(nb).repeat_interleave(Xo * Yo * Zo) * (Xo * Yo * Zo)
+    flat = imgs.reshape(-1, C)
+    dx = (x - x0.to(x.dtype)).unsqueeze(1)
+    dy = (y - y0.to(y.dtype)).unsqueeze(1)
+    dz = (z - z0.to(z.dtype)).unsqueeze(1)
+    out = 0
+    for xi, wx in ((x0, 1 - dx), (x1, dx)):
+        for yi, wy in ((y0, 1 - dy), (y1, dy)):
+            for zi, wz in ((z0, 1 - dz), (z1, dz)):
+                out = out + (wx * wy * wz) * flat[base + xi * (Y * Z) + yi * Z + zi]
+    return out.reshape(nb, Xo, Yo, Zo, C)
+
+
+def batch_warp2d(imgs, mappings, out_shape):
+    """mappings [B,2,X,Y] (transform.py:206-236)."""
+    nb = out_shape[0]
+    c = mappings.reshape(nb, 2, -1)
+    return interpolate2d(imgs, c[:, 0].reshape(-1), c[:, 1].reshape(-1), out_shape)
+
+
+def batch_warp3d(imgs, mappings, out_shape):
+    """mappings [B,3,X,Y,Z] (transform.py:238-269)."""
+    nb = out_shape[0]
+    c = mappings.reshape(nb, 3, -1)
+    return interpolate3d(imgs, c[:, 0].reshape(-1), c[:, 1].reshape(-1),
+                         c[:, 2].reshape(-1), out_shape)
+
+
+def affine_warp2d(imgs, theta):
+    """batch_affine_warp2d (transform.py:435-470) -- only used by the KAT."""
+    B, X, Y, _ = imgs.shape
+    th = theta.reshape(-1, 2, 3)
+    g = mgrid(X, Y, dtype=imgs.dtype).reshape(1, 2, -1).expand(B, -1, -1)
+    tg = th[:, :, :2] @ g + th[:, :, 2:]
+    return batch_warp2d(imgs, tg.reshape(B, 2, X, Y), [B, X, Y])
+
+
+# --------------------------------------------------------------------------
+# A3  rotate                                                transform.py:611-628
+# --------------------------------------------------------------------------
+
+def rotate(d, rot_mat):
+    """d [B,D,H,W,C], rot_mat [V,3,3] -> [B*V,D,H,W,C].
+
+    tile d V times (620), coords = R @ mgrid (621-625), trilinear warp (627).
+    """
+    B, D, H, W, C = d.shape
+    V = rot_mat.shape[0]
+    nb = B * V
+    dd = d.repeat(V, 1, 1, 1, 1)
+    r = rot_mat.to(d.dtype).repeat(B, 1, 1)
+    g = mgrid(D, H, W, dtype=d.dtype).reshape(1, 3, -1).expand(nb, -1, -1)
+    g = (r @ g).reshape(nb, 3, D, H, W)
+    return batch_warp3d(dd, g, [nb, D, H, W])
+
+
+# --------------------------------------------------------------------------
+# A11  advect (order 1)                                     transform.py:557-569
+# --------------------------------------------------------------------------
+
+def advect(d, vel):
+    """d [1,D,H,W,C], vel [1,D,H,W,3] in normalised units; x' = x - v (566)."""
+    assert d.shape[0] == 1  # n_batch hard-wired to 1 (558)
+    _, D, H, W, _ = d.shape
+    g = mgrid(D, H, W, dtype=d.dtype).unsqueeze(0) - vel.permute(0, 4, 1, 2, 3)
+    return batch_warp3d(d, g, [1, D, H, W])
+
+
+def advect2d(d, vel):
+    """2-D branch, transform.py:583-588."""
+    assert d.shape[0] == 1
+    _, H, W, _ = d.shape
+    g = mgrid(H, W, dtype=d.dtype).unsqueeze(0) - vel.permute(0, 3, 1, 2)
+    return batch_warp2d(d, g, [1, H, W])
+
+
+def transport(g, v, a, b, recursive=True):
+    """StylerBase._transport_tf (styler_base.py:76-89): move field g from frame
+    a to frame b through the per-frame velocities v[F,D,H,W,3]."""
+    if a < b:
+        if recursive:
+            for i in range(a, b):
+                g = advect(g, v[i:i + 1])
+        else:
+            g = advect(g, v[a:a + 1] * (b - a))
+    elif a > b:
+        if recursive:
+            for i in reversed(range(b, a)):
+                g = advect(g, -v[i:i + 1])
+        else:
+            g = advect(g, -v[a - 1:a] * (a - b))
+    return g
+
+
+# --------------------------------------------------------------------------
+# A9  smoothing conv + clamp                                styler_3p.py:112-125
+# --------------------------------------------------------------------------
+
+class _TFMaximum0(torch.autograd.Function):
+    """tf.maximum(d, 0): TF routes the gradient to ``d`` where d >= 0 (ties go
+    to the first argument), unlike torch.relu (zero at 0)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.clamp_min(x, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * (x >= 0).to(g.dtype)
+
+
+def smooth_kernel3d(k, dtype=torch.float32):
+    """k1=[1,k,1]; k3 = k1 (x) k1 (x) k1 / sum  (styler_3p.py:114-120)."""
+    k1 = torch.tensor([1.0, float(k), 1.0], dtype=dtype)
+    k3 = torch.einsum("i,j,k->ijk", k1, k1, k1)
+    return k3 / k3.sum()
+
+
+def smooth3d_relu(d, k):
+    """d [B,D,H,W,1] -> conv3d SAME (zero pad) with the (k+2)^-3 kernel, then
+    max(.,0)  (styler_3p.py:112-125).  k<=0 skips the conv."""
+    if k > 0:
+        w = smooth_kernel3d(k, d.dtype)[None, None]
+        x = d.permute(0, 4, 1, 2, 3)
+        x = F.conv3d(x, w, padding=1)
+        d = x.permute(0, 2, 3, 4, 1)
+    return _TFMaximum0.apply(d)
+
+
+# --------------------------------------------------------------------------
+# A4  render                                                styler_3p.py:147-158
+# --------------------------------------------------------------------------
+
+def render(d, transmit, liquid=False):
+    """d [B,D,H,W,1] -> [B,H,W,1].
+
+    smoke: T = exp(-tau*cumsum(d[:,::-1]))[:,::-1] (155); I = sum(d*T, axis=1)
+    (156-157); I /= max over the WHOLE tensor (158, gradient flows through
+    the max, ties split equally as TF's reduce_max gradient does).
+    liquid: 1 - exp(-tau * sum_z d) (150-152).
+    """
+    if liquid:
+        tr = torch.exp(-torch.cumsum(d.flip(1), dim=1) * transmit)
+        return 1 - tr[:, -1]
+    tr = torch.exp(-torch.cumsum(d.flip(1), dim=1) * transmit).flip(1)
+    img = (d * tr).sum(dim=1)
+    return img / img.amax()
+
+
+def render_unnormalised(d, transmit):
+    tr = torch.exp(-torch.cumsum(d.flip(1), dim=1) * transmit).flip(1)
+    return (d * tr).sum(dim=1)
+
+
+def render_adjoint_closed_form(d, transmit, g_img):
+    """dI/dd[k] = T[k] - tau * sum_{z<=k} d[z] T[z]; used to cross-check
+    autograd of the un-normalised integral."""
+    tr = torch.exp(-torch.cumsum(d.flip(1), dim=1) * transmit).flip(1)
+    pre = torch.cumsum(d * tr, dim=1)
+    return (tr - transmit * pre) * g_img.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------
+# A5  _plugin_to_loss_net                     styler_base.py:33-45, vgg.py:50-53
+# --------------------------------------------------------------------------
+
+VGG_MEAN = (0.485 * 255, 0.456 * 255, 0.406 * 255)  # vgg.py:18-20
+
+
+def tf1_resize_bilinear(x, oh, ow):
+    """tf.compat.v1.image.resize(BILINEAR): align_corners=False, no half-pixel
+    centres: src = dst * in/out; x1 = min(x0+1, in-1).   x [B,H,W,C]."""
+    B, H, W, C = x.shape
+    sy = torch.arange(oh, dtype=x.dtype) * (H / oh)
+    sx = torch.arange(ow, dtype=x.dtype) * (W / ow)
+    y0 = torch.floor(sy).long(); y1 = torch.clamp(y0 + 1, max=H - 1)
+    x0 = torch.floor(sx).long(); x1 = torch.clamp(x0 + 1, max=W - 1)
+    ly = (sy - y0.to(x.dtype)).view(1, oh, 1, 1)
+    lx = (sx - x0.to(x.dtype)).view(1, 1, ow, 1)
+    top = x[:, y0][:, :, x0] * (1 - lx) + x[:, y0][:, :, x1] * lx
+    bot = x[:, y1][:, :, x0] * (1 - lx) + x[:, y1][:, :, x1] * lx
+    return top * (1 - ly) + bot * ly
+
+
+_TF_BICUBIC_TABLE = 1024
+
+
+def _tf1_bicubic_axis(n_in, n_out, dtype):
+    """Indices/weights of TF's legacy ResizeBicubic (A=-0.75, 1024-entry
+    coefficient table, align_corners=False, half_pixel_centers=False)."""
+    a = -0.75
+    t = np.arange(_TF_BICUBIC_TABLE + 1, dtype=np.float32) / np.float32(_TF_BICUBIC_TABLE)
+    c0 = ((a + 2) * t - (a + 3)) * t * t + 1
+    t1 = t + 1
+    c1 = ((a * t1 - 5 * a) * t1 + 8 * a) * t1 - 4 * a
+    scale = np.float32(n_in) / np.float32(n_out)
+    src = np.arange(n_out, dtype=np.float32) * scale
+    loc = np.floor(src).astype(np.int64)
+    off = np.rint((src - loc) * _TF_BICUBIC_TABLE).astype(np.int64)
+    w = np.stack([c1[off], c0[off], c0[_TF_BICUBIC_TABLE - off], c1[_TF_BICUBIC_TABLE - off]], 1)
+    idx = np.clip(np.stack([loc - 1, loc, loc + 1, loc + 2], 1), 0, n_in - 1)
+    return torch.from_numpy(idx), torch.from_numpy(w.astype(np.float64)).to(dtype)
+
+
+def tf1_resize_bicubic(x, oh, ow):
+    """tf.compat.v1.image.resize(BICUBIC) on [B,H,W,C] (styler_base.py:166)."""
+    B, H, W, C = x.shape
+    iy, wy = _tf1_bicubic_axis(H, oh, x.dtype)
+    ix, wx = _tf1_bicubic_axis(W, ow, x.dtype)
+    rows = (x[:, iy] * wy.view(1, oh, 4, 1, 1)).sum(2)          # [B,oh,W,C]
+    return (rows[:, :, ix] * wx.view(1, 1, ow, 4, 1)).sum(3)    # [B,oh,ow,C]
+
+
+def plugin_to_loss_net(d, resize_scale=1.0, is_color=False):
+    """[B,H,W,1 or 3] in [0,1] -> d_img [B,H',W',3] in 0..255
+    (styler_base.py:33-45).  Mean subtraction happens inside vgg (vgg.py:51)."""
+    if not np.isclose(resize_scale, 1):
+        h = int(np.float32(resize_scale) * np.float32(d.shape[1]))
+        w = int(np.float32(resize_scale) * np.float32(d.shape[2]))
+        d = tf1_resize_bilinear(d, h, w)
+    d = d * 255
+    if not is_color:
+        d = torch.cat([d] * 3, dim=-1)
+    return d
+
+
+# --------------------------------------------------------------------------
+# A6  VGG-19 (slim, avg-pool)                                     vgg.py:89-120
+# --------------------------------------------------------------------------
+
+VGG19_CFG = (("conv1", 2, 64), ("conv2", 2, 128), ("conv3", 4, 256),
+             ("conv4", 4, 512), ("conv5", 4, 512))
+
+
+def vgg19_layer_names(upto="conv5_1"):
+    names = []
+    for blk, reps, _ in VGG19_CFG:
+        for i in range(reps):
+            names.append("%s_%d" % (blk, i + 1))
+            if names[-1] == upto:
+                return names
+    return names
+
+
+def synthetic_vgg19_weights(seed=123, upto="conv5_1", dtype=np.float32, width_div=1):
+    """Seeded He-normal stand-in for vgg_19_2016_08_28 (not shipped, no
+    network): w ~ N(0, 2/(9 Cin)) HWIO [3,3,Cin,Cout], b ~ 0.01 N(0,1), drawn
+    layer by layer from RandomState(seed)."""
+    rng = np.random.RandomState(seed)
+    out = OrderedDict()
+    cin = 3
+    for blk, reps, cout in VGG19_CFG:
+        cout = max(cout // width_div, 4)
+        for i in range(reps):
+            name = "%s_%d" % (blk, i + 1)
+            w = rng.randn(3, 3, cin, cout) * math.sqrt(2.0 / (9 * cin))
+            b = rng.randn(cout) * 0.01
+            out[name] = (w.astype(dtype), b.astype(dtype))
+            cin = cout
+            if name == upto:
+                return out
+    return out
+
+
+def vgg19_features(d_img, weights, upto="conv5_1"):
+    """d_img [B,H,W,3] 0..255 -> OrderedDict name -> [B,h,w,C] post-ReLU.
+
+    preprocess: subtract RGB mean only (vgg.py:50-53); conv 3x3 SAME stride 1 +
+    bias + ReLU (vgg.py:44-48, slim.conv2d defaults); slim.avg_pool2d [2,2]
+    => stride 2, VALID (odd sizes floor) (vgg.py:93-104); end points are the
+    post-ReLU conv outputs (vgg.py:55-66).
+    """
+    x = d_img - torch.tensor(VGG_MEAN, dtype=d_img.dtype)
+    x = x.permute(0, 3, 1, 2)
+    feats = OrderedDict()
+    for blk, reps, _ in VGG19_CFG:
+        for i in range(reps):
+            name = "%s_%d" % (blk, i + 1)
+            w, b = weights[name]
+            w = torch.as_tensor(w, dtype=x.dtype).permute(3, 2, 0, 1)  # HWIO -> OIHW
+            x = F.relu(F.conv2d(x, w, torch.as_tensor(b, dtype=x.dtype), padding=1))
+            feats[name] = x.permute(0, 2, 3, 1)
+            if name == upto:
+                return feats
+        x = F.avg_pool2d(x, 2, 2)  # VALID, floor
+        feats["pool" + blk[-1]] = x.permute(0, 2, 3, 1)
+    return feats
+
+
+# --------------------------------------------------------------------------
+# A7  Gram + style loss                           styler_base.py:96-102, 152-185
+# --------------------------------------------------------------------------
+
+def gram_matrix(x, batch_size=None):
+    """x [B,h,w,C] -> [B',C,C], G = F^T F with F = reshape(x[i], (hw, C)); the
+    reference loops range(batch_size) only (styler_base.py:98)."""
+    nb = x.shape[0] if batch_size is None else batch_size
+    g = []
+    for i in range(nb):
+        f = x[i].reshape(-1, x.shape[-1])
+        g.append(f.t() @ f)
+    return torch.stack(g)
+
+
+def style_loss(feats, style_feats, layers, w_layers, w_style=1.0, batch_size=None,
+               d_gray=None, style_mask_on_ref=False):
+    """sum_l w_l * sum((G/denom - Gs/denom_s)^2) * w_style
+    (styler_base.py:152-185).  denom = 2*h*w*C (157,162).  With ``d_gray``
+    (style_mask=True): feature *= bicubic_resize(d_gray) and
+    denom = 2*area*C (165-173)."""
+    total = 0
+    per_layer = []
+    for name, wl in zip(layers, w_layers):
+        f = feats[name]; s = style_feats[name]
+        denom = 2.0 * f.shape[1] * f.shape[2] * f.shape[3]
+        sdenom = 2.0 * s.shape[1] * s.shape[2] * s.shape[3]
+        if d_gray is not None:
+            m = tf1_resize_bicubic(d_gray, f.shape[1], f.shape[2])
+            f = f * m
+            area = m[..., 0].sum(dim=(1, 2), keepdim=True)
+            denom = 2 * area * f.shape[3]
+            if style_mask_on_ref:
+                s = s * m
+                sdenom = denom
+        g = gram_matrix(f, batch_size) / denom
+        gs = gram_matrix(s, batch_size) / sdenom
+        ll = ((g - gs) ** 2).sum()
+        per_layer.append(ll)
+        total = total + wl * ll
+    return total * w_style, per_layer
+
+
+# --------------------------------------------------------------------------
+# A12  TV loss                                            styler_base.py:211-213
+# --------------------------------------------------------------------------
+
+def tv_loss(d_img):
+    """reduce_mean over batch of tf.image.total_variation: sum|dh| + sum|dw|."""
+    dh = (d_img[:, 1:] - d_img[:, :-1]).abs().sum(dim=(1, 2, 3))
+    dw = (d_img[:, :, 1:] - d_img[:, :, :-1]).abs().sum(dim=(1, 2, 3))
+    return (dh + dw).mean()
+
+
+# --------------------------------------------------------------------------
+# A8  SPH splat: W, p2g, p2g_wavg     transform.py:1233-1267,1310-1453,1577-1704
+# --------------------------------------------------------------------------
+
+class _SafeSqrt(torch.autograd.Function):
+    """sqrt with gradient 0 at 0.  The reference's tf.sqrt yields NaN there
+    (0*inf) and hides it with np.nan_to_num on the updated variable
+    (styler_3p.py:337,340,360); the build uses the analytic limit instead
+    (documented deviation)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.sqrt(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return torch.where(y > 0, g / (2 * y), torch.zeros_like(g))
+
+
+def cubic_W(q, h, is_3d):
+    """cubic spline (transform.py:1234-1245)."""
+    sigma = 8 / math.pi / h ** 3 if is_3d else 40 / 7 / math.pi / h ** 2
+    inner = torch.where(q <= 0.5, 6 * (q ** 3 - q ** 2) + 1, 2 * (1 - q) ** 3)
+    return torch.where(q > 1, torch.zeros_like(q), sigma * inner)
+
+
+def _splat_common(p, domain, res, nsize, clip, eps):
+    """Shared prologue of p2g / p2g_wavg (transform.py:1315-1343)."""
+    dt = p.dtype
+    dom = torch.tensor([float(v) for v in domain], dtype=dt)
+    p = p * dom
+    if clip:
+        p = torch.minimum(torch.clamp_min(p, 0), dom - eps)
+        valid = torch.ones(p.shape[:-1], dtype=torch.bool)
+    else:
+        valid = ((p >= 0) & (p < dom)).all(dim=-1)
+    # cell_size = (domain / res)[0] in the graph dtype (1328-1330)
+    cell = float((dom[0] / torch.tensor(float(res[0]), dtype=dt)).item())
+    fl = torch.floor(p / cell)
+    idx = fl.long()
+    r = p - (fl + 0.5) * cell
+    return r, idx, valid, cell
+
+
+def _scatter_nd(idx_list, upd, res, valid, C):
+    """tf.scatter_nd into zeros(res+[C]); out-of-range indices are dropped as
+    the TF GPU kernel does (the reference ran on GPU)."""
+    ok = valid.clone()
+    lin = torch.zeros_like(idx_list[0])
+    for k, n in zip(idx_list, res):
+        ok = ok & (k >= 0) & (k < n)
+        lin = lin * n + k.clamp(0, n - 1)
+    out = torch.zeros(int(np.prod(res)), C, dtype=upd.dtype)
+    out = out.index_add(0, lin[ok], upd[ok])
+    return out.reshape(*res, C)
+
+
+def p2g(p, domain, res, radius, rest_density, nsize, pc=None, pd=None, is_2d=True,
+        clip=True, support=4, eps=1e-6):
+    """p [1,N,d] in [0,1] ordered (z,y,x)/(y,x) -> [1,*res,1 or C].
+    transform.py:1310-1453: mass = 0.8(2r)^d rho0 (1348-1352); for every offset
+    n in [-nsize,nsize]^d: q = |r - n*cell| / (radius*support) (1363,1416),
+    scatter mass*W(q) at idx+n (1366-1380, 1419-1430); colour mode
+    mass*W*pc/pd (1382-1390, 1433-1441); flip H at the end (1404, 1452)."""
+    assert p.shape[0] == 1
+    nd = 2 if is_2d else 3
+    res = [int(v) for v in res]
+    r, idx, valid, cell = _splat_common(p[0], domain, res, nsize, clip, eps)
+    h = radius * support
+    mass = 0.8 * (2 * radius) ** nd * rest_density
+    C = 1 if pc is None else pc.shape[-1]
+    out = 0
+    offs = range(-nsize, nsize + 1)
+    import itertools
+    for n in itertools.product(offs, repeat=nd):
+        nn = torch.tensor(n, dtype=r.dtype)
+        dist = _SafeSqrt.apply(((r - nn * cell) ** 2).sum(-1))
+        w = cubic_W(dist / h, h, not is_2d)
+        if pc is None:
+            upd = (mass * w).unsqueeze(-1)
+        else:
+            upd = mass * w.unsqueeze(-1) * pc[0]
+            upd = upd / (rest_density if pd is None else pd[0])
+        out = out + _scatter_nd([idx[:, k] + n[k] for k in range(nd)], upd, res, valid, C)
+    out = out.flip(0 if is_2d else 1)      # H axis of [H,W,C] / [D,H,W,C]
+    return out.unsqueeze(0)
+
+
+def p2g_wavg(p, x, domain, res, radius, nsize, is_2d=True, clip=True, support=4, eps=1e-6):
+    """weighted average splat (transform.py:1577-1704) with the cubic kernel as
+    styler_3p.py:83 calls it: sum(w*x)/sum(w) where sum(w) > eps else sum(w*x)."""
+    assert p.shape[0] == 1
+    nd = 2 if is_2d else 3
+    res = [int(v) for v in res]
+    r, idx, valid, cell = _splat_common(p[0], domain, res, nsize, clip, eps)
+    h = radius * support
+    C = x.shape[-1]
+    wsum = 0; xsum = 0
+    import itertools
+    for n in itertools.product(range(-nsize, nsize + 1), repeat=nd):
+        nn = torch.tensor(n, dtype=r.dtype)
+        dist = _SafeSqrt.apply(((r - nn * cell) ** 2).sum(-1))
+        w = cubic_W(dist / h, h, not is_2d).unsqueeze(-1)
+        ids = [idx[:, k] + n[k] for k in range(nd)]
+        wsum = wsum + _scatter_nd(ids, w, res, valid, 1)
+        xsum = xsum + _scatter_nd(ids, w * x[0], res, valid, C)
+    ax = 0 if is_2d else 1
+    wsum = wsum.flip(ax); xsum = xsum.flip(ax)
+    safe = torch.where(wsum > eps, wsum, torch.ones_like(wsum))
+    out = torch.where(wsum > eps, xsum / safe, xsum)
+    return out.unsqueeze(0)
+
+
+def p2g_numpy_loops(p, domain, res, radius, rest_density, nsize, support=4, is_2d=False):
+    """Independent pure-Python restatement of p2g (density mode, clip=False) for
+    tiny cases; pins the vectorised version above."""
+    p = np.asarray(p, np.float64)
+    nd = p.shape[-1]
+    res = [int(v) for v in res]
+    out = np.zeros(res, np.float64)
+    cell = float(domain[0]) / res[0]
+    h = radius * support
+    sigma = 8 / math.pi / h ** 3 if nd == 3 else 40 / 7 / math.pi / h ** 2
+    mass = 0.8 * (2 * radius) ** nd * rest_density
+    import itertools
+    for a in range(p.shape[0]):
+        pos = p[a] * np.asarray(domain, np.float64)
+        if np.any(pos < 0) or np.any(pos >= np.asarray(domain)):
+            continue
+        ci = np.floor(pos / cell).astype(int)
+        for n in itertools.product(range(-nsize, nsize + 1), repeat=nd):
+            cj = ci + np.array(n)
+            if np.any(cj < 0) or np.any(cj >= np.array(res)):
+                continue
+            q = np.linalg.norm(pos - (cj + 0.5) * cell) / h
+            if q > 1:
+                continue
+            w = 6 * (q ** 3 - q ** 2) + 1 if q <= 0.5 else 2 * (1 - q) ** 3
+            out[tuple(cj)] += mass * sigma * w
+    return np.flip(out, axis=0 if nd == 2 else 1)[None, ..., None]
+
+
+# --------------------------------------------------------------------------
+# A10  TF ApplyAdam
+# --------------------------------------------------------------------------
+
+class TFAdam:
+    """tf.compat.v1.train.AdamOptimizer semantics (styler_3p.py:320):
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); x -= lr_t*m/(sqrt(v)+eps) -- epsilon is
+    added to the un-bias-corrected sqrt(v) (differs from torch.optim.Adam)."""
+
+    def __init__(self, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.m = None; self.v = None; self.t = 0
+
+    def step(self, x, g, lr):
+        if self.m is None:
+            self.m = torch.zeros_like(x); self.v = torch.zeros_like(x)
+        self.t += 1
+        self.m = self.b1 * self.m + (1 - self.b1) * g
+        self.v = self.b2 * self.v + (1 - self.b2) * g * g
+        # TF computes lr_t in the variable's dtype (float32 graph)
+        if x.dtype == torch.float32:
+            b1p = np.float32(self.b1) ** np.float32(self.t)
+            b2p = np.float32(self.b2) ** np.float32(self.t)
+            lr_t = float(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
+        else:
+            lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        return x - lr_t * self.m / (torch.sqrt(self.v) + self.eps)
+
+
+# --------------------------------------------------------------------------
+# Assembled forward graphs
+# --------------------------------------------------------------------------
+
+def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
+    """TNST-style grid path assembled from the reference's operators
+    (SURVEY.md section 0.1): d^ = advect(d0, vel) (transform.py:557-569) ->
+    smooth+max (styler_3p.py:112-125) -> rotate (133) -> render (147-158) ->
+    loss net (styler_base.py:33-57) -> style loss (152-185).
+    ``rot`` [V,3,3]; views are summed (views=sum mode): each view is rendered
+    and normalised separately (v_batch=1 semantics) and the losses are added.
+    Returns (total_loss, per_view_losses, d_out)."""
+    d = advect(d0, vel) if vel is not None else d0
+    d_out = smooth3d_relu(d, cfg["k"])
+    total = 0
+    per_view = []
+    for v in range(rot.shape[0]):
+        dr = rotate(d_out, rot[v:v + 1]) if cfg.get("rotate", True) else d_out
+        img = render(dr, cfg["transmit"], cfg.get("render_liquid", False))
+        d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
+        feats = vgg19_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"])
+        l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
+        per_view.append(l)
+        total = total + l
+    return total, per_view, d_out
+
+
+def style_target_features(style_img, weights, layers, upto=None):
+    """_style_feature (styler_base.py:249-278): the style image is fed directly
+    at d_img (0..255, before mean subtraction)."""
+    feats = vgg19_features(style_img, weights, layers[-1] if upto is None else upto)
+    return {k: feats[k].detach() for k in layers}
+
+
+def last_layer(layers):
+    order = vgg19_layer_names("conv5_4")
+    return max(layers, key=order.index)
