@@ -1,0 +1,200 @@
+/*
+ * nfs_hip.h -- C ABI of libnfs_hip.so: the MI355X (gfx950) operator library for
+ * the stylisation hot path of byungsook/neural-flow-style.
+ *
+ * The reference has no FFI (it is 100% Python on TensorFlow-1.15 stock ops), so
+ * the boundary is the set of module-level operators its Styler graph is built
+ * from.  Each entry point below names the reference code it replaces
+ * (file:line relative to the reference tree).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless it says host;
+ *     kernels never allocate; no hidden synchronisation; all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - all tensors are float32, dense, channels-last, in the reference's layouts
+ *     ([B,D,H,W,C] volumes, [B,H,W,C] images, particles [N,3] ordered (z,y,x));
+ *   - return value 0 = ok, <0 = error (NFS_E*), message via nfs_last_error()
+ *     (thread-local); no exceptions cross the ABI;
+ *   - "accumulate" outputs (g_d of the scatter adjoints) are += targets: the
+ *     caller zeroes them once per iteration, which is what lets views accumulate.
+ */
+#ifndef NFS_HIP_H
+#define NFS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFS_OK 0
+#define NFS_EINVAL (-1)  /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define NFS_ELAUNCH (-2) /* HIP launch/runtime error */
+
+typedef void* nfs_stream_t;
+
+int nfs_version(void);
+const char* nfs_last_error(void);
+/* number of CUs of the current device (used by host-side tile heuristics) */
+int nfs_device_cus(void);
+
+/* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------
+ * imgs [B,X,Y,Z,C], coords [B,3,X,Y,Z] normalised [-1,1] (axis order = array order),
+ * out [B,X,Y,Z,C].  Border-replicating trilinear gather.  bwd: g_imgs += scatter,
+ * g_coords (nullable) overwritten. */
+int nfs_warp3d_fwd(const float* imgs, const float* coords, float* out,
+                   int B, int X, int Y, int Z, int C, nfs_stream_t stream);
+int nfs_warp3d_bwd(const float* imgs, const float* coords, const float* g_out,
+                   float* g_imgs_acc, float* g_coords,
+                   int B, int X, int Y, int Z, int C, nfs_stream_t stream);
+
+/* ---- A3: rotate (transform.py:611-628) ----------------------------------------------
+ * d [D,H,W,C] (one volume, tiled V times by the reference), rot [V,9] row-major 3x3
+ * acting on (D,H,W)-ordered normalised coords, out [V,D,H,W,C].  Coordinates are
+ * computed in-register (no mgrid tensor).  bwd: g_d [D,H,W,C] += over all views. */
+int nfs_rotate_fwd(const float* d, const float* rot, float* out,
+                   int V, int D, int H, int W, int C, nfs_stream_t stream);
+int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc,
+                   int V, int D, int H, int W, int C, nfs_stream_t stream);
+
+/* ---- A11: advect, order 1 (transform.py:557-569) ------------------------------------
+ * d [D,H,W,C], vel [D,H,W,3] normalised units (component k moves along array axis k),
+ * out [D,H,W,C] = trilinear(d, mgrid - vel).  bwd: g_d_acc (nullable) +=, g_vel
+ * (nullable) overwritten. */
+int nfs_advect_fwd(const float* d, const float* vel, float* out,
+                   int D, int H, int W, int C, nfs_stream_t stream);
+int nfs_advect_bwd(const float* d, const float* vel, const float* g_out,
+                   float* g_d_acc, float* g_vel,
+                   int D, int H, int W, int C, nfs_stream_t stream);
+
+/* ---- A9: smoothing conv + clamp (styler_3p.py:112-125) ------------------------------
+ * out = max(conv3d_SAME(d, [1,k,1]^3/(k+2)^3), 0), d/out [D,H,W].  k<=0 skips the conv.
+ * out stores -0.0f where the pre-activation was negative, so the TF Maximum gradient
+ * mask (pre >= 0) is recoverable from the sign bit; numerically -0.0f == 0.0f.
+ * bwd: g_d = conv(g_out * (pre >= 0)), overwritten. */
+int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float k,
+                          nfs_stream_t stream);
+int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d,
+                          int D, int H, int W, float k, nfs_stream_t stream);
+
+/* ---- A4: render block (styler_3p.py:147-158) -----------------------------------------
+ * d [V,D,H,W] (C=1), img [V,H,W]: smoke (liquid=0) I = sum_z d[z]*exp(-tau*sum_{z'>=z} d[z'])
+ * (un-normalised; the global-max division is nfs_maxnorm_*), liquid=1: 1-exp(-tau*sum_z d).
+ * raysum [V,H,W] = sum_z d is saved for the adjoint.  bwd overwrites g_d [V,D,H,W]. */
+int nfs_render_fwd(const float* d, float* img, float* raysum,
+                   int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
+int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d,
+                   int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
+
+/* fused A3+A4: never materialises the [V,D,H,W] rotated volume.  d [D,H,W], rot [V,9].
+ * bwd: g_d_acc [D,H,W] += over all views and samples (float atomics). */
+int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* raysum,
+                          int V, int D, int H, int W, float tau, int liquid,
+                          nfs_stream_t stream);
+int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,
+                          const float* g_img, float* g_d_acc,
+                          int V, int D, int H, int W, float tau, int liquid,
+                          nfs_stream_t stream);
+
+/* d /= reduce_max(d) (styler_3p.py:158): G groups of n contiguous floats, one max per
+ * group (v_batch views form one group; v_batch=1 => per view).  gmax [G] is written by
+ * fwd and read by bwd; the max gradient is split equally among ties like TF's. */
+int nfs_maxnorm_fwd(const float* img, float* out, float* gmax, int G, int n,
+                    nfs_stream_t stream);
+int nfs_maxnorm_bwd(const float* img, const float* gmax, const float* g_out, float* g_img,
+                    int G, int n, nfs_stream_t stream);
+
+/* ---- A5: _plugin_to_loss_net + vgg.preprocess (styler_base.py:33-45, vgg.py:50-53) ---
+ * img [B,H,W,Cin] in [0,1] (Cin=1 grey or 3 colour) -> d_img [B,H2,W2,3] in 0..255
+ * (optional TF1 legacy bilinear resize, *255, grey->3ch) and x = d_img - mean.
+ * Either output may be NULL.  bwd takes g wrt x (== g wrt d_img) and overwrites g_img. */
+int nfs_loss_net_input_fwd(const float* img, float* d_img, float* x,
+                           int B, int H, int W, int Cin, int H2, int W2, nfs_stream_t stream);
+int nfs_loss_net_input_bwd(const float* g_x, float* g_img,
+                           int B, int H, int W, int Cin, int H2, int W2, nfs_stream_t stream);
+
+/* ---- A6: VGG-19 conv / pool (vgg.py:44-48, 89-108) ------------------------------------
+ * 3x3 SAME stride-1 conv on NHWC as implicit GEMM on the f32 MFMA (exact f32).
+ * Weights are frozen: pack them once.  kind 0 = forward (HWIO [3,3,Ci,Co] ->
+ * packed, GEMM N=Co, K=9*Ci), kind 1 = data-gradient (taps flipped, N=Ci, K=9*Co).
+ * nfs_conv3x3_packed_floats gives the packed buffer size in floats. */
+int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind);
+int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind,
+                     nfs_stream_t stream);
+/* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable */
+int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y,
+                    int B, int H, int W, int Ci, int Co, int relu, nfs_stream_t stream);
+/* gx = dgrad(gy) * (x_in > 0 if x_in) + (addend if addend); gy [B,H,W,Co] is the gradient
+ * wrt the conv's pre-activation, gx [B,H,W,Ci]. */
+int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in,
+                      const float* addend, float* gx,
+                      int B, int H, int W, int Ci, int Co, nfs_stream_t stream);
+/* slim.avg_pool2d [2,2]: stride 2, VALID (odd sizes floor).  x [B,H,W,C] -> y [B,H/2,W/2,C].
+ * bwd: gx = 0.25*gy[h/2,w/2] (0 outside the pooled area) * (x > 0 if x) + (addend if addend) */
+int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream);
+int nfs_avgpool2_bwd(const float* gy, const float* x, const float* addend, float* gx,
+                     int B, int H, int W, int C, nfs_stream_t stream);
+
+/* ---- A7: Gram matrix + style loss (styler_base.py:96-102, 152-185) --------------------
+ * F [B,HW,C] -> G [B,C,C] = F^T F * scale[b] (f32 MFMA, split over pixels, atomically
+ * accumulated: G must be zeroed by the caller).  The factor applied to image b is
+ * scale * (scale_dev ? scale_dev[b] : 1): `scale` = 1/(2*HW*C) in the plain case; scale_dev is a
+ * DEVICE array [B] for the style_mask variant whose denominator 2*area_b*C lives on the GPU. */
+int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* scale_dev, float scale,
+                 nfs_stream_t stream);
+/* loss_acc[b] += weight * sum((G[b]-Gs[bs])^2) where bs = b % Bs; Dmat [B,C,C] = 2*weight*(G-Gs)
+ * (the symmetric matrix nfs_gram_bwd multiplies by). */
+int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* Dmat,
+                       int B, int Bs, int C, float weight, nfs_stream_t stream);
+/* dF [B,HW,C] = scale[b] * 2 * F @ Dmat[b], optionally masked by (F > 0) (F is a post-ReLU
+ * activation: this folds the ReLU gradient of the style layer). */
+int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, int C,
+                 const float* scale_dev, float scale, int relu_mask, nfs_stream_t stream);
+
+/* ---- A12: TV loss (styler_base.py:211-213) --------------------------------------------
+ * loss_acc[0] += weight * mean_b(sum|dh| + sum|dw|) on d_img [B,H,W,3]; g_acc (nullable) +=. */
+int nfs_tv_loss(const float* d_img, float* loss_acc, float* g_acc, int B, int H, int W, int C,
+                float weight, nfs_stream_t stream);
+
+/* ---- A8: SPH splat (transform.py:1233-1267, 1310-1453, 1577-1704) ---------------------
+ * p [N,nd] in [0,1] ordered (z,y,x)/(y,x); grid [res...,C] H-flipped like the reference.
+ * mode 0: density, grid += mass*W                      (p2g, pc=None)
+ * mode 1: colour,  grid += mass*W*attr/pd              (p2g, pc=attr[N,C], pd[N] or rest_density)
+ * mode 2: weighted-average accumulation: grid += W*attr, wsum += W (p2g_wavg; finish with
+ *         nfs_p2g_wavg_finish).  grid/wsum must be zeroed by the caller. */
+typedef struct {
+  int nd;            /* 2 or 3 */
+  int res[3];        /* grid resolution (array order) */
+  float domain[3];   /* domain size (array order) */
+  float radius, support, rest_density;
+  int nsize, clip, mode;
+} nfs_splat_cfg;
+int nfs_p2g_fwd(const float* p, const float* attr, const float* pd, float* grid, float* wsum,
+                int N, int C, const nfs_splat_cfg* cfg_host, nfs_stream_t stream);
+/* g_p [N,nd] / g_attr [N,C] / g_pd [N] overwritten (each nullable).  For mode 2 pass the
+ * gradients wrt the raw accumulators (from nfs_p2g_wavg_finish_bwd) as g_grid / g_wsum. */
+int nfs_p2g_bwd(const float* p, const float* attr, const float* pd, const float* g_grid,
+                const float* g_wsum, float* g_p, float* g_attr, float* g_pd,
+                int N, int C, const nfs_splat_cfg* cfg_host, nfs_stream_t stream);
+/* out = wsum > eps ? xsum/wsum : xsum (transform.py:1701-1703); n cells x C channels */
+int nfs_p2g_wavg_finish(const float* xsum, const float* wsum, float* out, int64_t n, int C,
+                        float eps, nfs_stream_t stream);
+int nfs_p2g_wavg_finish_bwd(const float* xsum, const float* wsum, const float* g_out,
+                            float* g_xsum, float* g_wsum, int64_t n, int C, float eps,
+                            nfs_stream_t stream);
+
+/* ---- A10: TF ApplyAdam (styler_3p.py:320-323) -----------------------------------------
+ * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; x -= lr_t*m/(sqrt(v)+eps), lr_t =
+ * lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  NaN gradients are NOT sanitised. */
+int nfs_adam_tf_step(float* x, float* m, float* v, const float* g, int64_t n,
+                     float lr_t, float beta1, float beta2, float eps, nfs_stream_t stream);
+
+/* small helpers used by the host loop */
+int nfs_fill(float* x, float value, int64_t n, nfs_stream_t stream);
+int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream); /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFS_HIP_H */

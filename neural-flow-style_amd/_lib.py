@@ -1,0 +1,112 @@
+"""ctypes loader for libnfs_hip.so (the C ABI declared in include/nfs_hip.h).
+
+The HIP library is the product path: there is NO CPU fallback.  If the shared
+object is missing, importing an op raises immediately (``NfsLibraryError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnfs_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+
+class NfsLibraryError(RuntimeError):
+    pass
+
+
+class SplatCfg(C.Structure):
+    _fields_ = [("nd", C.c_int), ("res", C.c_int * 3), ("domain", C.c_float * 3),
+                ("radius", C.c_float), ("support", C.c_float), ("rest_density", C.c_float),
+                ("nsize", C.c_int), ("clip", C.c_int), ("mode", C.c_int)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+SIGNATURES = {
+    "nfs_version": [],
+    "nfs_last_error": [],
+    "nfs_device_cus": [],
+    "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_rotate_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_advect_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "nfs_advect_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "nfs_smooth3d_relu_fwd": [_P, _P, _I, _I, _I, _F, _P],
+    "nfs_smooth3d_relu_bwd": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "nfs_render_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_render_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_rotate_render_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_maxnorm_fwd": [_P, _P, _P, _I, _I, _P],
+    "nfs_maxnorm_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "nfs_loss_net_input_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_loss_net_input_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_conv3x3_packed_floats": [_I, _I, _I],
+    "nfs_conv3x3_pack": [_P, _P, _I, _I, _I, _P],
+    "nfs_conv3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "nfs_avgpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "nfs_gram_fwd": [_P, _P, _I, _I, _I, _P, _F, _P],
+    "nfs_style_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
+    "nfs_tv_loss": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "nfs_p2g_fwd": [_P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],
+    "nfs_p2g_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],
+    "nfs_p2g_wavg_finish": [_P, _P, _P, _L, _I, _F, _P],
+    "nfs_p2g_wavg_finish_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "nfs_adam_tf_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P],
+    "nfs_fill": [_P, _F, _L, _P],
+    "nfs_axpy": [_P, _P, _F, _L, _P],
+}
+_RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libnfs_hip.so (in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC_DIR, "-j", str(os.cpu_count() or 4)],
+                       capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise NfsLibraryError("building libnfs_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NfsLibraryError(
+                "libnfs_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "-- there is no CPU fallback for the product path" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NfsLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, argt in SIGNATURES.items():
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                raise NfsLibraryError("libnfs_hip.so does not export %s (stale build?)" % name)
+            f.argtypes = argt
+            f.restype = _RESTYPE.get(name, C.c_int)
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise with nfs_last_error() on failure."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, L.nfs_last_error().decode()))
+    return rc

@@ -1,0 +1,26 @@
+// Error channel, version and device query of libnfs_hip.so.
+#include "common.h"
+
+namespace nfs {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace nfs
+
+extern "C" {
+int nfs_version(void) { return 100; }
+const char* nfs_last_error(void) { return nfs::g_err; }
+int nfs_device_cus(void) {
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    nfs::set_error("nfs_device_cus: no HIP device");
+    return NFS_ELAUNCH;
+  }
+  return p.multiProcessorCount;
+}
+}

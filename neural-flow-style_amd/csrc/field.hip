@@ -1,0 +1,367 @@
+// Field-side elementwise / small-stencil kernels, all HBM-bound:
+//   A9  smoothing conv + clamp        (styler_3p.py:112-125)
+//   A10 TF ApplyAdam                  (styler_3p.py:320-323)
+//   A5  loss-net input                (styler_base.py:33-45, vgg.py:50-53)
+//   A6  2x2 average pool              (vgg.py:93-104)
+//   A12 total variation               (styler_base.py:211-213)
+#include "common.h"
+
+namespace nfs {
+
+// ---- A9 ------------------------------------------------------------------------------
+// Each thread produces 4 consecutive W outputs of one (z,y) row from 9 neighbour rows of
+// 6 values: 13.5 loads/output instead of 27; rows are re-served by L1/L2, so HBM traffic
+// is ~ one read + one write of the volume (8 B/cell).
+template <bool BWD>
+__global__ void __launch_bounds__(256) smooth3d_kernel(const float* __restrict__ in, const float* __restrict__ act,
+                                                       float* __restrict__ out, int D, int H, int W, float k) {
+  const int W4 = (W + 3) >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)D * H * W4) return;
+  const int xg = (int)(gid % W4);
+  const int y = (int)((gid / W4) % H);
+  const int z = (int)(gid / ((int64_t)W4 * H));
+  const int x0 = xg * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (k > 0.f) {
+    const float k1[3] = {1.f, k, 1.f};
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = z + dz;
+      if (zz < 0 || zz >= D) continue;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int64_t row = ((int64_t)zz * H + yy) * W;
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x0 - 1 + j;
+          float t = 0.f;
+          if (xx >= 0 && xx < W) {
+            t = in[row + xx];
+            if (BWD) t = signbit(act[row + xx]) ? 0.f : t;  // g_out * (pre >= 0)
+          }
+          v[j] = t;
+        }
+        const float wr = k1[dz + 1] * k1[dy + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += wr * (v[j] + k * v[j + 1] + v[j + 2]);
+      }
+    }
+    const float inv = 1.f / ((k + 2.f) * (k + 2.f) * (k + 2.f));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= inv;
+  } else {
+    const int64_t row = ((int64_t)z * H + y) * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x0 + j < W) {
+        float t = in[row + x0 + j];
+        if (BWD) t = signbit(act[row + x0 + j]) ? 0.f : t;
+        acc[j] = t;
+      }
+  }
+  const int64_t orow = ((int64_t)z * H + y) * W;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (x0 + j >= W) break;
+    float r = acc[j];
+    // forward: max(pre,0) with the sign bit carrying (pre < 0) for the TF Maximum gradient
+    if (!BWD) r = (r >= 0.f) ? fabsf(r) : (r < 0.f ? -0.0f : r);
+    out[orow + x0 + j] = r;
+  }
+}
+
+// ---- A10 -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ x, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, int64_t n, float lr_t, float b1,
+                                                   float b2, float eps) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n) {
+    float4 X = *reinterpret_cast<float4*>(x + i4), M = *reinterpret_cast<float4*>(m + i4),
+           Vv = *reinterpret_cast<float4*>(v + i4);
+    const float4 G = *reinterpret_cast<const float4*>(g + i4);
+    float* xp = &X.x; float* mp = &M.x; float* vp = &Vv.x; const float* gp = &G.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mp[j] = b1 * mp[j] + (1.f - b1) * gp[j];
+      vp[j] = b2 * vp[j] + (1.f - b2) * gp[j] * gp[j];
+      xp[j] -= lr_t * mp[j] / (sqrtf(vp[j]) + eps);
+    }
+    *reinterpret_cast<float4*>(x + i4) = X;
+    *reinterpret_cast<float4*>(m + i4) = M;
+    *reinterpret_cast<float4*>(v + i4) = Vv;
+  } else {
+    for (int64_t i = i4; i < n; ++i) {
+      const float gi = g[i];
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      x[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ x, float value, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = value;
+}
+__global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a,
+                                                   int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+// ---- A5 ------------------------------------------------------------------------------
+__constant__ float kVggMean[3] = {0.485f * 255.f, 0.456f * 255.f, 0.406f * 255.f};  // vgg.py:18-20
+
+struct Lerp { int i0, i1; float w; };
+__device__ __forceinline__ Lerp tf1_lerp(int dst, int n_in, int n_out) {
+  // legacy tf.image.resize: src = dst * in/out (no half-pixel centres), i1 = min(i0+1, in-1)
+  const float scale = (float)n_in / (float)n_out;
+  const float s = (float)dst * scale;
+  Lerp l;
+  l.i0 = (int)floorf(s);
+  l.i1 = min(l.i0 + 1, n_in - 1);
+  l.w = s - (float)l.i0;
+  return l;
+}
+
+__global__ void __launch_bounds__(256) loss_net_input_fwd_kernel(const float* __restrict__ img,
+                                                                 float* __restrict__ d_img, float* __restrict__ xo,
+                                                                 int B, int H, int W, int Cin, int H2, int W2) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H2 * W2) return;
+  const int x2 = (int)(gid % W2);
+  const int y2 = (int)((gid / W2) % H2);
+  const int b = (int)(gid / ((int64_t)W2 * H2));
+  const float* im = img + (int64_t)b * H * W * Cin;
+  float val[3];
+  const bool resize = (H2 != H) || (W2 != W);
+  for (int c = 0; c < Cin; ++c) {
+    float r;
+    if (!resize) {
+      r = im[((int64_t)y2 * W + x2) * Cin + c];
+    } else {
+      const Lerp ly = tf1_lerp(y2, H, H2), lx = tf1_lerp(x2, W, W2);
+      const float tl = im[((int64_t)ly.i0 * W + lx.i0) * Cin + c], tr = im[((int64_t)ly.i0 * W + lx.i1) * Cin + c];
+      const float bl = im[((int64_t)ly.i1 * W + lx.i0) * Cin + c], br = im[((int64_t)ly.i1 * W + lx.i1) * Cin + c];
+      const float top = tl + (tr - tl) * lx.w, bot = bl + (br - bl) * lx.w;
+      r = top + (bot - top) * ly.w;
+    }
+    val[c] = r * 255.f;
+  }
+  if (Cin == 1) val[1] = val[2] = val[0];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (d_img) d_img[gid * 3 + c] = val[c];
+    if (xo) xo[gid * 3 + c] = val[c] - kVggMean[c];
+  }
+}
+
+__global__ void __launch_bounds__(256) loss_net_input_bwd_kernel(const float* __restrict__ g_x,
+                                                                 float* __restrict__ g_img, int B, int H, int W,
+                                                                 int Cin, int H2, int W2) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H2 * W2) return;
+  const int x2 = (int)(gid % W2);
+  const int y2 = (int)((gid / W2) % H2);
+  const int b = (int)(gid / ((int64_t)W2 * H2));
+  float g[3] = {g_x[gid * 3] * 255.f, g_x[gid * 3 + 1] * 255.f, g_x[gid * 3 + 2] * 255.f};
+  if (Cin == 1) g[0] = g[0] + g[1] + g[2];
+  float* gi = g_img + (int64_t)b * H * W * Cin;
+  const bool resize = (H2 != H) || (W2 != W);
+  if (!resize) {
+    for (int c = 0; c < Cin; ++c) gi[((int64_t)y2 * W + x2) * Cin + c] = g[c];
+    return;
+  }
+  const Lerp ly = tf1_lerp(y2, H, H2), lx = tf1_lerp(x2, W, W2);
+  for (int c = 0; c < Cin; ++c) {
+    atomicAdd(gi + ((int64_t)ly.i0 * W + lx.i0) * Cin + c, g[c] * (1.f - ly.w) * (1.f - lx.w));
+    atomicAdd(gi + ((int64_t)ly.i0 * W + lx.i1) * Cin + c, g[c] * (1.f - ly.w) * lx.w);
+    atomicAdd(gi + ((int64_t)ly.i1 * W + lx.i0) * Cin + c, g[c] * ly.w * (1.f - lx.w));
+    atomicAdd(gi + ((int64_t)ly.i1 * W + lx.i1) * Cin + c, g[c] * ly.w * lx.w);
+  }
+}
+
+// ---- A6 pool -------------------------------------------------------------------------
+// channels-last, 4 channels (one float4) per thread
+__global__ void __launch_bounds__(256) avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                           int H, int W, int C4) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * Ho * Wo * C4) return;
+  const int c = (int)(gid % C4);
+  const int j = (int)((gid / C4) % Wo);
+  const int i = (int)((gid / ((int64_t)C4 * Wo)) % Ho);
+  const int b = (int)(gid / ((int64_t)C4 * Wo * Ho));
+  const float4* xp = reinterpret_cast<const float4*>(x) + (((int64_t)b * H + 2 * i) * W + 2 * j) * C4 + c;
+  const float4 a = xp[0], bq = xp[C4], cq = xp[(int64_t)W * C4], dq = xp[(int64_t)W * C4 + C4];
+  float4 r;
+  r.x = (a.x + bq.x + cq.x + dq.x) * 0.25f;
+  r.y = (a.y + bq.y + cq.y + dq.y) * 0.25f;
+  r.z = (a.z + bq.z + cq.z + dq.z) * 0.25f;
+  r.w = (a.w + bq.w + cq.w + dq.w) * 0.25f;
+  reinterpret_cast<float4*>(y)[gid] = r;
+}
+
+__global__ void __launch_bounds__(256) avgpool2_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           const float* __restrict__ addend, float* __restrict__ gx,
+                                                           int B, int H, int W, int C4) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H * W * C4) return;
+  const int c = (int)(gid % C4);
+  const int w = (int)((gid / C4) % W);
+  const int h = (int)((gid / ((int64_t)C4 * W)) % H);
+  const int b = (int)(gid / ((int64_t)C4 * W * H));
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((h >> 1) < Ho && (w >> 1) < Wo) {
+    const float4 t = reinterpret_cast<const float4*>(gy)[(((int64_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C4 + c];
+    g = make_float4(t.x * 0.25f, t.y * 0.25f, t.z * 0.25f, t.w * 0.25f);
+  }
+  if (x) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[gid];
+    g.x = xv.x > 0.f ? g.x : 0.f; g.y = xv.y > 0.f ? g.y : 0.f;
+    g.z = xv.z > 0.f ? g.z : 0.f; g.w = xv.w > 0.f ? g.w : 0.f;
+  }
+  if (addend) {
+    const float4 a = reinterpret_cast<const float4*>(addend)[gid];
+    g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+  }
+  reinterpret_cast<float4*>(gx)[gid] = g;
+}
+
+// ---- A12 -----------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(256) tv_kernel(const float* __restrict__ x, float* __restrict__ loss,
+                                                 float* __restrict__ g, int B, int H, int W, int C, float scale) {
+  __shared__ float red[16];
+  const int64_t n = (int64_t)B * H * W * C;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float part = 0.f;
+  if (gid < n) {
+    const int w = (int)((gid / C) % W);
+    const int h = (int)((gid / ((int64_t)C * W)) % H);
+    const float v = x[gid];
+    float gv = 0.f;
+    if (h + 1 < H) { const float dlt = x[gid + (int64_t)W * C] - v; part += fabsf(dlt); gv -= sgn(dlt); }
+    if (w + 1 < W) { const float dlt = x[gid + C] - v; part += fabsf(dlt); gv -= sgn(dlt); }
+    if (h > 0) gv += sgn(v - x[gid - (int64_t)W * C]);
+    if (w > 0) gv += sgn(v - x[gid - C]);
+    if (g) g[gid] += scale * gv;
+  }
+  part = block_sum(part, red);
+  if (threadIdx.x == 0 && part != 0.f) atomicAdd(loss, part * scale);
+}
+
+}  // namespace nfs
+
+using namespace nfs;
+
+extern "C" {
+
+int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float k, nfs_stream_t stream) {
+  NFS_REQUIRE(d && out, "nfs_smooth3d_relu_fwd: null pointer");
+  NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_fwd: non-positive dimension");
+  const int64_t n = (int64_t)D * H * ((W + 3) / 4);
+  hipLaunchKernelGGL(smooth3d_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d,
+                     (const float*)nullptr, out, D, H, W, k);
+  return check_launch("nfs_smooth3d_relu_fwd");
+}
+
+int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d, int D, int H, int W, float k,
+                          nfs_stream_t stream) {
+  NFS_REQUIRE(out && g_out && g_d, "nfs_smooth3d_relu_bwd: null pointer");
+  NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_bwd: non-positive dimension");
+  const int64_t n = (int64_t)D * H * ((W + 3) / 4);
+  hipLaunchKernelGGL(smooth3d_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g_out, out, g_d,
+                     D, H, W, k);
+  return check_launch("nfs_smooth3d_relu_bwd");
+}
+
+int nfs_adam_tf_step(float* x, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
+                     float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(x && m && v && g, "nfs_adam_tf_step: null pointer");
+  NFS_REQUIRE(n > 0, "nfs_adam_tf_step: n must be positive");
+  NFS_REQUIRE((((uintptr_t)x | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0,
+              "nfs_adam_tf_step: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), x, m, v, g, n,
+                     lr_t, beta1, beta2, eps);
+  return check_launch("nfs_adam_tf_step");
+}
+
+int nfs_fill(float* x, float value, int64_t n, nfs_stream_t stream) {
+  NFS_REQUIRE(x && n > 0, "nfs_fill: bad argument");
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, value, n);
+  return check_launch("nfs_fill");
+}
+
+int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream) {
+  NFS_REQUIRE(x && y && n > 0, "nfs_axpy: bad argument");
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), y, x, a, n);
+  return check_launch("nfs_axpy");
+}
+
+int nfs_loss_net_input_fwd(const float* img, float* d_img, float* x, int B, int H, int W, int Cin, int H2, int W2,
+                           nfs_stream_t stream) {
+  NFS_REQUIRE(img && (d_img || x), "nfs_loss_net_input_fwd: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "nfs_loss_net_input_fwd: non-positive dimension");
+  NFS_REQUIRE(Cin == 1 || Cin == 3, "nfs_loss_net_input_fwd: Cin must be 1 or 3");
+  const int64_t n = (int64_t)B * H2 * W2;
+  hipLaunchKernelGGL(loss_net_input_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), img, d_img,
+                     x, B, H, W, Cin, H2, W2);
+  return check_launch("nfs_loss_net_input_fwd");
+}
+
+int nfs_loss_net_input_bwd(const float* g_x, float* g_img, int B, int H, int W, int Cin, int H2, int W2,
+                           nfs_stream_t stream) {
+  NFS_REQUIRE(g_x && g_img, "nfs_loss_net_input_bwd: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "nfs_loss_net_input_bwd: non-positive dimension");
+  NFS_REQUIRE(Cin == 1 || Cin == 3, "nfs_loss_net_input_bwd: Cin must be 1 or 3");
+  if (H2 != H || W2 != W) {
+    if (hipMemsetAsync(g_img, 0, sizeof(float) * (size_t)B * H * W * Cin, as_stream(stream)) != hipSuccess) {
+      set_error("nfs_loss_net_input_bwd: memset failed");
+      return NFS_ELAUNCH;
+    }
+  }
+  const int64_t n = (int64_t)B * H2 * W2;
+  hipLaunchKernelGGL(loss_net_input_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g_x, g_img,
+                     B, H, W, Cin, H2, W2);
+  return check_launch("nfs_loss_net_input_bwd");
+}
+
+int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(x && y, "nfs_avgpool2_fwd: null pointer");
+  NFS_REQUIRE(B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "nfs_avgpool2_fwd: need H,W >= 2 and C %% 4 == 0");
+  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, y, B, H, W,
+                     C / 4);
+  return check_launch("nfs_avgpool2_fwd");
+}
+
+int nfs_avgpool2_bwd(const float* gy, const float* x, const float* addend, float* gx, int B, int H, int W, int C,
+                     nfs_stream_t stream) {
+  NFS_REQUIRE(gy && gx, "nfs_avgpool2_bwd: null pointer");
+  NFS_REQUIRE(B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "nfs_avgpool2_bwd: need H,W >= 2 and C %% 4 == 0");
+  const int64_t n = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), gy, x, addend, gx,
+                     B, H, W, C / 4);
+  return check_launch("nfs_avgpool2_bwd");
+}
+
+int nfs_tv_loss(const float* d_img, float* loss_acc, float* g_acc, int B, int H, int W, int C, float weight,
+                nfs_stream_t stream) {
+  NFS_REQUIRE(d_img && loss_acc, "nfs_tv_loss: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "nfs_tv_loss: non-positive dimension");
+  const int64_t n = (int64_t)B * H * W * C;
+  hipLaunchKernelGGL(tv_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d_img, loss_acc, g_acc, B, H,
+                     W, C, weight / (float)B);
+  return check_launch("nfs_tv_loss");
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// A8: SPH particle -> grid splat (transform.py:1233-1267 W, 1310-1453 p2g, 1577-1704
+// p2g_wavg) and its adjoint.  The reference issues (2*nsize+1)^d separate ScatterNd ops
+// with N x (d+1) index tensors each; here one thread owns a particle, evaluates the whole
+// neighbourhood in registers and scatters with float atomics (forward) / gathers
+// (backward, no atomics).  HBM-bound: N*(4*nd+4*C) B of particle data + the touched cells.
+#include "common.h"
+
+namespace nfs {
+
+struct SplatDev {
+  int nd, mode, nsize, clip;
+  int res[3];
+  float dom[3];
+  float cell, h, sigma, mass, rest_density;
+};
+
+__device__ __forceinline__ float cubic_w(float q, float sigma) {
+  if (q > 1.f) return 0.f;
+  if (q <= 0.5f) return sigma * (6.f * (q * q * q - q * q) + 1.f);
+  const float t = 1.f - q;
+  return sigma * 2.f * t * t * t;
+}
+__device__ __forceinline__ float cubic_dw(float q, float sigma) {
+  if (q > 1.f) return 0.f;
+  if (q <= 0.5f) return sigma * 6.f * (3.f * q * q - 2.f * q);
+  const float t = 1.f - q;
+  return -sigma * 6.f * t * t;
+}
+
+struct Particle {
+  bool valid;
+  int idx[3];
+  float r[3];
+  bool grad_ok[3];  // clip mode: gradient passes the clamp
+};
+
+__device__ __forceinline__ Particle load_particle(const SplatDev& s, const float* __restrict__ p, int64_t a) {
+  Particle P;
+  P.valid = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { P.idx[k] = 0; P.r[k] = 0.f; P.grad_ok[k] = true; }
+  for (int k = 0; k < s.nd; ++k) {
+    float v = p[a * s.nd + k] * s.dom[k];
+    if (s.clip) {
+      const float hi = s.dom[k] - 1e-6f;
+      P.grad_ok[k] = (v >= 0.f) && (v <= hi);
+      v = fminf(fmaxf(v, 0.f), hi);
+    } else if (!(v >= 0.f && v < s.dom[k])) {
+      P.valid = false;
+    }
+    const float fl = floorf(v / s.cell);
+    P.idx[k] = (int)fl;
+    P.r[k] = v - (fl + 0.5f) * s.cell;
+  }
+  return P;
+}
+
+// linear cell index with the H flip of the reference (axis 0 in 2-D, axis 1 in 3-D), or -1
+__device__ __forceinline__ int64_t cell_index(const SplatDev& s, const int* c) {
+  int64_t lin = 0;
+  const int hax = s.nd == 2 ? 0 : 1;
+  for (int k = 0; k < s.nd; ++k) {
+    if (c[k] < 0 || c[k] >= s.res[k]) return -1;
+    const int ck = (k == hax) ? s.res[k] - 1 - c[k] : c[k];
+    lin = lin * s.res[k] + ck;
+  }
+  return lin;
+}
+
+__global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* __restrict__ p,
+                                                      const float* __restrict__ attr, const float* __restrict__ pd,
+                                                      float* __restrict__ grid, float* __restrict__ wsum, int N,
+                                                      int C) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const Particle P = load_particle(s, p, a);
+  if (!P.valid) return;
+  const int span = 2 * s.nsize + 1;
+  const int total = s.nd == 2 ? span * span : span * span * span;
+  float coef = 1.f;
+  if (s.mode == 0) coef = s.mass;
+  if (s.mode == 1) coef = s.mass / (pd ? pd[a] : s.rest_density);
+  for (int o = 0; o < total; ++o) {
+    int n[3] = {0, 0, 0};
+    if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
+    else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
+    float d2 = 0.f;
+    int c[3];
+    for (int k = 0; k < s.nd; ++k) {
+      const float rr = P.r[k] - (float)n[k] * s.cell;
+      d2 += rr * rr;
+      c[k] = P.idx[k] + n[k];
+    }
+    const float w = cubic_w(sqrtf(d2) / s.h, s.sigma);
+    if (w == 0.f) continue;
+    const int64_t ci = cell_index(s, c);
+    if (ci < 0) continue;
+    if (s.mode == 0) {
+      atomicAdd(grid + ci, coef * w);
+    } else {
+      for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * attr[a * C + ch]);
+      if (s.mode == 2) atomicAdd(wsum + ci, w);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) p2g_bwd_kernel(SplatDev s, const float* __restrict__ p,
+                                                      const float* __restrict__ attr, const float* __restrict__ pd,
+                                                      const float* __restrict__ g_grid,
+                                                      const float* __restrict__ g_wsum, float* __restrict__ g_p,
+                                                      float* __restrict__ g_attr, float* __restrict__ g_pd, int N,
+                                                      int C) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const Particle P = load_particle(s, p, a);
+  float gp[3] = {0.f, 0.f, 0.f};
+  float ga[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 4
+  float gpd = 0.f;
+  if (P.valid) {
+    const int span = 2 * s.nsize + 1;
+    const int total = s.nd == 2 ? span * span : span * span * span;
+    const float pdv = (s.mode == 1) ? (pd ? pd[a] : s.rest_density) : 1.f;
+    float coef = 1.f;
+    if (s.mode == 0) coef = s.mass;
+    if (s.mode == 1) coef = s.mass / pdv;
+    for (int o = 0; o < total; ++o) {
+      int n[3] = {0, 0, 0};
+      if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
+      else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
+      float d2 = 0.f, rr[3] = {0.f, 0.f, 0.f};
+      int c[3];
+      for (int k = 0; k < s.nd; ++k) {
+        rr[k] = P.r[k] - (float)n[k] * s.cell;
+        d2 += rr[k] * rr[k];
+        c[k] = P.idx[k] + n[k];
+      }
+      const float dist = sqrtf(d2);
+      const float q = dist / s.h;
+      if (q > 1.f) continue;
+      const int64_t ci = cell_index(s, c);
+      if (ci < 0) continue;
+      const float w = cubic_w(q, s.sigma);
+      // dL/dW for this (particle, cell)
+      float gw;
+      if (s.mode == 0) {
+        gw = coef * g_grid[ci];
+      } else {
+        float dot = 0.f;
+        for (int ch = 0; ch < C; ++ch) {
+          const float g = g_grid[ci * C + ch];
+          dot += attr[a * C + ch] * g;
+          ga[ch] += coef * w * g;
+        }
+        gw = coef * dot;
+        if (s.mode == 1) gpd -= coef * w * dot / pdv;
+        if (s.mode == 2) gw += g_wsum[ci];
+      }
+      if (g_p && dist > 0.f) {  // safe sqrt: zero gradient at the cell centre
+        const float f = gw * cubic_dw(q, s.sigma) / (dist * s.h);
+        for (int k = 0; k < s.nd; ++k) gp[k] += f * rr[k];
+      }
+    }
+  }
+  if (g_p)
+    for (int k = 0; k < s.nd; ++k) g_p[a * s.nd + k] = P.grad_ok[k] ? gp[k] * s.dom[k] : 0.f;
+  if (g_attr)
+    for (int ch = 0; ch < C; ++ch) g_attr[a * C + ch] = ga[ch];
+  if (g_pd) g_pd[a] = gpd;
+}
+
+__global__ void __launch_bounds__(256) wavg_finish_kernel(const float* __restrict__ xsum,
+                                                          const float* __restrict__ wsum, float* __restrict__ out,
+                                                          int64_t n, int C, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float w = wsum[i];
+  for (int c = 0; c < C; ++c) out[i * C + c] = w > eps ? xsum[i * C + c] / w : xsum[i * C + c];
+}
+
+__global__ void __launch_bounds__(256) wavg_finish_bwd_kernel(const float* __restrict__ xsum,
+                                                              const float* __restrict__ wsum,
+                                                              const float* __restrict__ g_out,
+                                                              float* __restrict__ g_xsum, float* __restrict__ g_wsum,
+                                                              int64_t n, int C, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float w = wsum[i];
+  float gw = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = g_out[i * C + c];
+    if (w > eps) {
+      g_xsum[i * C + c] = g / w;
+      gw -= g * xsum[i * C + c] / (w * w);
+    } else {
+      g_xsum[i * C + c] = g;
+    }
+  }
+  g_wsum[i] = gw;
+}
+
+static int make_dev_cfg(const nfs_splat_cfg* c, int C, SplatDev& s) {
+  NFS_REQUIRE(c, "p2g: null config");
+  NFS_REQUIRE(c->nd == 2 || c->nd == 3, "p2g: nd must be 2 or 3");
+  NFS_REQUIRE(c->mode >= 0 && c->mode <= 2, "p2g: mode must be 0..2");
+  NFS_REQUIRE(c->nsize >= 0 && c->nsize <= 8, "p2g: nsize out of range");
+  NFS_REQUIRE(C >= 1 && C <= 4, "p2g: 1 <= C <= 4");
+  s.nd = c->nd; s.mode = c->mode; s.nsize = c->nsize; s.clip = c->clip;
+  for (int k = 0; k < 3; ++k) { s.res[k] = c->res[k]; s.dom[k] = c->domain[k]; }
+  for (int k = 0; k < c->nd; ++k) NFS_REQUIRE(c->res[k] > 0 && c->domain[k] > 0.f, "p2g: bad res/domain");
+  s.cell = c->domain[0] / (float)c->res[0];  // cell_size[0] (transform.py:1328-1330)
+  s.h = c->radius * c->support;
+  const double pi = 3.14159265358979323846;
+  s.sigma = (float)(c->nd == 3 ? 8.0 / pi / ((double)s.h * s.h * s.h) : 40.0 / 7.0 / pi / ((double)s.h * s.h));
+  const double d2r = 2.0 * c->radius;
+  s.mass = (float)(0.8 * (c->nd == 3 ? d2r * d2r * d2r : d2r * d2r) * c->rest_density);
+  s.rest_density = c->rest_density;
+  return NFS_OK;
+}
+
+}  // namespace nfs
+
+using namespace nfs;
+
+extern "C" {
+
+int nfs_p2g_fwd(const float* p, const float* attr, const float* pd, float* grid, float* wsum, int N, int C,
+                const nfs_splat_cfg* cfg_host, nfs_stream_t stream) {
+  NFS_REQUIRE(p && grid && N > 0, "nfs_p2g_fwd: bad argument");
+  SplatDev s;
+  if (int e = make_dev_cfg(cfg_host, C, s)) return e;
+  NFS_REQUIRE(s.mode == 0 || attr, "nfs_p2g_fwd: attr required for mode 1/2");
+  NFS_REQUIRE(s.mode != 2 || wsum, "nfs_p2g_fwd: wsum required for mode 2");
+  NFS_REQUIRE(s.mode != 0 || C == 1, "nfs_p2g_fwd: density mode has C=1");
+  hipLaunchKernelGGL(p2g_fwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, grid,
+                     wsum, N, C);
+  return check_launch("nfs_p2g_fwd");
+}
+
+int nfs_p2g_bwd(const float* p, const float* attr, const float* pd, const float* g_grid, const float* g_wsum,
+                float* g_p, float* g_attr, float* g_pd, int N, int C, const nfs_splat_cfg* cfg_host,
+                nfs_stream_t stream) {
+  NFS_REQUIRE(p && g_grid && N > 0, "nfs_p2g_bwd: bad argument");
+  SplatDev s;
+  if (int e = make_dev_cfg(cfg_host, C, s)) return e;
+  NFS_REQUIRE(s.mode == 0 || attr, "nfs_p2g_bwd: attr required for mode 1/2");
+  NFS_REQUIRE(s.mode != 2 || g_wsum, "nfs_p2g_bwd: g_wsum required for mode 2");
+  NFS_REQUIRE(s.mode != 0 || (!g_attr && !g_pd), "nfs_p2g_bwd: density mode has no attr/pd gradient");
+  hipLaunchKernelGGL(p2g_bwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, g_grid,
+                     g_wsum, g_p, g_attr, g_pd, N, C);
+  return check_launch("nfs_p2g_bwd");
+}
+
+int nfs_p2g_wavg_finish(const float* xsum, const float* wsum, float* out, int64_t n, int C, float eps,
+                        nfs_stream_t stream) {
+  NFS_REQUIRE(xsum && wsum && out && n > 0 && C > 0, "nfs_p2g_wavg_finish: bad argument");
+  hipLaunchKernelGGL(wavg_finish_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), xsum, wsum, out, n,
+                     C, eps);
+  return check_launch("nfs_p2g_wavg_finish");
+}
+
+int nfs_p2g_wavg_finish_bwd(const float* xsum, const float* wsum, const float* g_out, float* g_xsum, float* g_wsum,
+                            int64_t n, int C, float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(xsum && wsum && g_out && g_xsum && g_wsum && n > 0 && C > 0, "nfs_p2g_wavg_finish_bwd: bad argument");
+  hipLaunchKernelGGL(wavg_finish_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), xsum, wsum,
+                     g_out, g_xsum, g_wsum, n, C, eps);
+  return check_launch("nfs_p2g_wavg_finish_bwd");
+}
+
+}  // extern "C"

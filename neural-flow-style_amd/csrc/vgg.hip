@@ -1,0 +1,387 @@
+// A6: VGG-19 3x3 SAME convolution (+bias+ReLU) and its data gradient as an implicit
+// GEMM on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32, 157 TFLOP/s peak,
+// the same peak as the f32 VALU but reachable with one wave per SIMD), vgg.py:44-48,89-108.
+//
+// GEMM view (NHWC):  M = output pixels, N = output channels, K = 9 taps x input channels.
+//   block  = 256 threads = 4 waves (2 M x 2 N), tile 128 pixel slots x BN channels
+//   M tile = TH x TW spatial patch of the row-stacked batch (rows of all images stacked;
+//            TH*TW <= 128, any TW: MFMA rows just enumerate the patch's pixels), so the
+//            (TH+2)x(TW+2) halo patch is staged in LDS ONCE per 32-channel chunk and
+//            re-used by all 9 taps (9x fewer global reads than im2col);
+//   K loop = 32-channel chunks x 9 taps; per tap the [BN][32] weight slab is staged
+//            through registers into a double-buffered LDS tile (prefetch of tap t+1 is
+//            in flight while tap t is multiplied);
+//   LDS rows are padded to 36 floats so the ds_read_b128 operand fetches are
+//   bank-conflict-free (36*n mod 64 hits 16 distinct 16-B slots per 16-lane group).
+//   Each lane fetches 4 consecutive k (one b128) and feeds 4 MFMA steps with them: the
+//   k order inside a chunk is permuted identically for A and B, which a sum permits.
+// Weights are frozen, so they are packed once on the device into [chunk][tap][N][32].
+#include "common.h"
+
+namespace nfs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 32;        // channels per K chunk
+constexpr int LDS_STRIDE = 36;  // padded row (floats)
+constexpr int BM = 128;
+constexpr int PATCH_MAX = 256;  // max (TH+2)*(TW+2)
+
+struct ConvArgs {
+  const float* x;       // [B,H,W,Kc]  input of the GEMM (fwd: activations, dgrad: gy)
+  const float* wp;      // packed [Kc/32][9][Nc][32]
+  const float* aux0;    // fwd: bias [Nc] (nullable); dgrad: x_in [B,H,W,Nc] for the ReLU mask (nullable)
+  const float* aux1;    // dgrad: addend [B,H,W,Nc] (nullable)
+  float* y;             // [B,H,W,Nc]
+  int B, H, W, Kc, Nc;
+  int TH, TW, tiles_c;
+  int relu;
+};
+
+template <int BN, int MODE>
+__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int NT = BN / 64;  // 32-wide N tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                  // [PATCH_MAX][36]
+  float* wl = smem + PATCH_MAX * LDS_STRIDE;            // [2][BN][36]
+  int* rowpix = reinterpret_cast<int*>(wl + 2 * BN * LDS_STRIDE);  // [128]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int tr = blockIdx.x / a.tiles_c, tc = blockIdx.x - tr * a.tiles_c;
+  const int n0 = blockIdx.y * BN;
+  const int TH = a.TH, TW = a.TW, PW = TW + 2;
+  const int PP = (TH + 2) * PW;
+  const int rows_total = a.B * a.H;
+  const int r0 = tr * TH, c0 = tc * TW;
+
+  // row -> global pixel table for the epilogue
+  if (t < BM) {
+    int pix = -1;
+    if (t < TH * TW) {
+      const int ty = t / TW, tx = t - ty * TW;
+      const int r = r0 + ty, c = c0 + tx;
+      if (r < rows_total && c < a.W) pix = r * a.W + c;
+    }
+    rowpix[t] = pix;
+  }
+
+  // per-lane A/B fragment bases
+  int abase[2];
+  bool up_ok[2], dn_ok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int m = wm * 64 + mt * 32 + i;
+    if (m >= TH * TW) m = 0;
+    const int ty = m / TW, tx = m - ty * TW;
+    abase[mt] = (ty * PW + tx) * LDS_STRIDE + 4 * h;
+    const int yy = (r0 + ty) % a.H;
+    up_ok[mt] = yy > 0;           // input row y-1 belongs to the same image
+    dn_ok[mt] = yy < a.H - 1;     // input row y+1 belongs to the same image
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * (BN / 2) + nt * 32 + i) * LDS_STRIDE + 4 * h;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int nchunks = a.Kc / KC;
+  const int niter = nchunks * 9;
+  constexpr int WREG = BN / 32;  // float4 per thread per weight slab
+  float4 wreg[WREG];
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+  auto load_w = [&](int it) {
+    // slab (chunk, tap) = it ; rows n0..n0+BN of [Nc][32]
+    const int64_t base4 = ((int64_t)it * a.Nc + n0) * (KC / 4);
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) wreg[r] = wp4[base4 + t + 256 * r];
+  };
+  load_w(0);
+
+  for (int it = 0; it < niter; ++it) {
+    const int chunk = it / 9, tap = it - chunk * 9;
+    if (tap == 0) {
+      __syncthreads();  // every wave is done with the previous chunk's patch
+      const int q = t & 7;
+      for (int pp = t >> 3; pp < PP; pp += 32) {
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int s = r0 + pr - 1, xc = c0 + pc - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s >= 0 && s < rows_total && xc >= 0 && xc < a.W)
+          v = *reinterpret_cast<const float4*>(a.x + ((int64_t)s * a.W + xc) * a.Kc + chunk * KC + 4 * q);
+        *reinterpret_cast<float4*>(patch + pp * LDS_STRIDE + 4 * q) = v;
+      }
+    }
+    float* wcur = wl + (it & 1) * BN * LDS_STRIDE;
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) {
+      const int f = t + 256 * r;
+      *reinterpret_cast<float4*>(wcur + (f >> 3) * LDS_STRIDE + 4 * (f & 7)) = wreg[r];
+    }
+    __syncthreads();
+    if (it + 1 < niter) load_w(it + 1);
+
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int tapoff = (dy * PW + dx) * LDS_STRIDE;
+    const bool z0 = (dy == 0 && !up_ok[0]) || (dy == 2 && !dn_ok[0]);
+    const bool z1 = (dy == 0 && !up_ok[1]) || (dy == 2 && !dn_ok[1]);
+#pragma unroll
+    for (int c = 0; c < KC / 8; ++c) {
+      float4 av[2], bv[NT];
+      av[0] = *reinterpret_cast<const float4*>(patch + abase[0] + tapoff + 8 * c);
+      av[1] = *reinterpret_cast<const float4*>(patch + abase[1] + tapoff + 8 * c);
+      if (z0) av[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z1) av[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(wcur + bbase[nt] + 8 * c);
+      const float* ap0 = &av[0].x; const float* ap1 = &av[1].x;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = (&bv[nt].x)[jj];
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap0[jj], b, acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap1[jj], b, acc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int pix = rowpix[row];
+      if (pix < 0) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + i;
+        const int64_t idx = (int64_t)pix * a.Nc + n;
+        float v = acc[mt][nt][r];
+        if (MODE == 0) {
+          if (a.aux0) v += a.aux0[n];
+          if (a.relu) v = fmaxf(v, 0.f);
+        } else {
+          if (a.aux0) v = a.aux0[idx] > 0.f ? v : 0.f;
+          if (a.aux1) v += a.aux1[idx];
+        }
+        a.y[idx] = v;
+      }
+    }
+  }
+}
+
+// ---- first layer (Ci = 3): direct VALU kernels; 0.5 % of the FLOPs -------------------------
+// fwd: thread = (pixel, 4 consecutive output channels); weights HWIO [9][3][Co] in LDS.
+__global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int H, int W, int Co, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Co]
+  for (int k = threadIdx.x; k < 27 * Co; k += blockDim.x) sw[k] = w[k];
+  __syncthreads();
+  const int CQ = Co >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * H * W * CQ) return;
+  const int cq = (int)(gid % CQ);
+  const int64_t pix = gid / CQ;
+  const int xx = (int)(pix % W);
+  const int yy = (int)((pix / W) % H);
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    if (yy + dy < 0 || yy + dy >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (xx + dx < 0 || xx + dx >= W) continue;
+      const float* xp = x + (pix + (int64_t)dy * W + dx) * 3;
+      const int tap = (dy + 1) * 3 + dx + 1;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float xv = xp[ci];
+        const float4 wv = *reinterpret_cast<const float4*>(sw + (tap * 3 + ci) * Co + 4 * cq);
+        acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+      }
+    }
+  }
+  if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+  *reinterpret_cast<float4*>(y + pix * Co + 4 * cq) = acc;
+}
+
+// dgrad to the 3-channel image: thread = pixel; packed [tap'][Co][3] (taps pre-flipped) in LDS.
+__global__ void __launch_bounds__(256) conv3x3_c3_dgrad_kernel(const float* __restrict__ gy,
+                                                               const float* __restrict__ wp, float* __restrict__ gx,
+                                                               int B, int H, int W, int Co) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [9][Co][3]
+  for (int k = threadIdx.x; k < 27 * Co; k += blockDim.x) sw[k] = wp[k];
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (int64_t)B * H * W) return;
+  const int xx = (int)(pix % W);
+  const int yy = (int)((pix / W) % H);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int dy = -1; dy <= 1; ++dy) {
+    if (yy + dy < 0 || yy + dy >= H) continue;
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (xx + dx < 0 || xx + dx >= W) continue;
+      const float4* gp = reinterpret_cast<const float4*>(gy + (pix + (int64_t)dy * W + dx) * Co);
+      const float* ws = sw + ((dy + 1) * 3 + dx + 1) * Co * 3;
+      for (int c4 = 0; c4 < (Co >> 2); ++c4) {
+        const float4 g = gp[c4];
+        const float* wq = ws + c4 * 12;
+        a0 += g.x * wq[0] + g.y * wq[3] + g.z * wq[6] + g.w * wq[9];
+        a1 += g.x * wq[1] + g.y * wq[4] + g.z * wq[7] + g.w * wq[10];
+        a2 += g.x * wq[2] + g.y * wq[5] + g.z * wq[8] + g.w * wq[11];
+      }
+    }
+  }
+  gx[pix * 3] = a0; gx[pix * 3 + 1] = a1; gx[pix * 3 + 2] = a2;
+}
+
+// packing: kind 0: Wp[chunk][tap][n=co][kc] = w[tap][chunk*32+kc][co]
+//          kind 1: Wp[chunk][tap][n=ci][kc] = w[8-tap][ci][chunk*32+kc]
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co,
+                                                   int kind) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)9 * Ci * Co) return;
+  if (Ci == 3) {
+    if (kind == 0) { wp[gid] = w[gid]; return; }
+    // [tap'][co][ci] = w[8-tap'][ci][co]
+    const int ci = (int)(gid % 3);
+    const int co = (int)((gid / 3) % Co);
+    const int tp = (int)(gid / (3 * Co));
+    wp[gid] = w[((int64_t)(8 - tp) * 3 + ci) * Co + co];
+    return;
+  }
+  const int Nc = kind == 0 ? Co : Ci;
+  const int kc = (int)(gid % KC);
+  const int n = (int)((gid / KC) % Nc);
+  const int tap = (int)((gid / ((int64_t)KC * Nc)) % 9);
+  const int chunk = (int)(gid / ((int64_t)KC * Nc * 9));
+  float v;
+  if (kind == 0) v = w[((int64_t)tap * Ci + chunk * KC + kc) * Co + n];
+  else v = w[((int64_t)(8 - tap) * Ci + n) * Co + chunk * KC + kc];
+  wp[gid] = v;
+}
+
+// choose the spatial M tile: maximise useful pixel slots, prefer wide tiles
+static void pick_tile(int B, int H, int W, int& TH, int& TW, int& tiles_r, int& tiles_c) {
+  double best = -1.0;
+  const int rows = B * H;
+  for (int tw = 4; tw <= 128 && tw <= ((W + 3) / 4) * 4; ++tw) {
+    const int twc = tw > W ? W : tw;
+    int th = BM / twc;
+    if (th > rows) th = rows;
+    if (th < 1) continue;
+    while (th > 1 && (th + 2) * (twc + 2) > PATCH_MAX) --th;
+    if ((th + 2) * (twc + 2) > PATCH_MAX) continue;
+    const int tr = (rows + th - 1) / th, tcn = (W + twc - 1) / twc;
+    const double eff = (double)rows * W / ((double)tr * tcn * BM);
+    if (eff > best + 1e-9) { best = eff; TH = th; TW = twc; tiles_r = tr; tiles_c = tcn; }
+  }
+}
+
+static int g_cus = 0;
+static int device_cus() {
+  if (g_cus == 0) {
+    int c = nfs_device_cus();
+    g_cus = c > 0 ? c : 256;
+  }
+  return g_cus;
+}
+
+template <int MODE>
+static int launch_conv(const ConvArgs& base, hipStream_t s) {
+  ConvArgs a = base;
+  int tiles_r = 0;
+  a.TH = 0;
+  pick_tile(a.B, a.H, a.W, a.TH, a.TW, tiles_r, a.tiles_c);
+  NFS_REQUIRE(a.TH > 0, "conv3x3: no valid tile for %dx%dx%d", a.B, a.H, a.W);
+  const int mtiles = tiles_r * a.tiles_c;
+  const bool big = (a.Nc % 128 == 0) && ((int64_t)mtiles * (a.Nc / 128) >= 2 * (int64_t)device_cus());
+  if (big) {
+    constexpr int BN = 128;
+    const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<BN, MODE>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), dim3(mtiles, a.Nc / BN), dim3(256), lds, s, a);
+  } else {
+    constexpr int BN = 64;
+    const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), dim3(mtiles, a.Nc / BN), dim3(256), lds, s, a);
+  }
+  return check_launch(MODE == 0 ? "nfs_conv3x3_fwd" : "nfs_conv3x3_dgrad");
+}
+
+}  // namespace nfs
+
+using namespace nfs;
+
+extern "C" {
+
+int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind) {
+  (void)kind;
+  if (Ci <= 0 || Co <= 0) return 0;
+  return (int64_t)9 * Ci * Co;
+}
+
+int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind, nfs_stream_t stream) {
+  NFS_REQUIRE(w_hwio && packed, "nfs_conv3x3_pack: null pointer");
+  NFS_REQUIRE(kind == 0 || kind == 1, "nfs_conv3x3_pack: kind must be 0 or 1");
+  NFS_REQUIRE(Ci == 3 || (Ci % 64 == 0), "nfs_conv3x3_pack: Ci must be 3 or a multiple of 64");
+  NFS_REQUIRE(Co % 64 == 0, "nfs_conv3x3_pack: Co must be a multiple of 64");
+  const int64_t n = (int64_t)9 * Ci * Co;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), w_hwio, packed, Ci, Co,
+                     kind);
+  return check_launch("nfs_conv3x3_pack");
+}
+
+int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y, int B, int H, int W, int Ci,
+                    int Co, int relu, nfs_stream_t stream) {
+  NFS_REQUIRE(x && packed_fwd && y, "nfs_conv3x3_fwd: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_fwd: non-positive dimension");
+  NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd: too many pixels");
+  NFS_REQUIRE(Co > 0 && Co % 64 == 0, "nfs_conv3x3_fwd: Co must be a multiple of 64");
+  if (Ci == 3) {
+    const int64_t n = (int64_t)B * H * W * (Co / 4);
+    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 27 * Co * sizeof(float),
+                       as_stream(stream), x, packed_fwd, bias, y, B, H, W, Co, relu);
+    return check_launch("nfs_conv3x3_fwd(c3)");
+  }
+  NFS_REQUIRE(Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd: Ci must be 3 or a multiple of 32");
+  ConvArgs a{x, packed_fwd, bias, nullptr, y, B, H, W, Ci, Co, 0, 0, 0, relu};
+  return launch_conv<0>(a, as_stream(stream));
+}
+
+int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in, const float* addend, float* gx,
+                      int B, int H, int W, int Ci, int Co, nfs_stream_t stream) {
+  NFS_REQUIRE(gy && packed_dgrad && gx, "nfs_conv3x3_dgrad: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_dgrad: non-positive dimension");
+  NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad: too many pixels");
+  NFS_REQUIRE(Co > 0 && Co % 32 == 0, "nfs_conv3x3_dgrad: Co must be a multiple of 32");
+  if (Ci == 3) {
+    NFS_REQUIRE(!x_in && !addend, "nfs_conv3x3_dgrad: Ci=3 takes no mask/addend");
+    const int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(conv3x3_c3_dgrad_kernel, dim3(blocks_for(n, 256)), dim3(256), 27 * Co * sizeof(float),
+                       as_stream(stream), gy, packed_dgrad, gx, B, H, W, Co);
+    return check_launch("nfs_conv3x3_dgrad(c3)");
+  }
+  NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
+  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, B, H, W, Co, Ci, 0, 0, 0, 0};
+  return launch_conv<1>(a, as_stream(stream));
+}
+
+}  // extern "C"

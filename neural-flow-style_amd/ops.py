@@ -1,0 +1,337 @@
+"""Tensor-level bindings of the C ABI (include/nfs_hip.h).
+
+PyTorch is plumbing only: it owns device memory and the stream.  Every function
+takes contiguous float32 CUDA tensors, passes raw pointers + the current stream
+through ctypes and returns freshly allocated (or caller-supplied) outputs.
+There is no CPU path: a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SplatCfg
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("expected a contiguous float32 CUDA tensor, got %s %s contiguous=%s"
+                         % (t.device, t.dtype, t.is_contiguous()))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _zeros(shape, like):
+    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+# ---- A2 / A3 / A11 ------------------------------------------------------------------
+
+def warp3d_fwd(imgs, coords):
+    B, X, Y, Z, Cn = imgs.shape
+    out = _empty(imgs.shape, imgs)
+    _lib.call("nfs_warp3d_fwd", _ptr(imgs), _ptr(coords), _ptr(out), B, X, Y, Z, Cn, _stream())
+    return out
+
+
+def warp3d_bwd(imgs, coords, g_out, need_coords=True):
+    B, X, Y, Z, Cn = imgs.shape
+    g_imgs = _zeros(imgs.shape, imgs)
+    g_coords = _empty(coords.shape, imgs) if need_coords else None
+    _lib.call("nfs_warp3d_bwd", _ptr(imgs), _ptr(coords), _ptr(g_out), _ptr(g_imgs), _ptr(g_coords),
+              B, X, Y, Z, Cn, _stream())
+    return g_imgs, g_coords
+
+
+def rotate_fwd(d, rot):
+    """d [D,H,W,C], rot [V,3,3] -> [V,D,H,W,C]"""
+    D, H, W, Cn = d.shape
+    V = rot.shape[0]
+    out = _empty((V, D, H, W, Cn), d)
+    _lib.call("nfs_rotate_fwd", _ptr(d), _ptr(rot), _ptr(out), V, D, H, W, Cn, _stream())
+    return out
+
+
+def rotate_bwd(g_out, rot, g_d_acc=None):
+    V, D, H, W, Cn = g_out.shape
+    if g_d_acc is None:
+        g_d_acc = _zeros((D, H, W, Cn), g_out)
+    _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _stream())
+    return g_d_acc
+
+
+def advect_fwd(d, vel, out=None):
+    D, H, W, Cn = d.shape
+    if out is None:
+        out = _empty(d.shape, d)
+    _lib.call("nfs_advect_fwd", _ptr(d), _ptr(vel), _ptr(out), D, H, W, Cn, _stream())
+    return out
+
+
+def advect_bwd(d, vel, g_out, need_d=True, need_vel=True, g_d_acc=None, g_vel=None):
+    D, H, W, Cn = d.shape
+    if need_d and g_d_acc is None:
+        g_d_acc = _zeros(d.shape, d)
+    if need_vel and g_vel is None:
+        g_vel = _empty(vel.shape, d)
+    _lib.call("nfs_advect_bwd", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(g_d_acc if need_d else None),
+              _ptr(g_vel if need_vel else None), D, H, W, Cn, _stream())
+    return g_d_acc, g_vel
+
+
+# ---- A9 -----------------------------------------------------------------------------
+
+def smooth3d_relu_fwd(d, k, out=None):
+    D, H, W = d.shape
+    if out is None:
+        out = _empty(d.shape, d)
+    _lib.call("nfs_smooth3d_relu_fwd", _ptr(d), _ptr(out), D, H, W, float(k), _stream())
+    return out
+
+
+def smooth3d_relu_bwd(out, g_out, k, g_d=None):
+    D, H, W = out.shape
+    if g_d is None:
+        g_d = _empty(out.shape, out)
+    _lib.call("nfs_smooth3d_relu_bwd", _ptr(out), _ptr(g_out), _ptr(g_d), D, H, W, float(k), _stream())
+    return g_d
+
+
+# ---- A4 -----------------------------------------------------------------------------
+
+def render_fwd(d, tau, liquid=False):
+    """d [V,D,H,W] -> (img [V,H,W] un-normalised, raysum [V,H,W])"""
+    V, D, H, W = d.shape
+    img = _empty((V, H, W), d); rs = _empty((V, H, W), d)
+    _lib.call("nfs_render_fwd", _ptr(d), _ptr(img), _ptr(rs), V, D, H, W, float(tau), int(liquid), _stream())
+    return img, rs
+
+
+def render_bwd(d, raysum, g_img, tau, liquid=False):
+    V, D, H, W = d.shape
+    g_d = _empty(d.shape, d)
+    _lib.call("nfs_render_bwd", _ptr(d), _ptr(raysum), _ptr(g_img), _ptr(g_d), V, D, H, W, float(tau),
+              int(liquid), _stream())
+    return g_d
+
+
+def rotate_render_fwd(d, rot, tau, liquid=False, img=None, raysum=None):
+    """d [D,H,W], rot [V,3,3] -> (img [V,H,W], raysum [V,H,W])"""
+    D, H, W = d.shape
+    V = rot.shape[0]
+    if img is None:
+        img = _empty((V, H, W), d)
+    if raysum is None:
+        raysum = _empty((V, H, W), d)
+    _lib.call("nfs_rotate_render_fwd", _ptr(d), _ptr(rot), _ptr(img), _ptr(raysum), V, D, H, W, float(tau),
+              int(liquid), _stream())
+    return img, raysum
+
+
+def rotate_render_bwd(d, rot, raysum, g_img, tau, liquid=False, g_d_acc=None):
+    D, H, W = d.shape
+    V = rot.shape[0]
+    if g_d_acc is None:
+        g_d_acc = _zeros(d.shape, d)
+    _lib.call("nfs_rotate_render_bwd", _ptr(d), _ptr(rot), _ptr(raysum), _ptr(g_img), _ptr(g_d_acc), V, D, H, W,
+              float(tau), int(liquid), _stream())
+    return g_d_acc
+
+
+def maxnorm_fwd(img, groups, out=None, gmax=None):
+    n = img.numel() // groups
+    if out is None:
+        out = _empty(img.shape, img)
+    if gmax is None:
+        gmax = _empty((groups,), img)
+    _lib.call("nfs_maxnorm_fwd", _ptr(img), _ptr(out), _ptr(gmax), groups, n, _stream())
+    return out, gmax
+
+
+def maxnorm_bwd(img, gmax, g_out, g_img=None):
+    groups = gmax.numel()
+    n = img.numel() // groups
+    if g_img is None:
+        g_img = _empty(img.shape, img)
+    _lib.call("nfs_maxnorm_bwd", _ptr(img), _ptr(gmax), _ptr(g_out), _ptr(g_img), groups, n, _stream())
+    return g_img
+
+
+# ---- A5 -----------------------------------------------------------------------------
+
+def loss_net_input_fwd(img, H2=None, W2=None, want_d_img=True, want_x=True):
+    """img [B,H,W,Cin] in [0,1] -> (d_img [B,H2,W2,3] 0..255, x = d_img - mean)"""
+    B, H, W, Cin = img.shape
+    H2 = H if H2 is None else H2
+    W2 = W if W2 is None else W2
+    d_img = _empty((B, H2, W2, 3), img) if want_d_img else None
+    x = _empty((B, H2, W2, 3), img) if want_x else None
+    _lib.call("nfs_loss_net_input_fwd", _ptr(img), _ptr(d_img), _ptr(x), B, H, W, Cin, H2, W2, _stream())
+    return d_img, x
+
+
+def loss_net_input_bwd(g_x, H, W, Cin):
+    B, H2, W2, _ = g_x.shape
+    g_img = _empty((B, H, W, Cin), g_x)
+    _lib.call("nfs_loss_net_input_bwd", _ptr(g_x), _ptr(g_img), B, H, W, Cin, H2, W2, _stream())
+    return g_img
+
+
+# ---- A6 -----------------------------------------------------------------------------
+
+def conv3x3_pack(w_hwio, kind):
+    """w [3,3,Ci,Co] -> packed device buffer for kind 0 (fwd) / 1 (dgrad)"""
+    _, _, Ci, Co = w_hwio.shape
+    n = _lib.lib().nfs_conv3x3_packed_floats(Ci, Co, kind)
+    packed = _empty((n,), w_hwio)
+    _lib.call("nfs_conv3x3_pack", _ptr(w_hwio), _ptr(packed), Ci, Co, kind, _stream())
+    return packed
+
+
+def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None):
+    B, H, W, Ci = x.shape
+    if out is None:
+        out = _empty((B, H, W, Co), x)
+    _lib.call("nfs_conv3x3_fwd", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), B, H, W, Ci, Co, int(relu), _stream())
+    return out
+
+
+def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None):
+    B, H, W, Co = gy.shape
+    if out is None:
+        out = _empty((B, H, W, Ci), gy)
+    _lib.call("nfs_conv3x3_dgrad", _ptr(gy), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out), B, H, W, Ci, Co,
+              _stream())
+    return out
+
+
+def avgpool2_fwd(x, out=None):
+    B, H, W, Cn = x.shape
+    if out is None:
+        out = _empty((B, H // 2, W // 2, Cn), x)
+    _lib.call("nfs_avgpool2_fwd", _ptr(x), _ptr(out), B, H, W, Cn, _stream())
+    return out
+
+
+def avgpool2_bwd(gy, x_shape, x=None, addend=None, out=None):
+    B, H, W, Cn = x_shape
+    if out is None:
+        out = _empty(tuple(x_shape), gy)
+    _lib.call("nfs_avgpool2_bwd", _ptr(gy), _ptr(x), _ptr(addend), _ptr(out), B, H, W, Cn, _stream())
+    return out
+
+
+# ---- A7 / A12 -----------------------------------------------------------------------
+
+def gram_fwd(F, scale, scale_dev=None, G=None):
+    """F [B,h,w,C] (or [B,HW,C]) -> G [B,C,C] = scale * F^T F"""
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    if G is None:
+        G = _zeros((B, Cn, Cn), F)
+    else:
+        G.zero_()
+    _lib.call("nfs_gram_fwd", _ptr(F), _ptr(G), B, HW, Cn, _ptr(scale_dev), float(scale), _stream())
+    return G
+
+
+def style_loss_fwd(G, Gs, weight, loss_acc, Dmat=None):
+    B, Cn, _ = G.shape
+    if Dmat is None:
+        Dmat = _empty(G.shape, G)
+    _lib.call("nfs_style_loss_fwd", _ptr(G), _ptr(Gs), _ptr(loss_acc), _ptr(Dmat), B, Gs.shape[0], Cn, float(weight),
+              _stream())
+    return Dmat
+
+
+def gram_bwd(F, Dmat, scale, scale_dev=None, relu_mask=True, out=None):
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    if out is None:
+        out = _empty(F.shape, F)
+    _lib.call("nfs_gram_bwd", _ptr(F), _ptr(Dmat), _ptr(out), B, HW, Cn, _ptr(scale_dev), float(scale),
+              int(relu_mask), _stream())
+    return out
+
+
+def tv_loss(d_img, weight, loss_acc, g_acc=None):
+    B, H, W, Cn = d_img.shape
+    _lib.call("nfs_tv_loss", _ptr(d_img), _ptr(loss_acc), _ptr(g_acc), B, H, W, Cn, float(weight), _stream())
+
+
+# ---- A8 -----------------------------------------------------------------------------
+
+def make_splat_cfg(nd, res, domain, radius, support, rest_density, nsize, clip, mode):
+    c = SplatCfg()
+    c.nd = nd
+    for k in range(3):
+        c.res[k] = int(res[k]) if k < nd else 1
+        c.domain[k] = float(domain[k]) if k < nd else 1.0
+    c.radius = float(radius); c.support = float(support); c.rest_density = float(rest_density)
+    c.nsize = int(nsize); c.clip = int(bool(clip)); c.mode = int(mode)
+    return c
+
+
+def p2g_fwd(p, cfg, attr=None, pd=None):
+    """p [N,nd]; returns grid [res..., C] (mode 0/1) or (xsum, wsum) (mode 2)"""
+    N = p.shape[0]
+    Cn = 1 if attr is None else attr.shape[-1]
+    res = [cfg.res[k] for k in range(cfg.nd)]
+    grid = _zeros(tuple(res) + (Cn,), p)
+    wsum = _zeros(tuple(res) + (1,), p) if cfg.mode == 2 else None
+    _lib.call("nfs_p2g_fwd", _ptr(p), _ptr(attr), _ptr(pd), _ptr(grid), _ptr(wsum), N, Cn, C.byref(cfg), _stream())
+    return (grid, wsum) if cfg.mode == 2 else grid
+
+
+def p2g_bwd(p, cfg, g_grid, attr=None, pd=None, g_wsum=None, need_p=True, need_attr=False, need_pd=False):
+    N = p.shape[0]
+    Cn = 1 if attr is None else attr.shape[-1]
+    g_p = _empty(p.shape, p) if need_p else None
+    g_attr = _empty(attr.shape, p) if need_attr else None
+    g_pd = _empty((N,), p) if need_pd else None
+    _lib.call("nfs_p2g_bwd", _ptr(p), _ptr(attr), _ptr(pd), _ptr(g_grid), _ptr(g_wsum), _ptr(g_p), _ptr(g_attr),
+              _ptr(g_pd), N, Cn, C.byref(cfg), _stream())
+    return g_p, g_attr, g_pd
+
+
+def p2g_wavg_finish(xsum, wsum, eps=1e-6):
+    Cn = xsum.shape[-1]
+    n = wsum.numel()
+    out = _empty(xsum.shape, xsum)
+    _lib.call("nfs_p2g_wavg_finish", _ptr(xsum), _ptr(wsum), _ptr(out), n, Cn, float(eps), _stream())
+    return out
+
+
+def p2g_wavg_finish_bwd(xsum, wsum, g_out, eps=1e-6):
+    Cn = xsum.shape[-1]
+    n = wsum.numel()
+    g_x = _empty(xsum.shape, xsum); g_w = _empty(wsum.shape, xsum)
+    _lib.call("nfs_p2g_wavg_finish_bwd", _ptr(xsum), _ptr(wsum), _ptr(g_out), _ptr(g_x), _ptr(g_w), n, Cn,
+              float(eps), _stream())
+    return g_x, g_w
+
+
+# ---- A10 ----------------------------------------------------------------------------
+
+def adam_tf_step(x, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    _lib.call("nfs_adam_tf_step", _ptr(x), _ptr(m), _ptr(v), _ptr(g), x.numel(), float(lr_t), float(beta1),
+              float(beta2), float(eps), _stream())
+
+
+def fill(x, value):
+    _lib.call("nfs_fill", _ptr(x), float(value), x.numel(), _stream())
+
+
+def axpy(y, x, a):
+    _lib.call("nfs_axpy", _ptr(y), _ptr(x), float(a), x.numel(), _stream())

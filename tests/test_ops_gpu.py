@@ -1,0 +1,334 @@
+"""Operator parity: every HIP entry point vs the CPU oracle on the same seeded
+inputs (through the C ABI).  Tolerance: relative L2 <= 1e-4 per operator for
+float32 (north_star's end-to-end bar is 1e-3; float atomics make the scatter
+adjoints run-to-run non-deterministic at ~1e-7)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nfs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import neural_flow_style_amd.ops as ops
+    return ops
+
+
+def dev(x):
+    return x.detach().float().contiguous().cuda()
+
+
+def rots(n, seed=0, big=False):
+    import neural_flow_style_amd.transform as T
+    rng = np.random.RandomState(seed)
+    m = [np.eye(3)]
+    for _ in range(n - 1):
+        phi, th = rng.uniform(-5, 5), rng.uniform(-10, 10)
+        if big:
+            phi, th = rng.uniform(-40, 40), rng.uniform(-60, 60)
+        m.append(T.rot_y_3d(th) @ T.rot_z_3d(phi))
+    return torch.tensor(np.stack(m), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(9, 7, 11, 1), (6, 8, 5, 3)])
+def test_warp3d(ops, shape):
+    torch.manual_seed(0)
+    X, Y, Z, C = shape
+    imgs = torch.randn(2, X, Y, Z, C)
+    coords = torch.rand(2, 3, X, Y, Z) * 2.6 - 1.3
+    imgs_r = imgs.clone().requires_grad_(); coords_r = coords.clone().requires_grad_()
+    ref = O.batch_warp3d(imgs_r, coords_r, [2, X, Y, Z])
+    out = ops.warp3d_fwd(dev(imgs), dev(coords))
+    assert rel(out, ref) < TOL
+    g = torch.randn_like(ref)
+    gi, gc = torch.autograd.grad(ref, (imgs_r, coords_r), g)
+    gi_h, gc_h = ops.warp3d_bwd(dev(imgs), dev(coords), dev(g))
+    assert rel(gi_h, gi) < TOL
+    assert rel(gc_h, gc) < TOL
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_rotate(ops, big):
+    torch.manual_seed(1)
+    d = torch.rand(1, 10, 12, 9, 2).requires_grad_()
+    R = rots(3, 1, big)
+    ref = O.rotate(d, R)
+    out = ops.rotate_fwd(dev(d[0]), dev(R))
+    assert rel(out, ref) < TOL
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gd_h = ops.rotate_bwd(dev(g), dev(R))
+    assert rel(gd_h, gd[0]) < TOL
+
+
+def test_advect(ops):
+    torch.manual_seed(2)
+    d = torch.rand(1, 11, 9, 13, 1).requires_grad_()
+    v = (torch.randn(1, 11, 9, 13, 3) * 0.25).requires_grad_()
+    ref = O.advect(d, v)
+    out = ops.advect_fwd(dev(d[0]), dev(v[0]))
+    assert rel(out, ref[0]) < TOL
+    g = torch.randn_like(ref)
+    gd, gv = torch.autograd.grad(ref, (d, v), g)
+    gd_h, gv_h = ops.advect_bwd(dev(d[0]), dev(v[0]), dev(g[0]))
+    assert rel(gd_h, gd[0]) < TOL
+    assert rel(gv_h, gv[0]) < TOL
+
+
+@pytest.mark.parametrize("k", [3.0, 0.0])
+@pytest.mark.parametrize("shape", [(7, 9, 13), (8, 8, 16)])
+def test_smooth3d_relu(ops, k, shape):
+    torch.manual_seed(3)
+    d = torch.randn(1, *shape, 1)
+    d[0, :2] = 0.0  # exact zeros: TF's Maximum gradient passes at pre == 0
+    d = d.requires_grad_()
+    ref = O.smooth3d_relu(d, k)
+    out = ops.smooth3d_relu_fwd(dev(d[0, ..., 0]), k)
+    assert rel(out, ref[0, ..., 0]) < TOL
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gd_h = ops.smooth3d_relu_bwd(out, dev(g[0, ..., 0]), k)
+    assert rel(gd_h, gd[0, ..., 0]) < TOL
+
+
+@pytest.mark.parametrize("liquid", [False, True])
+def test_render_and_maxnorm(ops, liquid):
+    torch.manual_seed(4)
+    d = torch.rand(3, 17, 8, 9, 1).requires_grad_()
+    tau = 0.2
+    ref = O.render(d, tau, liquid)  # whole batch = one normalisation group (v_batch = 3)
+    img, rs = ops.render_fwd(dev(d[..., 0]), tau, liquid)
+    if liquid:
+        out = img
+    else:
+        out, gmax = ops.maxnorm_fwd(img, 1)
+    assert rel(out, ref[..., 0]) < TOL
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gi = dev(g[..., 0])
+    if not liquid:
+        gi = ops.maxnorm_bwd(img, gmax, gi)
+    gd_h = ops.render_bwd(dev(d[..., 0]), rs, gi, tau, liquid)
+    assert rel(gd_h, gd[..., 0]) < TOL
+
+
+def test_maxnorm_ties_split_like_tf(ops):
+    x = torch.tensor([[1.0, 3.0, 3.0, 2.0]]).requires_grad_()
+    y = x / x.amax()
+    g = torch.tensor([[0.5, -1.0, 2.0, 0.25]])
+    (gx,) = torch.autograd.grad(y, x, g)
+    out, gmax = ops.maxnorm_fwd(dev(x), 1)
+    gx_h = ops.maxnorm_bwd(dev(x), gmax, dev(g))
+    assert rel(gx_h, gx) < 1e-6
+
+
+@pytest.mark.parametrize("liquid", [False, True])
+def test_rotate_render_fused(ops, liquid):
+    torch.manual_seed(5)
+    d = torch.rand(1, 14, 12, 10, 1).requires_grad_()
+    R = rots(4, 5)
+    tau = 0.15
+    dr = O.rotate(d, R)
+    ref = torch.cat([O.render(dr[v:v + 1], tau, liquid) for v in range(4)])  # per-view max (v_batch=1)
+    img, rs = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, liquid)
+    if liquid:
+        out = img
+    else:
+        out, gmax = ops.maxnorm_fwd(img, 4)
+    assert rel(out, ref[..., 0]) < TOL
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gi = dev(g[..., 0])
+    if not liquid:
+        gi = ops.maxnorm_bwd(img, gmax, gi)
+    gd_h = ops.rotate_render_bwd(dev(d[0, ..., 0]), dev(R), rs, gi, tau, liquid)
+    assert rel(gd_h, gd[0, ..., 0]) < TOL
+    # fused == unfused HIP
+    img2, _ = ops.render_fwd(ops.rotate_fwd(dev(d[0]), dev(R))[..., 0].contiguous(), tau, liquid)
+    assert rel(img2, img) < 1e-5
+
+
+@pytest.mark.parametrize("cin,scale", [(1, 1.0), (3, 1.0), (1, 1.5)])
+def test_loss_net_input(ops, cin, scale):
+    torch.manual_seed(6)
+    img = torch.rand(2, 10, 12, cin).requires_grad_()
+    ref = O.plugin_to_loss_net(img, scale, is_color=(cin == 3))
+    H2, W2 = ref.shape[1:3]
+    d_img, x = ops.loss_net_input_fwd(dev(img), H2, W2)
+    assert rel(d_img, ref) < TOL
+    assert rel(x, ref - torch.tensor(O.VGG_MEAN)) < TOL
+    g = torch.randn_like(ref)
+    (gi,) = torch.autograd.grad(ref, img, g)
+    gi_h = ops.loss_net_input_bwd(dev(g), 10, 12, cin)
+    assert rel(gi_h, gi) < TOL
+
+
+def _conv_ref(x, w, b, relu=True):
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), torch.as_tensor(w).permute(3, 2, 0, 1),
+                                   None if b is None else torch.as_tensor(b), padding=1)
+    if relu:
+        y = torch.relu(y)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 3, 64), (2, 13, 11, 64, 64), (3, 25, 25, 64, 128),
+                                          (1, 12, 12, 128, 256), (2, 7, 50, 128, 128), (8, 6, 6, 256, 128)])
+def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
+    rng = np.random.RandomState(7)
+    x = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32).requires_grad_()
+    w = (rng.randn(3, 3, Ci, Co) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = (rng.randn(Co) * 0.1).astype(np.float32)
+    ref = _conv_ref(x, w, b)
+    wf = ops.conv3x3_pack(dev(torch.tensor(w)), 0)
+    out = ops.conv3x3_fwd(dev(x), wf, dev(torch.tensor(b)), Co, relu=True)
+    assert rel(out, ref) < TOL
+    # data gradient wrt x given the gradient wrt the pre-activation
+    gy = torch.tensor(rng.randn(B, H, W, Co), dtype=torch.float32)
+    pre = _conv_ref(x, w, b, relu=False)
+    (gx,) = torch.autograd.grad(pre, x, gy)
+    wd = ops.conv3x3_pack(dev(torch.tensor(w)), 1)
+    gx_h = ops.conv3x3_dgrad(dev(gy), wd, Ci)
+    assert rel(gx_h, gx) < TOL
+    if Ci != 3:
+        xin = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
+        add = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
+        gx_m = ops.conv3x3_dgrad(dev(gy), wd, Ci, x_in=dev(xin), addend=dev(add))
+        assert rel(gx_m, gx * (xin > 0) + add) < TOL
+
+
+def test_avgpool2(ops):
+    torch.manual_seed(8)
+    x = torch.randn(2, 7, 9, 8).requires_grad_()
+    ref = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    out = ops.avgpool2_fwd(dev(x))
+    assert rel(out, ref) < TOL
+    g = torch.randn_like(ref)
+    (gx,) = torch.autograd.grad(ref, x, g)
+    gx_h = ops.avgpool2_bwd(dev(g), x.shape)
+    assert rel(gx_h, gx) < TOL
+    add = torch.randn_like(x)
+    gx_m = ops.avgpool2_bwd(dev(g), x.shape, x=dev(x), addend=dev(add))
+    assert rel(gx_m, gx * (x > 0) + add) < TOL
+
+
+@pytest.mark.parametrize("B,HW,C", [(2, 300, 64), (1, 1000, 128), (3, 37, 256), (1, 144, 512)])
+def test_gram_style_loss(ops, B, HW, C):
+    torch.manual_seed(9)
+    F = torch.relu(torch.randn(B, HW, C)).requires_grad_()
+    Fs = torch.relu(torch.randn(1, HW, C))
+    denom = 2.0 * HW * C
+    G = torch.stack([f.t() @ f for f in F]) / denom
+    Gs = torch.stack([f.t() @ f for f in Fs]) / denom
+    wgt = 0.7
+    loss = wgt * ((G - Gs) ** 2).sum()
+    (gF,) = torch.autograd.grad(loss, F)
+    Gh = ops.gram_fwd(dev(F), 1.0 / denom)
+    Gsh = ops.gram_fwd(dev(Fs), 1.0 / denom)
+    assert rel(Gh, G) < TOL
+    lacc = torch.zeros(B, device="cuda")
+    Dm = ops.style_loss_fwd(Gh, Gsh, wgt, lacc)
+    assert abs(float(lacc.sum()) - float(loss)) / float(loss) < TOL
+    dF = ops.gram_bwd(dev(F), Dm, 1.0 / denom, relu_mask=False)
+    assert rel(dF, gF) < TOL
+    dFm = ops.gram_bwd(dev(F), Dm, 1.0 / denom, relu_mask=True)
+    assert rel(dFm, gF * (F > 0)) < TOL
+
+
+def test_tv_loss(ops):
+    torch.manual_seed(10)
+    x = (torch.rand(2, 9, 11, 3) * 255).requires_grad_()
+    ref = O.tv_loss(x) * 0.01
+    (gx,) = torch.autograd.grad(ref, x)
+    lacc = torch.zeros(1, device="cuda"); g = torch.zeros(x.shape, device="cuda")
+    ops.tv_loss(dev(x), 0.01, lacc, g)
+    assert abs(float(lacc) - float(ref)) / float(ref) < TOL
+    assert rel(g, gx) < TOL
+
+
+def test_adam_tf(ops):
+    torch.manual_seed(11)
+    x0 = torch.randn(1003); opt = O.TFAdam()
+    x = dev(x0); m = torch.zeros_like(x); v = torch.zeros_like(x)
+    xr = x0.clone()
+    b1p = np.float32(1); b2p = np.float32(1)
+    for t in range(5):
+        g = torch.randn(1003) * (1e-7 if t % 2 else 1.0)
+        xr = opt.step(xr, g, 0.1)
+        b1p = np.float32(b1p * np.float32(0.9)); b2p = np.float32(b2p * np.float32(0.999))
+        lr_t = np.float32(0.1) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p)
+        ops.adam_tf_step(x, m, v, dev(g), float(lr_t))
+    assert rel(x, xr) < 1e-5
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_p2g_density(ops, nd):
+    rng = np.random.RandomState(12)
+    N = 500
+    p = torch.tensor(rng.uniform(-0.03, 1.03, (1, N, nd)), dtype=torch.float32).requires_grad_()
+    if nd == 3:
+        res, dom, radius, nsize = [12, 14, 10], [12., 14., 10.], 0.5, 1
+    else:
+        res, dom, radius, nsize = [16, 32], [1.6, 3.2], 0.025, 2
+    ref = O.p2g(p, dom, res, radius, 1000., nsize, is_2d=(nd == 2), clip=False)
+    cfg = ops.make_splat_cfg(nd, res, dom, radius, 4, 1000., nsize, False, 0)
+    out = ops.p2g_fwd(dev(p[0]), cfg)
+    assert rel(out, ref[0]) < TOL
+    g = torch.randn_like(ref)
+    (gp,) = torch.autograd.grad(ref, p, g)
+    gp_h, _, _ = ops.p2g_bwd(dev(p[0]), cfg, dev(g[0]))
+    assert rel(gp_h, gp[0]) < 5e-4
+
+
+def test_p2g_colour_2d(ops):
+    rng = np.random.RandomState(13)
+    N = 400
+    p = torch.tensor(rng.uniform(0, 1, (1, N, 2)), dtype=torch.float32)
+    c = torch.tensor(rng.uniform(0, 1, (1, N, 3)), dtype=torch.float32).requires_grad_()
+    r = torch.tensor(rng.uniform(800, 1200, (1, N, 1)), dtype=torch.float32)
+    res, dom = [16, 32], [1.6, 3.2]
+    ref = O.p2g(p, dom, res, 0.025, 1000., 2, pc=c, pd=r, is_2d=True, clip=False)
+    cfg = ops.make_splat_cfg(2, res, dom, 0.025, 4, 1000., 2, False, 1)
+    out = ops.p2g_fwd(dev(p[0]), cfg, attr=dev(c[0]), pd=dev(r[0, :, 0]))
+    assert rel(out, ref[0]) < TOL
+    g = torch.randn_like(ref)
+    (gc,) = torch.autograd.grad(ref, c, g)
+    _, gc_h, _ = ops.p2g_bwd(dev(p[0]), cfg, dev(g[0]), attr=dev(c[0]), pd=dev(r[0, :, 0]), need_p=False,
+                             need_attr=True)
+    assert rel(gc_h, gc[0]) < TOL
+
+
+def test_p2g_wavg_3d(ops):
+    rng = np.random.RandomState(14)
+    N = 600
+    p = torch.tensor(rng.uniform(-0.02, 1.02, (1, N, 3)), dtype=torch.float32).requires_grad_()
+    x = torch.tensor(rng.uniform(0, 1, (1, N, 1)), dtype=torch.float32).requires_grad_()
+    res, dom = [10, 12, 8], [10., 12., 8.]
+    ref = O.p2g_wavg(p, x, dom, res, 0.5, 1, is_2d=False, clip=False, support=4)
+    cfg = ops.make_splat_cfg(3, res, dom, 0.5, 4, 1000., 1, False, 2)
+    xs, ws = ops.p2g_fwd(dev(p[0]), cfg, attr=dev(x[0]))
+    out = ops.p2g_wavg_finish(xs, ws)
+    assert rel(out, ref[0]) < TOL
+    g = torch.randn_like(ref)
+    gp, gx = torch.autograd.grad(ref, (p, x), g)
+    g_xs, g_ws = ops.p2g_wavg_finish_bwd(xs, ws, dev(g[0]))
+    gp_h, gx_h, _ = ops.p2g_bwd(dev(p[0]), cfg, g_xs, attr=dev(x[0]), g_wsum=g_ws, need_p=True, need_attr=True)
+    assert rel(gx_h, gx[0]) < TOL
+    assert rel(gp_h, gp[0]) < 5e-4
+
+
+def test_error_channel(ops):
+    from neural_flow_style_amd import _lib
+    with pytest.raises(RuntimeError, match="null pointer"):
+        _lib.call("nfs_render_fwd", None, None, None, 1, 1, 1, 1, 0.1, 0, None)
+    with pytest.raises(ValueError):
+        ops.render_fwd(torch.zeros(1, 2, 2, 2), 0.1)  # CPU tensor: no fallback
