@@ -103,10 +103,25 @@ def lib():
     return _lib
 
 
+# Optional live profiling (used by bench.py): when PROFILE is a dict, every call is bracketed by
+# two events recorded on the SAME stream the kernel is enqueued on; entries are
+# name -> [(start_event, end_event, args)].  Costs two event records per call, so it is off by
+# default and the headline timing in bench.py is taken with it off.
+PROFILE = None
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise with nfs_last_error() on failure."""
     L = lib()
-    rc = getattr(L, name)(*args)
+    if PROFILE is not None:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(*args)
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1, args))
+    else:
+        rc = getattr(L, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, L.nfs_last_error().decode()))
     return rc

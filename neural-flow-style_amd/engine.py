@@ -1,0 +1,187 @@
+"""The stylisation step: density volume -> (rotate+)render -> loss net -> Gram style
+loss, and the whole adjoint chain back to the volume, on the HIP kernels.
+
+This is the body of one ``sess.run(train_op)`` of the reference (styler_3p.py:147-164 +
+styler_base.py:33-57,127-231) with views batched: all V local views go through the
+renderer and VGG as one batch, the field gradient accumulates over views in one buffer.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class RenderStyleLoss(object):
+    """loss(d) = w_style * sum_v sum_l w_l * || G_l(vgg(render(rotate(d, R_v)))) - G_l^style ||^2
+    (+ w_tv * TV).  ``loss_and_grad`` returns the per-view losses and ADDS dL/dd to ``g_d``."""
+
+    def __init__(self, net, style_layer, w_style_layer, w_style=1.0, transmit=0.01, render_liquid=False,
+                 resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1):
+        self.net = net
+        self.layers = list(style_layer)
+        self.w_layers = [float(w) for w in w_style_layer]
+        assert len(self.layers) == len(self.w_layers)
+        self.w_style = float(w_style)
+        self.tau = float(transmit)
+        self.liquid = bool(render_liquid)
+        self.resize_scale = float(resize_scale)
+        self.rotate = bool(rotate)
+        self.w_tv = float(w_tv)
+        self.v_batch = int(v_batch)
+        order = [s[0] for s in net.seq]
+        self.top = max(self.layers, key=order.index)
+        self.style_grams = None
+
+    # -- style targets (styler_base.py:249-278: the style image enters at d_img) -------------
+    def out_hw(self, H, W):
+        if np.isclose(self.resize_scale, 1):
+            return H, W
+        # int(float32(scale) * float32(dim)) as the TF graph computes it (styler_base.py:36-37)
+        return int(np.float32(self.resize_scale) * np.float32(H)), int(np.float32(self.resize_scale) * np.float32(W))
+
+    def set_style_image(self, style_img):
+        """style_img: float32 [h,w,3] in 0..255 already at the loss-net input size"""
+        dev = self.net.device
+        s = torch.as_tensor(np.asarray(style_img, np.float32)).to(dev)
+        mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255], dtype=torch.float32, device=dev)
+        x = (s - mean).unsqueeze(0).contiguous()
+        acts = self.net.forward(x, self.top)
+        self.style_grams = {}
+        for name in self.layers:
+            F = acts[name]
+            _, h, w, c = F.shape
+            self.style_grams[name] = ops.gram_fwd(F, 1.0 / (2.0 * h * w * c))
+        return self.style_grams
+
+    # -- forward only (rendered image, used for the final inference) ------------------------
+    def render(self, d, rot):
+        if self.rotate:
+            img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.liquid)
+        else:
+            img, rs = ops.render_fwd(d.unsqueeze(0), self.tau, self.liquid)
+        gmax = None
+        V = img.shape[0]
+        if self.liquid:
+            norm = img
+        else:
+            norm, gmax = ops.maxnorm_fwd(img, max(V // self.v_batch, 1))
+        return img, rs, norm, gmax
+
+    def d_img(self, d, rot):
+        """the 0..255 3-channel image the loss net sees (``self.d_img`` of the reference)"""
+        _, _, norm, _ = self.render(d, rot)
+        V, H, W = norm.shape
+        H2, W2 = self.out_hw(H, W)
+        dimg, _ = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_x=False)
+        return dimg
+
+    # -- the hot step -----------------------------------------------------------------------
+    def loss_and_grad(self, d, rot, g_d):
+        """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
+        Returns loss per view [V] (device tensor)."""
+        assert self.style_grams is not None, "call set_style_image first"
+        D, H, W = d.shape
+        img, rs, norm, gmax = self.render(d, rot)
+        V = img.shape[0]
+        H2, W2 = self.out_hw(H, W)
+        dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0)
+        acts = self.net.forward(x, self.top)
+        loss = torch.zeros(V, dtype=torch.float32, device=d.device)
+        sg = {}
+        for name, wl in zip(self.layers, self.w_layers):
+            F = acts[name]
+            _, h, w, c = F.shape
+            scale = 1.0 / (2.0 * h * w * c)
+            G = ops.gram_fwd(F, scale)
+            Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
+            sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        g_x = self.net.backward(acts, sg, self.top)
+        if self.w_tv > 0:
+            tv = torch.zeros(1, dtype=torch.float32, device=d.device)
+            ops.tv_loss(dimg, self.w_tv, tv, g_x)
+            loss = loss + tv / V
+        g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
+        g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
+        if self.rotate:
+            ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
+        else:
+            g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.liquid)[0])
+        return loss
+
+
+class TFAdamState(object):
+    """tf.compat.v1.train.AdamOptimizer state (m, v, beta powers) living on the device; one
+    instance per ``opt_id`` (styler_3p.py:315-323), persisting across frames/views/octaves."""
+
+    def __init__(self, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.b1, self.b2, self.eps = np.float32(beta1), np.float32(beta2), np.float32(eps)
+        self.b1p, self.b2p = np.float32(1.0), np.float32(1.0)
+        self.m = None
+        self.v = None
+
+    def step(self, x, g, lr):
+        if self.m is None or self.m.shape != x.shape:
+            self.m = torch.zeros_like(x)
+            self.v = torch.zeros_like(x)
+        # beta powers are float32 variables multiplied once per step in TF
+        self.b1p = np.float32(self.b1p * self.b1)
+        self.b2p = np.float32(self.b2p * self.b2)
+        lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
+        ops.adam_tf_step(x, self.m, self.v, g, float(lr_t), float(self.b1), float(self.b2), float(self.eps))
+
+
+class GridStylizer(object):
+    """TNST-style grid path assembled from the reference's operators:
+        d^ = advect(d0, vel)  ->  smooth+max  ->  RenderStyleLoss
+    with the velocity field ``vel`` [D,H,W,3] (target 'v') or the density itself (target 'd')
+    as the Adam variable.  Views shard over ranks (``views=sum``): each rank evaluates its slice
+    of the rotation matrices, the field gradient is all-reduced (sum) and every rank applies the
+    identical Adam step."""
+
+    def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None):
+        self.loss = loss
+        self.d0 = d0.contiguous()
+        self.k = float(k)
+        self.target = target
+        self.lr = float(lr)
+        self.pg = process_group
+        self.adam = TFAdamState()
+        D, H, W = d0.shape
+        if target == "v":
+            self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
+        else:
+            self.var = d0.clone()
+        self.g_ds = torch.zeros_like(d0)
+
+    def forward_field(self):
+        if self.target == "v":
+            self.d_adv = ops.advect_fwd(self.d0.unsqueeze(-1), self.var).squeeze(-1)
+        else:
+            self.d_adv = self.var
+        self.d_s = ops.smooth3d_relu_fwd(self.d_adv, self.k)
+        return self.d_s
+
+    def gradient(self, rot_local):
+        """one forward+backward over the local views; returns (loss_per_view, grad wrt variable)"""
+        d_s = self.forward_field()
+        self.g_ds.zero_()
+        losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds)
+        g_adv = ops.smooth3d_relu_bwd(d_s, self.g_ds, self.k)
+        if self.target == "v":
+            _, g_var = ops.advect_bwd(self.d0.unsqueeze(-1), self.var, g_adv.unsqueeze(-1), need_d=False,
+                                      need_vel=True)
+        else:
+            g_var = g_adv
+        return losses, g_var
+
+    def step(self, rot_local):
+        losses, g = self.gradient(rot_local)
+        total = losses.sum()
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.pg)
+        self.adam.step(self.var, g, self.lr)
+        return total

@@ -1,0 +1,151 @@
+"""VGG-19 loss network (slim variant with average pooling) -- host-side mirror of the
+reference's ``vgg.py`` (vgg.py:44-120) driving the HIP conv / pool kernels.
+
+Weights are frozen.  They come from (a) an ``.npz`` converted offline from
+``vgg_19_2016_08_28`` (keys ``conv{b}_{i}/weights`` HWIO and ``conv{b}_{i}/biases``) or
+(b) a seeded synthetic He-normal initialisation (the checkpoint is not shipped with the
+reference and there is no network here).
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+# vgg.py:18-20 -- mean only (std is commented out in the reference), RGB order
+_R_MEAN = 0.485 * 255
+_G_MEAN = 0.456 * 255
+_B_MEAN = 0.406 * 255
+
+VGG19_BLOCKS = (("conv1", 2, 64), ("conv2", 2, 128), ("conv3", 4, 256), ("conv4", 4, 512), ("conv5", 4, 512))
+VGG16_BLOCKS = (("conv1", 2, 64), ("conv2", 2, 128), ("conv3", 3, 256), ("conv4", 3, 512), ("conv5", 3, 512))
+
+
+def layer_sequence(blocks=VGG19_BLOCKS):
+    """[('conv1_1', 'conv', 3, 64), ..., ('pool1', 'pool', 64, 64), ...] in network order"""
+    seq, cin = [], 3
+    for blk, reps, cout in blocks:
+        for i in range(reps):
+            seq.append(("%s_%d" % (blk, i + 1), "conv", cin, cout))
+            cin = cout
+        seq.append(("pool" + blk[-1], "pool", cout, cout))
+    return seq
+
+
+def synthetic_weights(seed=123, blocks=VGG19_BLOCKS, upto=None):
+    """w ~ N(0, 2/(9 Cin)) HWIO, b ~ 0.01 N(0,1), drawn layer by layer from RandomState(seed)."""
+    rng = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, kind, cin, cout in layer_sequence(blocks):
+        if kind != "conv":
+            continue
+        w = rng.randn(3, 3, cin, cout) * math.sqrt(2.0 / (9 * cin))
+        b = rng.randn(cout) * 0.01
+        out[name] = (w.astype(np.float32), b.astype(np.float32))
+        if name == upto:
+            break
+    return out
+
+
+def load_npz_weights(path, blocks=VGG19_BLOCKS):
+    z = np.load(path)
+    out = OrderedDict()
+    for name, kind, cin, cout in layer_sequence(blocks):
+        if kind != "conv":
+            continue
+        for wk in ("%s/weights" % name, "vgg_19/%s/%s/weights" % (name[:5], name), name + "_w"):
+            if wk in z:
+                break
+        else:
+            break
+        bk = wk.replace("weights", "biases").replace("_w", "_b")
+        w, b = np.asarray(z[wk], np.float32), np.asarray(z[bk], np.float32)
+        assert w.shape == (3, 3, cin, cout), (name, w.shape)
+        out[name] = (w, b)
+    return out
+
+
+class VGG(object):
+    """Forward caches the post-ReLU activations (end points, vgg.py:55-66); backward is
+    data-gradient only (weights frozen)."""
+
+    def __init__(self, weights, device, blocks=VGG19_BLOCKS):
+        self.device = torch.device(device)
+        self.seq = [s for s in layer_sequence(blocks)]
+        self.params = {}
+        for name, (w, b) in weights.items():
+            wt = torch.as_tensor(w, dtype=torch.float32).to(self.device).contiguous()
+            self.params[name] = dict(
+                fwd=ops.conv3x3_pack(wt, 0), dgrad=ops.conv3x3_pack(wt, 1),
+                bias=torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous(),
+                cin=wt.shape[2], cout=wt.shape[3])
+        self.names = list(weights.keys())
+
+    def plan(self, upto):
+        idx = [i for i, s in enumerate(self.seq) if s[0] == upto]
+        if not idx:
+            raise KeyError(upto)
+        plan = self.seq[:idx[0] + 1]
+        for name, kind, _, _ in plan:
+            if kind == "conv" and name not in self.params:
+                raise KeyError("no weights for %s" % name)
+        return plan
+
+    def forward(self, x, upto):
+        """x [B,H,W,3] (mean-subtracted) -> OrderedDict name -> [B,h,w,C] post-ReLU / pooled"""
+        acts = OrderedDict()
+        cur = x
+        for name, kind, cin, cout in self.plan(upto):
+            if kind == "conv":
+                p = self.params[name]
+                cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True)
+            else:
+                cur = ops.avgpool2_fwd(cur)
+            acts[name] = cur
+        return acts
+
+    def backward(self, acts, style_grads, upto):
+        """style_grads: name -> dL/d(pre-activation contribution) already masked by (act > 0)
+        (ops.gram_bwd(relu_mask=True)).  Returns dL/dx [B,H,W,3]."""
+        plan = self.plan(upto)
+        g = style_grads[upto]           # gradient wrt the pre-activation of the top conv
+        for li in range(len(plan) - 1, -1, -1):
+            name, kind, cin, cout = plan[li]
+            below = plan[li - 1] if li > 0 else None
+            if kind == "conv":
+                p = self.params[name]
+                if below is None:
+                    return ops.conv3x3_dgrad(g, p["dgrad"], cin)
+                bname, bkind = below[0], below[1]
+                if bkind == "conv":
+                    # below is a post-ReLU conv output: fold its ReLU mask and its style gradient
+                    g = ops.conv3x3_dgrad(g, p["dgrad"], cin, x_in=acts[bname], addend=style_grads.get(bname))
+                else:
+                    g = ops.conv3x3_dgrad(g, p["dgrad"], cin)   # gradient wrt the pooled tensor
+            else:
+                bname = below[0]                                 # the conv feeding this pool
+                xb = acts[bname]
+                g = ops.avgpool2_bwd(g, xb.shape, x=xb, addend=style_grads.get(bname))
+        raise AssertionError("unreachable")
+
+
+def load_vgg(model_path, device, seed=123):
+    """Counterpart of vgg.load_vgg (vgg.py:110-120): ``model_path`` 'vgg_19.ckpt' -> looks for a
+    converted 'vgg_19.npz' next to it; falls back to the seeded synthetic weights (stated in logs)."""
+    name = os.path.basename(model_path).split(".")[0]
+    blocks = VGG16_BLOCKS if "16" in name else VGG19_BLOCKS
+    npz = os.path.splitext(model_path)[0] + ".npz"
+    if os.path.exists(npz):
+        w = load_npz_weights(npz, blocks)
+        src = npz
+    else:
+        w = synthetic_weights(seed, blocks)
+        src = "synthetic(seed=%d)" % seed
+    net = VGG(w, device, blocks)
+    net.source = src
+    return net
