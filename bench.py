@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""Headline benchmark: stylisation iterations/sec on the 200^3 smoke grid with 8 views
+(BASELINE.json metric; workload = configs[2], the configuration the metric is quoted on).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one stylisation iteration: advect -> smooth/clamp -> for all 8 views: rotate+render
+-> VGG-19 conv1_1..conv5_1 -> Gram style loss -> full adjoint chain -> (all-reduce of the field
+gradient over ranks) -> TF-Adam update of the 200^3 x 3 velocity field.  The 8 views are sharded
+over the N ranks (strong scaling: total work is fixed).  Inputs are synthetic (seed 123) and
+resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  "roofline"     dominant kernel (the f32-MFMA 3x3 conv) measured live with events on the launch stream,
+  "kernels"      the same measurement for every kernel family (HBM GB/s or TFLOP/s + fraction of peak),
+  "cpu_baseline" the CPU oracle timed on this box's host cores on a bounded sample (N=1 only),
+  "parity"       gradient relative-L2 of the HIP path vs the oracle on a small case (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+STYLE_LAYERS = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=200)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=1, help="views in the bounded CPU sample")
+    return ap.parse_args()
+
+
+def build_problem(G, V, device, rank, world):
+    from neural_flow_style_amd import engine, vgg
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd import transform as T
+    rng = np.random.RandomState(123)
+    d0 = S.blob_density(G, rng)
+    vel = S.curl_velocity(G, rng, max_cells=2.0)
+    simg = S.style_image(G, G, rng)
+    mats = S.uniform_views(V)
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv5_1"), device)
+    loss = engine.RenderStyleLoss(net, STYLE_LAYERS, [1.0] * 5, 1.0, transmit=0.01)
+    loss.set_style_image(simg)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        pg = dist.group.WORLD
+    gs = engine.GridStylizer(loss, torch.tensor(d0, device=device), k=3, target="v", lr=1e-3, process_group=pg)
+    gs.var.copy_(torch.tensor(vel))
+    rot_local = T.rot_to_device(mats[rank::world], device)
+    return gs, rot_local, dict(d0=d0, vel=vel, simg=simg, mats=mats)
+
+
+# ---- algorithmic work per call ---------------------------------------
+def work_of(name, a):
+    """-> (kind, amount): kind 'B' bytes or 'F' flops, from the C-ABI call arguments"""
+    if name == "nfs_conv3x3_fwd":
+        B, H, W, Ci, Co = a[4:9]
+        return "F", 2.0 * B * H * W * 9 * Ci * Co
+    if name == "nfs_conv3x3_dgrad":
+        B, H, W, Ci, Co = a[5:10]
+        return "F", 2.0 * B * H * W * 9 * Ci * Co
+    if name == "nfs_gram_fwd":
+        B, HW, C = a[2:5]
+        return "F", 2.0 * B * HW * C * C
+    if name == "nfs_gram_bwd":
+        B, HW, C = a[3:6]
+        return "F", 2.0 * B * HW * C * C
+    if name == "nfs_rotate_render_fwd":
+        V, D, H, W = a[4:8]
+        return "B", 4.0 * V * D * H * W + 4.0 * V * H * W
+    if name == "nfs_rotate_render_bwd":
+        V, D, H, W = a[5:9]
+        return "B", 8.0 * V * D * H * W + 4.0 * V * H * W
+    if name == "nfs_advect_fwd":
+        D, H, W, C = a[3:7]
+        return "B", (8.0 * C + 12.0) * D * H * W
+    if name == "nfs_advect_bwd":
+        D, H, W, C = a[5:9]
+        return "B", ((12.0 if a[3] else 8.0) * C + 24.0) * D * H * W
+    if name in ("nfs_smooth3d_relu_fwd",):
+        D, H, W = a[2:5]
+        return "B", 8.0 * D * H * W
+    if name in ("nfs_smooth3d_relu_bwd",):
+        D, H, W = a[3:6]
+        return "B", 8.0 * D * H * W
+    if name == "nfs_adam_tf_step":
+        return "B", 28.0 * a[4]
+    return None, 0.0
+
+
+def kernel_table(profile, steps):
+    rows = []
+    for name, recs in sorted(profile.items()):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        kind, _ = work_of(name, recs[0][2])
+        amount = sum(work_of(name, r[2])[1] for r in recs)
+        row = {"kernel": name, "launches_per_step": len(recs) / steps, "ms_per_step": ms / steps,
+               "avg_launch_us": 1e3 * ms / len(recs)}
+        if kind == "B":
+            ach = amount / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+        elif kind == "F":
+            ach = amount / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def cpu_baseline(data, G, V, n_views):
+    """The oracle (CPU restatement of the reference graph; the TF-1.15 reference cannot run here)
+    timed on the host cores on a bounded sample: forward+backward of ``n_views`` of the V views at
+    the full grid size, extrapolated to one full iteration."""
+    from oracle import nfs_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    w = O.synthetic_vgg19_weights(123, upto="conv5_1")
+    sfe = O.style_target_features(torch.tensor(data["simg"])[None], w, STYLE_LAYERS, upto="conv5_1")
+    cfg = dict(k=3, transmit=0.01, style_layer=STYLE_LAYERS, w_style_layer=[1.0] * 5, w_style=1.0, upto="conv5_1")
+    d0 = torch.tensor(data["d0"])[None, ..., None]
+    vel = torch.tensor(data["vel"])[None].requires_grad_()
+    rot = torch.tensor(np.asarray(data["mats"][:n_views], np.float32))
+    t0 = time.perf_counter()
+    total, _, _ = O.grid_forward(d0, vel, rot, cfg, w, sfe)
+    (g,) = torch.autograd.grad(total, vel)
+    opt = O.TFAdam(); opt.step(vel.detach(), g, 1e-3)
+    dt = time.perf_counter() - t0
+    # prologue/epilogue (advect, smooth, their adjoints, Adam) are inside dt once; views dominate
+    est_iter = dt * V / n_views
+    return {"value": 1.0 / est_iter, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (PyTorch-CPU restatement, f32) fwd+bwd+Adam of %d of %d views at %d^3, %.1f s "
+                      "measured, scaled by %d/%d to one iteration" % (n_views, V, G, dt, V, n_views),
+            "seconds_measured": dt}
+
+
+def small_parity(device):
+    """gradient relative L2 of the HIP path vs the oracle on a 24^3, 3-view, 5-layer case"""
+    from oracle import nfs_oracle as O
+    from neural_flow_style_amd import engine, vgg
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd import transform as T
+    G, V = 24, 3
+    rng = np.random.RandomState(123)
+    d0 = S.blob_density(G, rng)
+    vel0 = (rng.randn(G, G, G, 3) * 0.3 / (G - 1)).astype(np.float32)
+    simg = S.style_image(G, G, rng)
+    mats = S.uniform_views(V)
+    w = O.synthetic_vgg19_weights(123, upto="conv5_1")
+    sfe = O.style_target_features(torch.tensor(simg)[None], w, STYLE_LAYERS, upto="conv5_1")
+    cfg = dict(k=3, transmit=0.05, style_layer=STYLE_LAYERS, w_style_layer=[1.0] * 5, w_style=1.0, upto="conv5_1")
+    v = torch.tensor(vel0)[None].requires_grad_()
+    total, _, _ = O.grid_forward(torch.tensor(d0)[None, ..., None], v, torch.tensor(np.asarray(mats, np.float32)),
+                                 cfg, w, sfe)
+    (go,) = torch.autograd.grad(total, v)
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv5_1"), device)
+    loss = engine.RenderStyleLoss(net, STYLE_LAYERS, [1.0] * 5, 1.0, transmit=0.05)
+    loss.set_style_image(simg)
+    gs = engine.GridStylizer(loss, torch.tensor(d0, device=device), k=3, target="v")
+    gs.var.copy_(torch.tensor(vel0))
+    _, gh = gs.gradient(T.rot_to_device(mats, device))
+    r = float((gh.double().cpu() - go[0].double()).norm() / go[0].double().norm())
+    return {"grad_rel_l2": r, "case": "24^3 grid, 3 views, conv1_1..conv5_1, vs CPU oracle", "tolerance": 1e-3}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert args.views % world == 0, "views must divide over ranks"
+
+    from neural_flow_style_amd import _lib
+    G, V = args.grid, args.views
+    gs, rot_local, data = build_problem(G, V, device, rank, world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gs.step(rot_local)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = gs.step(rot_local)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = {
+        "metric": "stylization iters/sec on 200^3 smoke grid, 8 views",
+        "value": args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "smokegun %d^3 single-frame, %d rotated views, VGG-19 conv1_1..conv5_1 Gram style "
+                               "loss, grid velocity variable through advect + TF-Adam (BASELINE configs[2])" % (G, V),
+                   "grid": G, "views": V, "views_per_rank": V // world, "image": [G, G],
+                   "style_layers": STYLE_LAYERS, "vgg_weights": "synthetic He-normal seed 123 (no checkpoint offline)",
+                   "parallelism": "views sharded over %d rank(s), all-reduce(sum) of the %d MB field gradient"
+                                  % (world, 4 * 3 * G ** 3 // 2 ** 20)},
+        "final_loss": float(last),
+    }
+
+    # ---- per-kernel live measurement (extra profiled steps, after the headline timing) -----------
+    if not args.no_kernel_profile:
+        psteps = max(2, min(args.steps, 5))
+        _lib.PROFILE = {}
+        for _ in range(psteps):
+            gs.step(rot_local)
+        torch.cuda.synchronize()
+        prof, _lib.PROFILE = _lib.PROFILE, None
+        rows = kernel_table(prof, psteps)
+        conv = [r for r in rows if r["kernel"] in ("nfs_conv3x3_fwd", "nfs_conv3x3_dgrad")]
+        ms = sum(r["ms_per_step"] for r in conv)
+        fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)  # TF/s * ms
+        n_launch = sum(r["launches_per_step"] for r in conv)
+        out["roofline"] = {"kernel": "conv3x3_mfma_kernel (fwd+dgrad, %d launches/step)" % n_launch,
+                           "bound": "mfma", "achieved": fl / ms, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": fl / ms / MFMA_F32_PEAK_TF, "traffic": None,
+                           "avg_launch_us": 1e3 * ms / n_launch, "ms_per_step": ms}
+        out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+
+    if rank == 0 and world == 1:
+        try:
+            out["parity"] = small_parity(device)
+        except Exception as e:  # pragma: no cover
+            out["parity"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, G, V, args.cpu_views)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
