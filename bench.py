@@ -88,8 +88,15 @@ def work_of(name, a):
         B, HW, C = a[3:6]
         return "F", 2.0 * B * HW * C * C
     if name == "nfs_rotate_render_fwd":
+        V, D, H, W = a[5:9]
+        # read d once per view + write img; + write of the kept rotated volume when requested
+        return "B", (8.0 if a[4] else 4.0) * V * D * H * W + 4.0 * V * H * W
+    if name == "nfs_render_bwd":
         V, D, H, W = a[4:8]
-        return "B", 4.0 * V * D * H * W + 4.0 * V * H * W
+        return "B", 8.0 * V * D * H * W + 4.0 * V * H * W
+    if name == "nfs_rotate_bwd":
+        V, D, H, W, C = a[3:8]
+        return "B", 4.0 * V * D * H * W * C + 8.0 * D * H * W * C
     if name == "nfs_rotate_render_bwd":
         V, D, H, W = a[5:9]
         return "B", 8.0 * V * D * H * W + 4.0 * V * H * W

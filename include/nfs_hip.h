@@ -52,11 +52,14 @@ int nfs_warp3d_bwd(const float* imgs, const float* coords, const float* g_out,
 /* ---- A3: rotate (transform.py:611-628) ----------------------------------------------
  * d [D,H,W,C] (one volume, tiled V times by the reference), rot [V,9] row-major 3x3
  * acting on (D,H,W)-ordered normalised coords, out [V,D,H,W,C].  Coordinates are
- * computed in-register (no mgrid tensor).  bwd: g_d [D,H,W,C] += over all views. */
+ * computed in-register (no mgrid tensor).  bwd: g_d [D,H,W,C] += over all views.
+ * `workspace` (device, >= 64 bytes, nullable): with C == 1 and a workspace the adjoint runs
+ * output-stationary (a block owns a tile of g_d, accumulates in 64-bit fixed point in LDS, no
+ * global atomics, bit-reproducible); otherwise it scatters with global float atomics. */
 int nfs_rotate_fwd(const float* d, const float* rot, float* out,
                    int V, int D, int H, int W, int C, nfs_stream_t stream);
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc,
-                   int V, int D, int H, int W, int C, nfs_stream_t stream);
+                   int V, int D, int H, int W, int C, float* workspace, nfs_stream_t stream);
 
 /* ---- A11: advect, order 1 (transform.py:557-569) ------------------------------------
  * d [D,H,W,C], vel [D,H,W,3] normalised units (component k moves along array axis k),
@@ -87,9 +90,12 @@ int nfs_render_fwd(const float* d, float* img, float* raysum,
 int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d,
                    int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
 
-/* fused A3+A4: never materialises the [V,D,H,W] rotated volume.  d [D,H,W], rot [V,9].
- * bwd: g_d_acc [D,H,W] += over all views and samples (float atomics). */
-int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* raysum,
+/* fused A3+A4: d [D,H,W], rot [V,9] -> img/raysum [V,H,W] in one pass over the rays.  d_rot
+ * (nullable, [V,D,H,W]) receives the rotated samples so that the adjoint can run as
+ * nfs_render_bwd(d_rot) + nfs_rotate_bwd (LDS-tiled, no global atomics); with d_rot = NULL
+ * nothing of size [V,D,H,W] is materialised and the adjoint is nfs_rotate_render_bwd
+ * (g_d_acc [D,H,W] += over all views and samples with global float atomics). */
+int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* raysum, float* d_rot,
                           int V, int D, int H, int W, float tau, int liquid,
                           nfs_stream_t stream);
 int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,

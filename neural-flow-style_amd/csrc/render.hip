@@ -32,9 +32,10 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(const float* __restrict
 }
 
 // dI/dd[k] = T[k] - tau * sum_{z<=k} d[z] T[z]; liquid: tau * exp(-tau * sum)
-__global__ void __launch_bounds__(256) render_bwd_kernel(const float* __restrict__ d,
+// g_d may alias d (in-place): every thread reads d[z] of its own column before writing g_d[z].
+__global__ void __launch_bounds__(256) render_bwd_kernel(const float* d,
                                                          const float* __restrict__ raysum,
-                                                         const float* __restrict__ g_img, float* __restrict__ g_d,
+                                                         const float* __restrict__ g_img, float* g_d,
                                                          int V, int D, int HW, float tau, int liquid) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)V * HW) return;
@@ -83,7 +84,8 @@ __device__ __forceinline__ float tri_sample1(const float* __restrict__ vol, cons
 __global__ void __launch_bounds__(256) rotate_render_fwd_kernel(const float* __restrict__ d,
                                                                 const float* __restrict__ rot,
                                                                 float* __restrict__ img, float* __restrict__ raysum,
-                                                                int V, int D, int H, int W, float tau, int liquid) {
+                                                                float* __restrict__ d_rot, int V, int D, int H,
+                                                                int W, float tau, int liquid) {
   const int HW = H * W;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)V * HW) return;
@@ -100,6 +102,7 @@ __global__ void __launch_bounds__(256) rotate_render_fwd_kernel(const float* __r
     Tri t; Axis ax, ay, az;
     tri_setup(cx, cy, cz, D, H, W, t, ax, ay, az);
     const float s = tri_sample1(d, t);
+    if (d_rot) d_rot[((int64_t)v * D + z) * HW + px] = s;  // rotated volume kept for the adjoint
     acc += s;
     I += s * expf(-acc * tau);
   }
@@ -216,13 +219,13 @@ int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, floa
   return check_launch("nfs_render_bwd");
 }
 
-int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* raysum, int V, int D, int H, int W,
-                          float tau, int liquid, nfs_stream_t stream) {
+int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* raysum, float* d_rot, int V, int D,
+                          int H, int W, float tau, int liquid, nfs_stream_t stream) {
   NFS_REQUIRE(d && rot && img, "nfs_rotate_render_fwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_rotate_render_fwd: non-positive dimension");
   const int64_t n = (int64_t)V * H * W;
   hipLaunchKernelGGL(rotate_render_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, rot, img,
-                     raysum, V, D, H, W, tau, liquid);
+                     raysum, d_rot, V, D, H, W, tau, liquid);
   return check_launch("nfs_rotate_render_fwd");
 }
 

@@ -96,15 +96,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
   const int nchunks = a.Kc / KC;
   const int niter = nchunks * 9;
   constexpr int WREG = BN / 32;  // float4 per thread per weight slab
-  float4 wreg[WREG];
-  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
-  auto load_w = [&](int it) {
-    // slab (chunk, tap) = it ; rows n0..n0+BN of [Nc][32]
-    const int64_t base4 = ((int64_t)it * a.Nc + n0) * (KC / 4);
-#pragma unroll
-    for (int r = 0; r < WREG; ++r) wreg[r] = wp4[base4 + t + 256 * r];
-  };
-  load_w(0);
+  // slab (chunk, tap) = it: rows n0..n0+BN of [Nc][32]; thread t owns float4 #(t + 256 r).
+  // Named registers (not an array): an indexed private array here ends up in scratch memory.
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp) + (int64_t)n0 * (KC / 4) + t;
+  const int64_t slab4 = (int64_t)a.Nc * (KC / 4);
+  float4 w0 = wp4[0], w1 = wp4[256], w2, w3;
+  if (WREG > 2) { w2 = wp4[512]; w3 = wp4[768]; }
 
   for (int it = 0; it < niter; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
@@ -121,13 +118,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
       }
     }
     float* wcur = wl + (it & 1) * BN * LDS_STRIDE;
-#pragma unroll
-    for (int r = 0; r < WREG; ++r) {
-      const int f = t + 256 * r;
-      *reinterpret_cast<float4*>(wcur + (f >> 3) * LDS_STRIDE + 4 * (f & 7)) = wreg[r];
+    {
+      float* wdst = wcur + (t >> 3) * LDS_STRIDE + 4 * (t & 7);   // f = t + 256 r -> row (f>>3) = (t>>3) + 32 r
+      *reinterpret_cast<float4*>(wdst) = w0;
+      *reinterpret_cast<float4*>(wdst + 32 * LDS_STRIDE) = w1;
+      if (WREG > 2) {
+        *reinterpret_cast<float4*>(wdst + 64 * LDS_STRIDE) = w2;
+        *reinterpret_cast<float4*>(wdst + 96 * LDS_STRIDE) = w3;
+      }
     }
     __syncthreads();
-    if (it + 1 < niter) load_w(it + 1);
+    if (it + 1 < niter) {
+      const float4* wn = wp4 + (int64_t)(it + 1) * slab4;
+      w0 = wn[0]; w1 = wn[256];
+      if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
+    }
 
     const int dy = tap / 3, dx = tap - dy * 3;
     const int tapoff = (dy * PW + dx) * LDS_STRIDE;
@@ -135,21 +140,24 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
     const bool z1 = (dy == 0 && !up_ok[1]) || (dy == 2 && !dn_ok[1]);
 #pragma unroll
     for (int c = 0; c < KC / 8; ++c) {
-      float4 av[2], bv[NT];
-      av[0] = *reinterpret_cast<const float4*>(patch + abase[0] + tapoff + 8 * c);
-      av[1] = *reinterpret_cast<const float4*>(patch + abase[1] + tapoff + 8 * c);
-      if (z0) av[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (z1) av[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 a0 = *reinterpret_cast<const float4*>(patch + abase[0] + tapoff + 8 * c);
+      float4 a1 = *reinterpret_cast<const float4*>(patch + abase[1] + tapoff + 8 * c);
+      if (z0) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z1) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float af0[4] = {a0.x, a0.y, a0.z, a0.w};
+      const float af1[4] = {a1.x, a1.y, a1.z, a1.w};
+      float bf[NT][4];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(wcur + bbase[nt] + 8 * c);
-      const float* ap0 = &av[0].x; const float* ap1 = &av[1].x;
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 bq = *reinterpret_cast<const float4*>(wcur + bbase[nt] + 8 * c);
+        bf[nt][0] = bq.x; bf[nt][1] = bq.y; bf[nt][2] = bq.z; bf[nt][3] = bq.w;
+      }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const float b = (&bv[nt].x)[jj];
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap0[jj], b, acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap1[jj], b, acc[1][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[jj], bf[nt][jj], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[jj], bf[nt][jj], acc[1][nt], 0, 0, 0);
         }
       }
     }

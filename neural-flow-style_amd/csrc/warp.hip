@@ -4,6 +4,7 @@
 // reference materialises 3 coordinate volumes + 8 index/weight/gather tensors).
 // HBM-bound: algorithmic bytes = read volume once + write output once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace nfs {
 
@@ -124,6 +125,196 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
   }
 }
 
+
+// ---- output-stationary adjoint of rotate for C = 1 -------------------------------------------
+// Global float atomics cap the scatter at ~90 G atomics/s (5.6 ms for 8 views of 200^3).  Here a
+// block OWNS a TZ x TY x TX tile of g_d in LDS.  For every view it inverse-maps the tile's
+// catchment box (tile +-1 cell; open-ended on volume faces, because out-of-range samples clamp
+// onto them) through the affine sample map x = A o + c and visits every sample of g_out inside the
+// integer bounding box (x fastest => coalesced reads), recomputes the forward stencil and
+// accumulates the corners that fall inside the tile with LDS atomics.  Measured on gfx950
+// (tools/lds_atomic_bench.hip): ds_add_f32 sustains only 0.33 lanes/clk/CU while ds_add_u64 runs
+// at 9.4 -- so the tile accumulates in 64-bit FIXED POINT: contributions are scaled by 2^k, with k
+// chosen from max|g_out| (a streaming pre-pass) so that no voxel sum can overflow; with ~49 bits
+// below the largest value this is more accurate than f32 accumulation and, integer adds being
+// associative, bit-reproducible.  Four samples per thread are in flight (loads issued before any
+// use).  One plain read-modify-write of g_d per tile at the end: no global atomics.
+constexpr int RT_Z = 16, RT_Y = 16, RT_X = 32;
+constexpr int RT_THREADS = 1024;
+constexpr int RT_VMAX = 32;  // views per launch (host loops over chunks)
+constexpr int RT_UNROLL = 4;
+
+struct ViewBox {           // per (block, view), in LDS
+  int lo[3], ext[3];       // sample bounding box (z,y,x) and extents
+  unsigned mx, my;         // magic reciprocals ceil(2^32/ext) for x and y
+};
+
+// max |x| over n floats -> *out (as float bits; non-negative floats order like unsigned ints)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    } else {
+      for (int64_t j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+    }
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
+}
+
+__global__ void __launch_bounds__(RT_THREADS) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,
+                                                                      const float* __restrict__ rot,
+                                                                      float* __restrict__ g_d,
+                                                                      const unsigned* __restrict__ gmax_bits,
+                                                                      float bound_factor, int V, int D, int H,
+                                                                      int W, int tiles_y, int tiles_x) {
+  __shared__ unsigned long long acc[RT_Z * RT_Y * RT_X];
+  __shared__ ViewBox vbox[RT_VMAX];
+  const int t = threadIdx.x;
+  const int bx = blockIdx.x % tiles_x;
+  const int by = (blockIdx.x / tiles_x) % tiles_y;
+  const int bz = blockIdx.x / (tiles_x * tiles_y);
+  const int z0 = bz * RT_Z, y0 = by * RT_Y, x0 = bx * RT_X;
+  const int z1 = min(z0 + RT_Z, D) - 1, y1 = min(y0 + RT_Y, H) - 1, x1 = min(x0 + RT_X, W) - 1;  // inclusive
+  for (int i = t; i < RT_Z * RT_Y * RT_X; i += RT_THREADS) acc[i] = 0ull;
+  // fixed-point scale 2^k: |any voxel sum| <= bound_factor * max|g_out| must stay below 2^62
+  const float gmax = __uint_as_float(*gmax_bits);
+  if (!(gmax > 0.f)) return;                      // all-zero (or NaN-free empty) gradient: nothing to add
+  int ebound;
+  frexpf(gmax * bound_factor, &ebound);           // gmax*bound_factor < 2^ebound
+  const int kexp = 62 - ebound;
+  const float fscale = ldexpf(1.f, min(max(kexp, -120), 120));
+  const float fscale2 = ldexpf(1.f, kexp - min(max(kexp, -120), 120));  // split: 2^k may exceed the float range
+
+  if (t < V) {
+    const float* r = rot + t * 9;
+    const int n[3] = {D, H, W};
+    const int tlo[3] = {z0, y0, x0}, thi[3] = {z1, y1, x1};
+    double A[3][3], c[3], big[3];
+    for (int a = 0; a < 3; ++a) {
+      const double ha = 0.5 * (n[a] - 1);
+      double rs = 0.0;
+      big[a] = 4.0;
+      for (int b = 0; b < 3; ++b) {
+        const double sb = n[b] > 1 ? 2.0 / (n[b] - 1) : 0.0;
+        A[a][b] = (double)r[a * 3 + b] * sb * ha;
+        rs += (double)r[a * 3 + b];
+        big[a] += fabs(A[a][b]) * (n[b] - 1);
+      }
+      c[a] = (1.0 - rs) * ha;
+      big[a] += fabs(c[a]);
+    }
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) -
+                       A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    int lo[3] = {0, 0, 0}, hi[3] = {D - 1, H - 1, W - 1};
+    if (fabs(det) > 1e-9) {
+      double inv[3][3];
+      inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
+      inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+      inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+      inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+      inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+      inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+      inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
+      inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+      inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+      // box centre / half widths in x-space -> centre / half extents in sample space
+      double oc[3] = {0, 0, 0}, oe[3] = {0, 0, 0};
+      for (int a = 0; a < 3; ++a) {
+        const double xl = (tlo[a] == 0) ? -big[a] : tlo[a] - 1.02;
+        const double xh = (thi[a] == n[a] - 1) ? big[a] : thi[a] + 1.02;
+        const double mid = 0.5 * (xl + xh) - c[a], half = 0.5 * (xh - xl);
+        for (int b = 0; b < 3; ++b) {
+          oc[b] += inv[b][a] * mid;
+          oe[b] += fabs(inv[b][a]) * half;
+        }
+      }
+      for (int b = 0; b < 3; ++b) {
+        lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]) - 1.0, 0.0), (double)n[b]);
+        hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]) + 1.0, (double)(n[b] - 1)), -1.0);
+      }
+    }
+    ViewBox vb;
+    for (int b = 0; b < 3; ++b) { vb.lo[b] = lo[b]; vb.ext[b] = max(hi[b] - lo[b] + 1, 0); }
+    vb.mx = vb.ext[2] > 1 ? (unsigned)(((1ull << 32) + vb.ext[2] - 1) / vb.ext[2]) : 0u;
+    vb.my = vb.ext[1] > 1 ? (unsigned)(((1ull << 32) + vb.ext[1] - 1) / vb.ext[1]) : 0u;
+    vbox[t] = vb;
+  }
+  __syncthreads();
+
+  for (int v = 0; v < V; ++v) {
+    const int lz = vbox[v].lo[0], ly = vbox[v].lo[1], lx = vbox[v].lo[2];
+    const int ey = vbox[v].ext[1], ex = vbox[v].ext[2];
+    const unsigned mx = vbox[v].mx, my = vbox[v].my;
+    const int total = vbox[v].ext[0] * ey * ex;
+    if (total <= 0) continue;
+    const float* r = rot + v * 9;
+    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+    const float* gv = g_out + (int64_t)v * D * H * W;
+    for (int base = t; base < total; base += RT_THREADS * RT_UNROLL) {
+      float gval[RT_UNROLL];
+      int oz[RT_UNROLL], oy[RT_UNROLL], ox[RT_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RT_UNROLL; ++u) {
+        const int i = base + u * RT_THREADS;
+        // i = (z*ey + y)*ex + x ; exact magic division (i < 2^22, ext < 2^11)
+        const int rowi = ex > 1 ? (int)__umulhi((unsigned)i, mx) : i;
+        ox[u] = i - rowi * ex;
+        const int zi = ey > 1 ? (int)__umulhi((unsigned)rowi, my) : rowi;
+        oy[u] = rowi - zi * ey;
+        oz[u] = zi;
+        gval[u] = 0.f;
+        if (i < total) gval[u] = gv[((int64_t)(lz + oz[u]) * H + (ly + oy[u])) * W + (lx + ox[u])];
+      }
+#pragma unroll
+      for (int u = 0; u < RT_UNROLL; ++u) {
+        const float g = gval[u];
+        if (g == 0.f) continue;
+        const float gz_ = lin_coord(lz + oz[u], D), gy_ = lin_coord(ly + oy[u], H), gx_ = lin_coord(lx + ox[u], W);
+        const Axis az = axis_setup(r0 * gz_ + r1 * gy_ + r2 * gx_, D);
+        if (az.i1 < z0 || az.i0 > z1) continue;
+        const Axis ay = axis_setup(r3 * gz_ + r4 * gy_ + r5 * gx_, H);
+        if (ay.i1 < y0 || ay.i0 > y1) continue;
+        const Axis ax = axis_setup(r6 * gz_ + r7 * gy_ + r8 * gx_, W);
+        if (ax.i1 < x0 || ax.i0 > x1) continue;
+        const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
+        const float wz[2] = {1.f - az.w1, az.w1}, wy[2] = {1.f - ay.w1, ay.w1}, wx[2] = {1.f - ax.w1, ax.w1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if (iz[a] < z0 || iz[a] > z1) continue;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (iy[b] < y0 || iy[b] > y1) continue;
+            const float wzy = wz[a] * wy[b] * g;
+            unsigned long long* arow = &acc[((iz[a] - z0) * RT_Y + (iy[b] - y0)) * RT_X - x0];
+#pragma unroll
+            for (int cI = 0; cI < 2; ++cI) {
+              if (ix[cI] < x0 || ix[cI] > x1) continue;
+              const float contrib = wzy * wx[cI];
+              if (contrib != 0.f)
+                atomicAdd(arow + ix[cI], (unsigned long long)__float2ll_rn(contrib * fscale * fscale2));
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < RT_Z * RT_Y * RT_X; i += RT_THREADS) {
+    const int lx_ = i % RT_X, ly_ = (i / RT_X) % RT_Y, lz_ = i / (RT_X * RT_Y);
+    const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
+    if (z < D && y < H && x < W) {
+      const long long q = (long long)acc[i];
+      if (q != 0) g_d[((int64_t)z * H + y) * W + x] += (float)ldexp((double)q, -kexp);
+    }
+  }
+}
+
 static int check_dims(int B, int X, int Y, int Z, int C) {
   NFS_REQUIRE(B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0, "warp: non-positive dimension");
   NFS_REQUIRE((int64_t)B * X * Y * Z * C < (int64_t)1 << 40, "warp: tensor too large");
@@ -169,9 +360,30 @@ int nfs_rotate_fwd(const float* d, const float* rot, float* out, int V, int D, i
 }
 
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, int D, int H, int W, int C,
-                   nfs_stream_t stream) {
+                   float* workspace, nfs_stream_t stream) {
   NFS_REQUIRE(g_out && rot && g_d_acc, "nfs_rotate_bwd: null pointer");
   if (int e = check_dims(V, D, H, W, C)) return e;
+  if (C == 1 && workspace) {
+    const int tz = (D + RT_Z - 1) / RT_Z, ty = (H + RT_Y - 1) / RT_Y, tx = (W + RT_X - 1) / RT_X;
+    unsigned* gmax_bits = reinterpret_cast<unsigned*>(workspace);
+    if (hipMemsetAsync(gmax_bits, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
+      set_error("nfs_rotate_bwd: memset failed");
+      return NFS_ELAUNCH;
+    }
+    const int64_t n = (int64_t)V * D * H * W;
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g_out, n, gmax_bits);
+    // a voxel collects, per view, unit total weight from interior samples and at most ~max(D,H,W)
+    // clamped samples per face direction; 4*nmax per view is a safe bound on the summed weights
+    const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
+    const float bound_factor = 4.f * (float)nmax * (float)V + 8.f;
+    for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
+      const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
+      hipLaunchKernelGGL(rotate_bwd_tiled_kernel, dim3(tz * ty * tx), dim3(RT_THREADS), 0, as_stream(stream),
+                         g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
+                         ty, tx);
+    }
+    return check_launch("nfs_rotate_bwd(tiled)");
+  }
   WarpArgs a{nullptr, rot, V, D, H, W, C, 0};
   const int64_t n = (int64_t)V * D * H * W;
   hipLaunchKernelGGL(warp_bwd_kernel<COORD_ROTATE>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a,

@@ -30,6 +30,7 @@ class RenderStyleLoss(object):
         self.rotate = bool(rotate)
         self.w_tv = float(w_tv)
         self.v_batch = int(v_batch)
+        self.two_pass_adjoint = True   # False: single fused adjoint with global atomics (less memory)
         order = [s[0] for s in net.seq]
         self.top = max(self.layers, key=order.index)
         self.style_grams = None
@@ -56,9 +57,12 @@ class RenderStyleLoss(object):
         return self.style_grams
 
     # -- forward only (rendered image, used for the final inference) ------------------------
-    def render(self, d, rot):
+    def render(self, d, rot, keep_rotated=False):
+        self.d_rot = None
         if self.rotate:
-            img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.liquid)
+            if keep_rotated:
+                self.d_rot = torch.empty((rot.shape[0],) + tuple(d.shape), dtype=torch.float32, device=d.device)
+            img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.liquid, d_rot=self.d_rot)
         else:
             img, rs = ops.render_fwd(d.unsqueeze(0), self.tau, self.liquid)
         gmax = None
@@ -83,7 +87,7 @@ class RenderStyleLoss(object):
         Returns loss per view [V] (device tensor)."""
         assert self.style_grams is not None, "call set_style_image first"
         D, H, W = d.shape
-        img, rs, norm, gmax = self.render(d, rot)
+        img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint)
         V = img.shape[0]
         H2, W2 = self.out_hw(H, W)
         dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0)
@@ -104,7 +108,13 @@ class RenderStyleLoss(object):
             loss = loss + tv / V
         g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
         g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
-        if self.rotate:
+        if self.rotate and self.d_rot is not None:
+            # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
+            # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
+            g_rot = ops.render_bwd(self.d_rot, rs, g_img, self.tau, self.liquid, g_d=self.d_rot)
+            ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1))
+            self.d_rot = None
+        elif self.rotate:
             ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
         else:
             g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.liquid)[0])
@@ -185,3 +195,96 @@ class GridStylizer(object):
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.pg)
         self.adam.step(self.var, g, self.lr)
         return total
+
+
+# --------------------------------------------------------------------------------------
+# 2-D colour path (styler_2p.py:91-102 + styler_base.py:152-185, 211-213)
+# --------------------------------------------------------------------------------------
+
+_TF_BICUBIC_TABLE = 1024
+
+
+def _tf1_bicubic_axis(n_in, n_out, device):
+    """indices / weights of TF's legacy ResizeBicubic (A=-0.75, 1024-entry coefficient table,
+    align_corners=False, half_pixel_centers=False) -- used by style_mask (styler_base.py:166)"""
+    a = -0.75
+    t = np.arange(_TF_BICUBIC_TABLE + 1, dtype=np.float32) / np.float32(_TF_BICUBIC_TABLE)
+    c0 = ((a + 2) * t - (a + 3)) * t * t + 1
+    t1 = t + 1
+    c1 = ((a * t1 - 5 * a) * t1 + 8 * a) * t1 - 4 * a
+    src = np.arange(n_out, dtype=np.float32) * (np.float32(n_in) / np.float32(n_out))
+    loc = np.floor(src).astype(np.int64)
+    off = np.rint((src - loc) * _TF_BICUBIC_TABLE).astype(np.int64)
+    w = np.stack([c1[off], c0[off], c0[_TF_BICUBIC_TABLE - off], c1[_TF_BICUBIC_TABLE - off]], 1)
+    idx = np.clip(np.stack([loc - 1, loc, loc + 1, loc + 2], 1), 0, n_in - 1)
+    return torch.as_tensor(idx, device=device), torch.as_tensor(w.astype(np.float32), device=device)
+
+
+def tf1_resize_bicubic(x, oh, ow):
+    """x [B,H,W,C] device tensor -> [B,oh,ow,C] (differentiable torch ops; tiny tensors)"""
+    B, H, W, C = x.shape
+    iy, wy = _tf1_bicubic_axis(H, oh, x.device)
+    ix, wx = _tf1_bicubic_axis(W, ow, x.device)
+    rows = (x[:, iy] * wy.view(1, oh, 4, 1, 1)).sum(2)
+    return (rows[:, :, ix] * wx.view(1, 1, ow, 4, 1)).sum(3)
+
+
+class ImageStyleLoss(object):
+    """Style (+TV) loss of a colour image d [B,H,W,3] in [0,1] (the 2-D colour stylizer):
+    d*255 -> VGG -> Gram; with ``style_mask`` the features are multiplied by the bicubic-resized
+    density mask and the Gram denominator becomes 2*area*C (styler_base.py:165-169)."""
+
+    def __init__(self, net, style_layer, w_style_layer, w_style=1.0, w_tv=0.0, resize_scale=1.0,
+                 style_mask=False, style_mask_on_ref=False):
+        assert not style_mask_on_ref, "style_mask_on_ref is not used by any reference driver"
+        self.net = net
+        self.layers = list(style_layer)
+        self.w_layers = [float(w) for w in w_style_layer]
+        self.w_style, self.w_tv = float(w_style), float(w_tv)
+        self.resize_scale = float(resize_scale)
+        self.style_mask = bool(style_mask)
+        order = [s[0] for s in net.seq]
+        self.top = max(self.layers, key=order.index)
+        self.style_grams = None
+
+    set_style_image = RenderStyleLoss.set_style_image
+    out_hw = RenderStyleLoss.out_hw
+
+    def d_img(self, d):
+        B, H, W, _ = d.shape
+        H2, W2 = self.out_hw(H, W)
+        dimg, _ = ops.loss_net_input_fwd(d.contiguous(), H2, W2, want_x=False)
+        return dimg
+
+    def loss_and_grad(self, d, d_gray=None):
+        """d [B,H,W,3]; d_gray [B,H,W,1] (mask, constant).  Returns (loss per image [B], dL/dd)."""
+        B, H, W, _ = d.shape
+        H2, W2 = self.out_hw(H, W)
+        dimg, x = ops.loss_net_input_fwd(d.contiguous(), H2, W2, want_d_img=self.w_tv > 0)
+        acts = self.net.forward(x, self.top)
+        loss = torch.zeros(B, dtype=torch.float32, device=d.device)
+        sg = {}
+        for name, wl in zip(self.layers, self.w_layers):
+            F = acts[name]
+            _, h, w, c = F.shape
+            if self.style_mask:
+                m = tf1_resize_bicubic(d_gray, h, w)                       # [B,h,w,1]
+                Fm = (F * m).contiguous()
+                area = m[..., 0].sum(dim=(1, 2))
+                scale_dev = (1.0 / (2.0 * area * c)).contiguous()
+                G = ops.gram_fwd(Fm, 1.0, scale_dev=scale_dev)
+                Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
+                dFm = ops.gram_bwd(Fm, Dm, 1.0, scale_dev=scale_dev, relu_mask=False)
+                sg[name] = (dFm * m * (F > 0)).contiguous()
+            else:
+                scale = 1.0 / (2.0 * h * w * c)
+                G = ops.gram_fwd(F, scale)
+                Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
+                sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        g_x = self.net.backward(acts, sg, self.top)
+        if self.w_tv > 0:
+            tv = torch.zeros(1, dtype=torch.float32, device=d.device)
+            ops.tv_loss(dimg, self.w_tv, tv, g_x)
+            loss = loss + tv / B
+        g_d = ops.loss_net_input_bwd(g_x, H, W, 3)
+        return loss, g_d

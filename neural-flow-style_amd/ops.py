@@ -63,11 +63,23 @@ def rotate_fwd(d, rot):
     return out
 
 
-def rotate_bwd(g_out, rot, g_d_acc=None):
+_workspaces = {}
+
+
+def workspace(device):
+    """small per-device scratch (64 floats) for entry points that need a device-side scalar"""
+    key = (device.type, device.index)
+    if key not in _workspaces:
+        _workspaces[key] = torch.zeros(64, dtype=torch.float32, device=device)
+    return _workspaces[key]
+
+
+def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True):
     V, D, H, W, Cn = g_out.shape
     if g_d_acc is None:
         g_d_acc = _zeros((D, H, W, Cn), g_out)
-    _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _stream())
+    ws = workspace(g_out.device) if (tiled and Cn == 1) else None
+    _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _ptr(ws), _stream())
     return g_d_acc
 
 
@@ -118,24 +130,26 @@ def render_fwd(d, tau, liquid=False):
     return img, rs
 
 
-def render_bwd(d, raysum, g_img, tau, liquid=False):
+def render_bwd(d, raysum, g_img, tau, liquid=False, g_d=None):
     V, D, H, W = d.shape
-    g_d = _empty(d.shape, d)
+    if g_d is None:
+        g_d = _empty(d.shape, d)
     _lib.call("nfs_render_bwd", _ptr(d), _ptr(raysum), _ptr(g_img), _ptr(g_d), V, D, H, W, float(tau),
               int(liquid), _stream())
     return g_d
 
 
-def rotate_render_fwd(d, rot, tau, liquid=False, img=None, raysum=None):
-    """d [D,H,W], rot [V,3,3] -> (img [V,H,W], raysum [V,H,W])"""
+def rotate_render_fwd(d, rot, tau, liquid=False, img=None, raysum=None, d_rot=None):
+    """d [D,H,W], rot [V,3,3] -> (img [V,H,W], raysum [V,H,W]); d_rot [V,D,H,W] (optional) is filled
+    with the rotated samples for the two-pass adjoint"""
     D, H, W = d.shape
     V = rot.shape[0]
     if img is None:
         img = _empty((V, H, W), d)
     if raysum is None:
         raysum = _empty((V, H, W), d)
-    _lib.call("nfs_rotate_render_fwd", _ptr(d), _ptr(rot), _ptr(img), _ptr(raysum), V, D, H, W, float(tau),
-              int(liquid), _stream())
+    _lib.call("nfs_rotate_render_fwd", _ptr(d), _ptr(rot), _ptr(img), _ptr(raysum), _ptr(d_rot), V, D, H, W,
+              float(tau), int(liquid), _stream())
     return img, raysum
 
 

@@ -1,0 +1,124 @@
+"""2-D colour stylizer -- host-side mirror of the reference's ``styler_2p.Styler``
+(styler_2p.py:14-315; BASELINE config 1, dambreak2d): per-particle colour ``c`` [N,3] is the
+Adam variable, splatted to an image by the SPH colour splat ``p2g(p, pc=c, pd=r)``.
+
+Forward graph (styler_2p.py:42-102):
+  d_gray = clip(p2g(p) / rest_density, 0, 1)            (mask; independent of the variable)
+  d      = clip(p2g(p, pc=clip(c,0,1), pd=r), 0, 1)     [1,H,W,3]
+  d_img  = d * 255 -> VGG -> Gram style loss (optionally masked by d_gray) + TV
+  d_out  = d * d_gray  (the returned image)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine
+from . import transform as T
+from . import vgg as vggmod
+from .styler_base import StylerBase
+from .util import denoise
+
+
+class Styler(StylerBase):
+    def __init__(self, self_dict):
+        StylerBase.__init__(self, self_dict)
+        assert self.batch_size == 1, "batch_size > 1 is not supported (frames are optimised one at a time)"
+        w_layers = list(self.w_style_layer)
+        if len(w_layers) == 1 and len(self.style_layer) > 1:
+            w_layers = w_layers * len(self.style_layer)
+        self.loss = engine.ImageStyleLoss(self.net, self.style_layer, w_layers, self.w_style, w_tv=self.w_tv,
+                                          resize_scale=self.resize_scale, style_mask=self.style_mask,
+                                          style_mask_on_ref=self.style_mask_on_ref)
+
+    def _dev(self, a):
+        return torch.as_tensor(np.asarray(a, np.float32)).to(self.device).contiguous()
+
+    def _density(self, p, res):
+        d = T.p2g(p.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
+                  support=self.support, clip=self.clip)
+        return torch.clamp(d / self.rest_density, 0, 1)                      # [1,H,W,1]
+
+    def _colour(self, p, r, var, res):
+        c_ = torch.clamp(var.unsqueeze(0), 0, 1)
+        d = T.p2g(p.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
+                  support=self.support, clip=self.clip, pc=c_, pd=r.unsqueeze(0))
+        return torch.clamp(d, 0, 1), c_[0]                                   # [1,H,W,3]
+
+    def render_test(self, params):
+        res = list(self.resolution)
+        out = []
+        for t in range(self.num_frames):
+            p, r = self._dev(params["p"][t]), self._dev(params["r"][t])
+            with torch.no_grad():
+                d, _ = self._colour(p, r, torch.full((p.shape[0], 3), 0.5, device=self.device), res)
+                out.append((d * self._density(p, res))[0].cpu().numpy())
+        return out
+
+    def run(self, params):
+        oct_size = []
+        hw = np.array(self.resolution)
+        for _ in range(self.octave_n):
+            oct_size.append(hw)
+            hw = (hw // self.octave_scale).astype(int)
+        oct_size.reverse()
+        print("input size for each octave", oct_size)
+
+        p = [self._dev(x) for x in params["p"]]
+        r = [self._dev(x) for x in params["r"]]
+        n = p[0].shape[0]
+        # colour init: noise around the VGG mean / 255 (styler_2p.py:189-192)
+        c_opt = self.rng.uniform(-5, 5, [self.num_frames, n, 3]).astype(np.float32)
+        c_opt += np.array([vggmod._R_MEAN, vggmod._G_MEAN, vggmod._B_MEAN], np.float32)
+        c_opt /= 255
+        g_opt = [self._dev(c_opt[i]) for i in range(self.num_frames)]
+
+        loss_history, d_intm, opt_ = [], [], {}
+        for octave in range(self.octave_n):
+            loss_history_o, d_intm_o = [], []
+            res = [int(v) for v in oct_size[octave]]
+            if self.style_img is not None:
+                self.loss.set_style_image(self._style_feature(self.style_img, res))
+            lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
+            for step in range(self.iter):
+                g_tmp = [None] * self.num_frames
+                for t in range(0, self.num_frames, self.batch_size):
+                    var = g_opt[t].clone().requires_grad_(True)
+                    opt_id = t // self.frames_per_opt
+                    if opt_id not in opt_:
+                        opt_[opt_id] = engine.TFAdamState()
+                    d, _ = self._colour(p[t], r[t], var, res)
+                    with torch.no_grad():
+                        d_gray = self._density(p[t], res)
+                    losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
+                    d.backward(g_d)
+                    x = var.detach().clone()
+                    opt_[opt_id].step(x, var.grad.contiguous(), lr)
+                    loss_history_o.append(float(losses.sum()))
+                    g_tmp[t] = torch.nan_to_num(x) - g_opt[t]
+                    if step == self.iter - 1 and octave < self.octave_n - 1:
+                        with torch.no_grad():
+                            dd, _ = self._colour(p[t], r[t], x, res)
+                            d_intm_o.append(((dd * d_gray) * 255).cpu().numpy().astype(np.uint8))
+                if self.window_sigma > 0 and self.num_frames > 1:
+                    stack = denoise(np.stack([g.cpu().numpy() for g in g_tmp]), sigma=(self.window_sigma, 0, 0))
+                    g_tmp = [self._dev(s) for s in stack]
+                for t in range(self.num_frames):
+                    g_opt[t] = g_opt[t] + g_tmp[t]
+            loss_history.append(loss_history_o)
+            if octave < self.octave_n - 1:
+                d_intm.append(np.concatenate(d_intm_o, axis=0))
+
+        result = {"l": loss_history, "d_intm": d_intm}
+        res = [int(v) for v in oct_size[-1]]
+        c_sty, d_sty = [], []
+        for t in range(self.num_frames):
+            with torch.no_grad():
+                d, c_ = self._colour(p[t], r[t], g_opt[t], res)
+                d_gray = self._density(p[t], res)
+                c_sty.append((c_ * torch.clamp(r[t] / self.rest_density, 0, 1)).cpu().numpy())
+                d_sty.append(((d * d_gray)[0] * 255).cpu().numpy().astype(np.uint8))
+        result["c"] = c_sty
+        result["d"] = np.array(d_sty)
+        result["opt"] = [g.cpu().numpy() for g in g_opt]
+        return result

@@ -1,0 +1,263 @@
+"""3-D particle stylizer -- host-side mirror of the reference's ``styler_3p.Styler``
+(styler_3p.py:14-439): same constructor / ``run(params) -> dict`` surface and the same
+outer loop (octaves x iterations x frame batches x views, TF-Adam per ``opt_id``, update
+masking, temporal Gaussian smoothing of the per-particle updates, frame interpolation,
+final inference), driving the HIP kernels instead of a TF-1.15 graph.
+
+Forward graph per frame (styler_3p.py:42-164):
+  'd': r + clip(r_opt,-1,1) -> sum_k p2g_wavg(p, r_k, support / kernel_scale^k)
+  'p': p + v              -> p2g(p) / rest_density        (+ pressure loss, 96-98)
+  -> 3x3x3 smoothing conv -> max(.,0) = d_out -> [rotate] -> render -> max-normalise
+  -> x255, grey->3ch = d_img -> VGG-19 -> Gram style loss (+TV).
+The particle side runs through ``torch.autograd`` (custom Functions wrapping the splat
+kernels); the render/VGG/loss side is the explicit ``engine.RenderStyleLoss`` chain.
+
+Differences from the reference, all deliberate and documented:
+  * ``views_mode='sum'`` (build extension): one Adam step on the gradient of the summed view
+    losses; the reference-faithful default is ``'sequential'`` (one step per view-batch, iterates
+    averaged, styler_3p.py:326-352).
+  * the sqrt in the SPH kernel has zero gradient at 0 (analytic limit) instead of NaN-then-
+    ``nan_to_num`` (styler_3p.py:337,340,360).
+  * ``batch_size`` must be 1 (as every reference driver sets it): with batch_size>1 the reference
+    couples the frames of a batch through the global max of the render (styler_3p.py:158).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine, ops
+from . import transform as T
+from .styler_base import StylerBase
+from .util import denoise
+
+
+class _SmoothRelu(torch.autograd.Function):
+    """conv3d SAME with [1,k,1]^3/(k+2)^3 then tf.maximum(d,0) (styler_3p.py:112-125)"""
+
+    @staticmethod
+    def forward(ctx, d, k):
+        out = ops.smooth3d_relu_fwd(d.contiguous().reshape(d.shape[1:4]), k)
+        ctx.k = k
+        ctx.save_for_backward(out)
+        ctx.shape = d.shape
+        return out.reshape(d.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        gd = ops.smooth3d_relu_bwd(out, g.contiguous().reshape(out.shape), ctx.k)
+        return gd.reshape(ctx.shape), None
+
+
+class Styler(StylerBase):
+    def __init__(self, self_dict):
+        StylerBase.__init__(self, self_dict)
+        assert self.batch_size == 1, "batch_size > 1 is not supported (see module docstring)"
+        if self.rotate:
+            self.rot_mat_, self.views = T.rot_mat(self.phi0, self.phi1, self.phi_unit, self.theta0, self.theta1,
+                                                  self.theta_unit, sample_type=self.sample_type, rng=self.rng,
+                                                  nv=self.n_views)
+            if self.n_views is None:
+                self.n_views = len(self.views)
+            print("# vps:", self.n_views)
+            assert self.n_views % self.v_batch == 0
+        self.loss = self._make_loss(rotate=self.rotate)
+        self._identity = T.rot_to_device([np.identity(3)], self.device)
+        self.pg = None   # set by the driver for multi-GPU views=sum runs
+
+    # ---- forward graph: variable -> d_out [1,D,H,W,1] (autograd) ---------------------------------
+    def _field(self, p, r, var, res):
+        """p [N,3], r [N,nk] device tensors; var = the optimised tensor ([N,3] or [N,nk])"""
+        pressure = None
+        p_ = p.unsqueeze(0)
+        if "p" in self.target_field:
+            p_ = p_ + var.unsqueeze(0)
+        if "d" in self.target_field:
+            r_ = r.unsqueeze(0) + torch.clamp(var.unsqueeze(0), -1, 1)      # "necessary!" (styler_3p.py:74)
+            d_ = None
+            for k in range(self.num_kernels):
+                support = self.support / self.kernel_scale ** k
+                d_hat = T.p2g_wavg(p_, r_[..., k:k + 1], self.domain, res, self.radius, self.nsize, kernel="cubic",
+                                   support=support, clip=self.clip, is_2d=False)
+                d_ = d_hat if d_ is None else d_ + d_hat
+        else:
+            d_ = T.p2g(p_, self.domain, res, self.radius, self.rest_density, self.nsize, support=self.support,
+                       clip=self.clip, is_2d=False)
+            d_ = d_ / self.rest_density
+            if self.w_pressure > 0:
+                pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
+        d_out = _SmoothRelu.apply(d_, float(self.k)) if self.k > 0 else _SmoothRelu.apply(d_, 0.0)
+        return p_[0], d_out, pressure
+
+    def _value_and_grad(self, p, r, var, res, rot):
+        """loss (per view, device) and d loss / d var for one frame"""
+        v = var.detach().clone().requires_grad_(True)
+        _, d_out, pressure = self._field(p, r, v, res)
+        d3 = d_out.detach().reshape(d_out.shape[1:4]).contiguous()
+        g_d = torch.zeros_like(d3)
+        losses = self.loss.loss_and_grad(d3, rot, g_d)
+        extra = None
+        if pressure is not None:
+            extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
+            losses = losses + extra.detach() / losses.numel()
+        heads, grads = [d_out], [g_d.reshape(d_out.shape)]
+        if extra is not None:
+            heads.append(extra); grads.append(torch.ones_like(extra))
+        torch.autograd.backward(heads, grads)
+        return losses, v.grad
+
+    def _rot(self, lo, hi):
+        return T.rot_to_device(self.rot_mat_[lo:hi], self.device)
+
+    def _resample_views(self):
+        if "uniform" not in self.sample_type:
+            self.rot_mat_, self.views = T.rot_mat(self.phi0, self.phi1, self.phi_unit, self.theta0, self.theta1,
+                                                  self.theta_unit, sample_type=self.sample_type, rng=self.rng,
+                                                  nv=self.n_views)
+
+    def _dev(self, a):
+        return torch.as_tensor(np.asarray(a, np.float32)).to(self.device).contiguous()
+
+    # ---- debug helper: rendered images of the un-stylised input ------------------------------------
+    def render_test(self, params):
+        imgs = []
+        for t in range(self.num_frames):
+            p = self._dev(params["p"][t])
+            n = p.shape[0]
+            r = self._dev(params["r"][t]) if "d" in self.target_field else None
+            var = torch.zeros(n, 3 if "p" in self.target_field else self.num_kernels, device=self.device)
+            with torch.no_grad():
+                _, d_out, _ = self._field(p, r, var, list(self.resolution))
+                dimg = self.loss.d_img(d_out.reshape(d_out.shape[1:4]).contiguous(), self._identity)
+            imgs.append(dimg[0].cpu().numpy().astype(np.uint8))
+        return imgs
+
+    # ---- the optimisation loop (styler_3p.py:229-439) ----------------------------------------------
+    def run(self, params):
+        if abs(self.lr_scale - 1) > 1e-7 and not isinstance(self.lr, list):
+            self.lr = [self.lr / self.lr_scale ** i for i in range(self.octave_n)]
+
+        oct_size = []
+        dhw = np.array(self.resolution)
+        for _ in range(self.octave_n):
+            oct_size.append(dhw)
+            dhw = (dhw // self.octave_scale).astype(int)
+        oct_size.reverse()
+        print("input size for each octave", oct_size)
+
+        p = [self._dev(x) for x in params["p"]]
+        r = [self._dev(x) for x in params["r"]] if "d" in self.target_field else [None] * self.num_frames
+        nvar = 3 if "p" in self.target_field else self.num_kernels
+        g_opt = [torch.zeros(p[i].shape[0], nvar, device=self.device) for i in range(self.num_frames)]
+        mode = getattr(self, "views_mode", "sequential")
+
+        loss_history, d_intm, opt_ = [], [], {}
+        for octave in range(self.octave_n):
+            loss_history_o, d_intm_o = [], []
+            res = [int(v) for v in oct_size[octave]]
+            if self.style_img is not None:
+                self.loss.set_style_image(self._style_feature(self.style_img, res[1:]))
+            lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
+
+            for step in range(self.iter):
+                g_tmp = [None] * self.num_frames
+                for t in range(0, self.num_frames, self.batch_size * self.interp):
+                    var = g_opt[t].clone()                       # variable re-assigned from g_opt (312)
+                    opt_id = t // self.frames_per_opt
+                    if opt_id not in opt_:
+                        opt_[opt_id] = engine.TFAdamState()
+                    adam = opt_[opt_id]
+
+                    if self.rotate and mode == "sequential":
+                        acc, l_ = None, []
+                        for i in range(0, self.n_views, self.v_batch):
+                            losses, g = self._value_and_grad(p[t], r[t], var, res, self._rot(i, i + self.v_batch))
+                            adam.step(var, g.contiguous(), lr)
+                            l_.append(losses.sum())
+                            cur = torch.nan_to_num(var)
+                            acc = cur.clone() if acc is None else acc + cur
+                        loss_history_o.append(float(torch.stack(l_).mean()))
+                        self._resample_views()
+                        new = acc / (self.n_views / self.v_batch)
+                    else:
+                        if self.rotate:
+                            nvw = len(self.rot_mat_)
+                            rank, world = self._rank_world()
+                            rot = self._rot(0, nvw)[rank::world].contiguous()
+                        else:
+                            rot = self._identity
+                        losses, g = self._value_and_grad(p[t], r[t], var, res, rot)
+                        total = losses.sum()
+                        if self.pg is not None:
+                            import torch.distributed as dist
+                            g = g.contiguous()
+                            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+                            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.pg)
+                        adam.step(var, g.contiguous(), lr)
+                        loss_history_o.append(float(total))
+                        if self.rotate:
+                            self._resample_views()
+                        new = torch.nan_to_num(var)
+
+                    upd = new - g_opt[t]
+                    if "d" in self.target_field:
+                        upd = upd * r[t][..., 0:1]                  # masking by original density (361-363)
+                    g_tmp[t] = upd
+
+                    if step == self.iter - 1 and octave < self.octave_n - 1:
+                        with torch.no_grad():
+                            _, d_out, _ = self._field(p[t], r[t], var, res)
+                            dimg = self.loss_d_img(d_out)
+                        d_intm_o.append(dimg.cpu().numpy().astype(np.uint8))
+
+                idx = list(range(0, self.num_frames, self.interp))
+                if self.window_sigma > 0 and self.num_frames > 1:
+                    stack = np.stack([g_tmp[i].cpu().numpy() for i in idx])
+                    stack = denoise(stack, sigma=(self.window_sigma, 0, 0))
+                    for j, i in enumerate(idx):
+                        g_tmp[i] = self._dev(stack[j])
+                for i in idx:
+                    g_opt[i] = g_opt[i] + g_tmp[i]
+
+            loss_history.append(loss_history_o)
+            if octave < self.octave_n - 1:
+                d_intm.append(np.concatenate(d_intm_o, axis=0))
+
+        if self.interp > 1:
+            w = np.linspace(0, 1, self.interp + 1)
+            for t in range(0, self.num_frames - 1, self.interp):
+                for i in range(1, self.interp):
+                    if t + self.interp < self.num_frames:
+                        g_opt[t + i] = g_opt[t] * float(1 - w[i]) + g_opt[t + self.interp] * float(w[i])
+
+        result = {"l": loss_history, "d_intm": d_intm, "v": None, "c": None}
+        res = [int(v) for v in oct_size[-1]]
+        p_sty, v_sty, d_sty, r_sty = [], [], [], []
+        for t in range(self.num_frames):
+            with torch.no_grad():
+                p_out, d_out, _ = self._field(p[t], r[t], g_opt[t], res)
+                dimg = self.loss_d_img(d_out)
+            p_sty.append(p_out.cpu().numpy())
+            if "p" in self.target_field:
+                v_sty.append(g_opt[t].cpu().numpy())
+            d_sty.append(torch.abs(d_out[0]).cpu().numpy())      # abs(): drop the sign-bit mask of -0.0
+            r_sty.append(dimg[0].cpu().numpy().astype(np.uint8))
+        result["p"] = p_sty
+        if "p" in self.target_field:
+            result["v"] = v_sty
+        result["d"] = np.array(d_sty)
+        result["r"] = np.array(r_sty)
+        result["opt"] = [g.cpu().numpy() for g in g_opt]          # build extension: the optimised variables
+        return result
+
+    def loss_d_img(self, d_out):
+        """d_img with the identity rotation (styler_3p.py:366-369, 416-420)"""
+        d3 = d_out.reshape(d_out.shape[1:4]).contiguous()
+        return self.loss.d_img(d3, self._identity)
+
+    def _rank_world(self):
+        if self.pg is None:
+            return 0, 1
+        import torch.distributed as dist
+        return dist.get_rank(self.pg), dist.get_world_size(self.pg)

@@ -1,0 +1,105 @@
+"""Host-side mirror of the reference's ``StylerBase`` (styler_base.py:11-346).
+
+Same attribute surface: every ``config`` attribute is copied onto the object
+(styler_base.py:14-15); ``load_img(hw)`` loads / tiles / crops the style image
+(311-346); the loss terms of ``_loss`` that the BASELINE configurations use (style
+152-185, TV 211-213, pressure 228-230) are evaluated by ``engine.RenderStyleLoss`` on
+the HIP kernels.  The Inception-pb network, content / histogram / density-preservation
+losses are out of scope and raise.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import engine, ops, util
+from . import transform as T
+from . import vgg as vggmod
+from .config import complete
+
+
+class StylerBase(object):
+    def __init__(self, self_dict):
+        complete(self_dict)
+        for arg in vars(self_dict):
+            setattr(self, arg, getattr(self_dict, arg))
+        if not torch.cuda.is_available():
+            raise RuntimeError("the stylizer runs on the HIP kernels only (no CPU fallback): no GPU visible")
+        gpu = 0
+        if "LOCAL_RANK" in os.environ:
+            gpu = int(os.environ["LOCAL_RANK"])
+        elif str(getattr(self, "gpu_id", "0")).lstrip("-").isdigit() and int(self.gpu_id) >= 0:
+            gpu = int(self.gpu_id) % max(torch.cuda.device_count(), 1)
+        self.device = torch.device("cuda", gpu)
+        torch.cuda.set_device(self.device)
+        self.model_path = os.path.join(self.data_dir, self.model_dir, self.network)
+        if "vgg" not in self.model_path:
+            raise NotImplementedError(
+                "network=%r: only the VGG loss network (vgg_19.ckpt) is on the MI355X hot path; the "
+                "Inception-v1 graph (tensorflow_inception_graph.pb) is out of scope" % self.network)
+        if getattr(self, "w_content", 0) and getattr(self, "content_target", ""):
+            raise NotImplementedError("content loss is Inception-only in the reference (out of scope)")
+        if getattr(self, "w_hist", 0):
+            raise NotImplementedError("histogram loss is out of scope (SURVEY.md section 2 row 6)")
+        if getattr(self, "w_density", 0):
+            raise NotImplementedError("density-preservation loss is out of scope")
+        self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123))
+        self.content_img = None
+        self.style_img = None
+
+    # -- _plugin_to_loss_net / _loss: built once, evaluated by the engine --------------------------
+    def _make_loss(self, rotate, render_liquid=None):
+        w_layers = list(self.w_style_layer)
+        if len(w_layers) == 1 and len(self.style_layer) > 1:
+            w_layers = w_layers * len(self.style_layer)
+        return engine.RenderStyleLoss(
+            self.net, self.style_layer, w_layers, self.w_style, transmit=self.transmit,
+            render_liquid=self.render_liquid if render_liquid is None else render_liquid,
+            resize_scale=self.resize_scale, rotate=rotate, w_tv=self.w_tv, v_batch=self.v_batch)
+
+    # -- _style_feature (styler_base.py:249-278) -----------------------------------------------------
+    def _style_feature(self, style_target, style_shp=None):
+        style_target = np.array(style_target, np.float32)
+        if style_target.shape[-1] == 4:           # RGBA: premultiply by alpha (252-255)
+            m = style_target[..., -1] / 255
+            style_target = style_target[..., :-1] * np.stack([m] * 3, axis=-1)
+        if style_shp is not None:
+            if not np.isclose(self.resize_scale, 1):
+                style_shp = [int(s * self.resize_scale) for s in style_shp]
+            if tuple(style_target.shape[:2]) != tuple(int(s) for s in style_shp):
+                style_target = util.resize(style_target, style_shp, order=3)
+        return style_target
+
+    # -- load_img (styler_base.py:311-346) -----------------------------------------------------------
+    def load_img(self, hw=None):
+        from PIL import Image
+        self.content_img = None
+        self.style_img = None
+        has_style = isinstance(self.style_target, np.ndarray) or bool(self.style_target)
+        if self.w_style > 0 and has_style:
+            if isinstance(self.style_target, np.ndarray):
+                img = np.float32(self.style_target)          # build extension: in-memory style image
+            else:
+                img = np.float32(Image.open(self.style_target))
+            if img.ndim == 2:
+                img = np.stack([img] * 3, -1)
+            if self.style_tiling > 1:
+                img = np.tile(img, (self.style_tiling, self.style_tiling, 1))
+            if hw is not None:
+                img = util.crop_ratio(img, hw[1] / hw[0])
+            self.style_img = img
+
+    # -- _transport (styler_base.py:59-89): move a grid field from frame a to frame b ----------------
+    def _transport(self, g, v, a, b, recursive=True):
+        """g [D,H,W,C] device tensor, v [F,D,H,W,3] device tensor (advect units)"""
+        if a < b:
+            steps = [v[i] for i in range(a, b)] if recursive else [v[a] * (b - a)]
+        elif a > b:
+            steps = [-v[i] for i in reversed(range(b, a))] if recursive else [-v[a - 1] * (a - b)]
+        else:
+            steps = []
+        for u in steps:
+            g = ops.advect_fwd(g.contiguous(), u.contiguous())
+        return g

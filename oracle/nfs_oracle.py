@@ -644,3 +644,115 @@ def style_target_features(style_img, weights, layers, upto=None):
 def last_layer(layers):
     order = vgg19_layer_names("conv5_4")
     return max(layers, key=order.index)
+
+
+# --------------------------------------------------------------------------
+# A10  outer loops (styler_3p.py:229-439, styler_2p.py:165-315) -- CPU restatement
+# --------------------------------------------------------------------------
+
+def particle_field(p, r, var, cfg, res):
+    """styler_3p.py:42-128: variable -> d_out [1,D,H,W,1] (and the pressure field for 'p')."""
+    tf_ = cfg["target_field"]
+    p_ = p.unsqueeze(0)
+    pressure = None
+    if "p" in tf_:
+        p_ = p_ + var.unsqueeze(0)
+    if "d" in tf_:
+        r_ = r.unsqueeze(0) + torch.clamp(var.unsqueeze(0), -1, 1)
+        d_ = 0
+        for k in range(cfg["num_kernels"]):
+            support = cfg["support"] / cfg["kernel_scale"] ** k
+            d_ = d_ + p2g_wavg(p_, r_[..., k:k + 1], cfg["domain"], res, cfg["radius"], cfg["nsize"], is_2d=False,
+                               clip=cfg["clip"], support=support)
+    else:
+        d_ = p2g(p_, cfg["domain"], res, cfg["radius"], cfg["rest_density"], cfg["nsize"], is_2d=False,
+                 clip=cfg["clip"], support=cfg["support"]) / cfg["rest_density"]
+        if cfg.get("w_pressure", 0) > 0:
+            pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
+    return p_[0], smooth3d_relu(d_, cfg["k"]), pressure
+
+
+def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
+    _, d_out, pressure = particle_field(p, r, var, cfg, res)
+    total = 0
+    for v in range(rot.shape[0]):
+        dr = rotate(d_out, rot[v:v + 1]) if cfg["rotate"] else d_out
+        img = render(dr, cfg["transmit"], cfg.get("render_liquid", False))
+        d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
+        feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"]))
+        l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"])
+        if cfg.get("w_tv", 0):
+            l = l + tv_loss(d_img) * cfg["w_tv"]
+        total = total + l
+    if pressure is not None:
+        total = total + (pressure ** 2).mean() * cfg["w_pressure"]
+    return total
+
+
+def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequential"):
+    """The reference's Styler.run for one octave list / uniform views (no Poisson re-sampling):
+    returns (loss history per octave, list of optimised variables, final d_out per frame)."""
+    from scipy.ndimage import gaussian_filter
+    dt = torch.float32
+    F_ = cfg["num_frames"]
+    p = [torch.tensor(np.asarray(x), dtype=dt) for x in params["p"]]
+    r = [torch.tensor(np.asarray(x), dtype=dt) for x in params["r"]] if "d" in cfg["target_field"] else [None] * F_
+    nvar = 3 if "p" in cfg["target_field"] else cfg["num_kernels"]
+    g_opt = [torch.zeros(p[i].shape[0], nvar, dtype=dt) for i in range(F_)]
+    oct_size = []
+    dhw = np.array(cfg["resolution"])
+    for _ in range(cfg["octave_n"]):
+        oct_size.append(dhw)
+        dhw = (dhw // cfg["octave_scale"]).astype(int)
+    oct_size.reverse()
+    rot_all = torch.tensor(np.asarray(rot_mats, np.float32)) if cfg["rotate"] else torch.eye(3)[None]
+    opt_ = {}
+    hist = []
+    for octave in range(cfg["octave_n"]):
+        res = [int(v) for v in oct_size[octave]]
+        simg = torch.tensor(np.asarray(style_img[octave], np.float32))[None]
+        sfe = style_target_features(simg, weights, cfg["style_layer"])
+        h_o = []
+        for step in range(cfg["iter"]):
+            g_tmp = [None] * F_
+            for t in range(0, F_, cfg["interp"]):
+                var = g_opt[t].clone()
+                opt = opt_.setdefault(t // cfg["frames_per_opt"], TFAdam())
+
+                def grad_at(v, rot):
+                    vv = v.clone().requires_grad_()
+                    l = particle_loss(p[t], r[t], vv, cfg, res, rot, weights, sfe)
+                    (g,) = torch.autograd.grad(l, vv)
+                    return l.detach(), g
+
+                if cfg["rotate"] and views_mode == "sequential":
+                    acc, ls = None, []
+                    vb = cfg["v_batch"]
+                    for i in range(0, rot_all.shape[0], vb):
+                        l, g = grad_at(var, rot_all[i:i + vb])
+                        var = opt.step(var, g, cfg["lr"])
+                        ls.append(float(l))
+                        cur = torch.nan_to_num(var)
+                        acc = cur.clone() if acc is None else acc + cur
+                    h_o.append(float(np.mean(ls)))
+                    new = acc / (rot_all.shape[0] / vb)
+                else:
+                    l, g = grad_at(var, rot_all)
+                    var = opt.step(var, g, cfg["lr"])
+                    h_o.append(float(l))
+                    new = torch.nan_to_num(var)
+                upd = new - g_opt[t]
+                if "d" in cfg["target_field"]:
+                    upd = upd * r[t][..., 0:1]
+                g_tmp[t] = upd
+            idx = list(range(0, F_, cfg["interp"]))
+            if cfg["window_sigma"] > 0 and F_ > 1:
+                st = gaussian_filter(np.stack([g_tmp[i].numpy() for i in idx]), sigma=(cfg["window_sigma"], 0, 0))
+                for j, i in enumerate(idx):
+                    g_tmp[i] = torch.tensor(st[j])
+            for i in idx:
+                g_opt[i] = g_opt[i] + g_tmp[i]
+        hist.append(h_o)
+    res = [int(v) for v in oct_size[-1]]
+    d_fin = [particle_field(p[t], r[t], g_opt[t], cfg, res)[1][0] for t in range(F_)]
+    return hist, g_opt, d_fin

@@ -71,6 +71,32 @@ def test_rotate(ops, big):
     assert rel(gd_h, gd[0]) < TOL
 
 
+@pytest.mark.parametrize("shape,big", [((10, 12, 9), False), ((21, 37, 45), True), ((40, 33, 70), False),
+                                       ((1, 20, 24), True)])
+def test_rotate_bwd_tiled_c1(ops, shape, big):
+    """C = 1 takes the LDS-tiled output-stationary adjoint (no global atomics); it must equal the
+    autograd adjoint for small and large rotations, non-cubic volumes and clamped (out-of-cube) samples."""
+    torch.manual_seed(21)
+    D, H, W = shape
+    d = torch.rand(1, D, H, W, 1).requires_grad_()
+    R = rots(4, 3, big)
+    R[3] = R[3] * 1.4          # not a pure rotation: scaling pushes many samples outside the cube
+    ref = O.rotate(d, R)
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gd_h = ops.rotate_bwd(dev(g), dev(R))
+    assert rel(gd_h, gd[0]) < TOL
+    assert torch.equal(gd_h, ops.rotate_bwd(dev(g), dev(R)))      # fixed-point accumulation: bit-reproducible
+    assert rel(ops.rotate_bwd(dev(g), dev(R), tiled=False), gd[0]) < TOL   # global-atomic fallback
+    for s in (1e-20, 1e20):                                        # the fixed-point scale follows max|g|
+        assert rel(ops.rotate_bwd(dev(g * s), dev(R)), gd[0] * s) < TOL
+    assert float(ops.rotate_bwd(dev(g * 0), dev(R)).abs().max()) == 0.0
+    # accumulate semantics: += into a pre-filled buffer
+    acc = torch.ones(D, H, W, 1, device="cuda")
+    ops.rotate_bwd(dev(g), dev(R), g_d_acc=acc)
+    assert rel(acc - 1.0, gd[0]) < TOL
+
+
 def test_advect(ops):
     torch.manual_seed(2)
     d = torch.rand(1, 11, 9, 13, 1).requires_grad_()
@@ -153,6 +179,13 @@ def test_rotate_render_fused(ops, liquid):
         gi = ops.maxnorm_bwd(img, gmax, gi)
     gd_h = ops.rotate_render_bwd(dev(d[0, ..., 0]), dev(R), rs, gi, tau, liquid)
     assert rel(gd_h, gd[0, ..., 0]) < TOL
+    # two-pass adjoint: kept rotated volume -> in-place render adjoint -> tiled rotate adjoint
+    d_rot = torch.empty(4, 14, 12, 10, device="cuda")
+    img3, rs3 = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, liquid, d_rot=d_rot)
+    assert rel(img3, img) < 1e-6 and rel(d_rot, dr[..., 0]) < TOL
+    g_rot = ops.render_bwd(d_rot, rs3, gi, tau, liquid, g_d=d_rot)
+    gd_2 = ops.rotate_bwd(g_rot.unsqueeze(-1), dev(R))
+    assert rel(gd_2[..., 0], gd[0, ..., 0]) < TOL
     # fused == unfused HIP
     img2, _ = ops.render_fwd(ops.rotate_fwd(dev(d[0]), dev(R))[..., 0].contiguous(), tau, liquid)
     assert rel(img2, img) < 1e-5

@@ -1,0 +1,91 @@
+"""The drop-in surface: ``Styler(config).run(params)`` (3-D particle 'd'/'p' fields and the 2-D
+colour field) against the CPU oracle's restatement of the reference loop, on seeded inputs."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nfs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a)).double(); b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _config(**over):
+    from neural_flow_style_amd.config import get_config
+    cfg, _ = get_config([])
+    cfg.network = "vgg_19.ckpt"
+    cfg.data_dir = "/nonexistent"
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    cfg.rng = np.random.RandomState(cfg.seed)
+    return cfg
+
+
+def _particles(G, n, nk, rng):
+    from neural_flow_style_amd import synthetic as S
+    p = S.blob_particles(n, rng)
+    p[:5] = -1.0                                        # padded slots (test_smokegun.py:48)
+    r = rng.uniform(0.2, 1.0, (n, nk)).astype(np.float32)
+    r[:5] = 0
+    return p, r
+
+
+@pytest.mark.parametrize("target,mode", [("d", "sequential"), ("d", "sum"), ("p", "sequential")])
+def test_styler3p_matches_oracle_loop(target, mode):
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_3p import Styler
+    G, n, nk, F = 16, 1500, 2, 2
+    rng = np.random.RandomState(5)
+    frames = [_particles(G, n, nk, rng) for _ in range(F)]
+    simg = S.style_image(G, G, rng)
+    layers = ["conv1_1", "conv2_1", "conv3_1"]
+    cfg = _config(resolution=[G, G, G], domain=[G, G, G], radius=0.5, nsize=1, support=4, rest_density=1000, k=3,
+                  clip=False, target_field=target, num_frames=F, batch_size=1, frames_per_opt=1, window_sigma=1.0,
+                  interp=1, lr=0.05 if target == "d" else 0.002, iter=3, octave_n=1, octave_scale=1.8,
+                  style_layer=layers, w_style_layer=[1, 1, 1], w_style=1.0, w_content=0, transmit=0.1,
+                  rotate=True, n_views=3, v_batch=1, sample_type="uniform", phi0=0, phi1=0, phi_unit=0,
+                  theta0=-10, theta1=10, theta_unit=10, resize_scale=1.0, views_mode=mode,
+                  style_target=simg, num_kernels=nk, kernel_scale=2, w_pressure=1e3 if target == "p" else 0)
+    st = Styler(cfg)
+    st.load_img([G, G])
+    params = {"p": [f[0] for f in frames], "r": [f[1] for f in frames]}
+    res = st.run(params)
+
+    ocfg = dict(vars(cfg))
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    hist, g_opt, d_fin = O.styler3p_run(ocfg, params, w, [simg], st.rot_mat_, views_mode=mode)
+    np.testing.assert_allclose(res["l"][0], hist[0], rtol=2e-3)
+    for t in range(F):
+        assert rel(res["opt"][t], g_opt[t]) < 2e-3
+        assert rel(res["d"][t], d_fin[t]) < 1e-3
+    assert res["d"].shape == (F, G, G, G, 1) and res["r"].shape == (F, G, G, 3) and res["r"].dtype == np.uint8
+    assert len(res["p"]) == F and res["p"][0].shape == (n, 3)
+
+
+def test_styler2p_colour_runs_and_decreases_loss():
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_2p import Styler
+    rng = np.random.RandomState(7)
+    p = S.dambreak_particles(40, rng)
+    n = p.shape[0]
+    r = rng.uniform(900, 1100, (n, 1)).astype(np.float32)
+    H = W = 64
+    simg = S.style_image(H, W, rng)
+    cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.025, nsize=2, support=4,
+                  rest_density=1000, clip=False, target_field="c", num_frames=1, batch_size=1, frames_per_opt=200,
+                  window_sigma=3, lr=0.01, iter=6, octave_n=2, octave_scale=1.7, style_layer=["conv2_1", "conv3_1"],
+                  w_style_layer=[0.5, 0.5], w_style=1.0, w_content=0, style_mask=True, w_tv=0.01, style_target=simg,
+                  resize_scale=1.0)
+    st = Styler(cfg)
+    st.load_img([H, W])
+    res = st.run({"p": [p], "r": [r]})
+    assert res["d"].shape == (1, H, W, 3) and res["d"].dtype == np.uint8
+    assert res["c"][0].shape == (n, 3)
+    l = res["l"][-1]
+    assert l[-1] < l[0]
