@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, parallel
 
 
 class RenderStyleLoss(object):
@@ -190,9 +190,7 @@ class GridStylizer(object):
         losses, g = self.gradient(rot_local)
         total = losses.sum()
         if self.pg is not None:
-            import torch.distributed as dist
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.pg)
+            parallel.all_reduce_sum_([g, total], group=self.pg)   # the one exchange step (RCCL over xGMI)
         self.adam.step(self.var, g, self.lr)
         return total
 

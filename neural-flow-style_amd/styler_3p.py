@@ -26,7 +26,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import engine, ops
+from . import engine, ops, parallel
 from . import transform as T
 from .styler_base import StylerBase
 from .util import denoise
@@ -190,10 +190,8 @@ class Styler(StylerBase):
                         losses, g = self._value_and_grad(p[t], r[t], var, res, rot)
                         total = losses.sum()
                         if self.pg is not None:
-                            import torch.distributed as dist
                             g = g.contiguous()
-                            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-                            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.pg)
+                            parallel.all_reduce_sum_([g, total], group=self.pg)
                         adam.step(var, g.contiguous(), lr)
                         loss_history_o.append(float(total))
                         if self.rotate:
@@ -257,7 +255,4 @@ class Styler(StylerBase):
         return self.loss.d_img(d3, self._identity)
 
     def _rank_world(self):
-        if self.pg is None:
-            return 0, 1
-        import torch.distributed as dist
-        return dist.get_rank(self.pg), dist.get_world_size(self.pg)
+        return (0, 1) if self.pg is None else parallel.rank_world(self.pg)
