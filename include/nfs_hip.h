@@ -128,14 +128,21 @@ int nfs_loss_net_input_bwd(const float* g_x, float* g_img,
 int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind);
 int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind,
                      nfs_stream_t stream);
+/* Split-K workspace: small layers (25^2, 12^2 pixels, or one view per GPU) give too few M x N
+ * tiles to fill 256 CUs, so the K = 9*C dimension is split across blocks and the partial sums
+ * go through `workspace` (device floats, nullable = never split).  Size for any split the
+ * library may choose: nfs_conv3x3_workspace_floats. */
+int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co);
 /* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable */
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y,
-                    int B, int H, int W, int Ci, int Co, int relu, nfs_stream_t stream);
+                    int B, int H, int W, int Ci, int Co, int relu,
+                    float* workspace, int64_t workspace_floats, nfs_stream_t stream);
 /* gx = dgrad(gy) * (x_in > 0 if x_in) + (addend if addend); gy [B,H,W,Co] is the gradient
  * wrt the conv's pre-activation, gx [B,H,W,Ci]. */
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in,
                       const float* addend, float* gx,
-                      int B, int H, int W, int Ci, int Co, nfs_stream_t stream);
+                      int B, int H, int W, int Ci, int Co,
+                      float* workspace, int64_t workspace_floats, nfs_stream_t stream);
 /* slim.avg_pool2d [2,2]: stride 2, VALID (odd sizes floor).  x [B,H,W,C] -> y [B,H/2,W/2,C].
  * bwd: gx = 0.25*gy[h/2,w/2] (0 outside the pooled area) * (x > 0 if x) + (addend if addend) */
 int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream);

@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;        // channels per K chunk
 constexpr int LDS_STRIDE = 36;  // padded row (floats)
 constexpr int BM = 128;
-constexpr int PATCH_MAX = 256;  // max (TH+2)*(TW+2)
+constexpr int PATCH_MAX = 192;  // max (TH+2)*(TW+2): 6 pixel rows of 32 per staging pass
 
 struct ConvArgs {
   const float* x;       // [B,H,W,Kc]  input of the GEMM (fwd: activations, dgrad: gy)
@@ -33,10 +33,24 @@ struct ConvArgs {
   const float* aux0;    // fwd: bias [Nc] (nullable); dgrad: x_in [B,H,W,Nc] for the ReLU mask (nullable)
   const float* aux1;    // dgrad: addend [B,H,W,Nc] (nullable)
   float* y;             // [B,H,W,Nc]
+  float* ws;            // split-K partial sums [ksplit][B*H*W][Nc] (ksplit > 1)
   int B, H, W, Kc, Nc;
   int TH, TW, tiles_c;
-  int relu;
+  int relu, ksplit;
 };
+
+// y = epilogue(acc): MODE 0 bias + ReLU, MODE 1 ReLU mask of the layer below + style-gradient addend
+template <int MODE>
+__device__ __forceinline__ float conv_epilogue(const ConvArgs& a, float v, int n, int64_t idx) {
+  if (MODE == 0) {
+    if (a.aux0) v += a.aux0[n];
+    if (a.relu) v = fmaxf(v, 0.f);
+  } else {
+    if (a.aux0) v = a.aux0[idx] > 0.f ? v : 0.f;
+    if (a.aux1) v += a.aux1[idx];
+  }
+  return v;
+}
 
 template <int BN, int MODE>
 __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
@@ -93,33 +107,65 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+  // split-K: this block multiplies chunks [cb, ce) of the K dimension
   const int nchunks = a.Kc / KC;
-  const int niter = nchunks * 9;
-  constexpr int WREG = BN / 32;  // float4 per thread per weight slab
-  // slab (chunk, tap) = it: rows n0..n0+BN of [Nc][32]; thread t owns float4 #(t + 256 r).
+  const int cb = (int)((int64_t)blockIdx.z * nchunks / a.ksplit);
+  const int ce = (int)((int64_t)(blockIdx.z + 1) * nchunks / a.ksplit);
+  const int it0 = cb * 9, it1 = ce * 9;
+
+  // halo patch: thread t stages float4 #(t&7) of patch pixels (t>>3) + 32 j, j < 6, through named
+  // registers (prefetched one chunk = 9 taps ahead).  Offsets are chunk-independent.
+  const int q4 = 4 * (t & 7);
+  int64_t poff[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pp = (t >> 3) + 32 * j;
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int srow = r0 + pr - 1, xc = c0 + pc - 1;
+    const bool ok = pp < PP && srow >= 0 && srow < rows_total && xc >= 0 && xc < a.W;
+    poff[j] = ok ? ((int64_t)srow * a.W + xc) * a.Kc + q4 : -1;
+  }
+  float4 p0, p1, p2, p3, p4, p5;
+#define NFS_LOAD_PATCH(chunk_)                                                                   \
+  {                                                                                              \
+    const float* xb = a.x + (chunk_) * KC;                                                       \
+    p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);                               \
+    if (poff[0] >= 0) p0 = *reinterpret_cast<const float4*>(xb + poff[0]);                       \
+    if (poff[1] >= 0) p1 = *reinterpret_cast<const float4*>(xb + poff[1]);                       \
+    if (poff[2] >= 0) p2 = *reinterpret_cast<const float4*>(xb + poff[2]);                       \
+    if (poff[3] >= 0) p3 = *reinterpret_cast<const float4*>(xb + poff[3]);                       \
+    if (poff[4] >= 0) p4 = *reinterpret_cast<const float4*>(xb + poff[4]);                       \
+    if (poff[5] >= 0) p5 = *reinterpret_cast<const float4*>(xb + poff[5]);                       \
+  }
+  NFS_LOAD_PATCH(cb)
+
+  // weight slab (chunk, tap) = it: rows n0..n0+BN of [Nc][32]; thread t owns float4 #(t + 256 r).
   // Named registers (not an array): an indexed private array here ends up in scratch memory.
+  constexpr int WREG = BN / 32;
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp) + (int64_t)n0 * (KC / 4) + t;
   const int64_t slab4 = (int64_t)a.Nc * (KC / 4);
-  float4 w0 = wp4[0], w1 = wp4[256], w2, w3;
-  if (WREG > 2) { w2 = wp4[512]; w3 = wp4[768]; }
+  float4 w0, w1, w2, w3;
+  {
+    const float4* wn = wp4 + (int64_t)it0 * slab4;
+    w0 = wn[0]; w1 = wn[256];
+    if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
+  }
 
-  for (int it = 0; it < niter; ++it) {
+  for (int it = it0; it < it1; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
     if (tap == 0) {
       __syncthreads();  // every wave is done with the previous chunk's patch
-      const int q = t & 7;
-      for (int pp = t >> 3; pp < PP; pp += 32) {
-        const int pr = pp / PW, pc = pp - pr * PW;
-        const int s = r0 + pr - 1, xc = c0 + pc - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s >= 0 && s < rows_total && xc >= 0 && xc < a.W)
-          v = *reinterpret_cast<const float4*>(a.x + ((int64_t)s * a.W + xc) * a.Kc + chunk * KC + 4 * q);
-        *reinterpret_cast<float4*>(patch + pp * LDS_STRIDE + 4 * q) = v;
-      }
+      float* pdst = patch + (t >> 3) * LDS_STRIDE + q4;
+      *reinterpret_cast<float4*>(pdst) = p0;
+      *reinterpret_cast<float4*>(pdst + 32 * LDS_STRIDE) = p1;
+      *reinterpret_cast<float4*>(pdst + 64 * LDS_STRIDE) = p2;
+      *reinterpret_cast<float4*>(pdst + 96 * LDS_STRIDE) = p3;
+      *reinterpret_cast<float4*>(pdst + 128 * LDS_STRIDE) = p4;
+      *reinterpret_cast<float4*>(pdst + 160 * LDS_STRIDE) = p5;
     }
     float* wcur = wl + (it & 1) * BN * LDS_STRIDE;
     {
-      float* wdst = wcur + (t >> 3) * LDS_STRIDE + 4 * (t & 7);   // f = t + 256 r -> row (f>>3) = (t>>3) + 32 r
+      float* wdst = wcur + (t >> 3) * LDS_STRIDE + q4;   // f = t + 256 r -> row (f>>3) = (t>>3) + 32 r
       *reinterpret_cast<float4*>(wdst) = w0;
       *reinterpret_cast<float4*>(wdst + 32 * LDS_STRIDE) = w1;
       if (WREG > 2) {
@@ -128,11 +174,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
-    if (it + 1 < niter) {
+    if (it + 1 < it1) {
       const float4* wn = wp4 + (int64_t)(it + 1) * slab4;
       w0 = wn[0]; w1 = wn[256];
       if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
     }
+    if (tap == 0 && chunk + 1 < ce) NFS_LOAD_PATCH(chunk + 1)   // consumed 9 taps later
 
     const int dy = tap / 3, dx = tap - dy * 3;
     const int tapoff = (dy * PW + dx) * LDS_STRIDE;
@@ -162,8 +209,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
       }
     }
   }
+#undef NFS_LOAD_PATCH
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* outp = a.ksplit > 1 ? a.ws + (int64_t)blockIdx.z * a.B * a.H * a.W * a.Nc : a.y;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -176,17 +225,30 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
         const int n = n0 + wn * (BN / 2) + nt * 32 + i;
         const int64_t idx = (int64_t)pix * a.Nc + n;
         float v = acc[mt][nt][r];
-        if (MODE == 0) {
-          if (a.aux0) v += a.aux0[n];
-          if (a.relu) v = fmaxf(v, 0.f);
-        } else {
-          if (a.aux0) v = a.aux0[idx] > 0.f ? v : 0.f;
-          if (a.aux1) v += a.aux1[idx];
-        }
-        a.y[idx] = v;
+        if (a.ksplit == 1) v = conv_epilogue<MODE>(a, v, n, idx);
+        outp[idx] = v;
       }
     }
   }
+}
+
+// split-K second pass: y = epilogue(sum_s ws[s]); fixed summation order => deterministic
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_reduce_kernel(ConvArgs a, int64_t mn) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= mn) return;
+  float4 s = *reinterpret_cast<const float4*>(a.ws + i4);
+  for (int k = 1; k < a.ksplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(a.ws + (int64_t)k * mn + i4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int n = (int)(i4 % a.Nc);
+  float4 o;
+  o.x = conv_epilogue<MODE>(a, s.x, n, i4);
+  o.y = conv_epilogue<MODE>(a, s.y, n + 1, i4 + 1);
+  o.z = conv_epilogue<MODE>(a, s.z, n + 2, i4 + 2);
+  o.w = conv_epilogue<MODE>(a, s.w, n + 3, i4 + 3);
+  *reinterpret_cast<float4*>(a.y + i4) = o;
 }
 
 // ---- first layer (Ci = 3): direct VALU kernels; 0.5 % of the FLOPs -------------------------
@@ -307,30 +369,62 @@ static int device_cus() {
   return g_cus;
 }
 
+// Tile-count model.  A launch is `rounds` waves of blocks over the CU slots; few, equal-sized
+// blocks quantise badly (160 blocks on 512 slots = 31 % of the chip), so the K dimension is split
+// until the grid is several rounds deep; the partial sums cost one extra pass over M x N.
+struct ConvPlan { int bn, ksplit; };
+static ConvPlan plan_conv(int mtiles, int Nc, int nchunks, int64_t mn, int64_t ws_floats) {
+  const int cus = device_cus();
+  ConvPlan best{64, 1};
+  double best_t = 1e30;
+  for (int bn = 64; bn <= 128; bn += 64) {
+    if (Nc % bn) continue;
+    const int slots = cus * (bn == 64 ? 3 : 2);        // blocks resident per CU (LDS-limited)
+    const double unit = bn == 64 ? 0.55 : 1.0;         // relative time of one (chunk,tap) step
+    for (int ks = 1; ks <= nchunks && ks <= 16; ++ks) {
+      if (ks > 1 && (int64_t)ks * mn > ws_floats) break;
+      const int64_t blocks = (int64_t)mtiles * (Nc / bn) * ks;
+      const double rounds = (double)((blocks + slots - 1) / slots);
+      const int steps = ((nchunks + ks - 1) / ks) * 9 + 3;   // +3: pipeline fill / epilogue
+      // one step of a 128-wide block = 128*128*32*2 flop at ~1/2.2 of a CU's 614 GF/s share
+      double tms = rounds * steps * unit * 1.9e-3 * (slots / (double)cus) / 2.0;
+      if (ks > 1) tms += (double)(ks + 1) * mn * 4.0 / 4.0e9 + 2.5e-3;   // partial sums: write + read
+      if (tms < best_t) { best_t = tms; best = ConvPlan{bn, ks}; }
+    }
+  }
+  return best;
+}
+
 template <int MODE>
-static int launch_conv(const ConvArgs& base, hipStream_t s) {
+static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s) {
   ConvArgs a = base;
   int tiles_r = 0;
   a.TH = 0;
   pick_tile(a.B, a.H, a.W, a.TH, a.TW, tiles_r, a.tiles_c);
   NFS_REQUIRE(a.TH > 0, "conv3x3: no valid tile for %dx%dx%d", a.B, a.H, a.W);
   const int mtiles = tiles_r * a.tiles_c;
-  const bool big = (a.Nc % 128 == 0) && ((int64_t)mtiles * (a.Nc / 128) >= 2 * (int64_t)device_cus());
-  if (big) {
+  const int64_t mn = (int64_t)a.B * a.H * a.W * a.Nc;
+  const ConvPlan plan = plan_conv(mtiles, a.Nc, a.Kc / KC, mn, ws ? ws_floats : 0);
+  a.ksplit = plan.ksplit;
+  a.ws = ws;
+  const dim3 grid(mtiles, a.Nc / plan.bn, plan.ksplit);
+  if (plan.bn == 128) {
     constexpr int BN = 128;
     const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<BN, MODE>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), dim3(mtiles, a.Nc / BN), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), grid, dim3(256), lds, s, a);
   } else {
     constexpr int BN = 64;
     const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), dim3(mtiles, a.Nc / BN), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), grid, dim3(256), lds, s, a);
   }
+  if (plan.ksplit > 1)
+    hipLaunchKernelGGL(conv_reduce_kernel<MODE>, dim3(blocks_for(mn / 4, 256)), dim3(256), 0, s, a, mn);
   return check_launch(MODE == 0 ? "nfs_conv3x3_fwd" : "nfs_conv3x3_dgrad");
 }
 
@@ -357,8 +451,14 @@ int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kin
   return check_launch("nfs_conv3x3_pack");
 }
 
+int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co) {
+  if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  const int64_t n = Ci > Co ? Ci : Co;
+  return (int64_t)16 * B * H * W * n;   // up to 16 K-splits of the larger of the two M x N outputs
+}
+
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y, int B, int H, int W, int Ci,
-                    int Co, int relu, nfs_stream_t stream) {
+                    int Co, int relu, float* workspace, int64_t workspace_floats, nfs_stream_t stream) {
   NFS_REQUIRE(x && packed_fwd && y, "nfs_conv3x3_fwd: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_fwd: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd: too many pixels");
@@ -370,12 +470,13 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
     return check_launch("nfs_conv3x3_fwd(c3)");
   }
   NFS_REQUIRE(Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd: Ci must be 3 or a multiple of 32");
-  ConvArgs a{x, packed_fwd, bias, nullptr, y, B, H, W, Ci, Co, 0, 0, 0, relu};
-  return launch_conv<0>(a, as_stream(stream));
+  ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1};
+  return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream));
 }
 
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in, const float* addend, float* gx,
-                      int B, int H, int W, int Ci, int Co, nfs_stream_t stream) {
+                      int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_floats,
+                      nfs_stream_t stream) {
   NFS_REQUIRE(gy && packed_dgrad && gx, "nfs_conv3x3_dgrad: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_dgrad: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad: too many pixels");
@@ -388,8 +489,8 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
     return check_launch("nfs_conv3x3_dgrad(c3)");
   }
   NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
-  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, B, H, W, Co, Ci, 0, 0, 0, 0};
-  return launch_conv<1>(a, as_stream(stream));
+  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1};
+  return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream));
 }
 
 }  // extern "C"

@@ -213,20 +213,46 @@ def conv3x3_pack(w_hwio, kind):
     return packed
 
 
-def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None):
+_conv_ws = {}
+
+
+def conv_workspace(device, floats):
+    """split-K scratch, grown on demand and shared by all conv calls of a device (calls on one stream
+    are ordered, so sharing is safe)"""
+    key = (device.type, device.index)
+    cur = _conv_ws.get(key)
+    if cur is None or cur.numel() < floats:
+        cur = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _conv_ws[key] = cur
+    return cur
+
+
+def _conv_ws_for(B, H, W, Ci, Co, device, splitk):
+    if not splitk:
+        return None, 0
+    # at most ~64 MB: the planner only splits when M x N is small
+    want = min(_lib.lib().nfs_conv3x3_workspace_floats(B, H, W, Ci, Co), 16 * 1024 * 1024)
+    ws = conv_workspace(device, want)
+    return ws, ws.numel()
+
+
+def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None, splitk=True):
     B, H, W, Ci = x.shape
     if out is None:
         out = _empty((B, H, W, Co), x)
-    _lib.call("nfs_conv3x3_fwd", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), B, H, W, Ci, Co, int(relu), _stream())
+    ws, nws = _conv_ws_for(B, H, W, Ci, Co, x.device, splitk)
+    _lib.call("nfs_conv3x3_fwd", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), B, H, W, Ci, Co, int(relu),
+              _ptr(ws), nws, _stream())
     return out
 
 
-def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None):
+def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True):
     B, H, W, Co = gy.shape
     if out is None:
         out = _empty((B, H, W, Ci), gy)
+    ws, nws = _conv_ws_for(B, H, W, Ci, Co, gy.device, splitk)
     _lib.call("nfs_conv3x3_dgrad", _ptr(gy), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out), B, H, W, Ci, Co,
-              _stream())
+              _ptr(ws), nws, _stream())
     return out
 
 
