@@ -150,12 +150,15 @@ int nfs_avgpool2_bwd(const float* gy, const float* x, const float* addend, float
                      int B, int H, int W, int C, nfs_stream_t stream);
 
 /* ---- A7: Gram matrix + style loss (styler_base.py:96-102, 152-185) --------------------
- * F [B,HW,C] -> G [B,C,C] = F^T F * scale[b] (f32 MFMA, split over pixels, atomically
- * accumulated: G must be zeroed by the caller).  The factor applied to image b is
+ * F [B,HW,C] -> G [B,C,C] = F^T F * scale[b] (f32 MFMA, split over pixel slabs).  With a
+ * workspace (>= nfs_gram_workspace_floats) the slab partials are summed by a second pass in a
+ * fixed order (deterministic, G overwritten); without one they are accumulated with float
+ * atomics and G must be zeroed by the caller.  The factor applied to image b is
  * scale * (scale_dev ? scale_dev[b] : 1): `scale` = 1/(2*HW*C) in the plain case; scale_dev is a
  * DEVICE array [B] for the style_mask variant whose denominator 2*area_b*C lives on the GPU. */
+int64_t nfs_gram_workspace_floats(int B, int HW, int C);
 int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* scale_dev, float scale,
-                 nfs_stream_t stream);
+                 float* workspace, int64_t workspace_floats, nfs_stream_t stream);
 /* loss_acc[b] += weight * sum((G[b]-Gs[bs])^2) where bs = b % Bs; Dmat [B,C,C] = 2*weight*(G-Gs)
  * (the symmetric matrix nfs_gram_bwd multiplies by). */
 int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* Dmat,

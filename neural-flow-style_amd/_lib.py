@@ -54,7 +54,8 @@ SIGNATURES = {
     "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "nfs_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "nfs_avgpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "nfs_gram_fwd": [_P, _P, _I, _I, _I, _P, _F, _P],
+    "nfs_gram_workspace_floats": [_I, _I, _I],
+    "nfs_gram_fwd": [_P, _P, _I, _I, _I, _P, _F, _P, _L, _P],
     "nfs_style_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_tv_loss": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -67,7 +68,7 @@ SIGNATURES = {
     "nfs_axpy": [_P, _P, _F, _L, _P],
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
-            "nfs_conv3x3_workspace_floats": C.c_int64}
+            "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64}
 
 _lib = None
 

@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GramArgs {
   const float* F;
   float* G;
+  float* ws;    // partial tiles [unit][64*64] (two-pass mode) or null (float atomics into G)
   const float* scale_dev;
   float scale;
   int B, HW, C;
@@ -72,9 +73,23 @@ __global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
   }
+  // acc[qa][qb][r]: G row = t1*64 + 2*row + qa, col = t2*64 + 2*(lane&31) + qb
+  if (a.ws) {
+    // two-pass mode: the raw partial tile goes to the workspace (float2 = 256-B coalesced rows);
+    // gram_reduce_kernel sums the slabs in a fixed order (deterministic, no atomics)
+    const int64_t full_unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float* wt = a.ws + full_unit * 4096;
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + qa;
+        *reinterpret_cast<float2*>(wt + row * 64 + 2 * i) = make_float2(acc[qa][0][r], acc[qa][1][r]);
+      }
+    return;
+  }
   const float sc = a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
   float* Gb = a.G + (int64_t)b * a.C * a.C;
-  // acc[qa][qb][r]: G row = t1*64 + 2*row + qa, col = t2*64 + 2*(lane&31) + qb
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -86,17 +101,32 @@ __global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
       }
 }
 
+// G[b][c1][c2] = scale_b * sum_slab ws[((b*npair + pair)*nslab + slab)][64x64 tile]
+__global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // element of G
+  const int64_t per_img = (int64_t)a.C * a.C;
+  if (e >= per_img * a.B) return;
+  const int b = (int)(e / per_img);
+  const int rem = (int)(e - (int64_t)b * per_img);
+  const int c1 = rem / a.C, c2 = rem - c1 * a.C;
+  const int pair = (c1 >> 6) * a.ntile + (c2 >> 6);
+  const float* p = a.ws + (((int64_t)b * a.ntile * a.ntile + pair) * a.nslab) * 4096 + (c1 & 63) * 64 + (c2 & 63);
+  float s = 0.f;
+  for (int k = 0; k < a.nslab; ++k) s += p[(int64_t)k * 4096];
+  a.G[e] = s * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
+}
+
 // loss += weight * sum (G - Gs)^2 ; Dmat = 2*weight*(G - Gs)
 __global__ void __launch_bounds__(256) style_loss_kernel(const float* __restrict__ G, const float* __restrict__ Gs,
                                                          float* __restrict__ loss, float* __restrict__ Dmat, int B,
                                                          int Bs, int CC, float weight) {
   __shared__ float red[16];
   const int b = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float part = 0.f;
-  if (e < CC) {
+  // grid-stride: at most 32 blocks per image => at most 32 same-address atomics per image
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < CC; e += (int64_t)gridDim.x * blockDim.x) {
     const float diff = G[(int64_t)b * CC + e] - Gs[(int64_t)(b % Bs) * CC + e];
-    part = weight * diff * diff;
+    part += weight * diff * diff;
     Dmat[(int64_t)b * CC + e] = 2.f * weight * diff;
   }
   part = block_sum(part, red);
@@ -186,25 +216,41 @@ using namespace nfs;
 
 extern "C" {
 
+static void gram_plan(GramArgs& a) {
+  a.ntile = a.C / 64;
+  // enough waves to fill the chip (>= ~4 per CU), slabs of >= 128 pixels
+  const int64_t pairs = (int64_t)a.B * a.ntile * a.ntile;
+  int64_t want = (4 * 256 + pairs - 1) / pairs;
+  if (want < 1) want = 1;
+  int slab = (int)((a.HW + want - 1) / want);
+  if (slab < 128) slab = 128;
+  slab = (slab + 1) & ~1;
+  a.slab = slab;
+  a.nslab = (a.HW + slab - 1) / slab;
+}
+
+int64_t nfs_gram_workspace_floats(int B, int HW, int C) {
+  if (B <= 0 || HW <= 0 || C <= 0 || C % 64) return 0;
+  GramArgs a;
+  a.B = B; a.HW = HW; a.C = C;
+  gram_plan(a);
+  return (int64_t)B * a.ntile * a.ntile * a.nslab * 4096 + 4 * 4096;
+}
+
 int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* scale_dev, float scale,
-                 nfs_stream_t stream) {
+                 float* workspace, int64_t workspace_floats, nfs_stream_t stream) {
   NFS_REQUIRE(F && G, "nfs_gram_fwd: null pointer");
   NFS_REQUIRE(B > 0 && HW > 0, "nfs_gram_fwd: non-positive dimension");
   NFS_REQUIRE(C > 0 && C % 64 == 0, "nfs_gram_fwd: C must be a multiple of 64");
   GramArgs a;
   a.F = F; a.G = G; a.scale_dev = scale_dev; a.scale = scale; a.B = B; a.HW = HW; a.C = C;
-  a.ntile = C / 64;
-  // enough waves to fill the chip (>= ~4 per CU), slabs of >= 128 pixels
-  const int64_t pairs = (int64_t)B * a.ntile * a.ntile;
-  int64_t want = (4 * 256 + pairs - 1) / pairs;
-  if (want < 1) want = 1;
-  int slab = (int)((HW + want - 1) / want);
-  if (slab < 128) slab = 128;
-  slab = (slab + 1) & ~1;
-  a.slab = slab;
-  a.nslab = (HW + slab - 1) / slab;
-  const int64_t units = pairs * a.nslab;
+  gram_plan(a);
+  const int64_t units = (int64_t)B * a.ntile * a.ntile * a.nslab;
+  a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
   hipLaunchKernelGGL(gram_fwd_kernel, dim3(blocks_for(units, 4)), dim3(256), 0, as_stream(stream), a);
+  if (a.ws)
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for((int64_t)B * C * C, 256)), dim3(256), 0, as_stream(stream),
+                       a);
   return check_launch("nfs_gram_fwd");
 }
 
@@ -213,8 +259,9 @@ int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* 
   NFS_REQUIRE(G && Gs && loss_acc && Dmat, "nfs_style_loss_fwd: null pointer");
   NFS_REQUIRE(B > 0 && Bs > 0 && C > 0, "nfs_style_loss_fwd: non-positive dimension");
   const int CC = C * C;
-  hipLaunchKernelGGL(style_loss_kernel, dim3(blocks_for(CC, 256), B), dim3(256), 0, as_stream(stream), G, Gs, loss_acc,
-                     Dmat, B, Bs, CC, weight);
+  const unsigned nb = blocks_for(CC, 256) < 32u ? blocks_for(CC, 256) : 32u;
+  hipLaunchKernelGGL(style_loss_kernel, dim3(nb, B), dim3(256), 0, as_stream(stream), G, Gs, loss_acc, Dmat, B, Bs,
+                     CC, weight);
   return check_launch("nfs_style_loss_fwd");
 }
 

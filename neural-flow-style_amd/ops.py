@@ -274,15 +274,20 @@ def avgpool2_bwd(gy, x_shape, x=None, addend=None, out=None):
 
 # ---- A7 / A12 -----------------------------------------------------------------------
 
-def gram_fwd(F, scale, scale_dev=None, G=None):
+def gram_fwd(F, scale, scale_dev=None, G=None, two_pass=True):
     """F [B,h,w,C] (or [B,HW,C]) -> G [B,C,C] = scale * F^T F"""
     B, Cn = F.shape[0], F.shape[-1]
     HW = F.numel() // (B * Cn)
+    ws, nws = None, 0
+    if two_pass:
+        nws = _lib.lib().nfs_gram_workspace_floats(B, HW, Cn)
+        ws = conv_workspace(F.device, nws)      # shared scratch (calls on one stream are ordered)
+        nws = ws.numel()
     if G is None:
-        G = _zeros((B, Cn, Cn), F)
-    else:
+        G = _empty((B, Cn, Cn), F) if two_pass else _zeros((B, Cn, Cn), F)
+    elif not two_pass:
         G.zero_()
-    _lib.call("nfs_gram_fwd", _ptr(F), _ptr(G), B, HW, Cn, _ptr(scale_dev), float(scale), _stream())
+    _lib.call("nfs_gram_fwd", _ptr(F), _ptr(G), B, HW, Cn, _ptr(scale_dev), float(scale), _ptr(ws), nws, _stream())
     return G
 
 

@@ -265,9 +265,11 @@ def test_gram_style_loss(ops, B, HW, C):
     wgt = 0.7
     loss = wgt * ((G - Gs) ** 2).sum()
     (gF,) = torch.autograd.grad(loss, F)
-    Gh = ops.gram_fwd(dev(F), 1.0 / denom)
+    Gh = ops.gram_fwd(dev(F), 1.0 / denom)                          # two-pass deterministic reduction
     Gsh = ops.gram_fwd(dev(Fs), 1.0 / denom)
     assert rel(Gh, G) < TOL
+    assert torch.equal(Gh, ops.gram_fwd(dev(F), 1.0 / denom))
+    assert rel(ops.gram_fwd(dev(F), 1.0 / denom, two_pass=False), G) < TOL   # float-atomic fallback
     lacc = torch.zeros(B, device="cuda")
     Dm = ops.style_loss_fwd(Gh, Gsh, wgt, lacc)
     assert abs(float(lacc.sum()) - float(loss)) / float(loss) < TOL
