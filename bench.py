@@ -239,8 +239,8 @@ def main():
                                "loss, grid velocity variable through advect + TF-Adam (BASELINE configs[2])" % (G, V),
                    "grid": G, "views": V, "views_per_rank": V // world, "image": [G, G],
                    "style_layers": STYLE_LAYERS, "vgg_weights": "synthetic He-normal seed 123 (no checkpoint offline)",
-                   "parallelism": "views sharded over %d rank(s), all-reduce(sum) of the %d MB field gradient"
-                                  % (world, 4 * 3 * G ** 3 // 2 ** 20)},
+                   "parallelism": "views sharded over %d rank(s), all-reduce(sum) of the %d MB density-field "
+                                  "gradient" % (world, 4 * G ** 3 // 2 ** 20)},
         "final_loss": float(last),
     }
 

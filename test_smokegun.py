@@ -1,0 +1,114 @@
+"""Counterpart of the reference driver ``test_smokegun.py`` (test_smokegun.py:16-200) on the
+MI355X build: same ``run(config)`` body -- build the Styler, load the style image, read the
+particle frames, ``styler.run(params)``, save ``%03d.png`` / ``%03d.npz`` (key ``x`` = ``d[:, ::-1]``)
+/ ``loss_plot.png`` -- with two differences: particles come from ``.npz`` files (keys ``position``
+[N,3] in world units (x,y,z), ``density`` [N,num_kernels]) instead of partio ``.bgeo``, and the
+``main()`` overrides select the VGG-19 style loss with rotated views (the reference hard-codes the
+Inception graph, which is out of scope).  Without a dataset it runs on seeded synthetic particles.
+
+    python test_smokegun.py --style_target data/image/fire_new.jpg --w_style 1 --iter 20
+"""
+import os
+
+import numpy as np
+
+from config import get_config
+from styler_3p import Styler
+from util import prepare_dirs_and_logger
+
+
+def load_frames(config):
+    p, r = [], []
+    nmax = 0
+    raw = []
+    for i in range(config.num_frames):
+        path = os.path.join(config.data_dir, config.dataset, config.d_path % (config.target_frame + i))
+        if not os.path.exists(path):
+            return None
+        z = np.load(path)
+        raw.append((np.asarray(z["position"], np.float32), np.asarray(z["density"], np.float32)))
+        nmax = max(nmax, raw[-1][0].shape[0])
+    for pos, den in raw:
+        p_ = np.ones([nmax, 3], np.float32) * -1              # padded slots sit outside the domain
+        r_ = np.zeros([nmax, config.num_kernels], np.float32)
+        n = pos.shape[0]
+        # normalise to [0,1] and order (z,y,x)  (test_smokegun.py:60-65)
+        p_[:n] = np.stack([pos[:, 2] / config.domain[0], pos[:, 1] / config.domain[1], pos[:, 0] / config.domain[2]], -1)
+        r_[:n] = den.reshape(n, -1)[:, :config.num_kernels]
+        p.append(p_); r.append(r_)
+    return {"p": p, "r": r}
+
+
+def synthetic_frames(config):
+    from neural_flow_style_amd import synthetic as S
+    rng = np.random.RandomState(config.seed)
+    n = 20000
+    p = [S.blob_particles(n, rng) for _ in range(config.num_frames)]
+    r = [rng.uniform(0.2, 1.0, (n, config.num_kernels)).astype(np.float32) for _ in range(config.num_frames)]
+    return {"p": p, "r": r}
+
+
+def run(config):
+    prepare_dirs_and_logger(config)
+    config.rng = np.random.RandomState(config.seed)
+    if not config.style_target:
+        from neural_flow_style_amd import synthetic as S
+        config.style_target = S.style_image(256, 256, np.random.RandomState(config.seed))
+        config.w_style = 1
+    styler = Styler(config)
+    styler.load_img(config.resolution[1:])
+    params = load_frames(config) or synthetic_frames(config)
+    result = styler.run(params)
+
+    from PIL import Image
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        for o, l_ in enumerate(result["l"]):
+            plt.plot(range(len(l_)), l_, label="oct %d" % o)
+        plt.legend()
+        plt.savefig(os.path.join(config.log_dir, "loss_plot.png"))
+    except Exception as e:  # plotting is optional
+        print("loss plot skipped:", e)
+    for i, img in enumerate(result["r"]):
+        Image.fromarray(img).save(os.path.join(config.log_dir, "%03d.png" % (config.target_frame + i)))
+    for i, d in enumerate(result["d"]):
+        np.savez_compressed(os.path.join(config.log_dir, "%03d.npz" % (config.target_frame + i)), x=d[:, ::-1])
+    return result
+
+
+def main(config):
+    config.dataset = "smokegun"
+    config.d_path = "pt_low_o2/%03d.npz"
+    config.num_kernels = 2
+    config.kernel_scale = 2
+    config.support = 4
+    config.radius = 0.5
+    config.nsize = 1
+    config.rest_density = 1000
+    if config.resolution == [384, 288]:          # flag default -> the driver's grid (test_smokegun.py:128)
+        config.resolution = [100, 150, 100]
+    config.domain = list(config.resolution)
+    config.clip = False
+    config.k = 3
+    config.batch_size = 1
+    config.frames_per_opt = 1
+    config.target_field = "d"
+    config.lr = 0.1
+    config.network = "vgg_19.ckpt"
+    if config.style_layer == ["conv3_1"]:
+        config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
+        config.w_style_layer = [1, 1, 1, 1, 1]
+    config.w_content = 0
+    config.octave_n = 1
+    config.transmit = 0.01
+    config.rotate = True
+    config.n_views = 8
+    config.resize_scale = 1.0
+    return run(config)
+
+
+if __name__ == "__main__":
+    cfg, _ = get_config()
+    main(cfg)

@@ -1,0 +1,7 @@
+"""Drop-in module name of the reference (`vgg.py`): re-exports the MI355X implementation
+`neural_flow_style_amd.vgg` so that a reference driver's `import vgg` keeps working."""
+from neural_flow_style_amd.vgg import *  # noqa: F401,F403
+from neural_flow_style_amd import vgg as _impl
+
+__all__ = [n for n in dir(_impl) if not n.startswith("__")]
+globals().update({n: getattr(_impl, n) for n in __all__})
