@@ -27,19 +27,27 @@ struct GramArgs {
   int ntile;    // C / 64
 };
 
+// One BLOCK per work unit: its 4 waves split the unit's pixel slab four ways (4 waves per SIMD
+// resident => the dependent global loads of the k loop overlap across waves; with one wave per
+// unit the kernel was HBM-latency-bound at 22 TF/s), then waves 1-3 park their accumulators in LDS
+// (lane-contiguous, conflict-free) and wave 0 adds them and emits the tile.
 __global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
-  const int lane = threadIdx.x & 63;
+  __shared__ float part[3][64][64];   // [wave-1][acc register][lane]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t unit = blockIdx.x;
   const int64_t per_img = (int64_t)a.nslab * a.ntile * a.ntile;
-  if (unit >= per_img * a.B) return;
   const int b = (int)(unit / per_img);
   unit -= (int64_t)b * per_img;
   const int pair = (int)(unit / a.nslab);
   const int sl = (int)(unit - (int64_t)pair * a.nslab);
   const int t1 = pair / a.ntile, t2 = pair - t1 * a.ntile;
-  const int p0 = sl * a.slab;
-  const int p1 = min(p0 + a.slab, a.HW);
+  const int s0 = sl * a.slab;
+  const int s1 = min(s0 + a.slab, a.HW);
+  // this wave's quarter (even number of pixels per quarter so that pairs never straddle waves)
+  const int quarter = ((((s1 - s0) + 1) / 2 + 3) / 4) * 2;
+  const int p0 = min(s0 + wid * quarter, s1);
+  const int p1 = min(p0 + quarter, s1);
   const float* Fb = a.F + (int64_t)b * a.HW * a.C;
   const float* pa = Fb + t1 * 64 + 2 * i;
   const float* pb = Fb + t2 * 64 + 2 * i;
@@ -52,17 +60,41 @@ __global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
-  int p = p0;
-#pragma unroll 4
-  for (; p + 1 < p1; p += 2) {
-    const float2 av = *reinterpret_cast<const float2*>(pa + (int64_t)(p + h) * a.C);
-    const float2 bv = *reinterpret_cast<const float2*>(pb + (int64_t)(p + h) * a.C);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+  // k loop, manually software-pipelined (hipcc refuses to unroll a loop around the MFMA builtin):
+  // 8 k-steps (= 16 pixels, 16 float2 loads) are in flight while the previous 8 are multiplied.
+  const int nsteps = (p1 - p0) >> 1;
+  const float* qa_ = pa + (int64_t)(p0 + h) * a.C;
+  const float* qb_ = pb + (int64_t)(p0 + h) * a.C;
+  const int64_t step = 2 * (int64_t)a.C;
+#define NFS_GRAM_LOAD(A_, B_, s_)                                                      \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
+    A_[u] = make_float2(0.f, 0.f); B_[u] = make_float2(0.f, 0.f);                      \
+    if ((s_) + u < nsteps) {                                                           \
+      A_[u] = *reinterpret_cast<const float2*>(qa_ + ((s_) + u) * step);               \
+      B_[u] = *reinterpret_cast<const float2*>(qb_ + ((s_) + u) * step);               \
+    }                                                                                  \
   }
-  if (p < p1) {  // odd tail: k=1 half contributes zero
+#define NFS_GRAM_MMA(A_, B_)                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                 \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].x, B_[u].x, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].x, B_[u].y, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].y, B_[u].x, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].y, B_[u].y, acc[1][1], 0, 0, 0);      \
+  }
+  {
+    float2 A0[8], B0[8], A1[8], B1[8];
+    NFS_GRAM_LOAD(A0, B0, 0)
+    for (int s0_ = 0; s0_ < nsteps; s0_ += 16) {
+      NFS_GRAM_LOAD(A1, B1, s0_ + 8)
+      NFS_GRAM_MMA(A0, B0)
+      NFS_GRAM_LOAD(A0, B0, s0_ + 16)
+      NFS_GRAM_MMA(A1, B1)
+    }
+  }
+#undef NFS_GRAM_LOAD
+#undef NFS_GRAM_MMA
+  if ((p1 - p0) & 1) {  // odd tail pixel: the k=1 half contributes zero
+    const int p = p1 - 1;
     float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
     if (h == 0) {
       av = *reinterpret_cast<const float2*>(pa + (int64_t)p * a.C);
@@ -73,12 +105,31 @@ __global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
   }
+  // block reduction of the 4 partial tiles
+  if (wid > 0) {
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wid - 1][(qa * 2 + qb) * 16 + r][lane] = acc[qa][qb][r];
+  }
+  __syncthreads();
+  if (wid > 0) return;
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (qa * 2 + qb) * 16 + r;
+        acc[qa][qb][r] += part[0][k][lane] + part[1][k][lane] + part[2][k][lane];
+      }
   // acc[qa][qb][r]: G row = t1*64 + 2*row + qa, col = t2*64 + 2*(lane&31) + qb
   if (a.ws) {
     // two-pass mode: the raw partial tile goes to the workspace (float2 = 256-B coalesced rows);
     // gram_reduce_kernel sums the slabs in a fixed order (deterministic, no atomics)
-    const int64_t full_unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    float* wt = a.ws + full_unit * 4096;
+    float* wt = a.ws + (int64_t)blockIdx.x * 4096;
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -172,26 +223,42 @@ __global__ void __launch_bounds__(256) gram_bwd_kernel(GramBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
-#pragma unroll 2
-  for (int k8 = 0; k8 < a.C; k8 += 8) {
-    const float4 a0 = *reinterpret_cast<const float4*>(arow[0] + k8);
-    const float4 a1 = *reinterpret_cast<const float4*>(arow[1] + k8);
-    float b0[4], b1[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const float* dr = Db + (int64_t)(k8 + 4 * h + jj) * a.C + ncol;
-      b0[jj] = dr[0];
-      b1[jj] = dr[32];
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const float x0 = (&a0.x)[jj], x1 = (&a1.x)[jj];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b0[jj], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b1[jj], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b0[jj], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b1[jj], acc[1][1], 0, 0, 0);
+  // K loop, manually double-buffered (the compiler does not unroll around the MFMA builtin): the
+  // operands of step k+1 (2 float4 of F, 8 dwords of D) are in flight while step k is multiplied.
+  const float* dcol = Db + (int64_t)(4 * h) * a.C + ncol;
+#define NFS_GB_LOAD(A0_, A1_, B0_, B1_, k8_)                                         \
+  {                                                                                  \
+    A0_ = *reinterpret_cast<const float4*>(arow[0] + (k8_));                         \
+    A1_ = *reinterpret_cast<const float4*>(arow[1] + (k8_));                         \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                               \
+      const float* dr = dcol + (int64_t)((k8_) + jj) * a.C;                          \
+      B0_[jj] = dr[0];                                                               \
+      B1_[jj] = dr[32];                                                              \
+    }                                                                                \
+  }
+#define NFS_GB_MMA(A0_, A1_, B0_, B1_)                                                              \
+  {                                                                                                 \
+    const float x0[4] = {A0_.x, A0_.y, A0_.z, A0_.w}, x1[4] = {A1_.x, A1_.y, A1_.z, A1_.w};         \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                              \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[jj], B0_[jj], acc[0][0], 0, 0, 0);        \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[jj], B1_[jj], acc[0][1], 0, 0, 0);        \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[jj], B0_[jj], acc[1][0], 0, 0, 0);        \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[jj], B1_[jj], acc[1][1], 0, 0, 0);        \
+    }                                                                                               \
+  }
+  {
+    float4 pa0, pa1, qa0, qa1;
+    float pb0[4], pb1[4], qb0[4], qb1[4];
+    NFS_GB_LOAD(pa0, pa1, pb0, pb1, 0)
+    for (int k8 = 0; k8 < a.C; k8 += 16) {        // C is a multiple of 64
+      NFS_GB_LOAD(qa0, qa1, qb0, qb1, k8 + 8)
+      NFS_GB_MMA(pa0, pa1, pb0, pb1)
+      if (k8 + 16 < a.C) NFS_GB_LOAD(pa0, pa1, pb0, pb1, k8 + 16)
+      NFS_GB_MMA(qa0, qa1, qb0, qb1)
     }
   }
+#undef NFS_GB_LOAD
+#undef NFS_GB_MMA
   const float sc = 2.f * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
   float* dFb = a.dF + (int64_t)b * a.HW * a.C;
 #pragma unroll
@@ -218,9 +285,10 @@ extern "C" {
 
 static void gram_plan(GramArgs& a) {
   a.ntile = a.C / 64;
-  // enough waves to fill the chip (>= ~4 per CU), slabs of >= 128 pixels
+  // one block (4 waves) per unit, 3 blocks resident per CU (48 KB of LDS each): aim at ~3 units per
+  // CU, slabs of >= 128 pixels
   const int64_t pairs = (int64_t)a.B * a.ntile * a.ntile;
-  int64_t want = (4 * 256 + pairs - 1) / pairs;
+  int64_t want = (3 * 256 + pairs - 1) / pairs;
   if (want < 1) want = 1;
   int slab = (int)((a.HW + want - 1) / want);
   if (slab < 128) slab = 128;
@@ -247,7 +315,7 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
   gram_plan(a);
   const int64_t units = (int64_t)B * a.ntile * a.ntile * a.nslab;
   a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
-  hipLaunchKernelGGL(gram_fwd_kernel, dim3(blocks_for(units, 4)), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(gram_fwd_kernel, dim3((unsigned)units), dim3(256), 0, as_stream(stream), a);
   if (a.ws)
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for((int64_t)B * C * C, 256)), dim3(256), 0, as_stream(stream),
                        a);
