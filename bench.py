@@ -142,6 +142,7 @@ def cpu_baseline(data, G, V, n_views):
     the full grid size, extrapolated to one full iteration."""
     from oracle import nfs_oracle as O
     torch.set_num_threads(os.cpu_count() or 1)
+    O.FAST_WARP = True   # multi-threaded grid_sample for the 8-tap warps (identical numerics, tested)
     w = O.synthetic_vgg19_weights(123, upto="conv5_1")
     sfe = O.style_target_features(torch.tensor(data["simg"])[None], w, STYLE_LAYERS, upto="conv5_1")
     cfg = dict(k=3, transmit=0.01, style_layer=STYLE_LAYERS, w_style_layer=[1.0] * 5, w_style=1.0, upto="conv5_1")

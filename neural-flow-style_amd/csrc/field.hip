@@ -9,68 +9,59 @@
 namespace nfs {
 
 // ---- A9 ------------------------------------------------------------------------------
-// Each thread produces 4 consecutive W outputs of one (z,y) row from 9 neighbour rows of
-// 6 values: 13.5 loads/output instead of 27; rows are re-served by L1/L2, so HBM traffic
-// is ~ one read + one write of the volume (8 B/cell).
+// z-marching separable stencil: a thread owns one (y,x) column of a z-chunk.  Per step it loads
+// the 3x3 (y,x) neighbourhood of ONE new plane (9 loads, coalesced along x), reduces it to the
+// 2-D filtered value and combines the last three of those along z -- 9 loads per output instead
+// of 27 (the 2-D sums are reused by three consecutive z).  HBM traffic = one read + one write.
+constexpr int SM_ZCHUNK = 25;
+
+template <bool BWD>
+__device__ __forceinline__ float smooth_plane(const float* __restrict__ in, const float* __restrict__ act, int z,
+                                              int y, int x, int D, int H, int W, const float* w1) {
+  if (z < 0 || z >= D) return 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    const int64_t row = ((int64_t)z * H + yy) * W;
+    float r = 0.f;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      float t = in[row + xx];
+      if (BWD) t = signbit(act[row + xx]) ? 0.f : t;   // g_out * (pre >= 0)
+      r += w1[dx + 1] * t;
+    }
+    s += w1[dy + 1] * r;
+  }
+  return s;
+}
+
 template <bool BWD>
 __global__ void __launch_bounds__(256) smooth3d_kernel(const float* __restrict__ in, const float* __restrict__ act,
                                                        float* __restrict__ out, int D, int H, int W, float k) {
-  const int W4 = (W + 3) >> 2;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)D * H * W4) return;
-  const int xg = (int)(gid % W4);
-  const int y = (int)((gid / W4) % H);
-  const int z = (int)(gid / ((int64_t)W4 * H));
-  const int x0 = xg * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (k > 0.f) {
-    const float k1[3] = {1.f, k, 1.f};
-#pragma unroll
-    for (int dz = -1; dz <= 1; ++dz) {
-      const int zz = z + dz;
-      if (zz < 0 || zz >= D) continue;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        const int64_t row = ((int64_t)zz * H + yy) * W;
-        float v[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const int xx = x0 - 1 + j;
-          float t = 0.f;
-          if (xx >= 0 && xx < W) {
-            t = in[row + xx];
-            if (BWD) t = signbit(act[row + xx]) ? 0.f : t;  // g_out * (pre >= 0)
-          }
-          v[j] = t;
-        }
-        const float wr = k1[dz + 1] * k1[dy + 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += wr * (v[j] + k * v[j + 1] + v[j + 2]);
-      }
-    }
-    const float inv = 1.f / ((k + 2.f) * (k + 2.f) * (k + 2.f));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] *= inv;
-  } else {
-    const int64_t row = ((int64_t)z * H + y) * W;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (x0 + j < W) {
-        float t = in[row + x0 + j];
-        if (BWD) t = signbit(act[row + x0 + j]) ? 0.f : t;
-        acc[j] = t;
-      }
-  }
-  const int64_t orow = ((int64_t)z * H + y) * W;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (x0 + j >= W) break;
-    float r = acc[j];
+  const int nzc = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
+  if (gid >= (int64_t)nzc * H * W) return;
+  const int x = (int)(gid % W);
+  const int y = (int)((gid / W) % H);
+  const int zc = (int)(gid / ((int64_t)W * H));
+  const int z0 = zc * SM_ZCHUNK, z1 = min(z0 + SM_ZCHUNK, D);
+  // 1-D weights [1,k,1]/(k+2); k <= 0 skips the conv (identity)
+  const float inv = k > 0.f ? 1.f / (k + 2.f) : 1.f;
+  const float w1[3] = {k > 0.f ? inv : 0.f, k > 0.f ? k * inv : 1.f, k > 0.f ? inv : 0.f};
+  float pm = smooth_plane<BWD>(in, act, z0 - 1, y, x, D, H, W, w1);
+  float pc = smooth_plane<BWD>(in, act, z0, y, x, D, H, W, w1);
+  for (int z = z0; z < z1; ++z) {
+    const float pn = smooth_plane<BWD>(in, act, z + 1, y, x, D, H, W, w1);
+    float r = w1[0] * pm + w1[1] * pc + w1[2] * pn;
     // forward: max(pre,0) with the sign bit carrying (pre < 0) for the TF Maximum gradient
     if (!BWD) r = (r >= 0.f) ? fabsf(r) : (r < 0.f ? -0.0f : r);
-    out[orow + x0 + j] = r;
+    out[((int64_t)z * H + y) * W + x] = r;
+    pm = pc;
+    pc = pn;
   }
 }
 
@@ -268,7 +259,7 @@ extern "C" {
 int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float k, nfs_stream_t stream) {
   NFS_REQUIRE(d && out, "nfs_smooth3d_relu_fwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_fwd: non-positive dimension");
-  const int64_t n = (int64_t)D * H * ((W + 3) / 4);
+  const int64_t n = (int64_t)((D + SM_ZCHUNK - 1) / SM_ZCHUNK) * H * W;
   hipLaunchKernelGGL(smooth3d_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d,
                      (const float*)nullptr, out, D, H, W, k);
   return check_launch("nfs_smooth3d_relu_fwd");
@@ -278,7 +269,7 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d, int 
                           nfs_stream_t stream) {
   NFS_REQUIRE(out && g_out && g_d, "nfs_smooth3d_relu_bwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_bwd: non-positive dimension");
-  const int64_t n = (int64_t)D * H * ((W + 3) / 4);
+  const int64_t n = (int64_t)((D + SM_ZCHUNK - 1) / SM_ZCHUNK) * H * W;
   hipLaunchKernelGGL(smooth3d_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g_out, out, g_d,
                      D, H, W, k);
   return check_launch("nfs_smooth3d_relu_bwd");

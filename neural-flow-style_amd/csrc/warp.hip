@@ -235,8 +235,9 @@ __global__ void __launch_bounds__(RT_THREADS) rotate_bwd_tiled_kernel(const floa
         }
       }
       for (int b = 0; b < 3; ++b) {
-        lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]) - 1.0, 0.0), (double)n[b]);
-        hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]) + 1.0, (double)(n[b] - 1)), -1.0);
+        // the catchment box already carries a 0.02-cell pad: no extra integer margin needed
+        lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]), 0.0), (double)n[b]);
+        hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]), (double)(n[b] - 1)), -1.0);
       }
     }
     ViewBox vb;

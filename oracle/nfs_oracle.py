@@ -108,8 +108,17 @@ def batch_warp2d(imgs, mappings, out_shape):
     return interpolate2d(imgs, c[:, 0].reshape(-1), c[:, 1].reshape(-1), out_shape)
 
 
+FAST_WARP = False  # set by bench.py's cpu_baseline only: multi-threaded F.grid_sample, proven identical to
+                   # the 8-gather restatement in tests/test_oracle_kat.py (fwd 1e-12, both gradients)
+
+
 def batch_warp3d(imgs, mappings, out_shape):
     """mappings [B,3,X,Y,Z] (transform.py:238-269)."""
+    if FAST_WARP and imgs.shape[0] == mappings.shape[0]:
+        grid = torch.stack([mappings[:, 2], mappings[:, 1], mappings[:, 0]], -1)
+        out = F.grid_sample(imgs.permute(0, 4, 1, 2, 3), grid, mode="bilinear", padding_mode="border",
+                            align_corners=True)
+        return out.permute(0, 2, 3, 4, 1)
     nb = out_shape[0]
     c = mappings.reshape(nb, 3, -1)
     return interpolate3d(imgs, c[:, 0].reshape(-1), c[:, 1].reshape(-1),
