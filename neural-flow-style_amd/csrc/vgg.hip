@@ -17,6 +17,7 @@
 //   k order inside a chunk is permuted identically for A and B, which a sum permits.
 // Weights are frozen, so they are packed once on the device into [chunk][tap][N][32].
 #include "common.h"
+#include <stdlib.h>
 
 namespace nfs {
 
@@ -37,6 +38,7 @@ struct ConvArgs {
   int B, H, W, Kc, Nc;
   int TH, TW, tiles_c;
   int relu, ksplit;
+  int dbg;              // timing ablations only (env NFS_CONV_DBG): 1 no fragment reads, 2 no barriers, 4 no W staging
 };
 
 // y = epilogue(acc): MODE 0 bias + ReLU, MODE 1 ReLU mask of the layer below + style-gradient addend
@@ -151,10 +153,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
     if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
   }
 
+  float af0[4] = {0, 0, 0, 0}, af1[4] = {0, 0, 0, 0}, bf[NT][4] = {};
   for (int it = it0; it < it1; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
     if (tap == 0) {
-      __syncthreads();  // every wave is done with the previous chunk's patch
+      if (!(a.dbg & 2)) __syncthreads();  // every wave is done with the previous chunk's patch
       float* pdst = patch + (t >> 3) * LDS_STRIDE + q4;
       *reinterpret_cast<float4*>(pdst) = p0;
       *reinterpret_cast<float4*>(pdst + 32 * LDS_STRIDE) = p1;
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
       *reinterpret_cast<float4*>(pdst + 160 * LDS_STRIDE) = p5;
     }
     float* wcur = wl + (it & 1) * BN * LDS_STRIDE;
-    {
+    if (!(a.dbg & 4) || it == it0) {
       float* wdst = wcur + (t >> 3) * LDS_STRIDE + q4;   // f = t + 256 r -> row (f>>3) = (t>>3) + 32 r
       *reinterpret_cast<float4*>(wdst) = w0;
       *reinterpret_cast<float4*>(wdst + 32 * LDS_STRIDE) = w1;
@@ -173,8 +176,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
         *reinterpret_cast<float4*>(wdst + 96 * LDS_STRIDE) = w3;
       }
     }
-    __syncthreads();
-    if (it + 1 < it1) {
+    if (!(a.dbg & 2)) __syncthreads();
+    if (it + 1 < it1 && !(a.dbg & 4)) {
       const float4* wn = wp4 + (int64_t)(it + 1) * slab4;
       w0 = wn[0]; w1 = wn[256];
       if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
@@ -187,17 +190,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
     const bool z1 = (dy == 0 && !up_ok[1]) || (dy == 2 && !dn_ok[1]);
 #pragma unroll
     for (int c = 0; c < KC / 8; ++c) {
+      if (!(a.dbg & 1) || it == it0) {
       float4 a0 = *reinterpret_cast<const float4*>(patch + abase[0] + tapoff + 8 * c);
       float4 a1 = *reinterpret_cast<const float4*>(patch + abase[1] + tapoff + 8 * c);
       if (z0) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (z1) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float af0[4] = {a0.x, a0.y, a0.z, a0.w};
-      const float af1[4] = {a1.x, a1.y, a1.z, a1.w};
-      float bf[NT][4];
+      af0[0] = a0.x; af0[1] = a0.y; af0[2] = a0.z; af0[3] = a0.w;
+      af1[0] = a1.x; af1[1] = a1.y; af1[2] = a1.z; af1[3] = a1.w;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float4 bq = *reinterpret_cast<const float4*>(wcur + bbase[nt] + 8 * c);
         bf[nt][0] = bq.x; bf[nt][1] = bq.y; bf[nt][2] = bq.z; bf[nt][3] = bq.w;
+      }
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -407,6 +411,8 @@ static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipSt
   const ConvPlan plan = plan_conv(mtiles, a.Nc, a.Kc / KC, mn, ws ? ws_floats : 0);
   a.ksplit = plan.ksplit;
   a.ws = ws;
+  static const int dbg = getenv("NFS_CONV_DBG") ? atoi(getenv("NFS_CONV_DBG")) : 0;
+  a.dbg = dbg;
   const dim3 grid(mtiles, a.Nc / plan.bn, plan.ksplit);
   if (plan.bn == 128) {
     constexpr int BN = 128;
@@ -470,7 +476,7 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
     return check_launch("nfs_conv3x3_fwd(c3)");
   }
   NFS_REQUIRE(Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd: Ci must be 3 or a multiple of 32");
-  ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1};
+  ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1, 0};
   return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream));
 }
 
@@ -489,7 +495,7 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
     return check_launch("nfs_conv3x3_dgrad(c3)");
   }
   NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
-  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1};
+  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
   return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream));
 }
 
