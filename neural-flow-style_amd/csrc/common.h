@@ -110,6 +110,48 @@ __device__ __forceinline__ void tri_setup(float cx, float cy, float cz, int X, i
       }
 }
 
+// 8-byte load of two W-adjacent cells from a 4-byte-aligned address (gfx950 global loads only need
+// dword alignment): the two x-corners of a trilinear stencil come from ONE load instead of two,
+// which halves the texture-address work of the gather-bound ray march.
+struct __attribute__((packed, aligned(4))) F2u { float x, y; };
+
+// the same stencil as tri_setup/tri_sample1, accumulated in the same order (x0,x1 inner)
+__device__ __forceinline__ float tri_sample_pairs(const float* __restrict__ vol, int H, int W, const Axis& az,
+                                                  const Axis& ay, const Axis& ax) {
+  const int xb = min(ax.i0, W - 2);                 // pair base; clamped stencils select below
+  const bool x0_lo = ax.i0 == xb, x1_lo = ax.i1 == xb;
+  const float wz[2] = {1.f - az.w1, az.w1}, wy[2] = {1.f - ay.w1, ay.w1}, wx[2] = {1.f - ax.w1, ax.w1};
+  const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1};
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const F2u p = *reinterpret_cast<const F2u*>(vol + ((int64_t)iz[a] * H + iy[b]) * W + xb);
+      const float v0 = x0_lo ? p.x : p.y, v1 = x1_lo ? p.x : p.y;
+      s += wz[a] * wy[b] * wx[0] * v0;
+      s += wz[a] * wy[b] * wx[1] * v1;
+    }
+  return s;
+}
+
+
+// the 8 corner values of the stencil in tri_setup order k = a*4 + b*2 + c (x-pairs from 8-byte loads)
+__device__ __forceinline__ void tri_gather_pairs(const float* __restrict__ vol, int H, int W, const Axis& az,
+                                                 const Axis& ay, const Axis& ax, float* v) {
+  const int xb = min(ax.i0, W - 2);
+  const bool x0_lo = ax.i0 == xb, x1_lo = ax.i1 == xb;
+  const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const F2u p = *reinterpret_cast<const F2u*>(vol + ((int64_t)iz[a] * H + iy[b]) * W + xb);
+      v[a * 4 + b * 2] = x0_lo ? p.x : p.y;
+      v[a * 4 + b * 2 + 1] = x1_lo ? p.x : p.y;
+    }
+}
+
 __device__ __forceinline__ float lin_coord(int i, int n) {
   // tf.linspace(-1, 1, n)[i] = -1 + i*step, step = 2/(n-1)   (transform.py:171-177)
   const float step = n > 1 ? 2.f / (float)(n - 1) : 0.f;

@@ -99,9 +99,15 @@ __global__ void __launch_bounds__(256) rotate_render_fwd_kernel(const float* __r
   for (int z = D - 1; z >= 0; --z) {
     float cx, cy, cz;
     ray_coords(r, D, H, W, z, h, w, cx, cy, cz);
-    Tri t; Axis ax, ay, az;
-    tri_setup(cx, cy, cz, D, H, W, t, ax, ay, az);
-    const float s = tri_sample1(d, t);
+    float s;
+    if (W >= 2) {
+      const Axis az = axis_setup(cx, D), ay = axis_setup(cy, H), ax = axis_setup(cz, W);
+      s = tri_sample_pairs(d, H, W, az, ay, ax);
+    } else {
+      Tri t; Axis ax, ay, az;
+      tri_setup(cx, cy, cz, D, H, W, t, ax, ay, az);
+      s = tri_sample1(d, t);
+    }
     if (d_rot) d_rot[((int64_t)v * D + z) * HW + px] = s;  // rotated volume kept for the adjoint
     acc += s;
     I += s * expf(-acc * tau);

@@ -56,6 +56,10 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a, float* __rest
   tri_setup(cx, cy, cz, a.X, a.Y, a.Z, t, ax, ay, az);
   const float* src = a.src + (a.src_batched ? (int64_t)b * n * a.C : 0);
   float* o = out + gid * a.C;
+  if (a.C == 1 && a.Z >= 2) {   // scalar volume: x-corner pairs from 8-byte loads
+    o[0] = tri_sample_pairs(src, a.Y, a.Z, ax, ay, az);
+    return;
+  }
   for (int c = 0; c < a.C; ++c) {
     float s = 0.f;
 #pragma unroll
@@ -97,8 +101,12 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
     if (g_coord) {
       const float* src = a.src + boff;
       float v[8];
+      if (a.C == 1 && a.Z >= 2) {
+        tri_gather_pairs(src, a.Y, a.Z, ax, ay, az, v);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = src[t.o[k] * a.C + c];
+        for (int k = 0; k < 8; ++k) v[k] = src[t.o[k] * a.C + c];
+      }
       // k = a*4 + b*2 + c  (x,y,z bits)
       const float dx = wy[0] * wz[0] * (v[4] - v[0]) + wy[0] * wz[1] * (v[5] - v[1]) +
                        wy[1] * wz[0] * (v[6] - v[2]) + wy[1] * wz[1] * (v[7] - v[3]);
