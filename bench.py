@@ -117,6 +117,24 @@ def work_of(name, a):
     return None, 0.0
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch (read + write) of a kernel family from the committed rocprofv3 PMC passes
+    (profiles/r*_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
+    this same command; counters cannot be read from inside the run).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        tab = json.load(open(files[-1]))["kernels"]
+        rows = [v for k, v in tab.items() if kernel_substr in k]
+        if not rows:
+            return None
+        return sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in rows) / len(rows)
+    except Exception:
+        return None
+
+
 def kernel_table(profile, steps):
     rows = []
     for name, recs in sorted(profile.items()):
@@ -260,7 +278,7 @@ def main():
         n_launch = sum(r["launches_per_step"] for r in conv)
         out["roofline"] = {"kernel": "conv3x3_mfma_kernel (fwd+dgrad, %d launches/step)" % n_launch,
                            "bound": "mfma", "achieved": fl / ms, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": fl / ms / MFMA_F32_PEAK_TF, "traffic": None,
+                           "frac": fl / ms / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv3x3_mfma_kernel"),
                            "avg_launch_us": 1e3 * ms / n_launch, "ms_per_step": ms}
         out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
 
