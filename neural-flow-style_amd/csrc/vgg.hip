@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;                                  // [PATCH_MAX][36]
   float* wl = smem + PATCH_MAX * LDS_STRIDE;            // [2][BN][36]
-  int* rowpix = reinterpret_cast<int*>(wl + 2 * BN * LDS_STRIDE);  // [128]
+  // rowpix sits behind max(operand buffers, staged output tile) so that the epilogue tile cannot overwrite it
+  constexpr int OPER_FLOATS = PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE;
+  constexpr int TILE_FLOATS = BM * (BN + 4);
+  int* rowpix = reinterpret_cast<int*>(smem + (OPER_FLOATS > TILE_FLOATS ? OPER_FLOATS : TILE_FLOATS));  // [128]
 
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -215,24 +218,52 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
   }
 #undef NFS_LOAD_PATCH
 
-  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* outp = a.ksplit > 1 ? a.ws + (int64_t)blockIdx.z * a.B * a.H * a.W * a.Nc : a.y;
+  // epilogue.  The C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) gives 4-byte stores at a
+  // row stride: measured store-issue-bound (~1.1 TB/s, up to 70 us fixed per launch).  So the tile is transposed
+  // through LDS (the operand buffers are free now) and leaves as float4 rows: 8x fewer, 16-byte store instructions.
+  constexpr int OS = BN + 4;                               // padded row stride of the staged tile
+  float* otile = smem;                                     // [128][OS] aliases patch + weight buffers
+  __syncthreads();                                         // every wave is done reading operands
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int pix = rowpix[row];
-      if (pix < 0) continue;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 32 + i;
-        const int64_t idx = (int64_t)pix * a.Nc + n;
-        float v = acc[mt][nt][r];
-        if (a.ksplit == 1) v = conv_epilogue<MODE>(a, v, n, idx);
-        outp[idx] = v;
+      for (int nt = 0; nt < NT; ++nt) otile[row * OS + wn * (BN / 2) + nt * 32 + i] = acc[mt][nt][r];
+    }
+  __syncthreads();
+  float* outp = a.ksplit > 1 ? a.ws + (int64_t)blockIdx.z * a.B * a.H * a.W * a.Nc : a.y;
+  constexpr int Q = BN / 4;                                // float4 per row
+#pragma unroll
+  for (int e = 0; e < (BM * Q) / 256; ++e) {
+    const int f = t + 256 * e;
+    const int row = f / Q, q = f - row * Q;
+    const int pix = rowpix[row];
+    if (pix < 0) continue;
+    float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    const int n = n0 + 4 * q;
+    const int64_t idx = (int64_t)pix * a.Nc + n;
+    if (a.ksplit == 1) {
+      if (MODE == 0) {
+        if (a.aux0) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.aux0 + n);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      } else {
+        if (a.aux0) {
+          const float4 xin = *reinterpret_cast<const float4*>(a.aux0 + idx);
+          v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
+          v.z = xin.z > 0.f ? v.z : 0.f; v.w = xin.w > 0.f ? v.w : 0.f;
+        }
+        if (a.aux1) {
+          const float4 ad = *reinterpret_cast<const float4*>(a.aux1 + idx);
+          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+        }
       }
     }
+    *reinterpret_cast<float4*>(outp + idx) = v;
   }
 }
 
@@ -416,7 +447,8 @@ static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipSt
   const dim3 grid(mtiles, a.Nc / plan.bn, plan.ksplit);
   if (plan.bn == 128) {
     constexpr int BN = 128;
-    const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
+    const size_t oper = PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE, tile = BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float) + BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<BN, MODE>),
@@ -426,7 +458,8 @@ static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipSt
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), grid, dim3(256), lds, s, a);
   } else {
     constexpr int BN = 64;
-    const size_t lds = (PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE) * sizeof(float) + BM * sizeof(int);
+    const size_t oper = PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE, tile = BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float) + BM * sizeof(int);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), grid, dim3(256), lds, s, a);
   }
   if (plan.ksplit > 1)
