@@ -97,10 +97,13 @@ def test_rotate_bwd_tiled_c1(ops, shape, big):
     assert rel(acc - 1.0, gd[0]) < TOL
 
 
-def test_advect(ops):
+@pytest.mark.parametrize("shape", [(11, 9, 13), (12, 10, 16), (8, 6, 2)])
+def test_advect(ops, shape):
+    """(11,9,13): generic one-voxel kernels; n % 4 == 0 shapes: the 4-voxel scalar kernels"""
     torch.manual_seed(2)
-    d = torch.rand(1, 11, 9, 13, 1).requires_grad_()
-    v = (torch.randn(1, 11, 9, 13, 3) * 0.25).requires_grad_()
+    D, H, W = shape
+    d = torch.rand(1, D, H, W, 1).requires_grad_()
+    v = (torch.randn(1, D, H, W, 3) * 0.25).requires_grad_()
     ref = O.advect(d, v)
     out = ops.advect_fwd(dev(d[0]), dev(v[0]))
     assert rel(out, ref[0]) < TOL
@@ -109,6 +112,10 @@ def test_advect(ops):
     gd_h, gv_h = ops.advect_bwd(dev(d[0]), dev(v[0]), dev(g[0]))
     assert rel(gd_h, gd[0]) < TOL
     assert rel(gv_h, gv[0]) < TOL
+    _, gv_only = ops.advect_bwd(dev(d[0]), dev(v[0]), dev(g[0]), need_d=False)     # velocity-only adjoint
+    assert rel(gv_only, gv[0]) < TOL
+    d2 = torch.rand(1, D, H, W, 2)                                                  # C > 1 stays generic
+    assert rel(ops.advect_fwd(dev(d2[0]), dev(v[0])), O.advect(d2, v.detach())[0]) < TOL
 
 
 @pytest.mark.parametrize("k", [3.0, 0.0])
