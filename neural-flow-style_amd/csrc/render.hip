@@ -96,21 +96,46 @@ __global__ void __launch_bounds__(256) rotate_render_fwd_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = rot[v * 9 + i];
   float acc = 0.f, I = 0.f;
-  for (int z = D - 1; z >= 0; --z) {
-    float cx, cy, cz;
-    ray_coords(r, D, H, W, z, h, w, cx, cy, cz);
-    float s;
-    if (W >= 2) {
+  if (W >= 2) {
+    // 4 samples (16 paired gathers) are issued before the serial transmittance update consumes them: a
+    // one-sample loop is bound by the L2 round trip of each step, not by bandwidth
+    int z = D - 1;
+    for (; z >= 3; z -= 4) {
+      float sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float cx, cy, cz;
+        ray_coords(r, D, H, W, z - u, h, w, cx, cy, cz);
+        const Axis az = axis_setup(cx, D), ay = axis_setup(cy, H), ax = axis_setup(cz, W);
+        sv[u] = tri_sample_pairs(d, H, W, az, ay, ax);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (d_rot) d_rot[((int64_t)v * D + (z - u)) * HW + px] = sv[u];  // rotated volume kept for the adjoint
+        acc += sv[u];
+        I += sv[u] * expf(-acc * tau);
+      }
+    }
+    for (; z >= 0; --z) {
+      float cx, cy, cz;
+      ray_coords(r, D, H, W, z, h, w, cx, cy, cz);
       const Axis az = axis_setup(cx, D), ay = axis_setup(cy, H), ax = axis_setup(cz, W);
-      s = tri_sample_pairs(d, H, W, az, ay, ax);
-    } else {
+      const float sone = tri_sample_pairs(d, H, W, az, ay, ax);
+      if (d_rot) d_rot[((int64_t)v * D + z) * HW + px] = sone;
+      acc += sone;
+      I += sone * expf(-acc * tau);
+    }
+  } else {
+    for (int z = D - 1; z >= 0; --z) {
+      float cx, cy, cz;
+      ray_coords(r, D, H, W, z, h, w, cx, cy, cz);
       Tri t; Axis ax, ay, az;
       tri_setup(cx, cy, cz, D, H, W, t, ax, ay, az);
-      s = tri_sample1(d, t);
+      const float sone = tri_sample1(d, t);
+      if (d_rot) d_rot[((int64_t)v * D + z) * HW + px] = sone;
+      acc += sone;
+      I += sone * expf(-acc * tau);
     }
-    if (d_rot) d_rot[((int64_t)v * D + z) * HW + px] = s;  // rotated volume kept for the adjoint
-    acc += s;
-    I += s * expf(-acc * tau);
   }
   img[gid] = liquid ? 1.f - expf(-acc * tau) : I;
   if (raysum) raysum[gid] = acc;
