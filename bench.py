@@ -266,6 +266,9 @@ def main():
     # ---- per-kernel live measurement (extra profiled steps, after the headline timing) -----------
     if not args.no_kernel_profile:
         psteps = max(2, min(args.steps, 5))
+        # clean per-kernel timings need a single stream (with two concurrent view groups the event pairs of one
+        # stream also count the other stream's kernels sharing the chip); the headline above uses the default
+        gs.loss.vgg_streams = 1
         _lib.PROFILE = {}
         for _ in range(psteps):
             gs.step(rot_local)

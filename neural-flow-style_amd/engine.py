@@ -7,6 +7,8 @@ renderer and VGG as one batch, the field gradient accumulates over views in one 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -31,6 +33,10 @@ class RenderStyleLoss(object):
         self.w_tv = float(w_tv)
         self.v_batch = int(v_batch)
         self.two_pass_adjoint = True   # False: single fused adjoint with global atomics (less memory)
+        # view groups that run concurrently through VGG on separate HIP streams (measured at 8 views of 200^2:
+        # 1 stream 7.32 ms/step, 2 streams 7.01, 4 streams 8.10); used when there are >= 4 local views
+        self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "2"))
+        self._streams = []
         order = [s[0] for s in net.seq]
         self.top = max(self.layers, key=order.index)
         self.style_grams = None
@@ -81,6 +87,19 @@ class RenderStyleLoss(object):
         dimg, _ = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_x=False)
         return dimg
 
+    def _vgg_loss_grad(self, x, loss):
+        """x [B,h,w,3] (mean-subtracted) -> dL/dx; adds the per-image style losses into ``loss`` [B]"""
+        acts = self.net.forward(x, self.top)
+        sg = {}
+        for name, wl in zip(self.layers, self.w_layers):
+            F = acts[name]
+            _, h, w, c = F.shape
+            scale = 1.0 / (2.0 * h * w * c)
+            G = ops.gram_fwd(F, scale)
+            Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
+            sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        return self.net.backward(acts, sg, self.top)
+
     # -- the hot step -----------------------------------------------------------------------
     def loss_and_grad(self, d, rot, g_d):
         """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
@@ -91,17 +110,26 @@ class RenderStyleLoss(object):
         V = img.shape[0]
         H2, W2 = self.out_hw(H, W)
         dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0)
-        acts = self.net.forward(x, self.top)
         loss = torch.zeros(V, dtype=torch.float32, device=d.device)
-        sg = {}
-        for name, wl in zip(self.layers, self.w_layers):
-            F = acts[name]
-            _, h, w, c = F.shape
-            scale = 1.0 / (2.0 * h * w * c)
-            G = ops.gram_fwd(F, scale)
-            Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
-            sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
-        g_x = self.net.backward(acts, sg, self.top)
+        nst = min(self.vgg_streams, V) if V >= 4 else 1
+        if nst <= 1:
+            g_x = self._vgg_loss_grad(x, loss)
+        else:
+            # Independent view groups on separate HIP streams: the fill/drain phases of one group's conv
+            # launches (first tiles, epilogue store tail, split-K reduce) overlap the other group's steady state.
+            g_x = torch.empty_like(x)
+            main = torch.cuda.current_stream(d.device)
+            if len(self._streams) < nst:
+                self._streams = [torch.cuda.Stream(d.device) for _ in range(nst)]
+            bounds = [V * i // nst for i in range(nst + 1)]
+            for si in range(nst):
+                st = self._streams[si]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    lo, hi = bounds[si], bounds[si + 1]
+                    g_x[lo:hi].copy_(self._vgg_loss_grad(x[lo:hi], loss[lo:hi]))
+            for si in range(nst):
+                main.wait_stream(self._streams[si])
         if self.w_tv > 0:
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
             ops.tv_loss(dimg, self.w_tv, tv, g_x)

@@ -68,7 +68,7 @@ _workspaces = {}
 
 def workspace(device):
     """small per-device scratch (64 floats) for entry points that need a device-side scalar"""
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)   # one per stream
     if key not in _workspaces:
         _workspaces[key] = torch.zeros(64, dtype=torch.float32, device=device)
     return _workspaces[key]
@@ -219,7 +219,7 @@ _conv_ws = {}
 def conv_workspace(device, floats):
     """split-K scratch, grown on demand and shared by all conv calls of a device (calls on one stream
     are ordered, so sharing is safe)"""
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)   # one per stream
     cur = _conv_ws.get(key)
     if cur is None or cur.numel() < floats:
         cur = torch.empty(int(floats), dtype=torch.float32, device=device)
