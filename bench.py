@@ -269,6 +269,7 @@ def main():
         # clean per-kernel timings need a single stream (with two concurrent view groups the event pairs of one
         # stream also count the other stream's kernels sharing the chip); the headline above uses the default
         gs.loss.vgg_streams = 1
+        gs.loss.view_groups = 1
         _lib.PROFILE = {}
         for _ in range(psteps):
             gs.step(rot_local)

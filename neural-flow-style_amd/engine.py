@@ -36,6 +36,7 @@ class RenderStyleLoss(object):
         # view groups that run concurrently through VGG on separate HIP streams (measured at 8 views of 200^2:
         # 1 stream 7.32 ms/step, 2 streams 7.01, 4 streams 8.10); used when there are >= 4 local views
         self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "2"))
+        self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "2"))
         self._streams = []
         order = [s[0] for s in net.seq]
         self.top = max(self.layers, key=order.index)
@@ -101,51 +102,66 @@ class RenderStyleLoss(object):
         return self.net.backward(acts, sg, self.top)
 
     # -- the hot step -----------------------------------------------------------------------
-    def loss_and_grad(self, d, rot, g_d):
-        """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
-        Returns loss per view [V] (device tensor)."""
-        assert self.style_grams is not None, "call set_style_image first"
+    def _chain(self, d, rot, g_d):
+        """render -> loss net -> Gram losses -> full adjoint for the views ``rot`` on the CURRENT stream;
+        g_d [D,H,W] += dL/dd; returns the per-view losses"""
         D, H, W = d.shape
         img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint)
+        d_rot = self.d_rot
+        self.d_rot = None
         V = img.shape[0]
         H2, W2 = self.out_hw(H, W)
         dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0)
         loss = torch.zeros(V, dtype=torch.float32, device=d.device)
-        nst = min(self.vgg_streams, V) if V >= 4 else 1
-        if nst <= 1:
-            g_x = self._vgg_loss_grad(x, loss)
-        else:
-            # Independent view groups on separate HIP streams: the fill/drain phases of one group's conv
-            # launches (first tiles, epilogue store tail, split-K reduce) overlap the other group's steady state.
-            g_x = torch.empty_like(x)
-            main = torch.cuda.current_stream(d.device)
-            if len(self._streams) < nst:
-                self._streams = [torch.cuda.Stream(d.device) for _ in range(nst)]
-            bounds = [V * i // nst for i in range(nst + 1)]
-            for si in range(nst):
-                st = self._streams[si]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    lo, hi = bounds[si], bounds[si + 1]
-                    g_x[lo:hi].copy_(self._vgg_loss_grad(x[lo:hi], loss[lo:hi]))
-            for si in range(nst):
-                main.wait_stream(self._streams[si])
+        g_x = self._vgg_loss_grad(x, loss)
         if self.w_tv > 0:
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
             ops.tv_loss(dimg, self.w_tv, tv, g_x)
             loss = loss + tv / V
         g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
         g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
-        if self.rotate and self.d_rot is not None:
+        if self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
-            g_rot = ops.render_bwd(self.d_rot, rs, g_img, self.tau, self.liquid, g_d=self.d_rot)
+            g_rot = ops.render_bwd(d_rot, rs, g_img, self.tau, self.liquid, g_d=d_rot)
             ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1))
-            self.d_rot = None
         elif self.rotate:
             ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
         else:
             g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.liquid)[0])
+        return loss
+
+    def loss_and_grad(self, d, rot, g_d):
+        """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
+        Returns loss per view [V] (device tensor).
+
+        With >= 4 local views (and per-view normalisation, v_batch == 1) the views are split into groups
+        whose whole chains run on separate HIP streams: the MFMA-bound conv launches of one group overlap
+        the VALU/LDS-bound render and rotate-adjoint kernels and the fill/drain phases of the other."""
+        assert self.style_grams is not None, "call set_style_image first"
+        V = rot.shape[0] if self.rotate else 1
+        ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
+        ngroups = min(ngroups, V)
+        if ngroups <= 1:
+            return self._chain(d, rot, g_d)
+        nst = min(self.vgg_streams, ngroups)
+        main = torch.cuda.current_stream(d.device)
+        if len(self._streams) < nst:
+            self._streams = [torch.cuda.Stream(d.device) for _ in range(nst)]
+        loss = torch.empty(V, dtype=torch.float32, device=d.device)
+        g_parts = [torch.zeros_like(g_d) for _ in range(nst)]     # one accumulator per stream (plain RMW inside)
+        bounds = [V * i // ngroups for i in range(ngroups + 1)]
+        for si in range(nst):
+            self._streams[si].wait_stream(main)
+        for gi in range(ngroups):
+            si = gi % nst
+            with torch.cuda.stream(self._streams[si]):
+                lo, hi = bounds[gi], bounds[gi + 1]
+                loss[lo:hi].copy_(self._chain(d, rot[lo:hi].contiguous(), g_parts[si]))
+        for si in range(nst):
+            main.wait_stream(self._streams[si])
+        for gp in g_parts:
+            ops.axpy(g_d, gp, 1.0)
         return loss
 
 
