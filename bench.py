@@ -280,7 +280,10 @@ def main():
         ms = sum(r["ms_per_step"] for r in conv)
         fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)  # TF/s * ms
         n_launch = sum(r["launches_per_step"] for r in conv)
-        out["roofline"] = {"kernel": "conv3x3_mfma_kernel (fwd+dgrad, %d launches/step)" % n_launch,
+        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA (fwd+dgrad, %d launches/step): direct implicit GEMM "
+                                     "(conv3x3_mfma_kernel) for 64-channel layers, Winograd F(2x2,3x3) in float32 "
+                                     "(winograd_gemm_kernel + transforms) for >=128-channel layers; achieved = "
+                                     "ALGORITHMIC direct-conv flops / time" % n_launch,
                            "bound": "mfma", "achieved": fl / ms, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                            "frac": fl / ms / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv3x3_mfma_kernel"),
                            "avg_launch_us": 1e3 * ms / n_launch, "ms_per_step": ms}

@@ -21,6 +21,14 @@
 
 namespace nfs {
 
+// winograd.hip
+int64_t winograd_workspace_floats(int B, int H, int W, int K, int N);
+int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
+int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
+                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s);
+// layers with >= 128 channels on both sides take the Winograd F(2x2,3x3) path (2.25x fewer MFMA flops)
+static inline bool winograd_eligible(int K, int N) { return K >= 128 && N >= 128 && K % 32 == 0 && N % 64 == 0; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 32;        // channels per K chunk
@@ -433,6 +441,12 @@ static ConvPlan plan_conv(int mtiles, int Nc, int nchunks, int64_t mn, int64_t w
 template <int MODE>
 static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s) {
   ConvArgs a = base;
+  static const bool no_wg = getenv("NFS_NO_WINOGRAD") != nullptr;   // timing comparisons only
+  if (!no_wg && winograd_eligible(a.Kc, a.Nc) && a.H >= 2 && a.W >= 2 && ws &&
+      ws_floats >= winograd_workspace_floats(a.B, a.H, a.W, a.Kc, a.Nc)) {
+    const float* U = a.wp + (int64_t)9 * a.Kc * a.Nc;               // Winograd weights follow the direct packing
+    return winograd_conv(a.x, U, a.aux0, a.aux1, a.y, ws, a.B, a.H, a.W, a.Kc, a.Nc, MODE, a.relu, device_cus(), s);
+  }
   int tiles_r = 0;
   a.TH = 0;
   pick_tile(a.B, a.H, a.W, a.TH, a.TW, tiles_r, a.tiles_c);
@@ -474,9 +488,9 @@ using namespace nfs;
 extern "C" {
 
 int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind) {
-  (void)kind;
   if (Ci <= 0 || Co <= 0) return 0;
-  return (int64_t)9 * Ci * Co;
+  const int K = kind == 0 ? Ci : Co, N = kind == 0 ? Co : Ci;
+  return (int64_t)9 * Ci * Co + (winograd_eligible(K, N) ? (int64_t)16 * Ci * Co : 0);
 }
 
 int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind, nfs_stream_t stream) {
@@ -487,13 +501,20 @@ int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kin
   const int64_t n = (int64_t)9 * Ci * Co;
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), w_hwio, packed, Ci, Co,
                      kind);
+  const int K = kind == 0 ? Ci : Co, N = kind == 0 ? Co : Ci;
+  if (winograd_eligible(K, N))
+    if (int e = winograd_pack(w_hwio, packed + n, Ci, Co, kind, as_stream(stream))) return e;
   return check_launch("nfs_conv3x3_pack");
 }
 
 int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co) {
   if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  if (winograd_eligible(Ci, Co) && winograd_eligible(Co, Ci) && H >= 2 && W >= 2)
+    return winograd_workspace_floats(B, H, W, Ci > Co ? Ci : Co, Ci > Co ? Ci : Co);
+  // direct path: up to 16 K-splits of the larger M x N output, capped at 128 MB (big layers never split)
   const int64_t n = Ci > Co ? Ci : Co;
-  return (int64_t)16 * B * H * W * n;   // up to 16 K-splits of the larger of the two M x N outputs
+  const int64_t want = (int64_t)16 * B * H * W * n;
+  return want < ((int64_t)32 << 20) ? want : ((int64_t)32 << 20);
 }
 
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y, int B, int H, int W, int Ci,

@@ -1,0 +1,353 @@
+// A6, wide layers: 3x3 convolution by Winograd F(2x2, 3x3) in float32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, summed over input channels,
+//
+// i.e. 16 independent GEMMs  M_k[tile, co] = sum_ci V_k[tile, ci] * U_k[ci, co]  (k = 0..15)
+// instead of 9 taps: 16 multiplies per 4 outputs = 2.25x fewer MFMA flops than the direct implicit
+// GEMM of vgg.hip.  All arithmetic stays float32 (transforms are +-1 / 0.5 combinations, products on the
+// exact-f32 MFMA); the result differs from the direct form only by f32 rounding (~1e-6 relative).
+// Used for layers with >= 128 input and output channels, where the 4x larger transformed activations are
+// still small (conv3_2 ... conv5_1 and their data gradients: 75 % of the VGG flops).
+//
+//   winograd_input_kernel   x [B,H,W,K]        -> V  [16][T][K]     T = B * ceil(H/2) * ceil(W/2) tiles
+//   winograd_gemm_kernel    V, U [16][K/32][N][32] -> M [16][T][N]  f32 MFMA, same fragment scheme as vgg.hip
+//   winograd_output_kernel  M                  -> y [B,H,W,N]       + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
+#include "common.h"
+
+namespace nfs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- weights: U_k[ci][co] = (G g G^T)[k], packed [16][K/32][N][32] --------------------------------
+// kind 0: GEMM K = Ci, N = Co, g = w[:, :, ci, co];  kind 1 (data gradient): K = Co, N = Ci,
+// g[r][s] = w[2-r][2-s][ci][co] (taps flipped), k index = co, n index = ci.
+__global__ void __launch_bounds__(256) winograd_pack_kernel(const float* __restrict__ w, float* __restrict__ up,
+                                                            int Ci, int Co, int kind) {
+  const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)Kc * Nc) return;
+  const int n = (int)(gid % Nc), k = (int)(gid / Nc);
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (kind == 0) g[r][s] = w[((int64_t)(r * 3 + s) * Ci + k) * Co + n];
+      else g[r][s] = w[((int64_t)((2 - r) * 3 + (2 - s)) * Ci + n) * Co + k];
+    }
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  float t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+    t[3][s] = g[2][s];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u[4] = {t[r][0], 0.5f * (t[r][0] + t[r][1] + t[r][2]), 0.5f * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int comp = r * 4 + s;
+      up[(((int64_t)comp * (Kc / 32) + k / 32) * Nc + n) * 32 + (k & 31)] = u[s];
+    }
+  }
+}
+
+// ---- input transform: one thread = one tile x 4 channels --------------------------------------------
+__global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                             int B, int H, int W, int K, int TH, int TW) {
+  const int K4 = K >> 2;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= T * K4) return;
+  const int c4 = (int)(gid % K4);
+  const int64_t tile = gid / K4;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+  float4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int yy = y0 + r, xx = x0 + s;
+      d[r][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        d[r][s] = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + yy) * W + xx) * K + 4 * c4);
+    }
+  // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]   V = B^T d B
+#define NFS_F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
+  float4 t[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    t[0][s] = NFS_F4(-, d[0][s], d[2][s]);
+    t[1][s] = NFS_F4(+, d[1][s], d[2][s]);
+    t[2][s] = NFS_F4(-, d[2][s], d[1][s]);
+    t[3][s] = NFS_F4(-, d[1][s], d[3][s]);
+  }
+  const int64_t comp_stride = T * K;
+  float* vo = V + tile * K + 4 * c4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 o0 = NFS_F4(-, t[r][0], t[r][2]);
+    const float4 o1 = NFS_F4(+, t[r][1], t[r][2]);
+    const float4 o2 = NFS_F4(-, t[r][2], t[r][1]);
+    const float4 o3 = NFS_F4(-, t[r][1], t[r][3]);
+    *reinterpret_cast<float4*>(vo + (int64_t)(r * 4 + 0) * comp_stride) = o0;
+    *reinterpret_cast<float4*>(vo + (int64_t)(r * 4 + 1) * comp_stride) = o1;
+    *reinterpret_cast<float4*>(vo + (int64_t)(r * 4 + 2) * comp_stride) = o2;
+    *reinterpret_cast<float4*>(vo + (int64_t)(r * 4 + 3) * comp_stride) = o3;
+  }
+}
+
+// ---- 16 batched GEMMs on the f32 MFMA ------------------------------------------------------------------
+// block = 4 waves (2 M x 2 N), tile 128 rows x BN columns, K in 32-wide chunks; both operand tiles are
+// prefetched into registers one chunk ahead and double-buffered in LDS (36-float padded rows, b128 fragment
+// reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
+constexpr int WG_KC = 32, WG_LS = 36, WG_BM = 128;
+
+struct WgGemmArgs {
+  const float* V;    // [16][T][K]
+  const float* U;    // [16][K/32][N][32]
+  float* M;          // [16][T][N]
+  int64_t T;
+  int K, N;
+};
+
+template <int BN>
+__global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
+  constexpr int NT = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][128][36]
+  float* Bs = smem + 2 * WG_BM * WG_LS;               // [2][BN][36]
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
+  const int comp = blockIdx.z;
+  const int64_t m0 = (int64_t)blockIdx.x * WG_BM;
+  const int n0 = blockIdx.y * BN;
+  const float* Vc = a.V + (int64_t)comp * a.T * a.K;
+  const float* Uc = a.U + (int64_t)comp * a.K * a.N;
+  const int nchunks = a.K / WG_KC;
+
+  // staging: thread t moves float4 #(t&7) of rows (t>>3) + 32 j
+  const int q4 = 4 * (t & 7), r0 = t >> 3;
+  const float* arow[4];
+  bool aok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t m = m0 + r0 + 32 * j;
+    aok[j] = m < a.T;
+    arow[j] = Vc + (aok[j] ? m : 0) * a.K + q4;
+  }
+  const float4* brow = reinterpret_cast<const float4*>(Uc) + (int64_t)n0 * (WG_KC / 4) + t;  // slab-linear
+  const int64_t bslab4 = (int64_t)a.N * (WG_KC / 4);
+  float4 a0, a1, a2, a3, b0, b1, b2, b3;
+#define NFS_WG_LOAD(c_)                                                                         \
+  {                                                                                             \
+    a0 = a1 = a2 = a3 = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+    if (aok[0]) a0 = *reinterpret_cast<const float4*>(arow[0] + (c_) * WG_KC);                  \
+    if (aok[1]) a1 = *reinterpret_cast<const float4*>(arow[1] + (c_) * WG_KC);                  \
+    if (aok[2]) a2 = *reinterpret_cast<const float4*>(arow[2] + (c_) * WG_KC);                  \
+    if (aok[3]) a3 = *reinterpret_cast<const float4*>(arow[3] + (c_) * WG_KC);                  \
+    const float4* bn_ = brow + (int64_t)(c_) * bslab4;                                          \
+    b0 = bn_[0]; b1 = bn_[256];                                                                 \
+    if (BN > 64) { b2 = bn_[512]; b3 = bn_[768]; }                                              \
+  }
+  NFS_WG_LOAD(0)
+
+  int abase[2], bbase[NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) abase[mt] = (wm * 64 + mt * 32 + i) * WG_LS + 4 * h;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * (BN / 2) + nt * 32 + i) * WG_LS + 4 * h;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  for (int c = 0; c < nchunks; ++c) {
+    float* Ac = As + (c & 1) * WG_BM * WG_LS;
+    float* Bc = Bs + (c & 1) * BN * WG_LS;
+    {
+      float* ad = Ac + r0 * WG_LS + q4;
+      *reinterpret_cast<float4*>(ad) = a0;
+      *reinterpret_cast<float4*>(ad + 32 * WG_LS) = a1;
+      *reinterpret_cast<float4*>(ad + 64 * WG_LS) = a2;
+      *reinterpret_cast<float4*>(ad + 96 * WG_LS) = a3;
+      float* bd = Bc + r0 * WG_LS + q4;
+      *reinterpret_cast<float4*>(bd) = b0;
+      *reinterpret_cast<float4*>(bd + 32 * WG_LS) = b1;
+      if (BN > 64) {
+        *reinterpret_cast<float4*>(bd + 64 * WG_LS) = b2;
+        *reinterpret_cast<float4*>(bd + 96 * WG_LS) = b3;
+      }
+    }
+    __syncthreads();                       // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    if (c + 1 < nchunks) NFS_WG_LOAD(c + 1)
+#pragma unroll
+    for (int s = 0; s < WG_KC / 8; ++s) {
+      const float4 x0 = *reinterpret_cast<const float4*>(Ac + abase[0] + 8 * s);
+      const float4 x1 = *reinterpret_cast<const float4*>(Ac + abase[1] + 8 * s);
+      const float af0[4] = {x0.x, x0.y, x0.z, x0.w}, af1[4] = {x1.x, x1.y, x1.z, x1.w};
+      float bf[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 bq = *reinterpret_cast<const float4*>(Bc + bbase[nt] + 8 * s);
+        bf[nt][0] = bq.x; bf[nt][1] = bq.y; bf[nt][2] = bq.z; bf[nt][3] = bq.w;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[jj], bf[nt][jj], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[jj], bf[nt][jj], acc[1][nt], 0, 0, 0);
+        }
+    }
+  }
+#undef NFS_WG_LOAD
+
+  // epilogue: transpose the tile through LDS, leave as float4 rows
+  constexpr int OS = BN + 4;
+  float* otile = smem;
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) otile[row * OS + wn * (BN / 2) + nt * 32 + i] = acc[mt][nt][r];
+    }
+  __syncthreads();
+  float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  constexpr int Q = BN / 4;
+#pragma unroll
+  for (int e = 0; e < (WG_BM * Q) / 256; ++e) {
+    const int f = t + 256 * e;
+    const int row = f / Q, q = f - row * Q;
+    const int64_t m = m0 + row;
+    if (m >= a.T) continue;
+    *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+  }
+}
+
+// ---- output transform + layer epilogue: one thread = one tile x 4 channels -----------------------------
+template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
+__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
+                                                              const float* __restrict__ aux1, float* __restrict__ y,
+                                                              int B, int H, int W, int N, int TH, int TW, int relu) {
+  const int N4 = N >> 2;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= T * N4) return;
+  const int c4 = (int)(gid % N4);
+  const int64_t tile = gid / N4;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int64_t comp_stride = T * N;
+  const float* mi = M + tile * N + 4 * c4;
+  float4 m[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) m[r][s] = *reinterpret_cast<const float4*>(mi + (int64_t)(r * 4 + s) * comp_stride);
+  // A^T = [[1,1,1,0],[0,1,-1,-1]]    Y = A^T m A
+  float4 t[2][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    t[0][s] = make_float4(m[0][s].x + m[1][s].x + m[2][s].x, m[0][s].y + m[1][s].y + m[2][s].y,
+                          m[0][s].z + m[1][s].z + m[2][s].z, m[0][s].w + m[1][s].w + m[2][s].w);
+    t[1][s] = make_float4(m[1][s].x - m[2][s].x - m[3][s].x, m[1][s].y - m[2][s].y - m[3][s].y,
+                          m[1][s].z - m[2][s].z - m[3][s].z, m[1][s].w - m[2][s].w - m[3][s].w);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int yy = 2 * ty + a;
+    if (yy >= H) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int xx = 2 * tx + c;
+      if (xx >= W) continue;
+      float4 v;
+      if (c == 0) v = make_float4(t[a][0].x + t[a][1].x + t[a][2].x, t[a][0].y + t[a][1].y + t[a][2].y,
+                                  t[a][0].z + t[a][1].z + t[a][2].z, t[a][0].w + t[a][1].w + t[a][2].w);
+      else v = make_float4(t[a][1].x - t[a][2].x - t[a][3].x, t[a][1].y - t[a][2].y - t[a][3].y,
+                           t[a][1].z - t[a][2].z - t[a][3].z, t[a][1].w - t[a][2].w - t[a][3].w);
+      const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + 4 * c4;
+      if (MODE == 0) {
+        if (aux0) {
+          const float4 bb = *reinterpret_cast<const float4*>(aux0 + 4 * c4);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      } else {
+        if (aux0) {
+          const float4 xin = *reinterpret_cast<const float4*>(aux0 + idx);
+          v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
+          v.z = xin.z > 0.f ? v.z : 0.f; v.w = xin.w > 0.f ? v.w : 0.f;
+        }
+        if (aux1) {
+          const float4 ad = *reinterpret_cast<const float4*>(aux1 + idx);
+          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+        }
+      }
+      *reinterpret_cast<float4*>(y + idx) = v;
+    }
+  }
+}
+
+// ---- host side (called from vgg.hip) ---------------------------------------------------------------------
+int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
+  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return 16 * T * ((int64_t)K + N);
+}
+
+int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
+  const int64_t n = (int64_t)Ci * Co;
+  hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
+  return check_launch("winograd_pack");
+}
+
+// x [B,H,W,K] -> y [B,H,W,N]; U packed by winograd_pack; ws >= winograd_workspace_floats
+int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
+                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s) {
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const int64_t T = (int64_t)B * TH * TW;
+  float* V = ws;
+  float* M = ws + 16 * T * K;
+  hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
+                     TW);
+  WgGemmArgs a{V, U, M, T, K, N};
+  const int mt = (int)((T + WG_BM - 1) / WG_BM);
+  // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
+  const bool wide = (N % 128 == 0) && ((int64_t)mt * (N / 128) * 16 >= 4 * (int64_t)cus);
+  if (wide) {
+    constexpr int BN = 128;
+    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, N / BN, 16), dim3(256), lds, s, a);
+  } else {
+    constexpr int BN = 64;
+    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, N / BN, 16), dim3(256), lds, s, a);
+  }
+  const unsigned ob = blocks_for(T * (N / 4), 256);
+  if (mode == 0)
+    hipLaunchKernelGGL(winograd_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+  else
+    hipLaunchKernelGGL(winograd_output_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+  return check_launch("winograd_conv");
+}
+
+}  // namespace nfs

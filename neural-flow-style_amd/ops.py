@@ -230,8 +230,7 @@ def conv_workspace(device, floats):
 def _conv_ws_for(B, H, W, Ci, Co, device, splitk):
     if not splitk:
         return None, 0
-    # at most ~64 MB: the planner only splits when M x N is small
-    want = min(_lib.lib().nfs_conv3x3_workspace_floats(B, H, W, Ci, Co), 16 * 1024 * 1024)
+    want = _lib.lib().nfs_conv3x3_workspace_floats(B, H, W, Ci, Co)   # split-K partials or Winograd V/M buffers
     ws = conv_workspace(device, want)
     return ws, ws.numel()
 
