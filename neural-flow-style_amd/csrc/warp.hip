@@ -379,20 +379,28 @@ __global__ void __launch_bounds__(RT_THREADS) rotate_bwd_tiled_kernel(const floa
         if (ax.i1 < x0 || ax.i0 > x1) continue;
         const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
         const float wz[2] = {1.f - az.w1, az.w1}, wy[2] = {1.f - ay.w1, ay.w1}, wx[2] = {1.f - ax.w1, ax.w1};
+        const float gs = g * fscale * fscale2;              // fixed-point scale applied once per sample
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           if (iz[a] < z0 || iz[a] > z1) continue;
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             if (iy[b] < y0 || iy[b] > y1) continue;
-            const float wzy = wz[a] * wy[b] * g;
-            unsigned long long* arow = &acc[((iz[a] - z0) * RT_Y + (iy[b] - y0)) * RT_X - x0];
+            const float wzy = wz[a] * wy[b] * gs;
+            const int rowi = ((iz[a] - z0) * RT_Y + (iy[b] - y0)) * RT_X - x0;   // 32-bit LDS index
 #pragma unroll
             for (int cI = 0; cI < 2; ++cI) {
               if (ix[cI] < x0 || ix[cI] > x1) continue;
-              const float contrib = wzy * wx[cI];
-              if (contrib != 0.f)
-                atomicAdd(arow + ix[cI], (unsigned long long)__float2ll_rn(contrib * fscale * fscale2));
+              const float c = wzy * wx[cI];
+              if (c != 0.f) {
+                // float -> 64-bit fixed point in ~7 instructions: a float carries 24 significant bits, so take
+                // them as an int32 at exponent s and shift (the library conversion is a ~15-instruction sequence)
+                int e;
+                (void)frexpf(c, &e);
+                const int sh = max(e - 24, 0);
+                const long long q = (long long)(int)rintf(ldexpf(c, -sh)) << sh;
+                atomicAdd(&acc[rowi + ix[cI]], (unsigned long long)q);
+              }
             }
           }
         }
