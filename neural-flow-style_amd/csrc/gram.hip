@@ -7,8 +7,8 @@
 //   (32 lanes = one 256-B row segment, fully coalesced), feeding two MFMA row blocks with
 //   MFMA row i <-> channel c0+2i+q -- accumulates 2x2 MFMA tiles and adds its partial tile to
 //   G with float atomics.  No LDS: every operand is used by exactly one wave.
-// gram_bwd: M = pixels, N = K = C.  A wave = (image, 64 pixels, 64 output channels); A rows are
-//   b128 reads of F (4 consecutive k per lane feed 4 MFMA steps, as in the conv kernel).
+// gram_bwd: dF_b = 2 s_b F_b D_b is a plain batched GEMM (M = pixels, N = K = C): it runs on the LDS-staged
+//   batched f32-MFMA GEMM of winograd.hip (D is symmetric: its rows are read as columns), ReLU mask fused.
 #include "common.h"
 
 namespace nfs {
@@ -184,98 +184,9 @@ __global__ void __launch_bounds__(256) style_loss_kernel(const float* __restrict
   if (threadIdx.x == 0) atomicAdd(loss + b, part);
 }
 
-struct GramBwdArgs {
-  const float* F;
-  const float* Dm;
-  float* dF;
-  const float* scale_dev;
-  float scale;
-  int B, HW, C;
-  int npb;   // pixel blocks (64) per image
-  int ntile; // C / 64
-  int relu_mask;
-};
-
-__global__ void __launch_bounds__(256) gram_bwd_kernel(GramBwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int i = lane & 31, h = lane >> 5;
-  int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t per_img = (int64_t)a.npb * a.ntile;
-  if (unit >= per_img * a.B) return;
-  const int b = (int)(unit / per_img);
-  unit -= (int64_t)b * per_img;
-  const int pb = (int)(unit / a.ntile);
-  const int nt0 = (int)(unit - (int64_t)pb * a.ntile);
-  const float* Fb = a.F + (int64_t)b * a.HW * a.C;
-  const float* Db = a.Dm + (int64_t)b * a.C * a.C;
-  const int pbase = pb * 64;
-  // A rows: pixels pbase + mt*32 + i (clamped; out-of-range rows are never stored)
-  const float* arow[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) arow[mt] = Fb + (int64_t)min(pbase + mt * 32 + i, a.HW - 1) * a.C + 4 * h;
-  const int ncol = nt0 * 64 + i;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-
-  // K loop, manually double-buffered (the compiler does not unroll around the MFMA builtin): the
-  // operands of step k+1 (2 float4 of F, 8 dwords of D) are in flight while step k is multiplied.
-  const float* dcol = Db + (int64_t)(4 * h) * a.C + ncol;
-#define NFS_GB_LOAD(A0_, A1_, B0_, B1_, k8_)                                         \
-  {                                                                                  \
-    A0_ = *reinterpret_cast<const float4*>(arow[0] + (k8_));                         \
-    A1_ = *reinterpret_cast<const float4*>(arow[1] + (k8_));                         \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                               \
-      const float* dr = dcol + (int64_t)((k8_) + jj) * a.C;                          \
-      B0_[jj] = dr[0];                                                               \
-      B1_[jj] = dr[32];                                                              \
-    }                                                                                \
-  }
-#define NFS_GB_MMA(A0_, A1_, B0_, B1_)                                                              \
-  {                                                                                                 \
-    const float x0[4] = {A0_.x, A0_.y, A0_.z, A0_.w}, x1[4] = {A1_.x, A1_.y, A1_.z, A1_.w};         \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                              \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[jj], B0_[jj], acc[0][0], 0, 0, 0);        \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[jj], B1_[jj], acc[0][1], 0, 0, 0);        \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[jj], B0_[jj], acc[1][0], 0, 0, 0);        \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[jj], B1_[jj], acc[1][1], 0, 0, 0);        \
-    }                                                                                               \
-  }
-  {
-    float4 pa0, pa1, qa0, qa1;
-    float pb0[4], pb1[4], qb0[4], qb1[4];
-    NFS_GB_LOAD(pa0, pa1, pb0, pb1, 0)
-    for (int k8 = 0; k8 < a.C; k8 += 16) {        // C is a multiple of 64
-      NFS_GB_LOAD(qa0, qa1, qb0, qb1, k8 + 8)
-      NFS_GB_MMA(pa0, pa1, pb0, pb1)
-      if (k8 + 16 < a.C) NFS_GB_LOAD(pa0, pa1, pb0, pb1, k8 + 16)
-      NFS_GB_MMA(qa0, qa1, qb0, qb1)
-    }
-  }
-#undef NFS_GB_LOAD
-#undef NFS_GB_MMA
-  const float sc = 2.f * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
-  float* dFb = a.dF + (int64_t)b * a.HW * a.C;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int px = pbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (px >= a.HW) continue;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int64_t idx = (int64_t)px * a.C + nt0 * 64 + nt * 32 + i;
-        float v = acc[mt][nt][r] * sc;
-        if (a.relu_mask) v = Fb[idx] > 0.f ? v : 0.f;
-        dFb[idx] = v;
-      }
-    }
-}
+// winograd.hip: batched f32-MFMA GEMM (LDS-staged, double-buffered) shared with the Winograd convolution
+int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
+                  int relu_mask, int cus, hipStream_t s);
 
 }  // namespace nfs
 
@@ -338,12 +249,10 @@ int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, in
   NFS_REQUIRE(F && Dmat && dF, "nfs_gram_bwd: null pointer");
   NFS_REQUIRE(B > 0 && HW > 0, "nfs_gram_bwd: non-positive dimension");
   NFS_REQUIRE(C > 0 && C % 64 == 0, "nfs_gram_bwd: C must be a multiple of 64");
-  GramBwdArgs a;
-  a.F = F; a.Dm = Dmat; a.dF = dF; a.scale_dev = scale_dev; a.scale = scale;
-  a.B = B; a.HW = HW; a.C = C; a.npb = (HW + 63) / 64; a.ntile = C / 64; a.relu_mask = relu_mask;
-  const int64_t units = (int64_t)B * a.npb * a.ntile;
-  hipLaunchKernelGGL(gram_bwd_kernel, dim3(blocks_for(units, 4)), dim3(256), 0, as_stream(stream), a);
-  return check_launch("nfs_gram_bwd");
+  // dF[b] = 2 * scale_b * F[b] @ D[b]: M = pixels, N = K = C; D is symmetric, so its rows serve as columns
+  static int cus = 0;
+  if (cus == 0) { const int c = nfs_device_cus(); cus = c > 0 ? c : 256; }
+  return gram_bwd_gemm(F, Dmat, dF, B, HW, C, 2.f * scale, scale_dev, relu_mask, cus, as_stream(stream));
 }
 
 }  // extern "C"

@@ -107,12 +107,19 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 // reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
 constexpr int WG_KC = 32, WG_LS = 36, WG_BM = 128;
 
+// Batched C_z = alpha_z * A_z B_z (optionally masked): the Winograd GEMMs (z = transform component) and the
+// Gram gradient dF_b = 2 s_b F_b D_b (z = image) share this kernel.
 struct WgGemmArgs {
-  const float* V;    // [16][T][K]
-  const float* U;    // [16][K/32][N][32]
-  float* M;          // [16][T][N]
+  const float* V;    // A: [Z][T][K] row-major
+  const float* U;    // B: element (k, n) of batch z at z*b_batch + (k/32)*b_chunk + n*b_row + k%32
+  float* M;          // C: [Z][T][N] row-major
   int64_t T;
   int K, N;
+  int64_t b_batch, b_chunk;
+  int b_row;
+  float alpha;               // C scale (1 for Winograd)
+  const float* alpha_dev;    // optional per-batch scale (device)
+  const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
 };
 
 template <int BN>
@@ -127,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   const int64_t m0 = (int64_t)blockIdx.x * WG_BM;
   const int n0 = blockIdx.y * BN;
   const float* Vc = a.V + (int64_t)comp * a.T * a.K;
-  const float* Uc = a.U + (int64_t)comp * a.K * a.N;
+  const float* Uc = a.U + (int64_t)comp * a.b_batch;
   const int nchunks = a.K / WG_KC;
 
   // staging: thread t moves float4 #(t&7) of rows (t>>3) + 32 j
@@ -140,8 +147,9 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     aok[j] = m < a.T;
     arow[j] = Vc + (aok[j] ? m : 0) * a.K + q4;
   }
-  const float4* brow = reinterpret_cast<const float4*>(Uc) + (int64_t)n0 * (WG_KC / 4) + t;  // slab-linear
-  const int64_t bslab4 = (int64_t)a.N * (WG_KC / 4);
+  // B rows n0 + (t>>3) + 32 r, float4 #(t&7) of the 32 k of a chunk
+  const float* brow = Uc + (int64_t)(n0 + r0) * a.b_row + q4;
+  const int64_t brs = (int64_t)32 * a.b_row;
   float4 a0, a1, a2, a3, b0, b1, b2, b3;
 #define NFS_WG_LOAD(c_)                                                                         \
   {                                                                                             \
@@ -150,9 +158,13 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     if (aok[1]) a1 = *reinterpret_cast<const float4*>(arow[1] + (c_) * WG_KC);                  \
     if (aok[2]) a2 = *reinterpret_cast<const float4*>(arow[2] + (c_) * WG_KC);                  \
     if (aok[3]) a3 = *reinterpret_cast<const float4*>(arow[3] + (c_) * WG_KC);                  \
-    const float4* bn_ = brow + (int64_t)(c_) * bslab4;                                          \
-    b0 = bn_[0]; b1 = bn_[256];                                                                 \
-    if (BN > 64) { b2 = bn_[512]; b3 = bn_[768]; }                                              \
+    const float* bn_ = brow + (int64_t)(c_) * a.b_chunk;                                        \
+    b0 = *reinterpret_cast<const float4*>(bn_);                                                 \
+    b1 = *reinterpret_cast<const float4*>(bn_ + brs);                                           \
+    if (BN > 64) {                                                                              \
+      b2 = *reinterpret_cast<const float4*>(bn_ + 2 * brs);                                     \
+      b3 = *reinterpret_cast<const float4*>(bn_ + 3 * brs);                                     \
+    }                                                                                           \
   }
   NFS_WG_LOAD(0)
 
@@ -225,6 +237,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     }
   __syncthreads();
   float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
   constexpr int Q = BN / 4;
 #pragma unroll
   for (int e = 0; e < (WG_BM * Q) / 256; ++e) {
@@ -232,7 +245,15 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     const int row = f / Q, q = f - row * Q;
     const int64_t m = m0 + row;
     if (m >= a.T) continue;
-    *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    const int64_t idx = m * a.N + n0 + 4 * q;
+    if (a.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)comp * a.T * a.N + idx);
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+      v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(Mc + idx) = v;
   }
 }
 
@@ -300,7 +321,39 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
   }
 }
 
-// ---- host side (called from vgg.hip) ---------------------------------------------------------------------
+// ---- host side -----------------------------------------------------------------------------------------------
+static void launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s) {
+  const int mt = (int)((a.T + WG_BM - 1) / WG_BM);
+  // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
+  const bool wide = (a.N % 128 == 0) && ((int64_t)mt * (a.N / 128) * Z >= 4 * (int64_t)cus);
+  if (wide) {
+    constexpr int BN = 128;
+    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, a.N / BN, Z), dim3(256), lds, s, a);
+  } else {
+    constexpr int BN = 64;
+    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
+    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, a.N / BN, Z), dim3(256), lds, s, a);
+  }
+}
+
+// dF[b] = alpha_b * F[b] @ D[b] (D symmetric, so row n of D serves as column n), optional (F > 0) mask
+int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
+                  int relu_mask, int cus, hipStream_t s) {
+  WgGemmArgs a{F, Dm, dF, (int64_t)HW, C, C, (int64_t)C * C, 32, C, alpha, alpha_dev, relu_mask ? F : nullptr};
+  launch_batched_gemm(a, B, cus, s);
+  return check_launch("gram_bwd_gemm");
+}
+
+// ---- Winograd host side (called from vgg.hip) ------------------------------------------------------------
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
   const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
   return 16 * T * ((int64_t)K + N);
@@ -321,27 +374,8 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   float* M = ws + 16 * T * K;
   hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
                      TW);
-  WgGemmArgs a{V, U, M, T, K, N};
-  const int mt = (int)((T + WG_BM - 1) / WG_BM);
-  // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
-  const bool wide = (N % 128 == 0) && ((int64_t)mt * (N / 128) * 16 >= 4 * (int64_t)cus);
-  if (wide) {
-    constexpr int BN = 128;
-    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
-    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, N / BN, 16), dim3(256), lds, s, a);
-  } else {
-    constexpr int BN = 64;
-    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
-    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, N / BN, 16), dim3(256), lds, s, a);
-  }
+  WgGemmArgs a{V, U, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
+  launch_batched_gemm(a, 16, cus, s);
   const unsigned ob = blocks_for(T * (N / 4), 256);
   if (mode == 0)
     hipLaunchKernelGGL(winograd_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
