@@ -221,26 +221,37 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
 }
 
 // ---- output-stationary adjoint of rotate for C = 1 -------------------------------------------
-// Global float atomics cap the scatter at ~90 G atomics/s (5.6 ms for 8 views of 200^3).  Here a
-// block OWNS a TZ x TY x TX tile of g_d in LDS.  For every view it inverse-maps the tile's
-// catchment box (tile +-1 cell; open-ended on volume faces, because out-of-range samples clamp
-// onto them) through the affine sample map x = A o + c and visits every sample of g_out inside the
-// integer bounding box (x fastest => coalesced reads), recomputes the forward stencil and
-// accumulates the corners that fall inside the tile with LDS atomics.  Measured on gfx950
-// (tools/lds_atomic_bench.hip): ds_add_f32 sustains only 0.33 lanes/clk/CU while ds_add_u64 runs
-// at 9.4 -- so the tile accumulates in 64-bit FIXED POINT: contributions are scaled by 2^k, with k
-// chosen from max|g_out| (a streaming pre-pass) so that no voxel sum can overflow; with ~49 bits
-// below the largest value this is more accurate than f32 accumulation and, integer adds being
-// associative, bit-reproducible.  Four samples per thread are in flight (loads issued before any
-// use).  One plain read-modify-write of g_d per tile at the end: no global atomics.
-constexpr int RT_Z = 16, RT_Y = 16, RT_X = 32;
+// Global float atomics cap the scatter at ~90 G atomics/s (5.6 ms for 8 views of 200^3), and LDS float
+// atomics are no better: measured on gfx950 (tools/lds_atomic_bench.hip) ds_add_f32 sustains 0.33
+// lanes/clk/CU while ds_add_u64 runs at 9.4.  So the tile accumulates in 64-bit FIXED POINT:
+// contributions are scaled by 2^k, with k chosen from max|g_out| (a streaming pre-pass) so that no voxel
+// sum can overflow; with ~49 bits below the largest value this is more accurate than f32 accumulation and,
+// integer adds being associative, bit-reproducible.
+// A block owns RT_TZ x RT_TY x RT_TX voxels of g_d and keeps them, plus a one-cell halo on every side, in
+// LDS as 64-bit fixed-point accumulators (LDS float atomics run at 1/40 of the integer rate on gfx950).
+// It walks, view by view, the output-lattice rows that cross its catchment (the samples whose base cell
+// lies in [tile_lo - 1, tile_hi]), each row clipped to the exact x-interval; a sample in the catchment adds
+// all 8 corners with compile-time LDS offsets and no per-corner tests (the halo absorbs the corners that
+// belong to neighbouring tiles; only the owned cells are written back).  No global atomics; the integer
+// sums make the result independent of the traversal order.
+#ifndef NFS_RT_TZ
+#define NFS_RT_TZ 14
+#define NFS_RT_TY 14
+#define NFS_RT_TX 30
+#define NFS_RT_GROUP 8
+#endif
+constexpr int RT_TZ = NFS_RT_TZ, RT_TY = NFS_RT_TY, RT_TX = NFS_RT_TX;
+constexpr int RT_LZ = RT_TZ + 2, RT_LY = RT_TY + 2, RT_LX = RT_TX + 2;
 constexpr int RT_THREADS = 1024;
-constexpr int RT_VMAX = 32;  // views per launch (host loops over chunks)
-constexpr int RT_UNROLL = 4;
+constexpr int RT_GROUP = NFS_RT_GROUP;   // lanes that share one lattice row
+constexpr int RT_VMAX = 32;   // views per launch (host loops over chunks)
 
-struct ViewBox {           // per (block, view), in LDS
-  int lo[3], ext[3];       // sample bounding box (z,y,x) and extents
-  unsigned mx, my;         // magic reciprocals ceil(2^32/ext) for x and y
+struct ViewRows {             // per (block, view), in LDS
+  // voxel-space sample coordinate of axis a at lattice point (oz,oy,ox): c + a0*oz + a1*oy + s*ox
+  float a0[3], a1[3], s[3], inv_s[3], c[3];
+  float lo[3], hi[3];         // catchment (padded) in voxel space
+  int z_lo, y_lo, x_lo, x_hi, ey, rows;
+  unsigned my;                // ceil(2^32 / ey)
 };
 
 // max |x| over n floats -> *out (as float bits; non-negative floats order like unsigned ints)
@@ -260,159 +271,209 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
 }
 
-__global__ void __launch_bounds__(RT_THREADS) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,
-                                                                      const float* __restrict__ rot,
-                                                                      float* __restrict__ g_d,
-                                                                      const unsigned* __restrict__ gmax_bits,
-                                                                      float bound_factor, int V, int D, int H,
-                                                                      int W, int tiles_y, int tiles_x) {
-  __shared__ unsigned long long acc[RT_Z * RT_Y * RT_X];
-  __shared__ ViewBox vbox[RT_VMAX];
+// catchment of one (tile, view).  Kept out of line: its double-precision temporaries must not raise the
+// register count of the hot loop.
+__device__ __attribute__((noinline)) void rotate_tile_catchment(const float* r, int D, int H, int W, int z0, int y0,
+                                                                 int x0, int z1, int y1, int x1, ViewRows* out) {
+  const int n[3] = {D, H, W};
+  const int tlo[3] = {z0, y0, x0}, thi[3] = {z1, y1, x1};
+  // cmin/cmax: the range the (unclamped) sample coordinate of axis a takes over the whole output lattice;
+  // a border tile also catches the samples clamped onto it, so its catchment extends to that range
+  double A[3][3], c[3], xl[3], xh[3];
+  for (int a = 0; a < 3; ++a) {
+    const double ha = 0.5 * (n[a] - 1);
+    double rs = 0.0, mn = 0.0, mx = 0.0;
+    for (int b = 0; b < 3; ++b) {
+      const double sb = n[b] > 1 ? 2.0 / (n[b] - 1) : 0.0;
+      A[a][b] = (double)r[a * 3 + b] * sb * ha;
+      rs += (double)r[a * 3 + b];
+      mn += fmin(A[a][b] * (n[b] - 1), 0.0);
+      mx += fmax(A[a][b] * (n[b] - 1), 0.0);
+    }
+    c[a] = (1.0 - rs) * ha;
+    // base cell floor(u) in [tlo-1, thi]  <=>  u in [tlo-1, thi+1); 0.05-cell pad covers the float evaluation
+    xl[a] = (tlo[a] == 0) ? fmin(c[a] + mn - 0.5, -1.05) : tlo[a] - 1.05;
+    xh[a] = (thi[a] == n[a] - 1) ? fmax(c[a] + mx + 0.5, n[a] + 0.05) : thi[a] + 1.05;
+  }
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) -
+                     A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  int lo[3] = {0, 0, 0}, hi[3] = {D - 1, H - 1, W - 1};
+  if (fabs(det) > 1e-9) {
+    double inv[3][3];
+    inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
+    inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+    inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+    inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
+    inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    // box centre / half widths in voxel space -> centre / half extents in lattice space
+    double oc[3] = {0, 0, 0}, oe[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+      const double mid = 0.5 * (xl[a] + xh[a]) - c[a], half = 0.5 * (xh[a] - xl[a]);
+      for (int b = 0; b < 3; ++b) {
+        oc[b] += inv[b][a] * mid;
+        oe[b] += fabs(inv[b][a]) * half;
+      }
+    }
+    for (int b = 0; b < 3; ++b) {
+      lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]), 0.0), (double)n[b]);
+      hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]), (double)(n[b] - 1)), -1.0);
+    }
+  }
+  ViewRows vr;
+  for (int a = 0; a < 3; ++a) {
+    vr.a0[a] = (float)A[a][0];
+    vr.a1[a] = (float)A[a][1];
+    vr.s[a] = (float)A[a][2];
+    vr.inv_s[a] = fabs(A[a][2]) > 1e-6 ? (float)(1.0 / A[a][2]) : 0.f;
+    vr.c[a] = (float)c[a];
+    vr.lo[a] = (float)xl[a];
+    vr.hi[a] = (float)xh[a];
+  }
+  const int ez = max(hi[0] - lo[0] + 1, 0), ey = max(hi[1] - lo[1] + 1, 0);
+  vr.z_lo = lo[0]; vr.y_lo = lo[1]; vr.x_lo = lo[2]; vr.x_hi = hi[2];
+  vr.ey = ey;
+  vr.rows = hi[2] >= lo[2] ? ez * ey : 0;
+  vr.my = ey > 1 ? (unsigned)(((1ull << 32) + ey - 1) / ey) : 0u;
+  *out = vr;
+}
+
+// one axis of the border-replicating trilinear stencil with the two corners at constant offsets: base cell
+// i0 (clipped), weights (w0, w1) of cells i0 and i0 + 1.  Where the reference's clipped corners coincide
+// (x < 0 or x >= n-1: both weights land on the border voxel and sum to 1) the whole weight goes to i0.
+struct AxisH { int i0; float w0, w1; };
+__device__ __forceinline__ AxisH axis_halo(float c, int n) {
+  const float x = (c + 1.f) * (float)(n - 1) * 0.5f;
+  float f = floorf(x);
+  f = fminf(fmaxf(f, -1.f), (float)n);
+  const int i = (int)f;
+  AxisH a;
+  a.i0 = min(max(i, 0), n - 1);
+  const bool same = (unsigned)i >= (unsigned)(n - 1);
+  const float w1 = x - (float)a.i0;
+  a.w1 = same ? 0.f : w1;
+  a.w0 = same ? 1.f : 1.f - w1;
+  return a;
+}
+
+__global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,
+                                                                         const float* __restrict__ rot,
+                                                                         float* __restrict__ g_d,
+                                                                         const unsigned* __restrict__ gmax_bits,
+                                                                         float bound_factor, int V, int D, int H,
+                                                                         int W, int tiles_y, int tiles_x) {
+  __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
+  __shared__ ViewRows vrows[RT_VMAX];
   const int t = threadIdx.x;
-  const int bx = blockIdx.x % tiles_x;
-  const int by = (blockIdx.x / tiles_x) % tiles_y;
-  const int bz = blockIdx.x / (tiles_x * tiles_y);
-  const int z0 = bz * RT_Z, y0 = by * RT_Y, x0 = bx * RT_X;
-  const int z1 = min(z0 + RT_Z, D) - 1, y1 = min(y0 + RT_Y, H) - 1, x1 = min(x0 + RT_X, W) - 1;  // inclusive
-  for (int i = t; i < RT_Z * RT_Y * RT_X; i += RT_THREADS) acc[i] = 0ull;
+  // launch order: x-border tiles first, then z-border, then the interior (border tiles also collect the
+  // clamped out-of-volume samples and run longest; starting them first keeps them off the tail)
+  const int tiles_z = gridDim.x / (tiles_x * tiles_y);
+  const int by = blockIdx.x % tiles_y;
+  const int oz_ = (blockIdx.x / tiles_y) % tiles_z;
+  const int ox_ = blockIdx.x / (tiles_y * tiles_z);
+  const int bz = oz_ == 0 ? 0 : (oz_ == 1 ? tiles_z - 1 : oz_ - 1);
+  const int bx = ox_ == 0 ? 0 : (ox_ == 1 ? tiles_x - 1 : ox_ - 1);
+  const int z0 = bz * RT_TZ, y0 = by * RT_TY, x0 = bx * RT_TX;
+  const int z1 = min(z0 + RT_TZ, D) - 1, y1 = min(y0 + RT_TY, H) - 1, x1 = min(x0 + RT_TX, W) - 1;  // inclusive
+  for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
   // fixed-point scale 2^k: |any voxel sum| <= bound_factor * max|g_out| must stay below 2^62
   const float gmax = __uint_as_float(*gmax_bits);
-  if (!(gmax > 0.f)) return;                      // all-zero (or NaN-free empty) gradient: nothing to add
+  if (!(gmax > 0.f)) return;                      // all-zero gradient: nothing to add
   int ebound;
   frexpf(gmax * bound_factor, &ebound);           // gmax*bound_factor < 2^ebound
   const int kexp = 62 - ebound;
-  const float fscale = ldexpf(1.f, min(max(kexp, -120), 120));
-  const float fscale2 = ldexpf(1.f, kexp - min(max(kexp, -120), 120));  // split: 2^k may exceed the float range
+  // samples are scaled by 2^(k-32): the integer part of a product is the high word, the fraction the low word
+  const int ks = kexp - 32;
+  const float fscale = ldexpf(1.f, min(max(ks, -120), 120));
+  const float fscale2 = ldexpf(1.f, ks - min(max(ks, -120), 120));  // split: 2^ks may exceed the float range
 
-  if (t < V) {
-    const float* r = rot + t * 9;
-    const int n[3] = {D, H, W};
-    const int tlo[3] = {z0, y0, x0}, thi[3] = {z1, y1, x1};
-    double A[3][3], c[3], big[3];
-    for (int a = 0; a < 3; ++a) {
-      const double ha = 0.5 * (n[a] - 1);
-      double rs = 0.0;
-      big[a] = 4.0;
-      for (int b = 0; b < 3; ++b) {
-        const double sb = n[b] > 1 ? 2.0 / (n[b] - 1) : 0.0;
-        A[a][b] = (double)r[a * 3 + b] * sb * ha;
-        rs += (double)r[a * 3 + b];
-        big[a] += fabs(A[a][b]) * (n[b] - 1);
-      }
-      c[a] = (1.0 - rs) * ha;
-      big[a] += fabs(c[a]);
-    }
-    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) -
-                       A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-    int lo[3] = {0, 0, 0}, hi[3] = {D - 1, H - 1, W - 1};
-    if (fabs(det) > 1e-9) {
-      double inv[3][3];
-      inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
-      inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
-      inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
-      inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
-      inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
-      inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
-      inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
-      inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
-      inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
-      // box centre / half widths in x-space -> centre / half extents in sample space
-      double oc[3] = {0, 0, 0}, oe[3] = {0, 0, 0};
-      for (int a = 0; a < 3; ++a) {
-        const double xl = (tlo[a] == 0) ? -big[a] : tlo[a] - 1.02;
-        const double xh = (thi[a] == n[a] - 1) ? big[a] : thi[a] + 1.02;
-        const double mid = 0.5 * (xl + xh) - c[a], half = 0.5 * (xh - xl);
-        for (int b = 0; b < 3; ++b) {
-          oc[b] += inv[b][a] * mid;
-          oe[b] += fabs(inv[b][a]) * half;
-        }
-      }
-      for (int b = 0; b < 3; ++b) {
-        // the catchment box already carries a 0.02-cell pad: no extra integer margin needed
-        lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]), 0.0), (double)n[b]);
-        hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]), (double)(n[b] - 1)), -1.0);
-      }
-    }
-    ViewBox vb;
-    for (int b = 0; b < 3; ++b) { vb.lo[b] = lo[b]; vb.ext[b] = max(hi[b] - lo[b] + 1, 0); }
-    vb.mx = vb.ext[2] > 1 ? (unsigned)(((1ull << 32) + vb.ext[2] - 1) / vb.ext[2]) : 0u;
-    vb.my = vb.ext[1] > 1 ? (unsigned)(((1ull << 32) + vb.ext[1] - 1) / vb.ext[1]) : 0u;
-    vbox[t] = vb;
-  }
+  if (t < V) rotate_tile_catchment(rot + t * 9, D, H, W, z0, y0, x0, z1, y1, x1, &vrows[t]);
   __syncthreads();
 
+  const int grp = t / RT_GROUP, gl = t % RT_GROUP;
+  constexpr int NGRP = RT_THREADS / RT_GROUP;
+  const unsigned nz = (unsigned)(z1 - z0 + 1), ny = (unsigned)(y1 - y0 + 1), nx = (unsigned)(x1 - x0 + 1);
   for (int v = 0; v < V; ++v) {
-    const int lz = vbox[v].lo[0], ly = vbox[v].lo[1], lx = vbox[v].lo[2];
-    const int ey = vbox[v].ext[1], ex = vbox[v].ext[2];
-    const unsigned mx = vbox[v].mx, my = vbox[v].my;
-    const int total = vbox[v].ext[0] * ey * ex;
-    if (total <= 0) continue;
+    const ViewRows& vr = vrows[v];
+    const int rows = vr.rows;
+    if (rows <= 0) continue;
     const float* r = rot + v * 9;
-    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+    const float r2 = r[2], r5 = r[5], r8 = r[8];
     const float* gv = g_out + (int64_t)v * D * H * W;
-    for (int base = t; base < total; base += RT_THREADS * RT_UNROLL) {
-      float gval[RT_UNROLL];
-      int oz[RT_UNROLL], oy[RT_UNROLL], ox[RT_UNROLL];
+    for (int row = grp; row < rows; row += NGRP) {
+      const int zi = vr.ey > 1 ? (int)__umulhi((unsigned)row, vr.my) : row;
+      const int oy = vr.y_lo + (row - zi * vr.ey), oz = vr.z_lo + zi;
+      // exact x-interval of this row inside the catchment slab of every axis
+      float ta = (float)vr.x_lo, tb = (float)vr.x_hi;
+      const float fz = (float)oz, fy = (float)oy;
 #pragma unroll
-      for (int u = 0; u < RT_UNROLL; ++u) {
-        const int i = base + u * RT_THREADS;
-        // i = (z*ey + y)*ex + x ; exact magic division (i < 2^22, ext < 2^11)
-        const int rowi = ex > 1 ? (int)__umulhi((unsigned)i, mx) : i;
-        ox[u] = i - rowi * ex;
-        const int zi = ey > 1 ? (int)__umulhi((unsigned)rowi, my) : rowi;
-        oy[u] = rowi - zi * ey;
-        oz[u] = zi;
-        gval[u] = 0.f;
-        if (i < total) gval[u] = gv[((int64_t)(lz + oz[u]) * H + (ly + oy[u])) * W + (lx + ox[u])];
+      for (int a = 0; a < 3; ++a) {
+        const float p = vr.c[a] + vr.a0[a] * fz + vr.a1[a] * fy;
+        if (vr.inv_s[a] != 0.f) {
+          const float u0 = (vr.lo[a] - p) * vr.inv_s[a], u1 = (vr.hi[a] - p) * vr.inv_s[a];
+          ta = fmaxf(ta, fminf(u0, u1) - 0.01f);
+          tb = fminf(tb, fmaxf(u0, u1) + 0.01f);
+        } else if (p < vr.lo[a] || p > vr.hi[a]) {
+          tb = ta - 2.f;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < RT_UNROLL; ++u) {
-        const float g = gval[u];
-        if (g == 0.f) continue;
-        const float gz_ = lin_coord(lz + oz[u], D), gy_ = lin_coord(ly + oy[u], H), gx_ = lin_coord(lx + ox[u], W);
-        const Axis az = axis_setup(r0 * gz_ + r1 * gy_ + r2 * gx_, D);
-        if (az.i1 < z0 || az.i0 > z1) continue;
-        const Axis ay = axis_setup(r3 * gz_ + r4 * gy_ + r5 * gx_, H);
-        if (ay.i1 < y0 || ay.i0 > y1) continue;
-        const Axis ax = axis_setup(r6 * gz_ + r7 * gy_ + r8 * gx_, W);
-        if (ax.i1 < x0 || ax.i0 > x1) continue;
-        const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
-        const float wz[2] = {1.f - az.w1, az.w1}, wy[2] = {1.f - ay.w1, ay.w1}, wx[2] = {1.f - ax.w1, ax.w1};
-        const float gs = g * fscale * fscale2;              // fixed-point scale applied once per sample
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          if (iz[a] < z0 || iz[a] > z1) continue;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            if (iy[b] < y0 || iy[b] > y1) continue;
-            const float wzy = wz[a] * wy[b] * gs;
-            const int rowi = ((iz[a] - z0) * RT_Y + (iy[b] - y0)) * RT_X - x0;   // 32-bit LDS index
-#pragma unroll
-            for (int cI = 0; cI < 2; ++cI) {
-              if (ix[cI] < x0 || ix[cI] > x1) continue;
-              const float c = wzy * wx[cI];
-              if (c != 0.f) {
-                // float -> 64-bit fixed point in ~7 instructions: a float carries 24 significant bits, so take
-                // them as an int32 at exponent s and shift (the library conversion is a ~15-instruction sequence)
-                int e;
-                (void)frexpf(c, &e);
-                const int sh = max(e - 24, 0);
-                const long long q = (long long)(int)rintf(ldexpf(c, -sh)) << sh;
-                atomicAdd(&acc[rowi + ix[cI]], (unsigned long long)q);
-              }
-            }
+      const int xa = (int)ceilf(ta), xb = (int)floorf(tb);
+      if (xb < xa) continue;
+      const float gz_ = lin_coord(oz, D), gy_ = lin_coord(oy, H);
+      const float pz = r[0] * gz_ + r[1] * gy_, py = r[3] * gz_ + r[4] * gy_, px = r[6] * gz_ + r[7] * gy_;
+      const float* grow = gv + ((int64_t)oz * H + oy) * W;
+      int ox = xa + gl;
+      float g = ox <= xb ? grow[ox] : 0.f;
+      while (ox <= xb) {
+        const int oxn = ox + RT_GROUP;
+        const float gn = oxn <= xb ? grow[oxn] : 0.f;
+        if (g != 0.f) {
+          const float gx_ = lin_coord(ox, W);
+          const AxisH az = axis_halo(pz + r2 * gx_, D);
+          const AxisH ay = axis_halo(py + r5 * gx_, H);
+          const AxisH ax = axis_halo(px + r8 * gx_, W);
+          const int lz = az.i0 - z0 + 1, ly = ay.i0 - y0 + 1, lx = ax.i0 - x0 + 1;   // halo'd local base cell
+          if ((unsigned)lz <= nz && (unsigned)ly <= ny && (unsigned)lx <= nx) {
+            const float gs = g * fscale * fscale2;
+            const float wz0 = gs * az.w0, wz1 = gs * az.w1;
+            const float w00 = wz0 * ay.w0, w01 = wz0 * ay.w1, w10 = wz1 * ay.w0, w11 = wz1 * ay.w1;
+            unsigned long long* cell = acc + (lz * RT_LY + ly) * RT_LX + lx;
+// float -> 64-bit two's-complement fixed point in 4 instructions: high word = floor (v_cvt_flr_i32_f32),
+// low word = fract * 2^32 (v_fract_f32 is < 1 by construction; v_cvt_u32_f32 saturates)
+#define NFS_RT_ADD(off_, w_)                                                                       \
+  {                                                                                                \
+    const float c_ = (w_);                                                                         \
+    unsigned lo_, hi_;                                                                             \
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi_) : "v"(c_));                                         \
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo_) : "v"(__builtin_amdgcn_fractf(c_) * 4294967296.f));     \
+    atomicAdd(cell + (off_), ((unsigned long long)hi_ << 32) | lo_);                               \
+  }
+            NFS_RT_ADD(0, w00 * ax.w0)
+            NFS_RT_ADD(1, w00 * ax.w1)
+            NFS_RT_ADD(RT_LX, w01 * ax.w0)
+            NFS_RT_ADD(RT_LX + 1, w01 * ax.w1)
+            NFS_RT_ADD(RT_LY * RT_LX, w10 * ax.w0)
+            NFS_RT_ADD(RT_LY * RT_LX + 1, w10 * ax.w1)
+            NFS_RT_ADD(RT_LY * RT_LX + RT_LX, w11 * ax.w0)
+            NFS_RT_ADD(RT_LY * RT_LX + RT_LX + 1, w11 * ax.w1)
+#undef NFS_RT_ADD
           }
         }
+        g = gn;
+        ox = oxn;
       }
     }
   }
   __syncthreads();
-  for (int i = t; i < RT_Z * RT_Y * RT_X; i += RT_THREADS) {
-    const int lx_ = i % RT_X, ly_ = (i / RT_X) % RT_Y, lz_ = i / (RT_X * RT_Y);
+  for (int i = t; i < RT_TZ * RT_TY * RT_TX; i += RT_THREADS) {
+    const int lx_ = i % RT_TX, ly_ = (i / RT_TX) % RT_TY, lz_ = i / (RT_TX * RT_TY);
     const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
     if (z < D && y < H && x < W) {
-      const long long q = (long long)acc[i];
+      const long long q = (long long)acc[((lz_ + 1) * RT_LY + ly_ + 1) * RT_LX + lx_ + 1];
       if (q != 0) g_d[((int64_t)z * H + y) * W + x] += (float)ldexp((double)q, -kexp);
     }
   }
@@ -467,7 +528,7 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
   NFS_REQUIRE(g_out && rot && g_d_acc, "nfs_rotate_bwd: null pointer");
   if (int e = check_dims(V, D, H, W, C)) return e;
   if (C == 1 && workspace) {
-    const int tz = (D + RT_Z - 1) / RT_Z, ty = (H + RT_Y - 1) / RT_Y, tx = (W + RT_X - 1) / RT_X;
+    const int tz = (D + RT_TZ - 1) / RT_TZ, ty = (H + RT_TY - 1) / RT_TY, tx = (W + RT_TX - 1) / RT_TX;
     unsigned* gmax_bits = reinterpret_cast<unsigned*>(workspace);
     if (hipMemsetAsync(gmax_bits, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
       set_error("nfs_rotate_bwd: memset failed");
