@@ -23,10 +23,11 @@ namespace nfs {
 
 // winograd.hip
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N);
+int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s);
-// layers with >= 128 channels on both sides take the Winograd F(2x2,3x3) path (2.25x fewer MFMA flops)
+// layers with >= 128 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops)
 static inline bool winograd_eligible(int K, int N) { return K >= 128 && N >= 128 && K % 32 == 0 && N % 64 == 0; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -490,7 +491,7 @@ extern "C" {
 int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind) {
   if (Ci <= 0 || Co <= 0) return 0;
   const int K = kind == 0 ? Ci : Co, N = kind == 0 ? Co : Ci;
-  return (int64_t)9 * Ci * Co + (winograd_eligible(K, N) ? (int64_t)16 * Ci * Co : 0);
+  return (int64_t)9 * Ci * Co + (winograd_eligible(K, N) ? winograd_packed_floats(Ci, Co) : 0);
 }
 
 int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind, nfs_stream_t stream) {

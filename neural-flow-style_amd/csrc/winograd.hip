@@ -1,17 +1,18 @@
-// A6, wide layers: 3x3 convolution by Winograd F(2x2, 3x3) in float32.
+// A6, wide layers: 3x3 convolution by Winograd F(m x m, 3x3) in float32, m = 4 (default) or 2.
 //
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, summed over input channels,
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per m x m output tile, summed over input channels,
 //
-// i.e. 16 independent GEMMs  M_k[tile, co] = sum_ci V_k[tile, ci] * U_k[ci, co]  (k = 0..15)
-// instead of 9 taps: 16 multiplies per 4 outputs = 2.25x fewer MFMA flops than the direct implicit
-// GEMM of vgg.hip.  All arithmetic stays float32 (transforms are +-1 / 0.5 combinations, products on the
-// exact-f32 MFMA); the result differs from the direct form only by f32 rounding (~1e-6 relative).
-// Used for layers with >= 128 input and output channels, where the 4x larger transformed activations are
-// still small (conv3_2 ... conv5_1 and their data gradients: 75 % of the VGG flops).
+// i.e. (m+2)^2 independent GEMMs  M_k[tile, co] = sum_ci V_k[tile, ci] * U_k[ci, co]  instead of 9 taps:
+// 36 multiplies per 16 outputs (m = 4: 4x fewer MFMA flops than the direct implicit GEMM of vgg.hip) or 16 per
+// 4 outputs (m = 2: 2.25x fewer).  All arithmetic stays float32 (products on the exact-f32 MFMA); the result
+// differs from the direct form only by f32 rounding: ~4e-7 relative L2 for m = 2 (same as direct), ~3e-6 for
+// m = 4 with the standard interpolation points 0, +-1, +-2, inf (what cuDNN's fp32 Winograd, which the
+// reference runs on, uses as well).  NFS_WINOGRAD_TILE=2 selects m = 2.
+// Used for layers with >= 128 input and output channels (conv2_2 ... conv5_1 and their data gradients).
 //
-//   winograd_input_kernel   x [B,H,W,K]        -> V  [16][T][K]     T = B * ceil(H/2) * ceil(W/2) tiles
-//   winograd_gemm_kernel    V, U [16][K/32][N][32] -> M [16][T][N]  f32 MFMA, same fragment scheme as vgg.hip
-//   winograd_output_kernel  M                  -> y [B,H,W,N]       + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
+//   winograd_input*_kernel   x [B,H,W,K]            -> V [(m+2)^2][T][K]    T = B * ceil(H/m) * ceil(W/m) tiles
+//   winograd_gemm_kernel     V, U [(m+2)^2][K/32][N][32] -> M [(m+2)^2][T][N]  f32 MFMA, fragment scheme of vgg.hip
+//   winograd_output*_kernel  M                      -> y [B,H,W,N]    + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
 #include "common.h"
 
 namespace nfs {
@@ -101,7 +102,168 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
   }
 }
 
-// ---- 16 batched GEMMs on the f32 MFMA ------------------------------------------------------------------
+// ---- F(4x4, 3x3): weights U_k = (G g G^T)[k], k = 0..35, packed [36][K/32][N][32] ----------------------
+// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+__device__ __forceinline__ void wg4_g(const float g0, const float g1, const float g2, float* u) {
+  u[0] = 0.25f * g0;
+  u[1] = (-1.f / 6.f) * (g0 + g1 + g2);
+  u[2] = (-1.f / 6.f) * (g0 - g1 + g2);
+  u[3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  u[4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  u[5] = g2;
+}
+
+__global__ void __launch_bounds__(256) winograd_pack4_kernel(const float* __restrict__ w, float* __restrict__ up,
+                                                             int Ci, int Co, int kind) {
+  const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)Kc * Nc) return;
+  const int n = (int)(gid % Nc), k = (int)(gid / Nc);
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (kind == 0) g[r][s] = w[((int64_t)(r * 3 + s) * Ci + k) * Co + n];
+      else g[r][s] = w[((int64_t)((2 - r) * 3 + (2 - s)) * Ci + n) * Co + k];
+    }
+  float t[6][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float u[6];
+    wg4_g(g[0][s], g[1][s], g[2][s], u);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t[r][s] = u[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float u[6];
+    wg4_g(t[r][0], t[r][1], t[r][2], u);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      up[(((int64_t)(r * 6 + q) * (Kc / 32) + k / 32) * Nc + n) * 32 + (k & 31)] = u[q];
+  }
+}
+
+// B^T (6x6) applied to a column / row of float2 channel pairs
+__device__ __forceinline__ float2 wg_lin(float a, float2 x, float b, float2 y) { return make_float2(a * x.x + b * y.x, a * x.y + b * y.y); }
+__device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
+  // [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0] [0,-2,-1,2,1,0] [0,2,-1,-2,1,0] [0,4,0,-5,0,1]
+  const float2 p = wg_lin(-4.f, d[2], 1.f, d[4]);     // d4 - 4 d2
+  const float2 q = wg_lin(-4.f, d[1], 1.f, d[3]);     // d3 - 4 d1
+  const float2 e = wg_lin(-1.f, d[2], 1.f, d[4]);     // d4 - d2
+  const float2 f = wg_lin(-2.f, d[1], 2.f, d[3]);     // 2 (d3 - d1)
+  o[0] = make_float2(4.f * d[0].x - 5.f * d[2].x + d[4].x, 4.f * d[0].y - 5.f * d[2].y + d[4].y);
+  o[1] = make_float2(p.x + q.x, p.y + q.y);
+  o[2] = make_float2(p.x - q.x, p.y - q.y);
+  o[3] = make_float2(e.x + f.x, e.y + f.y);
+  o[4] = make_float2(e.x - f.x, e.y - f.y);
+  o[5] = make_float2(4.f * d[1].x - 5.f * d[3].x + d[5].x, 4.f * d[1].y - 5.f * d[3].y + d[5].y);
+}
+
+// input transform: one thread = one 6x6 patch x 2 channels (a wave covers 128 contiguous channels per pixel)
+__global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                              int B, int H, int W, int K, int TH, int TW) {
+  const int K2 = K >> 1;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= T * K2) return;
+  const int c2 = (int)(gid % K2);
+  const int64_t tile = gid / K2;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+  float2 t[6][6];   // t[s][r]: column s after the vertical pass
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    float2 d[6];
+    const int xx = x0 + s;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = y0 + r;
+      d[r] = make_float2(0.f, 0.f);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+    }
+    wg4_bt(d, t[s]);
+  }
+  const int64_t comp_stride = T * K;
+  float* vo = V + tile * K + 2 * c2;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const float2 row[6] = {t[0][r], t[1][r], t[2][r], t[3][r], t[4][r], t[5][r]};
+    float2 o[6];
+    wg4_bt(row, o);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<float2*>(vo + (int64_t)(r * 6 + q) * comp_stride) = o[q];
+  }
+}
+
+// A^T (4x6) = [1,1,1,1,1,0] [0,1,-1,2,-2,0] [0,1,1,4,4,0] [0,1,-1,8,-8,1]
+__device__ __forceinline__ void wg4_at(const float2* m, float2* o) {
+  const float2 s12 = make_float2(m[1].x + m[2].x, m[1].y + m[2].y), d12 = make_float2(m[1].x - m[2].x, m[1].y - m[2].y);
+  const float2 s34 = make_float2(m[3].x + m[4].x, m[3].y + m[4].y), d34 = make_float2(m[3].x - m[4].x, m[3].y - m[4].y);
+  o[0] = make_float2(m[0].x + s12.x + s34.x, m[0].y + s12.y + s34.y);
+  o[1] = make_float2(d12.x + 2.f * d34.x, d12.y + 2.f * d34.y);
+  o[2] = make_float2(s12.x + 4.f * s34.x, s12.y + 4.f * s34.y);
+  o[3] = make_float2(d12.x + 8.f * d34.x + m[5].x, d12.y + 8.f * d34.y + m[5].y);
+}
+
+// output transform + layer epilogue: one thread = one 4x4 output tile x 2 channels
+template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
+__global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
+                                                               const float* __restrict__ aux1, float* __restrict__ y,
+                                                               int B, int H, int W, int N, int TH, int TW, int relu) {
+  const int N2 = N >> 1;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= T * N2) return;
+  const int c2 = (int)(gid % N2);
+  const int64_t tile = gid / N2;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int64_t comp_stride = T * N;
+  const float* mi = M + tile * N + 2 * c2;
+  float2 t[6][4];   // t[s][a]: column s after the vertical pass
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    float2 m[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 6 + s) * comp_stride);
+    wg4_at(m, t[s]);
+  }
+  float2 bias = make_float2(0.f, 0.f);
+  if (MODE == 0 && aux0) bias = *reinterpret_cast<const float2*>(aux0 + 2 * c2);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = 4 * ty + a;
+    if (yy >= H) continue;
+    const float2 row[6] = {t[0][a], t[1][a], t[2][a], t[3][a], t[4][a], t[5][a]};
+    float2 o[4];
+    wg4_at(row, o);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int xx = 4 * tx + c;
+      if (xx >= W) continue;
+      float2 v = o[c];
+      const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + 2 * c2;
+      if (MODE == 0) {
+        v.x += bias.x; v.y += bias.y;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+      } else {
+        if (aux0) {
+          const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
+          v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
+        }
+        if (aux1) {
+          const float2 ad = *reinterpret_cast<const float2*>(aux1 + idx);
+          v.x += ad.x; v.y += ad.y;
+        }
+      }
+      *reinterpret_cast<float2*>(y + idx) = v;
+    }
+  }
+}
+
+// ---- batched GEMMs on the f32 MFMA ------------------------------------------------------------------
 // block = 4 waves (2 M x 2 N), tile 128 rows x BN columns, K in 32-wide chunks; both operand tiles are
 // prefetched into registers one chunk ahead and double-buffered in LDS (36-float padded rows, b128 fragment
 // reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
@@ -354,33 +516,58 @@ int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int
 }
 
 // ---- Winograd host side (called from vgg.hip) ------------------------------------------------------------
-int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
-  const int64_t T = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  return 16 * T * ((int64_t)K + N);
+int winograd_tile() {
+  static const int m = [] { const char* e = getenv("NFS_WINOGRAD_TILE"); return (e && atoi(e) == 2) ? 2 : 4; }();
+  return m;
 }
+
+int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
+  const int64_t T2 = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2), T4 = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+  const int64_t comps = 16 * T2 > 36 * T4 ? 16 * T2 : 36 * T4;     // either tile size fits
+  return comps * ((int64_t)K + N);
+}
+
+// 36 floats per (ci, co): room for either tile size
+int64_t winograd_packed_floats(int Ci, int Co) { return (int64_t)36 * Ci * Co; }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
   const int64_t n = (int64_t)Ci * Co;
-  hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
+  if (winograd_tile() == 4)
+    hipLaunchKernelGGL(winograd_pack4_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
+  else
+    hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
 }
 
 // x [B,H,W,K] -> y [B,H,W,N]; U packed by winograd_pack; ws >= winograd_workspace_floats
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s) {
-  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const int m = winograd_tile(), comps = (m + 2) * (m + 2);
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
-  float* M = ws + 16 * T * K;
-  hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
-                     TW);
-  WgGemmArgs a{V, U, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
-  launch_batched_gemm(a, 16, cus, s);
-  const unsigned ob = blocks_for(T * (N / 4), 256);
-  if (mode == 0)
-    hipLaunchKernelGGL(winograd_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+  float* M = ws + comps * T * K;
+  if (m == 4)
+    hipLaunchKernelGGL(winograd_input4_kernel, dim3(blocks_for(T * (K / 2), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
+                       TW);
   else
-    hipLaunchKernelGGL(winograd_output_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+    hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
+                       TW);
+  WgGemmArgs a{V, U, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
+  launch_batched_gemm(a, comps, cus, s);
+  if (m == 4) {
+    const unsigned ob = blocks_for(T * (N / 2), 256);
+    if (mode == 0)
+      hipLaunchKernelGGL(winograd_output4_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+    else
+      hipLaunchKernelGGL(winograd_output4_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+  } else {
+    const unsigned ob = blocks_for(T * (N / 4), 256);
+    if (mode == 0)
+      hipLaunchKernelGGL(winograd_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+    else
+      hipLaunchKernelGGL(winograd_output_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+  }
   return check_launch("winograd_conv");
 }
 

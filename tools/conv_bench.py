@@ -35,5 +35,5 @@ def bench(B, reps=5):
 
 
 if __name__ == "__main__":
-    for B in (8, 1):
+    for B in [int(a) for a in sys.argv[1:]] or (8, 1):
         bench(B)
