@@ -27,8 +27,12 @@ int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s);
-// layers with >= 128 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops)
-static inline bool winograd_eligible(int K, int N) { return K >= 128 && N >= 128 && K % 32 == 0 && N % 64 == 0; }
+// layers with >= 64 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops); only the
+// 3-channel conv1_1 stays direct.  NFS_WINOGRAD_MIN_CH raises the threshold (timing comparisons).
+static inline bool winograd_eligible(int K, int N) {
+  static const int min_ch = [] { const char* e = getenv("NFS_WINOGRAD_MIN_CH"); return e ? atoi(e) : 64; }();
+  return K >= min_ch && N >= min_ch && K % 32 == 0 && N % 64 == 0;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -8,7 +8,7 @@
 // differs from the direct form only by f32 rounding: ~4e-7 relative L2 for m = 2 (same as direct), ~3e-6 for
 // m = 4 with the standard interpolation points 0, +-1, +-2, inf (what cuDNN's fp32 Winograd, which the
 // reference runs on, uses as well).  NFS_WINOGRAD_TILE=2 selects m = 2.
-// Used for layers with >= 128 input and output channels (conv2_2 ... conv5_1 and their data gradients).
+// Used for layers with >= 64 input and output channels (conv1_2 ... conv5_1 and their data gradients).
 //
 //   winograd_input*_kernel   x [B,H,W,K]            -> V [(m+2)^2][T][K]    T = B * ceil(H/m) * ceil(W/m) tiles
 //   winograd_gemm_kernel     V, U [(m+2)^2][K/32][N][32] -> M [(m+2)^2][T][N]  f32 MFMA, fragment scheme of vgg.hip
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
 // block = 4 waves (2 M x 2 N), tile 128 rows x BN columns, K in 32-wide chunks; both operand tiles are
 // prefetched into registers one chunk ahead and double-buffered in LDS (36-float padded rows, b128 fragment
 // reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
-constexpr int WG_KC = 32, WG_LS = 36, WG_BM = 128;
+constexpr int WG_KC = 32, WG_LS = 36, WG_BM = 128, WG_XCDS = 8;
 
 // Batched C_z = alpha_z * A_z B_z (optionally masked): the Winograd GEMMs (z = transform component) and the
 // Gram gradient dF_b = 2 s_b F_b D_b (z = image) share this kernel.
@@ -282,19 +282,27 @@ struct WgGemmArgs {
   float alpha;               // C scale (1 for Winograd)
   const float* alpha_dev;    // optional per-batch scale (device)
   const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
+  int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
 };
 
-template <int BN>
+template <int BN, int NBUF>
 __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   constexpr int NT = BN / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                   // [2][128][36]
-  float* Bs = smem + 2 * WG_BM * WG_LS;               // [2][BN][36]
+  float* As = smem;                                   // [NBUF][128][36]
+  float* Bs = smem + NBUF * WG_BM * WG_LS;            // [NBUF][BN][36]
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
-  const int comp = blockIdx.z;
-  const int64_t m0 = (int64_t)blockIdx.x * WG_BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with its own
+  // 4 MB L2).  Remap so that each XCD walks a CONTIGUOUS range of (batch, n, m) tiles: the ~64 workgroups an
+  // XCD runs at a time then share one batch's A and B panels, which fit its L2.
+  const int per_xcd = gridDim.x / WG_XCDS;
+  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;
+  if (logical >= a.mt * a.nt * a.Z) return;
+  const int comp = logical / (a.mt * a.nt);
+  const int rem = logical - comp * (a.mt * a.nt);
+  const int64_t m0 = (int64_t)(rem % a.mt) * WG_BM;
+  const int n0 = (rem / a.mt) * BN;
   const float* Vc = a.V + (int64_t)comp * a.T * a.K;
   const float* Uc = a.U + (int64_t)comp * a.b_batch;
   const int nchunks = a.K / WG_KC;
@@ -345,8 +353,9 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   for (int c = 0; c < nchunks; ++c) {
-    float* Ac = As + (c & 1) * WG_BM * WG_LS;
-    float* Bc = Bs + (c & 1) * BN * WG_LS;
+    float* Ac = As + (NBUF == 2 ? (c & 1) : 0) * WG_BM * WG_LS;
+    float* Bc = Bs + (NBUF == 2 ? (c & 1) : 0) * BN * WG_LS;
+    if (NBUF == 1 && c > 0) __syncthreads();          // single buffer: everyone is done reading chunk c-1
     {
       float* ad = Ac + r0 * WG_LS + q4;
       *reinterpret_cast<float4*>(ad) = a0;
@@ -484,26 +493,35 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
-static void launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s) {
+template <int BN, int NBUF>
+static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
+  const size_t oper = NBUF * (WG_BM + BN) * WG_LS, tile = WG_BM * (BN + 4);
+  const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN, NBUF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  hipLaunchKernelGGL((winograd_gemm_kernel<BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
+}
+
+static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
+  static const int nbuf = [] { const char* e = getenv("NFS_GEMM_NBUF"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  static const int force_bn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 0; }();
   const int mt = (int)((a.T + WG_BM - 1) / WG_BM);
   // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
-  const bool wide = (a.N % 128 == 0) && ((int64_t)mt * (a.N / 128) * Z >= 4 * (int64_t)cus);
+  bool wide = (a.N % 128 == 0) && ((int64_t)mt * (a.N / 128) * Z >= 4 * (int64_t)cus);
+  if (force_bn == 64) wide = false;
+  if (force_bn == 128 && a.N % 128 == 0) wide = true;
+  a.mt = mt;
+  a.Z = Z;
+  a.nt = a.N / (wide ? 128 : 64);
   if (wide) {
-    constexpr int BN = 128;
-    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
-    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, a.N / BN, Z), dim3(256), lds, s, a);
+    if (nbuf == 2) launch_gemm_variant<128, 2>(a, s); else launch_gemm_variant<128, 1>(a, s);
   } else {
-    constexpr int BN = 64;
-    const size_t oper = 2 * WG_BM * WG_LS + 2 * BN * WG_LS, tile = WG_BM * (BN + 4);
-    const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-    hipLaunchKernelGGL(winograd_gemm_kernel<BN>, dim3(mt, a.N / BN, Z), dim3(256), lds, s, a);
+    if (nbuf == 2) launch_gemm_variant<64, 2>(a, s); else launch_gemm_variant<64, 1>(a, s);
   }
 }
 
@@ -522,9 +540,9 @@ int winograd_tile() {
 }
 
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
-  const int64_t T2 = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2), T4 = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-  const int64_t comps = 16 * T2 > 36 * T4 ? 16 * T2 : 36 * T4;     // either tile size fits
-  return comps * ((int64_t)K + N);
+  const int m = winograd_tile();
+  const int64_t T = (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
+  return (m + 2) * (m + 2) * T * ((int64_t)K + N);
 }
 
 // 36 floats per (ci, co): room for either tile size

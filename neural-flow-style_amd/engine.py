@@ -33,10 +33,12 @@ class RenderStyleLoss(object):
         self.w_tv = float(w_tv)
         self.v_batch = int(v_batch)
         self.two_pass_adjoint = True   # False: single fused adjoint with global atomics (less memory)
-        # view groups that run concurrently through VGG on separate HIP streams (measured at 8 views of 200^2:
-        # 1 stream 7.32 ms/step, 2 streams 7.01, 4 streams 8.10); used when there are >= 4 local views
-        self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "2"))
-        self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "2"))
+        # optional: view groups that run concurrently through VGG on separate HIP streams (>= 4 local views).
+        # With the direct conv kernels two groups overlapped each other's launch tails (7.32 -> 7.01 ms/step);
+        # with the Winograd path one batch of all views on one stream is fastest (8 views of 200^2: 1 stream
+        # 4.73 ms/step, 2 streams 4.79, 4 streams 6.38), so that is the default.
+        self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "1"))
+        self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "1"))
         self._streams = []
         order = [s[0] for s in net.seq]
         self.top = max(self.layers, key=order.index)

@@ -98,3 +98,22 @@ def test_adam_trajectory_parity():
     np.testing.assert_allclose(lh, lo, rtol=2e-3)
     assert lh[-1] < lh[0]
     assert rel(gs.forward_field(), d_fin_o) < 1e-3
+
+
+def test_view_groups_on_streams_match_single_batch():
+    """optional concurrency mode (NFS_VIEW_GROUPS / NFS_VGG_STREAMS): splitting the views into groups that run
+    on separate HIP streams must give the same losses and field gradient as one batch on one stream"""
+    layers = ["conv1_1", "conv2_1", "conv3_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 4, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    res = []
+    for groups, streams in ((1, 1), (2, 2), (2, 1)):
+        loss.view_groups, loss.vgg_streams = groups, streams
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v")
+        gs.var.copy_(torch.tensor(vel0))
+        losses, g = gs.gradient(rot)
+        torch.cuda.synchronize()
+        res.append((losses.clone(), g.clone()))
+    for losses, g in res[1:]:
+        assert rel(losses, res[0][0]) < 1e-5
+        assert rel(g, res[0][1]) < 1e-5
