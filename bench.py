@@ -118,9 +118,10 @@ def work_of(name, a):
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch (read + write) of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/r*_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
-    this same command; counters cannot be read from inside the run).  None when no profile is committed."""
+    """Mean HBM bytes per launch (read + write) of a kernel (all template instances whose name contains
+    ``kernel_substr``) from the committed rocprofv3 PMC passes (profiles/r*_traffic.json, produced by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command; counters cannot be
+    read from inside the run).  None when no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
@@ -130,6 +131,9 @@ def pmc_traffic(kernel_substr):
         rows = [v for k, v in tab.items() if kernel_substr in k]
         if not rows:
             return None
+        if all("read_bytes_mean" in v for v in rows):
+            n = sum(v["launches_seen"] for v in rows)
+            return sum((v["read_bytes_mean"] + v["write_bytes_mean"]) * v["launches_seen"] for v in rows) / n
         return sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in rows) / len(rows)
     except Exception:
         return None
@@ -270,23 +274,39 @@ def main():
         # stream also count the other stream's kernels sharing the chip); the headline above uses the default
         gs.loss.vgg_streams = 1
         gs.loss.view_groups = 1
+        import ctypes
+        L = _lib.lib()
         _lib.PROFILE = {}
+        L.nfs_gemm_timer(1)                 # HIP event pair around every launch of the GEMM kernel, on its stream
         for _ in range(psteps):
             gs.step(rot_local)
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
+        g_ms, g_fl, g_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        L.nfs_gemm_timer_read(ctypes.byref(g_ms), ctypes.byref(g_fl), ctypes.byref(g_n))
+        L.nfs_gemm_timer(0)
         rows = kernel_table(prof, psteps)
         conv = [r for r in rows if r["kernel"] in ("nfs_conv3x3_fwd", "nfs_conv3x3_dgrad")]
         ms = sum(r["ms_per_step"] for r in conv)
         fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)  # TF/s * ms
         n_launch = sum(r["launches_per_step"] for r in conv)
-        out["roofline"] = {"kernel": "3x3 conv on the f32 MFMA (fwd+dgrad, %d launches/step): direct implicit GEMM "
-                                     "(conv3x3_mfma_kernel) for 64-channel layers, Winograd F(2x2,3x3) in float32 "
-                                     "(winograd_gemm_kernel + transforms) for >=128-channel layers; achieved = "
-                                     "ALGORITHMIC direct-conv flops / time" % n_launch,
-                           "bound": "mfma", "achieved": fl / ms, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": fl / ms / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv3x3_mfma_kernel"),
-                           "avg_launch_us": 1e3 * ms / n_launch, "ms_per_step": ms}
+        tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "nfs::winograd_gemm_kernel (batched f32-MFMA GEMM: the 36 Winograd F(4x4,3x3) products of every "
+                      ">=64-channel conv layer, forward and data gradient, and the Gram gradient): %d launches/step, "
+                      "%.2f ms/step = the largest share of the step" % (g_n.value // psteps, g_ms.value / psteps),
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+            "traffic": pmc_traffic("winograd_gemm_kernel"),
+            "flops_per_launch": g_fl.value / max(g_n.value, 1), "avg_launch_us": 1e3 * g_ms.value / max(g_n.value, 1),
+            "ms_per_step": g_ms.value / psteps,
+            "note": "achieved = executed MFMA flops (2*Z*T*K*N per launch) / summed launch durations, HIP events on "
+                    "the launch stream (nfs_gemm_timer)",
+            # the whole conv family seen from the operator boundary: what the layer computes (direct-conv flops)
+            # over the time of the ABI call (input transform + GEMM + output transform, or the direct kernel)
+            "conv_family": {"launches_per_step": n_launch, "ms_per_step": ms, "algorithmic_tflops": fl / ms,
+                            "algorithmic_over_mfma_peak": fl / ms / MFMA_F32_PEAK_TF,
+                            "note": "ALGORITHMIC direct-conv flops (2*B*H*W*9*Ci*Co) / ABI-call time; Winograd "
+                                    "executes 4x fewer multiplies, so this may exceed the MFMA peak"}}
         out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
 
     if rank == 0 and world == 1:

@@ -38,6 +38,13 @@ int nfs_version(void);
 const char* nfs_last_error(void);
 /* number of CUs of the current device (used by host-side tile heuristics) */
 int nfs_device_cus(void);
+/* Measurement aid for bench.py's roofline: while enabled, every launch of the batched f32-MFMA GEMM kernel
+ * (winograd_gemm_kernel: the Winograd products of the conv layers and the Gram gradient) is bracketed by a
+ * HIP event pair on the stream it is launched on.  nfs_gemm_timer_read synchronises the device, returns the
+ * summed kernel time [ms], the summed executed MFMA flops (2*Z*T*K*N per launch) and the launch count, and
+ * clears the record.  Disabled by default; no effect on results. */
+int nfs_gemm_timer(int enable);
+int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
 
 /* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------
  * imgs [B,X,Y,Z,C], coords [B,3,X,Y,Z] normalised [-1,1] (axis order = array order),
@@ -121,17 +128,21 @@ int nfs_loss_net_input_bwd(const float* g_x, float* g_img,
                            int B, int H, int W, int Cin, int H2, int W2, nfs_stream_t stream);
 
 /* ---- A6: VGG-19 conv / pool (vgg.py:44-48, 89-108) ------------------------------------
- * 3x3 SAME stride-1 conv on NHWC as implicit GEMM on the f32 MFMA (exact f32).
- * Weights are frozen: pack them once.  kind 0 = forward (HWIO [3,3,Ci,Co] ->
- * packed, GEMM N=Co, K=9*Ci), kind 1 = data-gradient (taps flipped, N=Ci, K=9*Co).
- * nfs_conv3x3_packed_floats gives the packed buffer size in floats. */
+ * 3x3 SAME stride-1 conv on NHWC in float32 on the f32 MFMA.  Layers with >= 64 channels on both
+ * sides run as Winograd F(4x4,3x3) (input transform -> 36 batched GEMMs -> output transform, all
+ * f32; differs from the direct form by f32 rounding, ~3e-6 relative L2 per layer), conv1_1 (3
+ * input channels) and shapes the Winograd path does not take run as a direct implicit GEMM.
+ * Weights are frozen: pack them once.  kind 0 = forward (HWIO [3,3,Ci,Co] -> packed, GEMM N=Co,
+ * K=Ci per tap), kind 1 = data-gradient (taps flipped, N=Ci, K=Co).  The packed buffer holds the
+ * direct packing (9*Ci*Co floats) followed, for Winograd-eligible layers, by the transformed
+ * weights G g G^T (36*Ci*Co floats); nfs_conv3x3_packed_floats gives the total in floats. */
 int64_t nfs_conv3x3_packed_floats(int Ci, int Co, int kind);
 int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kind,
                      nfs_stream_t stream);
-/* Split-K workspace: small layers (25^2, 12^2 pixels, or one view per GPU) give too few M x N
- * tiles to fill 256 CUs, so the K = 9*C dimension is split across blocks and the partial sums
- * go through `workspace` (device floats, nullable = never split).  Size for any split the
- * library may choose: nfs_conv3x3_workspace_floats. */
+/* Workspace (device floats): the Winograd path keeps the transformed activations V [36][T][K] and
+ * products M [36][T][N] there (T = B*ceil(H/4)*ceil(W/4) tiles); the direct path uses it for split-K
+ * partial sums when a layer gives too few M x N tiles to fill 256 CUs.  Without a workspace (NULL)
+ * or with one smaller than nfs_conv3x3_workspace_floats the layer runs direct and unsplit. */
 int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co);
 /* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable */
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y,

@@ -31,6 +31,8 @@ SIGNATURES = {
     "nfs_version": [],
     "nfs_last_error": [],
     "nfs_device_cus": [],
+    "nfs_gemm_timer": [_I],
+    "nfs_gemm_timer_read": [_P, _P, _P],
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -15,6 +15,9 @@
 //   winograd_output*_kernel  M                      -> y [B,H,W,N]    + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace nfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -493,6 +496,12 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
+// ---- optional per-launch event timing of the GEMM kernel (nfs_gemm_timer) ---------------------------------
+struct GemmTimerRec { hipEvent_t e0, e1; double flops; };
+static bool g_timer_on = false;
+static std::vector<GemmTimerRec> g_timer_recs;
+static std::mutex g_timer_mu;
+
 template <int BN, int NBUF>
 static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
   const size_t oper = NBUF * (WG_BM + BN) * WG_LS, tile = WG_BM * (BN + 4);
@@ -504,11 +513,19 @@ static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
     attr_done = true;
   }
   const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
+  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+  if (timed) (void)hipEventRecord(rec.e0, s);
   hipLaunchKernelGGL((winograd_gemm_kernel<BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
 }
 
 static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
-  static const int nbuf = [] { const char* e = getenv("NFS_GEMM_NBUF"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  static const int nbuf = [] { const char* e = getenv("NFS_GEMM_NBUF"); return (e && atoi(e) == 1) ? 1 : 2; }();
   static const int force_bn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 0; }();
   const int mt = (int)((a.T + WG_BM - 1) / WG_BM);
   // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
@@ -590,3 +607,33 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
 }
 
 }  // namespace nfs
+
+extern "C" {
+int nfs_gemm_timer(int enable) {
+  std::lock_guard<std::mutex> lk(nfs::g_timer_mu);
+  nfs::g_timer_on = enable != 0;
+  return NFS_OK;
+}
+
+int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches) {
+  NFS_REQUIRE(ms_total && flops_total && launches, "nfs_gemm_timer_read: null pointer");
+  if (hipDeviceSynchronize() != hipSuccess) {
+    nfs::set_error("nfs_gemm_timer_read: device synchronise failed");
+    return NFS_ELAUNCH;
+  }
+  std::lock_guard<std::mutex> lk(nfs::g_timer_mu);
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : nfs::g_timer_recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  *ms_total = ms;
+  *flops_total = fl;
+  *launches = (long long)nfs::g_timer_recs.size();
+  nfs::g_timer_recs.clear();
+  return NFS_OK;
+}
+}
+

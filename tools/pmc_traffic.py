@@ -45,6 +45,8 @@ def main():
         rd = 2.0 * 1024.0 * sum(fm) / len(fm)
         wr = 1024.0 * sum(wm) / len(wm)
         table[k] = {"launches_seen": len(fv), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                    # mean over ALL launches of the run (what an average-duration roofline needs)
+                    "read_bytes_mean": 2.0 * 1024.0 * sum(fv) / len(fv), "write_bytes_mean": 1024.0 * sum(wv) / len(wv),
                     "read_calibrated": not any(g in k for g in GATHER)}
     cal = None
     if "nfs::adam_kernel" in table:
