@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
 // block = 4 waves (2 M x 2 N), tile 128 rows x BN columns, K in 32-wide chunks; both operand tiles are
 // prefetched into registers one chunk ahead and double-buffered in LDS (36-float padded rows, b128 fragment
 // reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
-constexpr int WG_KC = 32, WG_LS = 36, WG_BM = 128, WG_XCDS = 8;
+constexpr int WG_KC = 32, WG_LS = 36, WG_XCDS = 8;
 
 // Batched C_z = alpha_z * A_z B_z (optionally masked): the Winograd GEMMs (z = transform component) and the
 // Gram gradient dF_b = 2 s_b F_b D_b (z = image) share this kernel.
@@ -288,12 +288,13 @@ struct WgGemmArgs {
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
 };
 
-template <int BN, int NBUF>
+template <int BM, int BN, int NBUF>
 __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
-  constexpr int NT = BN / 64;
+  constexpr int MT = BM / 64, NT = BN / 64;           // 32x32 MFMA tiles per wave (waves 2 x 2)
+  constexpr int AJ = BM / 32, BJ = BN / 32;           // float4 per thread and chunk for the A / B tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                   // [NBUF][128][36]
-  float* Bs = smem + NBUF * WG_BM * WG_LS;            // [NBUF][BN][36]
+  float* As = smem;                                   // [NBUF][BM][36]
+  float* Bs = smem + NBUF * BM * WG_LS;               // [NBUF][BN][36]
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
   // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with its own
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   if (logical >= a.mt * a.nt * a.Z) return;
   const int comp = logical / (a.mt * a.nt);
   const int rem = logical - comp * (a.mt * a.nt);
-  const int64_t m0 = (int64_t)(rem % a.mt) * WG_BM;
+  const int64_t m0 = (int64_t)(rem % a.mt) * BM;
   const int n0 = (rem / a.mt) * BN;
   const float* Vc = a.V + (int64_t)comp * a.T * a.K;
   const float* Uc = a.U + (int64_t)comp * a.b_batch;
@@ -312,10 +313,10 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
 
   // staging: thread t moves float4 #(t&7) of rows (t>>3) + 32 j
   const int q4 = 4 * (t & 7), r0 = t >> 3;
-  const float* arow[4];
-  bool aok[4];
+  const float* arow[AJ];
+  bool aok[AJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < AJ; ++j) {
     const int64_t m = m0 + r0 + 32 * j;
     aok[j] = m < a.T;
     arow[j] = Vc + (aok[j] ? m : 0) * a.K + q4;
@@ -323,52 +324,56 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   // B rows n0 + (t>>3) + 32 r, float4 #(t&7) of the 32 k of a chunk
   const float* brow = Uc + (int64_t)(n0 + r0) * a.b_row + q4;
   const int64_t brs = (int64_t)32 * a.b_row;
-  float4 a0, a1, a2, a3, b0, b1, b2, b3;
+  float4 a0, a1, a2, a3, b0, b1, b2, b3;            // named registers: an indexed array would go to scratch
 #define NFS_WG_LOAD(c_)                                                                         \
   {                                                                                             \
     a0 = a1 = a2 = a3 = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
     if (aok[0]) a0 = *reinterpret_cast<const float4*>(arow[0] + (c_) * WG_KC);                  \
     if (aok[1]) a1 = *reinterpret_cast<const float4*>(arow[1] + (c_) * WG_KC);                  \
-    if (aok[2]) a2 = *reinterpret_cast<const float4*>(arow[2] + (c_) * WG_KC);                  \
-    if (aok[3]) a3 = *reinterpret_cast<const float4*>(arow[3] + (c_) * WG_KC);                  \
+    if (AJ > 2) {                                                                               \
+      if (aok[AJ - 2]) a2 = *reinterpret_cast<const float4*>(arow[AJ - 2] + (c_) * WG_KC);      \
+      if (aok[AJ - 1]) a3 = *reinterpret_cast<const float4*>(arow[AJ - 1] + (c_) * WG_KC);      \
+    }                                                                                           \
     const float* bn_ = brow + (int64_t)(c_) * a.b_chunk;                                        \
     b0 = *reinterpret_cast<const float4*>(bn_);                                                 \
     b1 = *reinterpret_cast<const float4*>(bn_ + brs);                                           \
-    if (BN > 64) {                                                                              \
+    if (BJ > 2) {                                                                               \
       b2 = *reinterpret_cast<const float4*>(bn_ + 2 * brs);                                     \
       b3 = *reinterpret_cast<const float4*>(bn_ + 3 * brs);                                     \
     }                                                                                           \
   }
   NFS_WG_LOAD(0)
 
-  int abase[2], bbase[NT];
+  int abase[MT], bbase[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) abase[mt] = (wm * 64 + mt * 32 + i) * WG_LS + 4 * h;
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * (BM / 2) + mt * 32 + i) * WG_LS + 4 * h;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * (BN / 2) + nt * 32 + i) * WG_LS + 4 * h;
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   for (int c = 0; c < nchunks; ++c) {
-    float* Ac = As + (NBUF == 2 ? (c & 1) : 0) * WG_BM * WG_LS;
+    float* Ac = As + (NBUF == 2 ? (c & 1) : 0) * BM * WG_LS;
     float* Bc = Bs + (NBUF == 2 ? (c & 1) : 0) * BN * WG_LS;
     if (NBUF == 1 && c > 0) __syncthreads();          // single buffer: everyone is done reading chunk c-1
     {
       float* ad = Ac + r0 * WG_LS + q4;
       *reinterpret_cast<float4*>(ad) = a0;
       *reinterpret_cast<float4*>(ad + 32 * WG_LS) = a1;
-      *reinterpret_cast<float4*>(ad + 64 * WG_LS) = a2;
-      *reinterpret_cast<float4*>(ad + 96 * WG_LS) = a3;
+      if (AJ > 2) {
+        *reinterpret_cast<float4*>(ad + 64 * WG_LS) = a2;
+        *reinterpret_cast<float4*>(ad + 96 * WG_LS) = a3;
+      }
       float* bd = Bc + r0 * WG_LS + q4;
       *reinterpret_cast<float4*>(bd) = b0;
       *reinterpret_cast<float4*>(bd + 32 * WG_LS) = b1;
-      if (BN > 64) {
+      if (BJ > 2) {
         *reinterpret_cast<float4*>(bd + 64 * WG_LS) = b2;
         *reinterpret_cast<float4*>(bd + 96 * WG_LS) = b3;
       }
@@ -377,10 +382,12 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     if (c + 1 < nchunks) NFS_WG_LOAD(c + 1)
 #pragma unroll
     for (int s = 0; s < WG_KC / 8; ++s) {
-      const float4 x0 = *reinterpret_cast<const float4*>(Ac + abase[0] + 8 * s);
-      const float4 x1 = *reinterpret_cast<const float4*>(Ac + abase[1] + 8 * s);
-      const float af0[4] = {x0.x, x0.y, x0.z, x0.w}, af1[4] = {x1.x, x1.y, x1.z, x1.w};
-      float bf[NT][4];
+      float af[MT][4], bf[NT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 x = *reinterpret_cast<const float4*>(Ac + abase[mt] + 8 * s);
+        af[mt][0] = x.x; af[mt][1] = x.y; af[mt][2] = x.z; af[mt][3] = x.w;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float4 bq = *reinterpret_cast<const float4*>(Bc + bbase[nt] + 8 * s);
@@ -389,10 +396,10 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[jj], bf[nt][jj], acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[jj], bf[nt][jj], acc[1][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][jj], bf[nt][jj], acc[mt][nt], 0, 0, 0);
     }
   }
 #undef NFS_WG_LOAD
@@ -402,10 +409,10 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   float* otile = smem;
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int row = wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) otile[row * OS + wn * (BN / 2) + nt * 32 + i] = acc[mt][nt][r];
     }
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
   constexpr int Q = BN / 4;
 #pragma unroll
-  for (int e = 0; e < (WG_BM * Q) / 256; ++e) {
+  for (int e = 0; e < (BM * Q) / 256; ++e) {
     const int f = t + 256 * e;
     const int row = f / Q, q = f - row * Q;
     const int64_t m = m0 + row;
@@ -502,13 +509,13 @@ static bool g_timer_on = false;
 static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
 
-template <int BN, int NBUF>
+template <int BM, int BN, int NBUF>
 static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
-  const size_t oper = NBUF * (WG_BM + BN) * WG_LS, tile = WG_BM * (BN + 4);
+  const size_t oper = NBUF * (BM + BN) * WG_LS, tile = BM * (BN + 4);
   const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BN, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BM, BN, NBUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
@@ -516,7 +523,7 @@ static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
   if (timed) (void)hipEventRecord(rec.e0, s);
-  hipLaunchKernelGGL((winograd_gemm_kernel<BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((winograd_gemm_kernel<BM, BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
@@ -524,21 +531,52 @@ static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
+// Tile choice.  All co-resident blocks of a CU share its 4 MFMA pipes, so a CU's time is (number of tiles it
+// processes) x (tile work); blocks are dealt to CU slots as they free up.  cost = [full rounds x blocks/CU +
+// ceil(left-over blocks / CUs)] x BM x BN, with M padded to BM: small T (deep layers, few views per GPU) wants
+// BM = 64, a grid that just misses a round boundary wants the other aspect ratio.
+static void pick_gemm_tile(int64_t T, int N, int Z, int cus, int* bm_out, int* bn_out) {
+  static const int force_bm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 0; }();
+  static const int force_bn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 0; }();
+  double best = 1e300;
+  *bm_out = 128; *bn_out = 64;
+  const int bms[2] = {128, 64}, bns[2] = {64, 128};
+  for (int bi = 0; bi < 2; ++bi)
+    for (int ni = 0; ni < 2; ++ni) {
+      const int bm = bms[bi], bn = bns[ni];
+      if (N % bn) continue;
+      if (force_bm && bm != force_bm) continue;
+      if (force_bn && bn != force_bn && N % force_bn == 0) continue;
+      const size_t oper = 2 * (bm + bn) * WG_LS, tile = (size_t)bm * (bn + 4);
+      const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+      int bpc = (int)(160 * 1024 / lds);
+      const int vg = (bm * bn >= 128 * 128) ? 3 : 4;      // waves/SIMD the register budget allows
+      if (bpc > vg) bpc = vg;
+      const int64_t blocks = ((T + bm - 1) / bm) * (N / bn) * Z;
+      const int64_t slots = (int64_t)cus * bpc, full = blocks / slots, rem = blocks % slots;
+      double cost = (double)(full * bpc + (rem + cus - 1) / cus) * bm * bn;
+      cost *= 1.0 + 8.0 / (bm < bn ? bm : bn);            // smaller tiles: more operand traffic per flop
+      if (cost < best) { best = cost; *bm_out = bm; *bn_out = bn; }
+    }
+}
+
 static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   static const int nbuf = [] { const char* e = getenv("NFS_GEMM_NBUF"); return (e && atoi(e) == 1) ? 1 : 2; }();
-  static const int force_bn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 0; }();
-  const int mt = (int)((a.T + WG_BM - 1) / WG_BM);
-  // 128-wide N tiles when that still gives >= 2 rounds of blocks, else 64-wide
-  bool wide = (a.N % 128 == 0) && ((int64_t)mt * (a.N / 128) * Z >= 4 * (int64_t)cus);
-  if (force_bn == 64) wide = false;
-  if (force_bn == 128 && a.N % 128 == 0) wide = true;
-  a.mt = mt;
+  int bm, bn;
+  pick_gemm_tile(a.T, a.N, Z, cus, &bm, &bn);
+  a.mt = (int)((a.T + bm - 1) / bm);
+  a.nt = a.N / bn;
   a.Z = Z;
-  a.nt = a.N / (wide ? 128 : 64);
-  if (wide) {
-    if (nbuf == 2) launch_gemm_variant<128, 2>(a, s); else launch_gemm_variant<128, 1>(a, s);
+  if (nbuf == 2) {
+    if (bm == 128 && bn == 128) launch_gemm_variant<128, 128, 2>(a, s);
+    else if (bm == 128) launch_gemm_variant<128, 64, 2>(a, s);
+    else if (bn == 128) launch_gemm_variant<64, 128, 2>(a, s);
+    else launch_gemm_variant<64, 64, 2>(a, s);
   } else {
-    if (nbuf == 2) launch_gemm_variant<64, 2>(a, s); else launch_gemm_variant<64, 1>(a, s);
+    if (bm == 128 && bn == 128) launch_gemm_variant<128, 128, 1>(a, s);
+    else if (bm == 128) launch_gemm_variant<128, 64, 1>(a, s);
+    else if (bn == 128) launch_gemm_variant<64, 128, 1>(a, s);
+    else launch_gemm_variant<64, 64, 1>(a, s);
   }
 }
 

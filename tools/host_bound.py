@@ -1,0 +1,18 @@
+"""Is the step host-bound?  Time N steps with and without waiting for the GPU."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+for V in (1, 2, 8):
+    gs, rot, data = bench.build_problem(200, V, torch.device("cuda", 0), 0, 1)
+    for _ in range(3):
+        gs.step(rot)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        gs.step(rot)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("views %d: host issue %.3f ms/step, total %.3f ms/step" % (V, 1e3 * (t1 - t0) / 20, 1e3 * (t2 - t0) / 20))
