@@ -1,12 +1,15 @@
 // A7: Gram matrix G = F^T F, the style loss and its gradient dF = 2 F D
 // (styler_base.py:96-102, 152-185) on the f32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-// gram_fwd: M = N = C channels, K = pixels (up to 40000).  A wave is one independent work
-//   unit = (image, 64x64 tile of G, slab of pixels): it streams the two 64-channel column
-//   strips of F straight from global memory -- lane (i,h) reads the float2 F[p+h][c0+2i..]
-//   (32 lanes = one 256-B row segment, fully coalesced), feeding two MFMA row blocks with
-//   MFMA row i <-> channel c0+2i+q -- accumulates 2x2 MFMA tiles and adds its partial tile to
-//   G with float atomics.  No LDS: every operand is used by exactly one wave.
+// gram_fwd: M = N = C channels, K = pixels (up to 40000): a "TN" GEMM whose two operands are the same
+//   pixel-major matrix.  G is symmetric, so only the TS x TS tile pairs t1 <= t2 are computed (TS = 64;
+//   128 was measured slower) and the pixels are split into slabs of whole 32-pixel chunks so that the grid fills the
+//   chip.  A block (4 waves, 2 x 2) stages each chunk [32 px][TS ch] of both strips in LDS with coalesced
+//   float4 loads (prefetched one chunk ahead in registers, double-buffered in LDS; a diagonal pair stages one
+//   strip only) and reads MFMA fragments as conflict-free ds_read_b32 rows: the pixel-major layout IS the
+//   k-major operand layout of v_mfma_f32_32x32x2_f32, no transposition anywhere.  The partial tile goes to the
+//   workspace; gram_reduce_kernel sums the slabs in a fixed order, mirrors the lower triangle and applies the
+//   scale (deterministic).  Without a workspace the scaled tile (and its mirror) is added with float atomics.
 // gram_bwd: dF_b = 2 s_b F_b D_b is a plain batched GEMM (M = pixels, N = K = C): it runs on the LDS-staged
 //   batched f32-MFMA GEMM of winograd.hip (D is symmetric: its rows are read as columns), ReLU mask fused.
 #include "common.h"
@@ -18,153 +21,182 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GramArgs {
   const float* F;
   float* G;
-  float* ws;    // partial tiles [unit][64*64] (two-pass mode) or null (float atomics into G)
+  float* ws;    // partial tiles [b][pair][slab][TS*TS] (two-pass mode) or null (float atomics into G)
   const float* scale_dev;
   float scale;
   int B, HW, C;
-  int slab;     // pixels per wave (even)
+  int ts;       // tile size 64 / 128
+  int cps;      // 32-pixel chunks per slab
   int nslab;    // slabs per image
-  int ntile;    // C / 64
+  int ntile;    // C / ts
 };
 
-// One BLOCK per work unit: its 4 waves split the unit's pixel slab four ways (4 waves per SIMD
-// resident => the dependent global loads of the k loop overlap across waves; with one wave per
-// unit the kernel was HBM-latency-bound at 22 TF/s), then waves 1-3 park their accumulators in LDS
-// (lane-contiguous, conflict-free) and wave 0 adds them and emits the tile.
-__global__ void __launch_bounds__(256) gram_fwd_kernel(GramArgs a) {
-  __shared__ float part[3][64][64];   // [wave-1][acc register][lane]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
+constexpr int GR_KC = 32;
+
+template <int TS>
+__global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
+  constexpr int MT = TS / 64;                 // 32x32 MFMA tiles per wave and dimension (waves 2 x 2)
+  constexpr int J = TS / 32;                  // float4 per thread, chunk and strip
+  constexpr int R4 = TS / 4;                  // float4 per staged row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                           // [2][32][TS]
+  float* Bs = smem + 2 * GR_KC * TS;          // [2][32][TS]
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
+  // G is symmetric: only the tile pairs t1 <= t2 are computed
+  const int npair = a.ntile * (a.ntile + 1) / 2;
   int64_t unit = blockIdx.x;
-  const int64_t per_img = (int64_t)a.nslab * a.ntile * a.ntile;
+  const int64_t per_img = (int64_t)a.nslab * npair;
   const int b = (int)(unit / per_img);
   unit -= (int64_t)b * per_img;
   const int pair = (int)(unit / a.nslab);
   const int sl = (int)(unit - (int64_t)pair * a.nslab);
-  const int t1 = pair / a.ntile, t2 = pair - t1 * a.ntile;
-  const int s0 = sl * a.slab;
-  const int s1 = min(s0 + a.slab, a.HW);
-  // this wave's quarter (even number of pixels per quarter so that pairs never straddle waves)
-  const int quarter = ((((s1 - s0) + 1) / 2 + 3) / 4) * 2;
-  const int p0 = min(s0 + wid * quarter, s1);
-  const int p1 = min(p0 + quarter, s1);
+  int t1 = 0, t2 = pair;
+  while (t2 >= a.ntile - t1) { t2 -= a.ntile - t1; ++t1; }
+  t2 += t1;
+  const bool diag = t1 == t2;                 // both operands are the same strip: stage it once
+  const int total_chunks = (a.HW + GR_KC - 1) / GR_KC;
+  const int c_begin = sl * a.cps;
+  const int nchunks = min(a.cps, total_chunks - c_begin);
   const float* Fb = a.F + (int64_t)b * a.HW * a.C;
-  const float* pa = Fb + t1 * 64 + 2 * i;
-  const float* pb = Fb + t2 * 64 + 2 * i;
 
-  f32x16 acc[2][2];
+  // staging: thread t moves float4 #(t % R4) of rows t / R4 + (256 / R4) * j of the chunk
+  const int col4 = t % R4, row0 = t / R4;
+  constexpr int RSTEP = 256 / R4;
+  const float* ga = Fb + t1 * TS + 4 * col4;
+  const float* gb = Fb + t2 * TS + 4 * col4;
+  float4 a0, a1, a2, a3, b0, b1, b2, b3;      // named registers (an indexed array would go to scratch)
+#define NFS_GR_LD(dst_, base_, j_, c_)                                                          \
+  {                                                                                             \
+    const int p_ = (c_begin + (c_)) * GR_KC + row0 + RSTEP * (j_);                              \
+    dst_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+    if (p_ < a.HW) dst_ = *reinterpret_cast<const float4*>(base_ + (int64_t)p_ * a.C);          \
+  }
+#define NFS_GR_LOAD(c_)                                                                         \
+  {                                                                                             \
+    NFS_GR_LD(a0, ga, 0, c_) NFS_GR_LD(a1, ga, 1, c_)                                           \
+    if (J > 2) { NFS_GR_LD(a2, ga, 2, c_) NFS_GR_LD(a3, ga, 3, c_) }                            \
+    if (!diag) {                                                                                \
+      NFS_GR_LD(b0, gb, 0, c_) NFS_GR_LD(b1, gb, 1, c_)                                         \
+      if (J > 2) { NFS_GR_LD(b2, gb, 2, c_) NFS_GR_LD(b3, gb, 3, c_) }                          \
+    }                                                                                           \
+  }
+  b0 = b1 = b2 = b3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  a2 = a3 = b0;
+  NFS_GR_LOAD(0)
+
+  f32x16 acc[MT][MT];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < MT; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+    for (int y = 0; y < MT; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
-  // k loop, manually software-pipelined (hipcc refuses to unroll a loop around the MFMA builtin):
-  // 8 k-steps (= 16 pixels, 16 float2 loads) are in flight while the previous 8 are multiplied.
-  const int nsteps = (p1 - p0) >> 1;
-  const float* qa_ = pa + (int64_t)(p0 + h) * a.C;
-  const float* qb_ = pb + (int64_t)(p0 + h) * a.C;
-  const int64_t step = 2 * (int64_t)a.C;
-#define NFS_GRAM_LOAD(A_, B_, s_)                                                      \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                      \
-    A_[u] = make_float2(0.f, 0.f); B_[u] = make_float2(0.f, 0.f);                      \
-    if ((s_) + u < nsteps) {                                                           \
-      A_[u] = *reinterpret_cast<const float2*>(qa_ + ((s_) + u) * step);               \
-      B_[u] = *reinterpret_cast<const float2*>(qb_ + ((s_) + u) * step);               \
-    }                                                                                  \
-  }
-#define NFS_GRAM_MMA(A_, B_)                                                                      \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                 \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].x, B_[u].x, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].x, B_[u].y, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].y, B_[u].x, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u].y, B_[u].y, acc[1][1], 0, 0, 0);      \
-  }
-  {
-    float2 A0[8], B0[8], A1[8], B1[8];
-    NFS_GRAM_LOAD(A0, B0, 0)
-    for (int s0_ = 0; s0_ < nsteps; s0_ += 16) {
-      NFS_GRAM_LOAD(A1, B1, s0_ + 8)
-      NFS_GRAM_MMA(A0, B0)
-      NFS_GRAM_LOAD(A0, B0, s0_ + 16)
-      NFS_GRAM_MMA(A1, B1)
+  const int afrag = h * TS + wm * (TS / 2) + i;      // + (2 step) * TS + 32 mt
+  const int bfrag = h * TS + wn * (TS / 2) + i;
+  for (int c = 0; c < nchunks; ++c) {
+    float* Ac = As + (c & 1) * GR_KC * TS;
+    float* Bc = diag ? Ac : Bs + (c & 1) * GR_KC * TS;
+    {
+      float* ad = Ac + row0 * TS + 4 * col4;
+      *reinterpret_cast<float4*>(ad) = a0;
+      *reinterpret_cast<float4*>(ad + RSTEP * TS) = a1;
+      if (J > 2) {
+        *reinterpret_cast<float4*>(ad + 2 * RSTEP * TS) = a2;
+        *reinterpret_cast<float4*>(ad + 3 * RSTEP * TS) = a3;
+      }
+      if (!diag) {
+        float* bd = Bc + row0 * TS + 4 * col4;
+        *reinterpret_cast<float4*>(bd) = b0;
+        *reinterpret_cast<float4*>(bd + RSTEP * TS) = b1;
+        if (J > 2) {
+          *reinterpret_cast<float4*>(bd + 2 * RSTEP * TS) = b2;
+          *reinterpret_cast<float4*>(bd + 3 * RSTEP * TS) = b3;
+        }
+      }
+    }
+    __syncthreads();                        // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    if (c + 1 < nchunks) NFS_GR_LOAD(c + 1)
+#pragma unroll
+    for (int st = 0; st < GR_KC / 2; ++st) {
+      float af[MT], bf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = Ac[afrag + 2 * st * TS + 32 * m];
+#pragma unroll
+      for (int n = 0; n < MT; ++n) bf[n] = Bc[bfrag + 2 * st * TS + 32 * n];
+#pragma unroll
+      for (int n = 0; n < MT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
   }
-#undef NFS_GRAM_LOAD
-#undef NFS_GRAM_MMA
-  if ((p1 - p0) & 1) {  // odd tail pixel: the k=1 half contributes zero
-    const int p = p1 - 1;
-    float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
-    if (h == 0) {
-      av = *reinterpret_cast<const float2*>(pa + (int64_t)p * a.C);
-      bv = *reinterpret_cast<const float2*>(pb + (int64_t)p * a.C);
-    }
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
-  }
-  // block reduction of the 4 partial tiles
-  if (wid > 0) {
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[wid - 1][(qa * 2 + qb) * 16 + r][lane] = acc[qa][qb][r];
-  }
+#undef NFS_GR_LOAD
+#undef NFS_GR_LD
+
+  // epilogue: transpose the tile through LDS, leave as float4 rows
+  constexpr int OS = TS + 4;
+  float* otile = smem;
   __syncthreads();
-  if (wid > 0) return;
 #pragma unroll
-  for (int qa = 0; qa < 2; ++qa)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * (TS / 2) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = (qa * 2 + qb) * 16 + r;
-        acc[qa][qb][r] += part[0][k][lane] + part[1][k][lane] + part[2][k][lane];
-      }
-  // acc[qa][qb][r]: G row = t1*64 + 2*row + qa, col = t2*64 + 2*(lane&31) + qb
+      for (int n = 0; n < MT; ++n) otile[row * OS + wn * (TS / 2) + n * 32 + i] = acc[m][n][r];
+    }
+  __syncthreads();
   if (a.ws) {
-    // two-pass mode: the raw partial tile goes to the workspace (float2 = 256-B coalesced rows);
-    // gram_reduce_kernel sums the slabs in a fixed order (deterministic, no atomics)
-    float* wt = a.ws + (int64_t)blockIdx.x * 4096;
+    float* wt = a.ws + (int64_t)blockIdx.x * TS * TS;
 #pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + qa;
-        *reinterpret_cast<float2*>(wt + row * 64 + 2 * i) = make_float2(acc[qa][0][r], acc[qa][1][r]);
-      }
+    for (int e = 0; e < (TS * R4) / 256; ++e) {
+      const int f = t + 256 * e;
+      const int row = f / R4, q = f - row * R4;
+      *reinterpret_cast<float4*>(wt + row * TS + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    }
     return;
   }
   const float sc = a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
   float* Gb = a.G + (int64_t)b * a.C * a.C;
-#pragma unroll
-  for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        atomicAdd(Gb + (int64_t)(t1 * 64 + 2 * row + qa) * a.C + t2 * 64 + 2 * i + qb, acc[qa][qb][r] * sc);
-      }
+  for (int f = t; f < TS * TS; f += 256) {
+    const int row = f / TS, col = f - row * TS;
+    const float v = otile[row * OS + col] * sc;
+    const int gr = t1 * TS + row, gc = t2 * TS + col;
+    atomicAdd(Gb + (int64_t)gr * a.C + gc, v);
+    if (!diag) atomicAdd(Gb + (int64_t)gc * a.C + gr, v);   // mirrored tile
+  }
 }
 
-// G[b][c1][c2] = scale_b * sum_slab ws[((b*npair + pair)*nslab + slab)][64x64 tile]
+// G[b][c1][c2] = scale_b * sum_slab ws[((b*npair + pair)*nslab + slab)][TS x TS tile], pair = upper-triangular
+// index of (tile(c1), tile(c2)); elements below the diagonal come from the transposed tile.  blockDim (64, 4):
+// the 4 y-threads of an element sum interleaved slabs, then combine in a fixed order.
 __global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // element of G
+  __shared__ float red[4][64];
+  const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;   // element of G
   const int64_t per_img = (int64_t)a.C * a.C;
-  if (e >= per_img * a.B) return;
-  const int b = (int)(e / per_img);
-  const int rem = (int)(e - (int64_t)b * per_img);
-  const int c1 = rem / a.C, c2 = rem - c1 * a.C;
-  const int pair = (c1 >> 6) * a.ntile + (c2 >> 6);
-  const float* p = a.ws + (((int64_t)b * a.ntile * a.ntile + pair) * a.nslab) * 4096 + (c1 & 63) * 64 + (c2 & 63);
   float s = 0.f;
-  for (int k = 0; k < a.nslab; ++k) s += p[(int64_t)k * 4096];
-  a.G[e] = s * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
+  int b = 0;
+  const bool ok = e < per_img * a.B;
+  if (ok) {
+    b = (int)(e / per_img);
+    const int rem = (int)(e - (int64_t)b * per_img);
+    int c1 = rem / a.C, c2 = rem - c1 * a.C;
+    const int ts = a.ts;
+    if (c1 / ts > c2 / ts) { const int tmp = c1; c1 = c2; c2 = tmp; }   // lower triangle: read the mirrored tile
+    const int T1 = c1 / ts, T2 = c2 / ts, npair = a.ntile * (a.ntile + 1) / 2;
+    const int pair = T1 * a.ntile - T1 * (T1 - 1) / 2 + (T2 - T1);
+    const int64_t tile = (int64_t)ts * ts;
+    const float* p = a.ws + (((int64_t)b * npair + pair) * a.nslab) * tile + (c1 % ts) * ts + (c2 % ts);
+    for (int k = threadIdx.y; k < a.nslab; k += 4) s += p[(int64_t)k * tile];
+  }
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (ok && threadIdx.y == 0) {
+    const float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    a.G[e] = tot * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
+  }
 }
 
 // loss += weight * sum (G - Gs)^2 ; Dmat = 2*weight*(G - Gs)
@@ -194,26 +226,39 @@ using namespace nfs;
 
 extern "C" {
 
-static void gram_plan(GramArgs& a) {
-  a.ntile = a.C / 64;
-  // one block (4 waves) per unit, 3 blocks resident per CU (48 KB of LDS each): aim at ~3 units per
-  // CU, slabs of >= 128 pixels
-  const int64_t pairs = (int64_t)a.B * a.ntile * a.ntile;
-  int64_t want = (3 * 256 + pairs - 1) / pairs;
-  if (want < 1) want = 1;
-  int slab = (int)((a.HW + want - 1) / want);
-  if (slab < 128) slab = 128;
-  slab = (slab + 1) & ~1;
-  a.slab = slab;
-  a.nslab = (a.HW + slab - 1) / slab;
+static int gram_cus() {
+  static int cus = 0;
+  if (cus == 0) { const int c = nfs_device_cus(); cus = c > 0 ? c : 256; }
+  return cus;
+}
+
+static void gram_plan(GramArgs& a, int cus) {
+  static const int env_ts = [] { const char* e = getenv("NFS_GRAM_TS"); return e ? atoi(e) : 0; }();
+  static const int env_cps = [] { const char* e = getenv("NFS_GRAM_CPS"); return e ? atoi(e) : 0; }();
+  // measured (tools/gram_bench.py, NFS_GRAM_TS / NFS_GRAM_CPS sweeps): 64 x 64 tiles beat 128 x 128 at every VGG
+  // shape (4x more blocks, 4x smaller partial tiles), and ~16 chunks (512 pixels) per slab is the sweet spot
+  // between per-block fill/epilogue cost and the number of partial tiles the reduce pass has to read.
+  a.ts = 64;
+  if (env_ts == 128 && a.C % 128 == 0) a.ts = 128;
+  a.ntile = a.C / a.ts;
+  const int64_t pairs = (int64_t)a.B * a.ntile * (a.ntile + 1) / 2;
+  const int total_chunks = (a.HW + GR_KC - 1) / GR_KC;
+  int cps = 16;
+  // few images / few tile pairs: shorter slabs until the grid covers the chip twice (not below 4 chunks)
+  while (cps > 4 && pairs * ((total_chunks + cps - 1) / cps) < 2 * (int64_t)cus) cps >>= 1;
+  if (cps > total_chunks) cps = total_chunks;
+  if ((total_chunks + cps - 1) / cps > 256) cps = (total_chunks + 255) / 256;   // bound the reduce fan-in
+  if (env_cps > 0) cps = env_cps < total_chunks ? env_cps : total_chunks;
+  a.cps = cps;
+  a.nslab = (total_chunks + cps - 1) / cps;
 }
 
 int64_t nfs_gram_workspace_floats(int B, int HW, int C) {
   if (B <= 0 || HW <= 0 || C <= 0 || C % 64) return 0;
   GramArgs a;
   a.B = B; a.HW = HW; a.C = C;
-  gram_plan(a);
-  return (int64_t)B * a.ntile * a.ntile * a.nslab * 4096 + 4 * 4096;
+  gram_plan(a, gram_cus());
+  return (int64_t)B * (a.ntile * (a.ntile + 1) / 2) * a.nslab * a.ts * a.ts + 4 * 4096;
 }
 
 int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* scale_dev, float scale,
@@ -223,12 +268,24 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
   NFS_REQUIRE(C > 0 && C % 64 == 0, "nfs_gram_fwd: C must be a multiple of 64");
   GramArgs a;
   a.F = F; a.G = G; a.scale_dev = scale_dev; a.scale = scale; a.B = B; a.HW = HW; a.C = C;
-  gram_plan(a);
-  const int64_t units = (int64_t)B * a.ntile * a.ntile * a.nslab;
+  gram_plan(a, gram_cus());
+  const int64_t units = (int64_t)B * (a.ntile * (a.ntile + 1) / 2) * a.nslab;
   a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
-  hipLaunchKernelGGL(gram_fwd_kernel, dim3((unsigned)units), dim3(256), 0, as_stream(stream), a);
+  if (a.ts == 64) {
+    const size_t lds = 4 * GR_KC * 64 * sizeof(float);          // 32 KB (>= the 64 x 68 epilogue tile)
+    hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
+  } else {
+    const size_t lds = 128 * 132 * sizeof(float);               // epilogue tile 66 KB > 64 KB of operand buffers
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tn_kernel<128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(gram_tn_kernel<128>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
+  }
   if (a.ws)
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for((int64_t)B * C * C, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for((int64_t)B * C * C, 64)), dim3(64, 4), 0, as_stream(stream),
                        a);
   return check_launch("nfs_gram_fwd");
 }
@@ -250,9 +307,7 @@ int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, in
   NFS_REQUIRE(B > 0 && HW > 0, "nfs_gram_bwd: non-positive dimension");
   NFS_REQUIRE(C > 0 && C % 64 == 0, "nfs_gram_bwd: C must be a multiple of 64");
   // dF[b] = 2 * scale_b * F[b] @ D[b]: M = pixels, N = K = C; D is symmetric, so its rows serve as columns
-  static int cus = 0;
-  if (cus == 0) { const int c = nfs_device_cus(); cus = c > 0 ? c : 256; }
-  return gram_bwd_gemm(F, Dmat, dF, B, HW, C, 2.f * scale, scale_dev, relu_mask, cus, as_stream(stream));
+  return gram_bwd_gemm(F, Dmat, dF, B, HW, C, 2.f * scale, scale_dev, relu_mask, gram_cus(), as_stream(stream));
 }
 
 }  // extern "C"
