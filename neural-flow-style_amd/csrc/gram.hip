@@ -8,8 +8,8 @@
 //   float4 loads (prefetched one chunk ahead in registers, double-buffered in LDS; a diagonal pair stages one
 //   strip only) and reads MFMA fragments as conflict-free ds_read_b32 rows: the pixel-major layout IS the
 //   k-major operand layout of v_mfma_f32_32x32x2_f32, no transposition anywhere.  The partial tile goes to the
-//   workspace; gram_reduce_kernel sums the slabs in a fixed order, mirrors the lower triangle and applies the
-//   scale (deterministic).  Without a workspace the scaled tile (and its mirror) is added with float atomics.
+//   workspace; gram_reduce_kernel sums the slabs in a fixed order, applies the scale and writes the tile and
+//   its mirror image (deterministic).  Without a workspace the scaled tile (and its mirror) is added with float atomics.
 // gram_bwd: dF_b = 2 s_b F_b D_b is a plain batched GEMM (M = pixels, N = K = C): it runs on the LDS-staged
 //   batched f32-MFMA GEMM of winograd.hip (D is symmetric: its rows are read as columns), ReLU mask fused.
 #include "common.h"
@@ -169,34 +169,48 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   }
 }
 
-// G[b][c1][c2] = scale_b * sum_slab ws[((b*npair + pair)*nslab + slab)][TS x TS tile], pair = upper-triangular
-// index of (tile(c1), tile(c2)); elements below the diagonal come from the transposed tile.  blockDim (64, 4):
-// the 4 y-threads of an element sum interleaved slabs, then combine in a fixed order.
+// Second pass: a block owns GRD_ROWS rows of one (image, tile pair).  Its 4 waves sum interleaved slabs (wave g
+// takes slabs g, g+4, ...), the partial sums are combined in a fixed order (deterministic), scaled, written
+// into G as float4 rows and -- for an off-diagonal pair -- mirrored into the transposed tile.
+constexpr int GRD_ROWS = 4;
 __global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
-  __shared__ float red[4][64];
-  const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;   // element of G
-  const int64_t per_img = (int64_t)a.C * a.C;
-  float s = 0.f;
-  int b = 0;
-  const bool ok = e < per_img * a.B;
-  if (ok) {
-    b = (int)(e / per_img);
-    const int rem = (int)(e - (int64_t)b * per_img);
-    int c1 = rem / a.C, c2 = rem - c1 * a.C;
-    const int ts = a.ts;
-    if (c1 / ts > c2 / ts) { const int tmp = c1; c1 = c2; c2 = tmp; }   // lower triangle: read the mirrored tile
-    const int T1 = c1 / ts, T2 = c2 / ts, npair = a.ntile * (a.ntile + 1) / 2;
-    const int pair = T1 * a.ntile - T1 * (T1 - 1) / 2 + (T2 - T1);
-    const int64_t tile = (int64_t)ts * ts;
-    const float* p = a.ws + (((int64_t)b * npair + pair) * a.nslab) * tile + (c1 % ts) * ts + (c2 % ts);
-    for (int k = threadIdx.y; k < a.nslab; k += 4) s += p[(int64_t)k * tile];
+  constexpr int TS = 64;
+  __shared__ float4 part[4][64];
+  __shared__ float tile[GRD_ROWS][TS + 1];
+  const int t = threadIdx.x, lane = t & 63, g = t >> 6;
+  const int row = lane >> 4, q = lane & 15;
+  constexpr int groups = TS / GRD_ROWS;
+  const int npair = a.ntile * (a.ntile + 1) / 2;
+  int unit = blockIdx.x;
+  const int rg = unit % groups;
+  unit /= groups;
+  const int pair = unit % npair, b = unit / npair;
+  int t1 = 0, t2 = pair;
+  while (t2 >= a.ntile - t1) { t2 -= a.ntile - t1; ++t1; }
+  t2 += t1;
+  const int64_t tsz = (int64_t)TS * TS;
+  const float* p = a.ws + (((int64_t)b * npair + pair) * a.nslab) * tsz + (int64_t)(rg * GRD_ROWS + row) * TS + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = g; k < a.nslab; k += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(p + (int64_t)k * tsz);
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
   }
-  red[threadIdx.y][threadIdx.x] = s;
+  part[g][lane] = s;
   __syncthreads();
-  if (ok && threadIdx.y == 0) {
-    const float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    a.G[e] = tot * a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
-  }
+  if (g > 0) return;
+  const float sc = a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
+  const float4 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+  s.x = ((s.x + p1.x) + (p2.x + p3.x)) * sc; s.y = ((s.y + p1.y) + (p2.y + p3.y)) * sc;
+  s.z = ((s.z + p1.z) + (p2.z + p3.z)) * sc; s.w = ((s.w + p1.w) + (p2.w + p3.w)) * sc;
+  float* Gb = a.G + (int64_t)b * a.C * a.C;
+  *reinterpret_cast<float4*>(Gb + (int64_t)(t1 * TS + rg * GRD_ROWS + row) * a.C + t2 * TS + 4 * q) = s;
+  if (t1 == t2) return;
+  tile[row][4 * q] = s.x; tile[row][4 * q + 1] = s.y; tile[row][4 * q + 2] = s.z; tile[row][4 * q + 3] = s.w;
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done (single wave from here)
+  __builtin_amdgcn_wave_barrier();
+  // mirrored: G[t2*TS + c][t1*TS + rg*GRD_ROWS + 0..3] = tile[0..3][c], one float4 per lane (c = lane)
+  const float4 v = make_float4(tile[0][lane], tile[1][lane], tile[2][lane], tile[3][lane]);
+  *reinterpret_cast<float4*>(Gb + (int64_t)(t2 * TS + lane) * a.C + t1 * TS + rg * GRD_ROWS) = v;
 }
 
 // loss += weight * sum (G - Gs)^2 ; Dmat = 2*weight*(G - Gs)
@@ -233,13 +247,11 @@ static int gram_cus() {
 }
 
 static void gram_plan(GramArgs& a, int cus) {
-  static const int env_ts = [] { const char* e = getenv("NFS_GRAM_TS"); return e ? atoi(e) : 0; }();
   static const int env_cps = [] { const char* e = getenv("NFS_GRAM_CPS"); return e ? atoi(e) : 0; }();
-  // measured (tools/gram_bench.py, NFS_GRAM_TS / NFS_GRAM_CPS sweeps): 64 x 64 tiles beat 128 x 128 at every VGG
+  // measured (tools/gram_bench.py, tile-size / NFS_GRAM_CPS sweeps): 64 x 64 tiles beat 128 x 128 at every VGG
   // shape (4x more blocks, 4x smaller partial tiles), and ~16 chunks (512 pixels) per slab is the sweet spot
   // between per-block fill/epilogue cost and the number of partial tiles the reduce pass has to read.
   a.ts = 64;
-  if (env_ts == 128 && a.C % 128 == 0) a.ts = 128;
   a.ntile = a.C / a.ts;
   const int64_t pairs = (int64_t)a.B * a.ntile * (a.ntile + 1) / 2;
   const int total_chunks = (a.HW + GR_KC - 1) / GR_KC;
@@ -271,22 +283,12 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
   gram_plan(a, gram_cus());
   const int64_t units = (int64_t)B * (a.ntile * (a.ntile + 1) / 2) * a.nslab;
   a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
-  if (a.ts == 64) {
-    const size_t lds = 4 * GR_KC * 64 * sizeof(float);          // 32 KB (>= the 64 x 68 epilogue tile)
-    hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
-  } else {
-    const size_t lds = 128 * 132 * sizeof(float);               // epilogue tile 66 KB > 64 KB of operand buffers
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tn_kernel<128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(gram_tn_kernel<128>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
+  const size_t lds = 4 * GR_KC * 64 * sizeof(float);            // 32 KB (>= the 64 x 68 epilogue tile)
+  hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
+  if (a.ws) {
+    const unsigned rb = (unsigned)((int64_t)B * (a.ntile * (a.ntile + 1) / 2) * (64 / GRD_ROWS));
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(rb), dim3(256), 0, as_stream(stream), a);
   }
-  if (a.ws)
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for((int64_t)B * C * C, 64)), dim3(64, 4), 0, as_stream(stream),
-                       a);
   return check_launch("nfs_gram_fwd");
 }
 
