@@ -165,10 +165,11 @@ def test_maxnorm_ties_split_like_tf(ops):
     assert rel(gx_h, gx) < 1e-6
 
 
+@pytest.mark.parametrize("D", [14, 21, 32])   # 14: one thread per ray; >= 16: 4 depth segments per ray (21: ragged)
 @pytest.mark.parametrize("liquid", [False, True])
-def test_rotate_render_fused(ops, liquid):
+def test_rotate_render_fused(ops, liquid, D):
     torch.manual_seed(5)
-    d = torch.rand(1, 14, 12, 10, 1).requires_grad_()
+    d = torch.rand(1, D, 12, 10, 1).requires_grad_()
     R = rots(4, 5)
     tau = 0.15
     dr = O.rotate(d, R)
@@ -187,7 +188,7 @@ def test_rotate_render_fused(ops, liquid):
     gd_h = ops.rotate_render_bwd(dev(d[0, ..., 0]), dev(R), rs, gi, tau, liquid)
     assert rel(gd_h, gd[0, ..., 0]) < TOL
     # two-pass adjoint: kept rotated volume -> in-place render adjoint -> tiled rotate adjoint
-    d_rot = torch.empty(4, 14, 12, 10, device="cuda")
+    d_rot = torch.empty(4, D, 12, 10, device="cuda")
     img3, rs3 = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, liquid, d_rot=d_rot)
     assert rel(img3, img) < 1e-6 and rel(d_rot, dr[..., 0]) < TOL
     g_rot = ops.render_bwd(d_rot, rs3, gi, tau, liquid, g_d=d_rot)
