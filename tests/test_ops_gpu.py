@@ -119,7 +119,7 @@ def test_advect(ops, shape):
 
 
 @pytest.mark.parametrize("k", [3.0, 0.0])
-@pytest.mark.parametrize("shape", [(7, 9, 13), (8, 8, 16)])
+@pytest.mark.parametrize("shape", [(7, 9, 13), (8, 8, 16), (29, 19, 131)])   # last: 2 z-chunks, 3 row tiles, 3 column tiles
 def test_smooth3d_relu(ops, k, shape):
     torch.manual_seed(3)
     d = torch.randn(1, *shape, 1)
