@@ -342,24 +342,6 @@ __device__ __attribute__((noinline)) void rotate_tile_catchment(const float* r, 
   *out = vr;
 }
 
-// one axis of the border-replicating trilinear stencil with the two corners at constant offsets: base cell
-// i0 (clipped), weights (w0, w1) of cells i0 and i0 + 1.  Where the reference's clipped corners coincide
-// (x < 0 or x >= n-1: both weights land on the border voxel and sum to 1) the whole weight goes to i0.
-struct AxisH { int i0; float w0, w1; };
-__device__ __forceinline__ AxisH axis_halo(float c, int n) {
-  const float x = (c + 1.f) * (float)(n - 1) * 0.5f;
-  float f = floorf(x);
-  f = fminf(fmaxf(f, -1.f), (float)n);
-  const int i = (int)f;
-  AxisH a;
-  a.i0 = min(max(i, 0), n - 1);
-  const bool same = (unsigned)i >= (unsigned)(n - 1);
-  const float w1 = x - (float)a.i0;
-  a.w1 = same ? 0.f : w1;
-  a.w0 = same ? 1.f : 1.f - w1;
-  return a;
-}
-
 __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,
                                                                          const float* __restrict__ rot,
                                                                          float* __restrict__ g_d,
@@ -397,12 +379,11 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   const int grp = t / RT_GROUP, gl = t % RT_GROUP;
   constexpr int NGRP = RT_THREADS / RT_GROUP;
   const unsigned nz = (unsigned)(z1 - z0 + 1), ny = (unsigned)(y1 - y0 + 1), nx = (unsigned)(x1 - x0 + 1);
+  const float3 dm1 = make_float3((float)(D - 1), (float)(H - 1), (float)(W - 1));
   for (int v = 0; v < V; ++v) {
     const ViewRows& vr = vrows[v];
     const int rows = vr.rows;
     if (rows <= 0) continue;
-    const float* r = rot + v * 9;
-    const float r2 = r[2], r5 = r[5], r8 = r[8];
     const float* gv = g_out + (int64_t)v * D * H * W;
     for (int row = grp; row < rows; row += NGRP) {
       const int zi = vr.ey > 1 ? (int)__umulhi((unsigned)row, vr.my) : row;
@@ -410,9 +391,11 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
       // exact x-interval of this row inside the catchment slab of every axis
       float ta = (float)vr.x_lo, tb = (float)vr.x_hi;
       const float fz = (float)oz, fy = (float)oy;
+      float pv[3];                 // voxel coordinate of the row's sample ox = 0, per axis
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float p = vr.c[a] + vr.a0[a] * fz + vr.a1[a] * fy;
+        pv[a] = p;
         if (vr.inv_s[a] != 0.f) {
           const float u0 = (vr.lo[a] - p) * vr.inv_s[a], u1 = (vr.hi[a] - p) * vr.inv_s[a];
           ta = fmaxf(ta, fminf(u0, u1) - 0.01f);
@@ -423,8 +406,7 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
       }
       const int xa = (int)ceilf(ta), xb = (int)floorf(tb);
       if (xb < xa) continue;
-      const float gz_ = lin_coord(oz, D), gy_ = lin_coord(oy, H);
-      const float pz = r[0] * gz_ + r[1] * gy_, py = r[3] * gz_ + r[4] * gy_, px = r[6] * gz_ + r[7] * gy_;
+      const float sz = vr.s[0], sy = vr.s[1], sx = vr.s[2];
       const float* grow = gv + ((int64_t)oz * H + oy) * W;
       int ox = xa + gl;
       float g = ox <= xb ? grow[ox] : 0.f;
@@ -432,15 +414,22 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
         const int oxn = ox + RT_GROUP;
         const float gn = oxn <= xb ? grow[oxn] : 0.f;
         if (g != 0.f) {
-          const float gx_ = lin_coord(ox, W);
-          const AxisH az = axis_halo(pz + r2 * gx_, D);
-          const AxisH ay = axis_halo(py + r5 * gx_, H);
-          const AxisH ax = axis_halo(px + r8 * gx_, W);
-          const int lz = az.i0 - z0 + 1, ly = ay.i0 - y0 + 1, lx = ax.i0 - x0 + 1;   // halo'd local base cell
+          // lean stencil (same form as the ray march): the sample's voxel coordinate is affine in ox; border
+          // replication = clamp the coordinate, base cell min(floor, n-2), weights (1-w, w) with w in [0,1]
+          // (at the far border w = 1 puts the whole weight on voxel n-1, below 0 w = 0 puts it on voxel 0)
+          const float fx = (float)ox;
+          const float cz = __builtin_amdgcn_fmed3f(fmaf(sz, fx, pv[0]), 0.f, dm1.x);
+          const float cy = __builtin_amdgcn_fmed3f(fmaf(sy, fx, pv[1]), 0.f, dm1.y);
+          const float cx = __builtin_amdgcn_fmed3f(fmaf(sx, fx, pv[2]), 0.f, dm1.z);
+          const float bz = fminf(floorf(cz), dm1.x - 1.f), by_ = fminf(floorf(cy), dm1.y - 1.f),
+                      bx_ = fminf(floorf(cx), dm1.z - 1.f);
+          const float wz = cz - bz, wy = cy - by_, wx = cx - bx_;
+          const int lz = (int)bz - z0 + 1, ly = (int)by_ - y0 + 1, lx = (int)bx_ - x0 + 1;   // halo'd local base cell
           if ((unsigned)lz <= nz && (unsigned)ly <= ny && (unsigned)lx <= nx) {
             const float gs = g * fscale * fscale2;
-            const float wz0 = gs * az.w0, wz1 = gs * az.w1;
-            const float w00 = wz0 * ay.w0, w01 = wz0 * ay.w1, w10 = wz1 * ay.w0, w11 = wz1 * ay.w1;
+            const float wz1 = gs * wz, wz0 = gs - wz1;
+            const float w01 = wz0 * wy, w00 = wz0 - w01, w11 = wz1 * wy, w10 = wz1 - w11;
+            const float ax_w1 = wx, ax_w0 = 1.f - wx;
             unsigned long long* cell = acc + (lz * RT_LY + ly) * RT_LX + lx;
 // float -> 64-bit two's-complement fixed point in 4 instructions: high word = floor (v_cvt_flr_i32_f32),
 // low word = fract * 2^32 (v_fract_f32 is < 1 by construction; v_cvt_u32_f32 saturates)
@@ -452,14 +441,14 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
     asm("v_cvt_u32_f32 %0, %1" : "=v"(lo_) : "v"(__builtin_amdgcn_fractf(c_) * 4294967296.f));     \
     atomicAdd(cell + (off_), ((unsigned long long)hi_ << 32) | lo_);                               \
   }
-            NFS_RT_ADD(0, w00 * ax.w0)
-            NFS_RT_ADD(1, w00 * ax.w1)
-            NFS_RT_ADD(RT_LX, w01 * ax.w0)
-            NFS_RT_ADD(RT_LX + 1, w01 * ax.w1)
-            NFS_RT_ADD(RT_LY * RT_LX, w10 * ax.w0)
-            NFS_RT_ADD(RT_LY * RT_LX + 1, w10 * ax.w1)
-            NFS_RT_ADD(RT_LY * RT_LX + RT_LX, w11 * ax.w0)
-            NFS_RT_ADD(RT_LY * RT_LX + RT_LX + 1, w11 * ax.w1)
+            NFS_RT_ADD(0, w00 * ax_w0)
+            NFS_RT_ADD(1, w00 * ax_w1)
+            NFS_RT_ADD(RT_LX, w01 * ax_w0)
+            NFS_RT_ADD(RT_LX + 1, w01 * ax_w1)
+            NFS_RT_ADD(RT_LY * RT_LX, w10 * ax_w0)
+            NFS_RT_ADD(RT_LY * RT_LX + 1, w10 * ax_w1)
+            NFS_RT_ADD(RT_LY * RT_LX + RT_LX, w11 * ax_w0)
+            NFS_RT_ADD(RT_LY * RT_LX + RT_LX + 1, w11 * ax_w1)
 #undef NFS_RT_ADD
           }
         }
