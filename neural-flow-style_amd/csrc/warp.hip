@@ -138,31 +138,11 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
 // The generic kernel keeps one voxel per thread in flight and is bound by latency x occupancy
 // (~1.9 TB/s).  Here a thread owns 4 W-consecutive voxels: the 12 velocity floats arrive as three
 // float4 loads, the 16 x-corner pairs as 8-byte loads, all issued before use, 32-bit indexing.
-__device__ __forceinline__ void advect1_stencil(const float* __restrict__ d, int D, int H, int W, int vox, float v0,
-                                                float v1, float v2, Axis& az, Axis& ay, Axis& ax) {
-  const int w = vox % W;
-  const int hh = (vox / W) % H;
-  const int z = vox / (W * H);
-  az = axis_setup(lin_coord(z, D) - v0, D);
-  ay = axis_setup(lin_coord(hh, H) - v1, H);
-  ax = axis_setup(lin_coord(w, W) - v2, W);
-}
-
-__device__ __forceinline__ void gather_pairs32(const float* __restrict__ vol, int H, int W, const Axis& az,
-                                               const Axis& ay, const Axis& ax, float* v) {
-  const int xb = min(ax.i0, W - 2);
-  const bool x0_lo = ax.i0 == xb, x1_lo = ax.i1 == xb;
-  const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const F2u p = *reinterpret_cast<const F2u*>(vol + ((iz[a] * H + iy[b]) * W + xb));
-      v[a * 4 + b * 2] = x0_lo ? p.x : p.y;
-      v[a * 4 + b * 2 + 1] = x1_lo ? p.x : p.y;
-    }
-}
-
+// Scalar-field advect, 4 W-consecutive voxels per thread, lean stencil: the back-traced voxel coordinate is
+// x_a = index_a - vel_a * (n_a - 1)/2 (one FMA; lin_coord(i) - vel mapped to voxel space), border replication by
+// clamping it to [0, n-1], base cell min(floor, n-2), weight in [0,1]; the four row-pairs of the stencil are
+// dword-aligned 8-byte loads.  D, H, W >= 2.  The first form (per-corner index clamps, two runtime integer
+// divisions per voxel) spent ~150 VALU instructions per voxel on a 20-byte-per-voxel stream.
 template <bool BWD>
 __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* __restrict__ vel,
                                                       const float* __restrict__ g_out, float* __restrict__ out,
@@ -176,42 +156,63 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
   if (BWD) go = *reinterpret_cast<const float4*>(g_out + base);
   const float gg[4] = {go.x, go.y, go.z, go.w};
-  Axis az[4], ay[4], ax[4];
-  float cv[4][8];
+  const float hz = 0.5f * (float)(D - 1), hy = 0.5f * (float)(H - 1), hx = 0.5f * (float)(W - 1);
+  const float nz1 = (float)(D - 1), ny1 = (float)(H - 1), nx1 = (float)(W - 1);
+  const unsigned uW = (unsigned)W, uHW = (unsigned)(H * W);
+  int w = base % W;
+  const int t2 = base / W;
+  int h = t2 % H, z = t2 / H;
+  F2u p[4][4];
+  float wz[4], wy[4], wx[4], mz[4], my[4], mx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    advect1_stencil(d, D, H, W, base + j, vv[3 * j], vv[3 * j + 1], vv[3 * j + 2], az[j], ay[j], ax[j]);
-    gather_pairs32(d, H, W, az[j], ay[j], ax[j], cv[j]);
+    const float xz = fmaf(-vv[3 * j], hz, (float)z), xy = fmaf(-vv[3 * j + 1], hy, (float)h),
+                xx = fmaf(-vv[3 * j + 2], hx, (float)w);
+    const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
+                cx = __builtin_amdgcn_fmed3f(xx, 0.f, nx1);
+    const float bz = fminf(floorf(cz), nz1 - 1.f), by = fminf(floorf(cy), ny1 - 1.f), bx = fminf(floorf(cx), nx1 - 1.f);
+    wz[j] = cz - bz; wy[j] = cy - by; wx[j] = cx - bx;
+    if (BWD) {   // outside the volume both clipped corners coincide: no dependence on the coordinate
+      mz[j] = (xz >= 0.f && xz < nz1) ? hz : 0.f;
+      my[j] = (xy >= 0.f && xy < ny1) ? hy : 0.f;
+      mx[j] = (xx >= 0.f && xx < nx1) ? hx : 0.f;
+    }
+    const unsigned o = (unsigned)(int)bz * uHW + (unsigned)(int)by * uW + (unsigned)(int)bx;
+    p[j][0] = *reinterpret_cast<const F2u*>(d + o);
+    p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
+    p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
+    p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
+    if (++w == W) { w = 0; if (++h == H) { h = 0; ++z; } }
   }
   if (!BWD) {
     float r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float wz[2] = {1.f - az[j].w1, az[j].w1}, wy[2] = {1.f - ay[j].w1, ay[j].w1},
-                  wx[2] = {1.f - ax[j].w1, ax[j].w1};
-      float sacc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sacc += wz[k >> 2] * wy[(k >> 1) & 1] * wx[k & 1] * cv[j][k];
-      r[j] = sacc;
+      const float a00 = fmaf(wx[j], p[j][0].y - p[j][0].x, p[j][0].x), a01 = fmaf(wx[j], p[j][1].y - p[j][1].x, p[j][1].x);
+      const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
+      const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
+      r[j] = fmaf(wz[j], b1 - b0, b0);
     }
     *reinterpret_cast<float4*>(out + base) = make_float4(r[0], r[1], r[2], r[3]);
   } else {
     float gv[12];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float* v = cv[j];
-      const float wz[2] = {1.f - az[j].w1, az[j].w1}, wy[2] = {1.f - ay[j].w1, ay[j].w1},
-                  wx[2] = {1.f - ax[j].w1, ax[j].w1};
-      // k = a*4 + b*2 + c with (a,b,c) = (z,y,x) corner bits
-      const float dz = wy[0] * wx[0] * (v[4] - v[0]) + wy[0] * wx[1] * (v[5] - v[1]) +
-                       wy[1] * wx[0] * (v[6] - v[2]) + wy[1] * wx[1] * (v[7] - v[3]);
-      const float dy = wz[0] * wx[0] * (v[2] - v[0]) + wz[0] * wx[1] * (v[3] - v[1]) +
-                       wz[1] * wx[0] * (v[6] - v[4]) + wz[1] * wx[1] * (v[7] - v[5]);
-      const float dx = wz[0] * wy[0] * (v[1] - v[0]) + wz[0] * wy[1] * (v[3] - v[2]) +
-                       wz[1] * wy[0] * (v[5] - v[4]) + wz[1] * wy[1] * (v[7] - v[6]);
-      gv[3 * j] = -gg[j] * dz * ((float)(D - 1) * 0.5f);
-      gv[3 * j + 1] = -gg[j] * dy * ((float)(H - 1) * 0.5f);
-      gv[3 * j + 2] = -gg[j] * dx * ((float)(W - 1) * 0.5f);
+      const float e00 = p[j][0].y - p[j][0].x, e01 = p[j][1].y - p[j][1].x, e10 = p[j][2].y - p[j][2].x,
+                  e11 = p[j][3].y - p[j][3].x;
+      const float a00 = fmaf(wx[j], e00, p[j][0].x), a01 = fmaf(wx[j], e01, p[j][1].x);
+      const float a10 = fmaf(wx[j], e10, p[j][2].x), a11 = fmaf(wx[j], e11, p[j][3].x);
+      // d(sample)/d(coordinate) along each axis: difference of the two faces, interpolated in the other two
+      const float f0 = fmaf(wy[j], e01 - e00, e00), f1 = fmaf(wy[j], e11 - e10, e10);
+      const float dx = fmaf(wz[j], f1 - f0, f0);
+      const float g0 = a01 - a00, g1 = a11 - a10;
+      const float dy = fmaf(wz[j], g1 - g0, g0);
+      const float b0 = fmaf(wy[j], g0, a00), b1 = fmaf(wy[j], g1, a10);
+      const float dz = b1 - b0;
+      // coordinate = index - vel * (n-1)/2  =>  d/dvel = -(n-1)/2 * d/dcoordinate (mz/my/mx carry the factor)
+      gv[3 * j] = -gg[j] * dz * mz[j];
+      gv[3 * j + 1] = -gg[j] * dy * my[j];
+      gv[3 * j + 2] = -gg[j] * dx * mx[j];
     }
     float4* o4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;
     o4[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
@@ -549,7 +550,7 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   if (int e = check_dims(1, D, H, W, C)) return e;
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
-  if (C == 1 && W >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
+  if (C == 1 && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
     hipLaunchKernelGGL(advect1_kernel<false>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
                        (const float*)nullptr, out, D, H, W);
     return check_launch("nfs_advect_fwd(x4)");
@@ -566,7 +567,7 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* 
   if (int e = check_dims(1, D, H, W, C)) return e;
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
-  if (C == 1 && !g_d_acc && W >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
+  if (C == 1 && !g_d_acc && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
     hipLaunchKernelGGL(advect1_kernel<true>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
                        g_out, g_vel, D, H, W);
     return check_launch("nfs_advect_bwd(x4)");
