@@ -296,6 +296,7 @@ def main():
         # stream also count the other stream's kernels sharing the chip); the headline above uses the default
         gs.loss.vgg_streams = 1
         gs.loss.view_groups = 1
+        gs.loss.gram_side_stream = False
         import ctypes
         L = _lib.lib()
         _lib.PROFILE = {}

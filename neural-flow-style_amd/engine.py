@@ -37,6 +37,8 @@ class RenderStyleLoss(object):
         # With the direct conv kernels two groups overlapped each other's launch tails (7.32 -> 7.01 ms/step);
         # with the Winograd path one batch of all views on one stream is fastest (8 views of 200^2: 1 stream
         # 4.73 ms/step, 2 streams 4.79, 4 streams 6.38), so that is the default.
+        self.gram_side_stream = os.environ.get("NFS_GRAM_STREAM", "1") != "0"
+        self._side = None
         self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "1"))
         self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "1"))
         self._streams = []
@@ -90,17 +92,46 @@ class RenderStyleLoss(object):
         dimg, _ = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_x=False)
         return dimg
 
+    def _gram_job(self, name, F, loss):
+        """Gram matrix, style loss and the Gram gradient dF (ReLU-masked) of one style layer"""
+        wl = self.w_layers[self.layers.index(name)]
+        _, h, w, c = F.shape
+        scale = 1.0 / (2.0 * h * w * c)
+        G = ops.gram_fwd(F, scale)
+        Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
+        return ops.gram_bwd(F, Dm, scale, relu_mask=True)
+
     def _vgg_loss_grad(self, x, loss):
-        """x [B,h,w,3] (mean-subtracted) -> dL/dx; adds the per-image style losses into ``loss`` [B]"""
-        acts = self.net.forward(x, self.top)
+        """x [B,h,w,3] (mean-subtracted) -> dL/dx; adds the per-image style losses into ``loss`` [B].
+
+        The Gram work of a style layer (Gram matrix -> loss -> dF) depends only on that layer's activations, so it
+        is enqueued on a side stream as soon as the layer exists and overlaps the following convolutions (short
+        MFMA kernels that fill the launch tails of the conv GEMMs); the backward chain waits for it once."""
         sg = {}
-        for name, wl in zip(self.layers, self.w_layers):
-            F = acts[name]
-            _, h, w, c = F.shape
-            scale = 1.0 / (2.0 * h * w * c)
-            G = ops.gram_fwd(F, scale)
-            Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
-            sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        if not self.gram_side_stream:
+            acts = self.net.forward(x, self.top)
+            for name in self.layers:
+                sg[name] = self._gram_job(name, acts[name], loss)
+            return self.net.backward(acts, sg, self.top)
+        main = torch.cuda.current_stream(x.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x.device)
+        side = self._side
+        side.wait_stream(main)                      # ``loss`` / style targets were produced on the main stream
+
+        def on_layer(name, F):
+            if name not in self.layers:
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            F.record_stream(side)
+            with torch.cuda.stream(side):
+                sg[name] = self._gram_job(name, F, loss)
+            sg[name].record_stream(main)
+
+        acts = self.net.forward(x, self.top, on_layer=on_layer)
+        main.wait_stream(side)
         return self.net.backward(acts, sg, self.top)
 
     # -- the hot step -----------------------------------------------------------------------

@@ -96,8 +96,10 @@ class VGG(object):
                 raise KeyError("no weights for %s" % name)
         return plan
 
-    def forward(self, x, upto):
-        """x [B,H,W,3] (mean-subtracted) -> OrderedDict name -> [B,h,w,C] post-ReLU / pooled"""
+    def forward(self, x, upto, on_layer=None):
+        """x [B,H,W,3] (mean-subtracted) -> OrderedDict name -> [B,h,w,C] post-ReLU / pooled.
+        ``on_layer(name, tensor)`` is called right after a layer has been enqueued (the style loss uses it to
+        start that layer's Gram work on a second stream while the next convolutions run)."""
         acts = OrderedDict()
         cur = x
         for name, kind, cin, cout in self.plan(upto):
@@ -107,6 +109,8 @@ class VGG(object):
             else:
                 cur = ops.avgpool2_fwd(cur)
             acts[name] = cur
+            if on_layer is not None:
+                on_layer(name, cur)
         return acts
 
     def backward(self, acts, style_grads, upto):

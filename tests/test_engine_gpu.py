@@ -101,14 +101,15 @@ def test_adam_trajectory_parity():
 
 
 def test_view_groups_on_streams_match_single_batch():
-    """optional concurrency mode (NFS_VIEW_GROUPS / NFS_VGG_STREAMS): splitting the views into groups that run
-    on separate HIP streams must give the same losses and field gradient as one batch on one stream"""
+    """concurrency modes (NFS_VIEW_GROUPS / NFS_VGG_STREAMS / NFS_GRAM_STREAM): view groups on separate HIP
+    streams and the Gram work on a side stream must give the same losses and field gradient as one batch on
+    one stream"""
     layers = ["conv1_1", "conv2_1", "conv3_1"]
     d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 4, layers)
     rot = T.rot_to_device(mats, "cuda")
     res = []
-    for groups, streams in ((1, 1), (2, 2), (2, 1)):
-        loss.view_groups, loss.vgg_streams = groups, streams
+    for groups, streams, side in ((1, 1, False), (2, 2, True), (2, 1, True), (1, 1, True)):
+        loss.view_groups, loss.vgg_streams, loss.gram_side_stream = groups, streams, side
         gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v")
         gs.var.copy_(torch.tensor(vel0))
         losses, g = gs.gradient(rot)
