@@ -211,6 +211,14 @@ int nfs_p2g_wavg_finish_bwd(const float* xsum, const float* wsum, const float* g
                             float* g_xsum, float* g_wsum, int64_t n, int C, float eps,
                             nfs_stream_t stream);
 
+/* ---- g2p_linear / g2p_cubic (transform.py:771-1231) ----------------------
+ * g [X,Y,(Z),C] cell-centred grid, p [N,nd] in [0,1] (axis order = array order), out [N,C].
+ * x = p*n, base = floor(x-0.5); linear: cells base, base+1 clipped, dx = x-(clipped base+0.5);
+ * cubic: cells base-1..base+2 clipped, Catmull-Rom (_hermite) in t = x-(clipped base+0.5).
+ * Forward only: the reference's resampler (test_smokegun_resim.py) never differentiates it. */
+int nfs_g2p_fwd(const float* g, const float* p, float* out, int nd, int X, int Y, int Z, int C,
+                int64_t N, int cubic, nfs_stream_t stream);
+
 /* ---- A10: TF ApplyAdam (styler_3p.py:320-323) -----------------------------------------
  * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; x -= lr_t*m/(sqrt(v)+eps), lr_t =
  * lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller.  NaN gradients are NOT sanitised. */

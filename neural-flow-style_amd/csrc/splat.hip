@@ -217,6 +217,72 @@ static int make_dev_cfg(const nfs_splat_cfg* c, int C, SplatDev& s) {
   return NFS_OK;
 }
 
+
+// ---- grid -> particle sampling (transform.py:771-1231) ---------------------------------------
+// g [X,Y,(Z),C] cell-centred, p [N,nd] in [0,1] (axis order = array order): x = p * n, base = floor(x - 0.5).
+// linear: cells (base, base+1) clipped to [0,n-1], weight dx = x - (clipped base + 0.5) (so outside the centre
+// lattice both cells coincide and the value is the border cell's); cubic: cells base-1..base+2 clipped,
+// t = x - (clipped base + 0.5), Catmull-Rom weights of the reference's _hermite.  One thread per particle.
+struct G2PArgs {
+  const float* g;
+  const float* p;
+  float* out;
+  int nd, n[3], C, cubic;
+  int64_t N;
+};
+
+__device__ __forceinline__ void g2p_axis(float x, int n, int cubic, int* idx, float* w) {
+  const float fb = floorf(x - 0.5f);
+  const int b = (int)fminf(fmaxf(fb, -4.f), (float)n + 4.f);
+  if (!cubic) {
+    idx[0] = min(max(b, 0), n - 1);
+    idx[1] = min(max(b + 1, 0), n - 1);
+    const float dx = x - ((float)idx[0] + 0.5f);
+    w[0] = 1.f - dx; w[1] = dx;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) idx[k] = min(max(b - 1 + k, 0), n - 1);
+  const float t = x - ((float)idx[1] + 0.5f);
+  const float t2 = t * t, t3 = t2 * t;
+  w[0] = -0.5f * t3 + t2 - 0.5f * t;
+  w[1] = 1.5f * t3 - 2.5f * t2 + 1.f;
+  w[2] = -1.5f * t3 + 2.f * t2 + 0.5f * t;
+  w[3] = 0.5f * t3 - 0.5f * t2;
+}
+
+__global__ void __launch_bounds__(256) g2p_kernel(G2PArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N) return;
+  const int taps = a.cubic ? 4 : 2;
+  int ix[3][4];
+  float wx[3][4];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d < a.nd) {
+      g2p_axis(a.p[i * a.nd + d] * (float)a.n[d], a.n[d], a.cubic, ix[d], wx[d]);
+    } else {
+      ix[d][0] = 0; wx[d][0] = 1.f;
+    }
+  }
+  const int t2 = a.nd >= 3 ? taps : 1;
+  for (int c0 = 0; c0 < a.C; c0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cn = min(4, a.C - c0);
+    for (int ka = 0; ka < taps; ++ka)
+      for (int kb = 0; kb < taps; ++kb) {
+        const float wab = wx[0][ka] * wx[1][kb];
+        const int64_t rowb = (int64_t)ix[0][ka] * a.n[1] + ix[1][kb];
+        for (int kc = 0; kc < t2; ++kc) {
+          const float w = wab * wx[2][kc];
+          const float* gp = a.g + ((a.nd >= 3 ? rowb * a.n[2] + ix[2][kc] : rowb) * a.C + c0);
+          for (int c = 0; c < cn; ++c) acc[c] += w * gp[c];
+        }
+      }
+    for (int c = 0; c < cn; ++c) a.out[i * a.C + c0 + c] = acc[c];
+  }
+}
+
 }  // namespace nfs
 
 using namespace nfs;
@@ -264,6 +330,16 @@ int nfs_p2g_wavg_finish_bwd(const float* xsum, const float* wsum, const float* g
   hipLaunchKernelGGL(wavg_finish_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), xsum, wsum,
                      g_out, g_xsum, g_wsum, n, C, eps);
   return check_launch("nfs_p2g_wavg_finish_bwd");
+}
+
+int nfs_g2p_fwd(const float* g, const float* p, float* out, int nd, int X, int Y, int Z, int C, int64_t N, int cubic,
+                nfs_stream_t stream) {
+  NFS_REQUIRE(g && p && out, "nfs_g2p_fwd: null pointer");
+  NFS_REQUIRE((nd == 2 || nd == 3) && X > 0 && Y > 0 && (nd == 2 || Z > 0) && C > 0 && N > 0,
+              "nfs_g2p_fwd: bad dimension");
+  G2PArgs a{g, p, out, nd, {X, Y, nd == 3 ? Z : 1}, C, cubic ? 1 : 0, N};
+  hipLaunchKernelGGL(g2p_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), a);
+  return check_launch("nfs_g2p_fwd");
 }
 
 }  // extern "C"

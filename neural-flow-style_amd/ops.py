@@ -379,3 +379,18 @@ def fill(x, value):
 
 def axpy(y, x, a):
     _lib.call("nfs_axpy", _ptr(y), _ptr(x), float(a), x.numel(), _stream())
+
+
+# ---- SURVEY 8(f)-1 -------------------------------------------------------------------
+
+def g2p_fwd(g, p, cubic=True):
+    """g [X,Y,(Z),C] cell-centred grid, p [N,nd] in [0,1] -> [N,C]  (transform.py:771-1231, forward only)"""
+    nd = p.shape[-1]
+    assert g.dim() == nd + 1 and nd in (2, 3)
+    N, Cn = p.shape[0], g.shape[-1]
+    out = _empty((N, Cn), g)
+    X, Y = g.shape[0], g.shape[1]
+    Z = g.shape[2] if nd == 3 else 1
+    _lib.call("nfs_g2p_fwd", _ptr(g), _ptr(p), _ptr(out), nd, X, Y, Z, Cn, N, int(bool(cubic)), _stream())
+    return out
+

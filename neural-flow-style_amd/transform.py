@@ -276,3 +276,11 @@ def p2g_wavg(p, x, domain, res, radius, nsize, is_2d=True, kernel="cubic", eps=1
     nd = 2 if is_2d else 3
     cfg = ops.make_splat_cfg(nd, list(res), list(domain), radius, support, 1.0, nsize, clip, 2)
     return _P2GWavg.apply(p, x, cfg, eps)
+
+
+def g2p(g, p, is_2d=True, is_linear=False):
+    """grid -> particle sampling, g [1,X,Y,(Z),C] cell-centred, p [1,N,d] in [0,1] -> [1,N,C]
+    (transform.py:771-776: Catmull-Rom cubic unless ``is_linear``).  Forward only, like its only
+    consumer in the reference (the SimG2P resampler, test_smokegun_resim.py:36-47,96)."""
+    assert g.shape[0] == 1 and p.shape[0] == 1
+    return ops.g2p_fwd(g[0].detach().contiguous(), p[0].detach().contiguous(), cubic=not is_linear).unsqueeze(0)

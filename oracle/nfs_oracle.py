@@ -765,3 +765,127 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
     res = [int(v) for v in oct_size[-1]]
     d_fin = [particle_field(p[t], r[t], g_opt[t], cfg, res)[1][0] for t in range(F_)]
     return hist, g_opt, d_fin
+
+
+# --------------------------------------------------------------------------
+# grid -> particle sampling and the SimG2P resampler
+# (transform.py:771-1231, test_smokegun_resim.py:17-217).  Parity unpinned (the reference holds no
+# vectors for these); pinned here by analytic known answers (tests/test_oracle_kat.py).
+# --------------------------------------------------------------------------
+def _g2p_axis(x, n, cubic):
+    """one axis of g2p: cell-centred coordinate x in [0,n] -> (clipped indices, weights).
+    linear (transform.py:1140-1154, 1196-1197): x0 = floor(x-0.5), x1 = x0+1, both clipped to [0,n-1],
+    dx = x - (clipped x0 + 0.5), weights (1-dx, dx).
+    cubic (transform.py:811-836, 972-978, 1000-1001): x1 = floor(x-0.5); x0..x3 = x1-1..x1+2 clipped;
+    t = x - (clipped x1 + 0.5); Catmull-Rom weights of _hermite."""
+    i = torch.floor(x - 0.5).long()
+    if not cubic:
+        i0 = i.clamp(0, n - 1); i1 = (i + 1).clamp(0, n - 1)
+        dx = x - (i0.to(x.dtype) + 0.5)
+        return [i0, i1], [1.0 - dx, dx]
+    idx = [(i + k).clamp(0, n - 1) for k in (-1, 0, 1, 2)]
+    t = x - (idx[1].to(x.dtype) + 0.5)
+    t2, t3 = t * t, t * t * t
+    w = [-0.5 * t3 + t2 - 0.5 * t, 1.5 * t3 - 2.5 * t2 + 1.0, -1.5 * t3 + 2.0 * t2 + 0.5 * t, 0.5 * t3 - 0.5 * t2]
+    return idx, w
+
+
+def g2p(g, p, is_2d=True, is_linear=False):
+    """g [1,X,Y,(Z),C], p [1,N,d] in [0,1] (axis order = array order) -> [1,N,C]
+    (transform.py:771-776: cubic unless is_linear)."""
+    assert g.shape[0] == 1 and p.shape[0] == 1
+    nd = 2 if is_2d else 3
+    dims = list(g.shape[1:1 + nd])
+    C = g.shape[-1]
+    gf = g.reshape(-1, C)
+    ax = [_g2p_axis(p[0, :, a] * dims[a], dims[a], not is_linear) for a in range(nd)]
+    out = 0
+    import itertools
+    for combo in itertools.product(*[range(len(ax[a][0])) for a in range(nd)]):
+        flat = 0
+        w = 1.0
+        for a in range(nd):
+            flat = flat * dims[a] + ax[a][0][combo[a]]
+            w = w * ax[a][1][combo[a]]
+        out = out + w.unsqueeze(-1) * gf[flat]
+    return out.unsqueeze(0)
+
+
+def mac_to_centered(v_):
+    """mantaflow MAC-grid velocity [D,H,W,3] (x,y,z components on the low faces) -> cell-centred,
+    H flipped (test_smokegun_resim.py:233-243), numpy."""
+    vx = np.dstack((v_, np.zeros((v_.shape[0], v_.shape[1], 1, v_.shape[3]), v_.dtype)))
+    vx = (vx[:, :, 1:, 0] + vx[:, :, :-1, 0]) * 0.5
+    vy = np.hstack((v_, np.zeros((v_.shape[0], 1, v_.shape[2], v_.shape[3]), v_.dtype)))
+    vy = (vy[:, 1:, :, 1] + vy[:, :-1, :, 1]) * 0.5
+    vz = np.vstack((v_, np.zeros((1, v_.shape[1], v_.shape[2], v_.shape[3]), v_.dtype)))
+    vz = (vz[1:, :, :, 2] + vz[:-1, :, :, 2]) * 0.5
+    v = np.stack([vx, vy, vz], axis=-1)
+    return v[:, ::-1]
+
+
+def simg2p_advect(x, u):
+    """RK4 velocity sampling + advection with time step 0.5 (test_smokegun_resim.py:35-53).
+    x [N,3] in [0,1] (z,y,x), u [D,H,W,3] -> x_adv [N,3]"""
+    xb, ub = x.unsqueeze(0), u.unsqueeze(0)
+    v = g2p(ub, xb, is_2d=False)
+    v1 = g2p(ub, xb + v * 0.5, is_2d=False)
+    v2 = g2p(ub, xb + v1 * 0.5, is_2d=False)
+    v3 = g2p(ub, xb + v2, is_2d=False)
+    v = (v + v1 * 2 + v2 * 2 + v3) / 6
+    return (xb + v * 0.5)[0]
+
+
+def simg2p_pressure_loss(x_hat, cfg, res):
+    """mean(pressure^2), pressure = where(d_rec > 0, d_rec - rho0, 0) of the cubic splat with support 4,
+    clip=False (test_smokegun_resim.py:65-71)"""
+    d_rec = p2g(x_hat.unsqueeze(0), cfg["domain"], res, cfg["radius"], cfg["rest_density"], cfg["nsize"],
+                is_2d=False, clip=False, support=4)
+    pres = torch.where(d_rec > 0, d_rec - cfg["rest_density"], torch.zeros_like(d_rec))
+    return (pres ** 2).mean()
+
+
+def simg2p_density_sampling(x_hat, d, cfg, res):
+    """multi-scale particle density sampling (test_smokegun_resim.py:83-106): per octave sample the residual
+    d - d_hat_prev[:, :, ::-1] at the particles (cubic g2p), splat it back with support/octave_scale^o.
+    Returns r_smp [N,octave_n], d_smp [D,H,W] (clipped to 0..1), d_diff [D,H,W]"""
+    dd = d.unsqueeze(0).unsqueeze(-1)
+    xb = x_hat.unsqueeze(0)
+    r = []
+    d_hat = None
+    for o in range(cfg["octave_n"]):
+        if o > 0:
+            d_hi = d_hat
+            d_ = dd - d_hi.flip(2)
+        else:
+            d_ = dd
+        r_ = g2p(d_, xb, is_2d=False)
+        r.append(r_)
+        factor = cfg["octave_scale"] ** o
+        d_hat = p2g_wavg(xb, r_, cfg["domain"], res, cfg["radius"], cfg["nsize"], is_2d=False, clip=False,
+                         support=cfg["support"] / factor)
+        if o > 0:
+            d_hat = d_hat + d_hi
+    r_smp = torch.cat(r, dim=-1)[0]
+    d_smp = d_hat[0, ..., 0].clamp(0, 1)
+    d_diff = (dd.flip(2) - d_hat)[0].flip(1)[..., 0]
+    return r_smp, d_smp, d_diff
+
+
+def simg2p_optimize(p, d, u, cfg, res):
+    """SimG2P.optimize up to (not including) the seeding of new particles (test_smokegun_resim.py:168-199):
+    advect, `iter` TF-Adam steps on the particle displacement against the pressure loss, then the density
+    sampling at the redistributed positions.  Returns dict(p_adv, p_new, l, d_diff, r_smp, d_smp)."""
+    p_adv = simg2p_advect(p, u)
+    v = torch.zeros_like(p_adv)
+    opt = TFAdam()
+    losses = []
+    for _ in range(cfg["iter"]):
+        vv = v.clone().requires_grad_()
+        loss = simg2p_pressure_loss(p_adv + vv, cfg, res)
+        (g,) = torch.autograd.grad(loss, vv)
+        losses.append(float(loss))
+        v = opt.step(v, g, cfg["lr"])
+    p_new = p_adv + v
+    r_smp, d_smp, d_diff = simg2p_density_sampling(p_new, d, cfg, res)
+    return dict(p_adv=p_adv, p_new=p_new, l=losses, d_diff=d_diff, r_smp=r_smp, d_smp=d_smp)

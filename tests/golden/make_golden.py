@@ -25,7 +25,30 @@ def save(name, **kw):
     print(name, {k: np.asarray(v).shape for k, v in kw.items()})
 
 
+def make_g2p():
+    """(6) SURVEY 8(f)-1: grid -> particle sampling and the SimG2P resampler, seed 11"""
+    rng = np.random.RandomState(11)
+    g = torch.tensor(rng.randn(1, 9, 7, 11, 3).astype(np.float32))
+    p = torch.tensor(rng.uniform(-0.1, 1.1, (1, 300, 3)).astype(np.float32))
+    G = 12
+    zz, yy, xx = np.meshgrid(*[np.linspace(0, 1, G)] * 3, indexing="ij")
+    d = np.exp(-((zz - 0.5) ** 2 + (yy - 0.45) ** 2 + (xx - 0.55) ** 2) / 0.04).astype(np.float32)
+    d[d < 0.05] = 0
+    u = (rng.randn(G, G, G, 3) * 0.01).astype(np.float32)
+    cfg = dict(domain=[G, G, G], radius=0.5, rest_density=1000.0, nsize=1, support=4, octave_n=2, octave_scale=2.0,
+               lr=0.002, iter=3)
+    pid = np.array(np.where(d > 0.3)).T.astype(np.float64) + 0.5
+    x = torch.tensor((pid / G).astype(np.float32))
+    r = O.simg2p_optimize(x, torch.tensor(d), torch.tensor(u), cfg, [G, G, G])
+    save("ops_g2p.npz", seed=11, g=g, p=p, cubic=O.g2p(g, p, is_2d=False), linear=O.g2p(g, p, is_2d=False, is_linear=True),
+         d=d, u=u, x=x, p_adv=r["p_adv"], p_new=r["p_new"], losses=np.array(r["l"], np.float64), r_smp=r["r_smp"],
+         d_diff=r["d_diff"], cfg_keys=np.array(sorted(cfg)), cfg_vals=np.array([str(cfg[k]) for k in sorted(cfg)]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g2p":      # regenerate only the 8(f)-1 fixture
+        make_g2p()
+        return
     # (1) the reference's own known-answer vector
     save("warp2d_kat.npz", img=np.arange(25, dtype=np.float32).reshape(5, 5),
          zoom_in=np.array([[6, 6.5, 7, 7.5, 8], [8.5, 9, 9.5, 10, 10.5], [11, 11.5, 12, 12.5, 13],
@@ -97,6 +120,7 @@ def main():
     save("e2e_grid24.npz", seed=123, d0=d0, vel0=v0, style=simg, rot=mats,
          losses=np.array(losses), grad_first_step=g_first.astype(np.float32)[::2, ::2, ::2],
          d_final=d_fin.numpy().astype(np.float32)[::2, ::2, ::2], lr=0.002, transmit=0.05, layers=np.array(layers))
+    make_g2p()
 
 
 if __name__ == "__main__":

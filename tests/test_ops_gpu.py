@@ -375,3 +375,17 @@ def test_error_channel(ops):
         _lib.call("nfs_render_fwd", None, None, None, 1, 1, 1, 1, 0.1, 0, None)
     with pytest.raises(ValueError):
         ops.render_fwd(torch.zeros(1, 2, 2, 2), 0.1)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("nd,C", [(2, 1), (2, 3), (3, 1), (3, 3), (3, 5)])
+@pytest.mark.parametrize("linear", [False, True])
+def test_g2p(ops, nd, C, linear):
+    """SURVEY 8(f)-1: grid -> particle sampling (cubic Catmull-Rom / linear, cell-centred, clipped cells);
+    particles inside, on the border cells and outside [0,1]"""
+    torch.manual_seed(31)
+    dims = (9, 7) if nd == 2 else (9, 7, 11)
+    g = torch.randn(1, *dims, C)
+    p = torch.rand(1, 400, nd) * 1.3 - 0.15
+    ref = O.g2p(g, p, is_2d=(nd == 2), is_linear=linear)[0]
+    out = ops.g2p_fwd(dev(g[0]), dev(p[0]), cubic=not linear)
+    assert rel(out, ref) < TOL

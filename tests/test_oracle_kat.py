@@ -134,3 +134,45 @@ def test_vgg_shapes_and_avgpool_valid():
     assert f["conv2_1"].shape[1:3] == (12, 12)
     assert f["conv3_1"].shape[1:3] == (6, 6)
     assert f["conv5_1"].shape[1:3] == (1, 1)
+
+
+def test_g2p_known_answers():
+    """cell-centred sampling.  Linear g2p reproduces an affine field, cubic (Catmull-Rom)
+    reproduces a quadratic, both exactly at cell centres; outside the centre lattice the border cell is
+    replicated (both clipped cells coincide, transform.py:1145-1154)."""
+    torch.manual_seed(0)
+    X, Y, Z = 8, 7, 9
+    zz, yy, xx = torch.meshgrid(torch.arange(X) + 0.5, torch.arange(Y) + 0.5, torch.arange(Z) + 0.5, indexing="ij")
+    aff = (2 * zz - 3 * yy + 0.5 * xx + 1).double()[None, ..., None]
+    p = torch.rand(1, 64, 3).double() * 0.4 + 0.3                      # well inside: no clipped stencil cell
+    want = 2 * p[0, :, 0] * X - 3 * p[0, :, 1] * Y + 0.5 * p[0, :, 2] * Z + 1
+    for lin in (True, False):
+        got = O.g2p(aff, p, is_2d=False, is_linear=lin)[0, :, 0]
+        assert float((got - want).abs().max()) < 1e-12
+    quad = (zz ** 2 - yy * xx).double()[None, ..., None]
+    got = O.g2p(quad, p, is_2d=False)[0, :, 0]
+    want = (p[0, :, 0] * X) ** 2 - (p[0, :, 1] * Y) * (p[0, :, 2] * Z)
+    assert float((got - want).abs().max()) < 1e-12
+    # at a cell centre both interpolants return the cell value
+    g = torch.randn(1, 5, 6, 2, dtype=torch.float64)
+    pc = torch.tensor([[[2.5 / 5, 3.5 / 6]]], dtype=torch.float64)
+    for lin in (True, False):
+        assert torch.allclose(O.g2p(g, pc, is_2d=True, is_linear=lin)[0, 0], g[0, 2, 3])
+    # outside [0.5, n-0.5] the linear form replicates the border cell
+    po = torch.tensor([[[-0.2, 3.5 / 6], [1.3, 3.5 / 6], [0.01, 0.99]]], dtype=torch.float64)
+    out = O.g2p(g, po, is_2d=True, is_linear=True)[0]
+    assert torch.allclose(out[0], g[0, 0, 3]) and torch.allclose(out[1], g[0, 4, 3])
+    assert torch.allclose(out[2], g[0, 0, 5])
+
+
+def test_mac_to_centered_and_rk4_advect():
+    # a uniform MAC field stays uniform in the interior after face averaging (the zero-padded high face halves it)
+    v = np.ones((4, 5, 6, 3), np.float32) * np.array([1.0, 2.0, 3.0], np.float32)
+    c = O.mac_to_centered(v)
+    assert c.shape == v.shape
+    np.testing.assert_allclose(c[:-1, 1:, :-1], np.broadcast_to([1.0, 2.0, 3.0], (3, 4, 5, 3)))
+    np.testing.assert_allclose(c[0, 0, -1, 0], 0.5)
+    # constant velocity field: RK4 = explicit Euler, x_adv = x + 0.5 u
+    u = torch.zeros(6, 6, 6, 3, dtype=torch.float64) + torch.tensor([0.01, -0.02, 0.03], dtype=torch.float64)
+    x = torch.rand(10, 3, dtype=torch.float64) * 0.5 + 0.25
+    assert torch.allclose(O.simg2p_advect(x, u), x + 0.5 * u[0, 0, 0])
