@@ -154,6 +154,19 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
                       const float* addend, float* gx,
                       int B, int H, int W, int Ci, int Co,
                       float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+/* Fused forms for a conv that is followed by the 2x2 average pool (conv1_2, conv2_2, conv3_4, conv4_4):
+ * fwd_pool also writes y_pool [B,H/2,W/2,Co] = avg_pool2d(y); dgrad_pool takes the gradient at the POOLED
+ * resolution gy_pool [B,H/2,W/2,Co] plus the conv's own output x_out [B,H,W,Co] and forms
+ * 0.25*gy_pool[h/2,w/2]*(x_out>0) on the fly (x_in / addend as in nfs_conv3x3_dgrad).  On the Winograd path
+ * both are folded into the transforms (no separate pool kernels, no full-resolution round trip); otherwise
+ * they run the separate kernels (dgrad_pool then needs >= B*H*W*Co workspace floats). */
+int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y,
+                         float* y_pool, int B, int H, int W, int Ci, int Co, int relu,
+                         float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad,
+                           const float* x_in, const float* addend, float* gx,
+                           int B, int H, int W, int Ci, int Co,
+                           float* workspace, int64_t workspace_floats, nfs_stream_t stream);
 /* slim.avg_pool2d [2,2]: stride 2, VALID (odd sizes floor).  x [B,H,W,C] -> y [B,H/2,W/2,C].
  * bwd: gx = 0.25*gy[h/2,w/2] (0 outside the pooled area) * (x > 0 if x) + (addend if addend) */
 int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream);

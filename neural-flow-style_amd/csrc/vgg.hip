@@ -26,7 +26,8 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N);
 int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
-                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s);
+                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
+                  const float* xmask);
 // layers with >= 64 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops); only the
 // 3-channel conv1_1 stays direct.  NFS_WINOGRAD_MIN_CH raises the threshold (timing comparisons).
 static inline bool winograd_eligible(int K, int N) {
@@ -443,15 +444,29 @@ static ConvPlan plan_conv(int mtiles, int Nc, int nchunks, int64_t mn, int64_t w
   return best;
 }
 
-template <int MODE>
-static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s) {
-  ConvArgs a = base;
+static bool takes_winograd(const ConvArgs& a, const float* ws, int64_t ws_floats) {
   static const bool no_wg = getenv("NFS_NO_WINOGRAD") != nullptr;   // timing comparisons only
-  if (!no_wg && winograd_eligible(a.Kc, a.Nc) && a.H >= 2 && a.W >= 2 && ws &&
-      ws_floats >= winograd_workspace_floats(a.B, a.H, a.W, a.Kc, a.Nc)) {
+  return !no_wg && winograd_eligible(a.Kc, a.Nc) && a.H >= 2 && a.W >= 2 && ws &&
+         ws_floats >= winograd_workspace_floats(a.B, a.H, a.W, a.Kc, a.Nc);
+}
+
+// the pooled forms are only fused on the F(4x4) Winograd path
+static bool takes_fused_pool(const ConvArgs& a, const float* ws, int64_t ws_floats) {
+  static const bool tile4 = [] { const char* e = getenv("NFS_WINOGRAD_TILE"); return !(e && atoi(e) == 2); }();
+  static const bool off = getenv("NFS_NO_POOL_FUSION") != nullptr;   // timing comparisons only
+  return tile4 && !off && takes_winograd(a, ws, ws_floats);
+}
+
+template <int MODE>
+static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s, float* ypool = nullptr,
+                       const float* xmask = nullptr) {
+  ConvArgs a = base;
+  if (takes_winograd(a, ws, ws_floats)) {
     const float* U = a.wp + (int64_t)9 * a.Kc * a.Nc;               // Winograd weights follow the direct packing
-    return winograd_conv(a.x, U, a.aux0, a.aux1, a.y, ws, a.B, a.H, a.W, a.Kc, a.Nc, MODE, a.relu, device_cus(), s);
+    return winograd_conv(a.x, U, a.aux0, a.aux1, a.y, ws, a.B, a.H, a.W, a.Kc, a.Nc, MODE, a.relu, device_cus(), s,
+                         ypool, xmask);
   }
+  NFS_REQUIRE(!ypool && !xmask, "conv3x3: fused pooling needs the Winograd path");
   int tiles_r = 0;
   a.TH = 0;
   pick_tile(a.B, a.H, a.W, a.TH, a.TW, tiles_r, a.tiles_c);
@@ -556,6 +571,41 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
   NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
   ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
   return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream));
+}
+
+// conv + bias + ReLU that also emits the 2x2 VALID average pool of its output (vgg.py: conv*_2/_4 -> pool*).
+int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y, float* y_pool, int B, int H,
+                         int W, int Ci, int Co, int relu, float* workspace, int64_t workspace_floats,
+                         nfs_stream_t stream) {
+  NFS_REQUIRE(x && packed_fwd && y && y_pool, "nfs_conv3x3_fwd_pool: null pointer");
+  NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_fwd_pool: need H, W >= 2");
+  NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd_pool: too many pixels");
+  NFS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd_pool: Ci %% 32, Co %% 64 required");
+  ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1, 0};
+  if (takes_fused_pool(a, workspace, workspace_floats))
+    return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream), y_pool, nullptr);
+  if (int e = launch_conv<0>(a, workspace, workspace_floats, as_stream(stream))) return e;
+  return nfs_avgpool2_fwd(y, y_pool, B, H, W, Co, stream);
+}
+
+// data gradient of a conv whose output gradient arrives through the 2x2 average pool that follows its ReLU:
+// g_y = 0.25 * gy_pool[h/2, w/2] * (x_out > 0) (0 outside the pooled area) is formed inside the input transform.
+int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad, const float* x_in,
+                           const float* addend, float* gx, int B, int H, int W, int Ci, int Co, float* workspace,
+                           int64_t workspace_floats, nfs_stream_t stream) {
+  NFS_REQUIRE(gy_pool && x_out && packed_dgrad && gx, "nfs_conv3x3_dgrad_pool: null pointer");
+  NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_dgrad_pool: need H, W >= 2");
+  NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad_pool: too many pixels");
+  NFS_REQUIRE(Co > 0 && Co % 32 == 0 && Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad_pool: Co %% 32, Ci %% 64 required");
+  ConvArgs a{gy_pool, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
+  if (takes_fused_pool(a, workspace, workspace_floats))
+    return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, x_out);
+  // unfused: full-resolution gradient through the head of the workspace, conv on the rest
+  const int64_t n = (int64_t)B * H * W * Co;
+  NFS_REQUIRE(workspace && workspace_floats >= n, "nfs_conv3x3_dgrad_pool: workspace of >= B*H*W*Co floats required");
+  if (int e = nfs_avgpool2_bwd(gy_pool, x_out, nullptr, workspace, B, H, W, Co, stream)) return e;
+  a.x = workspace;
+  return launch_conv<1>(a, workspace + n, workspace_floats - n, as_stream(stream));
 }
 
 }  // extern "C"

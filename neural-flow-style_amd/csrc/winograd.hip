@@ -165,8 +165,13 @@ __device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
 }
 
 // input transform: one thread = one 6x6 patch x 2 channels (a wave covers 128 contiguous channels per pixel)
+// POOLED: the operand is not stored -- it is the gradient coming through a 2x2 VALID average pool below a ReLU,
+// d(y, x) = 0.25 * gpool[y/2, x/2] * (xmask[y, x] > 0) (0 outside the pooled area), formed on the fly
+// (the separate avgpool adjoint kernel and its full-resolution round trip through HBM disappear).
+template <bool POOLED>
 __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                              int B, int H, int W, int K, int TH, int TW) {
+                                                              int B, int H, int W, int K, int TH, int TW,
+                                                              const float* __restrict__ xmask) {
   const int K2 = K >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,8 +189,17 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
     for (int r = 0; r < 6; ++r) {
       const int yy = y0 + r;
       d[r] = make_float2(0.f, 0.f);
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+      if (!POOLED) {
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+      } else {
+        const int PH = H >> 1, PW = W >> 1;
+        if (yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW) {
+          const float2 g = *reinterpret_cast<const float2*>(x + (((int64_t)b * PH + (yy >> 1)) * PW + (xx >> 1)) * K + 2 * c2);
+          const float2 m = *reinterpret_cast<const float2*>(xmask + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+          d[r] = make_float2(m.x > 0.f ? 0.25f * g.x : 0.f, m.y > 0.f ? 0.25f * g.y : 0.f);
+        }
+      }
     }
     wg4_bt(d, t[s]);
   }
@@ -215,7 +229,8 @@ __device__ __forceinline__ void wg4_at(const float2* m, float2* o) {
 template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
 __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
-                                                               int B, int H, int W, int N, int TH, int TW, int relu) {
+                                                               int B, int H, int W, int N, int TH, int TW, int relu,
+                                                               float* __restrict__ ypool) {
   const int N2 = N >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,6 +240,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int64_t comp_stride = T * N;
   const float* mi = M + tile * N + 2 * c2;
+  float2 pool[2][2] = {{make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}};
   float2 t[6][4];   // t[s][a]: column s after the vertical pass
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
@@ -262,7 +278,21 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
         }
       }
       *reinterpret_cast<float2*>(y + idx) = v;
+      if (MODE == 0) { pool[a >> 1][c >> 1].x += v.x; pool[a >> 1][c >> 1].y += v.y; }
     }
+  }
+  // slim.avg_pool2d [2,2] VALID of the layer output: a 4x4 output tile holds 2x2 complete pooling windows
+  if (MODE == 0 && ypool) {
+    const int PH = H >> 1, PW = W >> 1;
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int py = 2 * ty + pa, px = 2 * tx + pc;
+        if (py < PH && px < PW)
+          *reinterpret_cast<float2*>(ypool + (((int64_t)b * PH + py) * PW + px) * N + 2 * c2) =
+              make_float2(0.25f * pool[pa][pc].x, 0.25f * pool[pa][pc].y);
+      }
   }
 }
 
@@ -613,16 +643,22 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
 }
 
 // x [B,H,W,K] -> y [B,H,W,N]; U packed by winograd_pack; ws >= winograd_workspace_floats
+// ypool (mode 0, nullable): also write the 2x2 average pool of y.  xmask (mode 1, nullable): x is a POOLED gradient
+// [B,H/2,W/2,K] that reaches the conv through the ReLU of xmask [B,H,W,K] (see winograd_input4_kernel<true>).
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
-                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s) {
+                  int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
+                  const float* xmask) {
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
   float* M = ws + comps * T * K;
-  if (m == 4)
-    hipLaunchKernelGGL(winograd_input4_kernel, dim3(blocks_for(T * (K / 2), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
-                       TW);
+  if (m == 4 && xmask)
+    hipLaunchKernelGGL(winograd_input4_kernel<true>, dim3(blocks_for(T * (K / 2), 256)), dim3(256), 0, s, x, V, B, H, W,
+                       K, TH, TW, xmask);
+  else if (m == 4)
+    hipLaunchKernelGGL(winograd_input4_kernel<false>, dim3(blocks_for(T * (K / 2), 256)), dim3(256), 0, s, x, V, B, H, W,
+                       K, TH, TW, (const float*)nullptr);
   else
     hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
                        TW);
@@ -631,9 +667,11 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   if (m == 4) {
     const unsigned ob = blocks_for(T * (N / 2), 256);
     if (mode == 0)
-      hipLaunchKernelGGL(winograd_output4_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+      hipLaunchKernelGGL(winograd_output4_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                         ypool);
     else
-      hipLaunchKernelGGL(winograd_output4_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu);
+      hipLaunchKernelGGL(winograd_output4_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                         (float*)nullptr);
   } else {
     const unsigned ob = blocks_for(T * (N / 4), 256);
     if (mode == 0)

@@ -255,6 +255,28 @@ def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True)
     return out
 
 
+def conv3x3_fwd_pool(x, packed, bias, Co, relu=True):
+    """conv + bias + ReLU and its 2x2 VALID average pool in one pass -> (y [B,H,W,Co], y_pool [B,H/2,W/2,Co])"""
+    B, H, W, Ci = x.shape
+    out = _empty((B, H, W, Co), x)
+    pooled = _empty((B, H // 2, W // 2, Co), x)
+    ws, nws = _conv_ws_for(B, H, W, Ci, Co, x.device, True)
+    _lib.call("nfs_conv3x3_fwd_pool", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), _ptr(pooled), B, H, W, Ci, Co,
+              int(relu), _ptr(ws), nws, _stream())
+    return out, pooled
+
+
+def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None):
+    """data gradient of a conv followed by ReLU + 2x2 average pool, from the gradient at the POOLED resolution
+    gy_pool [B,H/2,W/2,Co] and the conv's own output x_out [B,H,W,Co] -> gx [B,H,W,Ci]"""
+    B, H, W, Co = x_out.shape
+    out = _empty((B, H, W, Ci), x_out)
+    ws, nws = _conv_ws_for(B, H, W, Ci, Co, x_out.device, True)
+    _lib.call("nfs_conv3x3_dgrad_pool", _ptr(gy_pool), _ptr(x_out), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out),
+              B, H, W, Ci, Co, _ptr(ws), nws, _stream())
+    return out
+
+
 def avgpool2_fwd(x, out=None):
     B, H, W, Cn = x.shape
     if out is None:

@@ -102,12 +102,20 @@ class VGG(object):
         start that layer's Gram work on a second stream while the next convolutions run)."""
         acts = OrderedDict()
         cur = x
-        for name, kind, cin, cout in self.plan(upto):
+        plan = self.plan(upto)
+        pooled = None
+        for li, (name, kind, cin, cout) in enumerate(plan):
             if kind == "conv":
                 p = self.params[name]
-                cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True)
+                nxt_pool = li + 1 < len(plan) and plan[li + 1][1] == "pool"
+                if nxt_pool and cin % 32 == 0 and cur.shape[1] >= 2 and cur.shape[2] >= 2:
+                    # the conv feeds a 2x2 average pool: both outputs from one pass (pool folded into the transform)
+                    cur, pooled = ops.conv3x3_fwd_pool(cur, p["fwd"], p["bias"], cout, relu=True)
+                else:
+                    cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True)
             else:
-                cur = ops.avgpool2_fwd(cur)
+                cur = pooled if pooled is not None else ops.avgpool2_fwd(cur)
+                pooled = None
             acts[name] = cur
             if on_layer is not None:
                 on_layer(name, cur)
@@ -118,9 +126,20 @@ class VGG(object):
         (ops.gram_bwd(relu_mask=True)).  Returns dL/dx [B,H,W,3]."""
         plan = self.plan(upto)
         g = style_grads[upto]           # gradient wrt the pre-activation of the top conv
+        pooled_from = None              # set when g is still at the pooled resolution below conv `pooled_from`
         for li in range(len(plan) - 1, -1, -1):
             name, kind, cin, cout = plan[li]
             below = plan[li - 1] if li > 0 else None
+            if kind == "conv" and pooled_from == name:
+                # g is the gradient wrt the pool output: the pool adjoint and this conv's ReLU mask are folded into
+                # the data-gradient's input transform
+                pooled_from = None
+                p = self.params[name]
+                bname, bkind = below[0], below[1]
+                assert bkind == "conv"
+                g = ops.conv3x3_dgrad_pool(g, acts[name], p["dgrad"], cin, x_in=acts[bname],
+                                           addend=style_grads.get(bname))
+                continue
             if kind == "conv":
                 p = self.params[name]
                 if below is None:
@@ -134,7 +153,12 @@ class VGG(object):
             else:
                 bname = below[0]                                 # the conv feeding this pool
                 xb = acts[bname]
-                g = ops.avgpool2_bwd(g, xb.shape, x=xb, addend=style_grads.get(bname))
+                b2 = plan[li - 2] if li > 1 else None
+                if (style_grads.get(bname) is None and b2 is not None and b2[1] == "conv" and below[2] % 64 == 0
+                        and xb.shape[1] >= 2 and xb.shape[2] >= 2):
+                    pooled_from = bname                          # keep g pooled; fused into the conv below
+                else:
+                    g = ops.avgpool2_bwd(g, xb.shape, x=xb, addend=style_grads.get(bname))
         raise AssertionError("unreachable")
 
 

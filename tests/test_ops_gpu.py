@@ -223,7 +223,8 @@ def _conv_ref(x, w, b, relu=True):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 3, 64), (2, 13, 11, 64, 64), (3, 25, 25, 64, 128),
-                                          (1, 12, 12, 128, 256), (2, 7, 50, 128, 128), (8, 6, 6, 256, 128)])
+                                          (1, 12, 12, 128, 256), (2, 7, 50, 128, 128), (8, 6, 6, 256, 128),
+                                          (1, 25, 25, 512, 512), (1, 12, 12, 512, 512)])   # last two: K-split GEMMs
 def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
     rng = np.random.RandomState(7)
     x = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32).requires_grad_()
@@ -245,6 +246,30 @@ def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
         add = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
         gx_m = ops.conv3x3_dgrad(dev(gy), wd, Ci, x_in=dev(xin), addend=dev(add))
         assert rel(gx_m, gx * (xin > 0) + add) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128)])
+def test_conv3x3_fused_pool(ops, B, H, W, Ci, Co):
+    """conv + ReLU + 2x2 VALID average pool in one pass, and the data gradient taken from the POOLED gradient
+    (pool adjoint + ReLU mask folded into the Winograd input transform); odd sizes floor like slim.avg_pool2d"""
+    rng = np.random.RandomState(17)
+    x = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32).requires_grad_()
+    w = (rng.randn(3, 3, Ci, Co) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = (rng.randn(Co) * 0.1).astype(np.float32)
+    y = _conv_ref(x, w, b)
+    yp = torch.nn.functional.avg_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    wf = ops.conv3x3_pack(dev(torch.tensor(w)), 0)
+    y_h, yp_h = ops.conv3x3_fwd_pool(dev(x), wf, dev(torch.tensor(b)), Co, relu=True)
+    assert rel(y_h, y) < TOL and rel(yp_h, yp) < TOL
+    g = torch.tensor(rng.randn(*yp.shape), dtype=torch.float32)
+    (gx,) = torch.autograd.grad(yp, x, g)
+    wd = ops.conv3x3_pack(dev(torch.tensor(w)), 1)
+    gx_h = ops.conv3x3_dgrad_pool(dev(g), y_h, wd, Ci)
+    assert rel(gx_h, gx) < TOL
+    xin = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
+    add = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
+    gx_m = ops.conv3x3_dgrad_pool(dev(g), y_h, wd, Ci, x_in=dev(xin), addend=dev(add))
+    assert rel(gx_m, gx * (xin > 0) + add) < TOL
 
 
 def test_avgpool2(ops):
