@@ -81,6 +81,12 @@ def work_of(name, a):
     if name == "nfs_conv3x3_dgrad":
         B, H, W, Ci, Co = a[5:10]
         return "F", 2.0 * B * H * W * 9 * Ci * Co
+    if name == "nfs_conv3x3_fwd_pool":
+        B, H, W, Ci, Co = a[5:10]
+        return "F", 2.0 * B * H * W * 9 * Ci * Co
+    if name == "nfs_conv3x3_dgrad_pool":
+        B, H, W, Ci, Co = a[6:11]
+        return "F", 2.0 * B * H * W * 9 * Ci * Co
     if name == "nfs_gram_fwd":
         B, HW, C = a[2:5]
         return "F", 2.0 * B * HW * C * C
@@ -310,7 +316,8 @@ def main():
         L.nfs_gemm_timer(0)
         ov_us = event_pair_overhead_us(device)
         rows = kernel_table(prof, psteps, ov_us)
-        conv = [r for r in rows if r["kernel"] in ("nfs_conv3x3_fwd", "nfs_conv3x3_dgrad")]
+        conv = [r for r in rows if r["kernel"] in ("nfs_conv3x3_fwd", "nfs_conv3x3_dgrad", "nfs_conv3x3_fwd_pool",
+                                                   "nfs_conv3x3_dgrad_pool")]
         ms = sum(r["ms_per_step"] for r in conv)
         fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)  # TF/s * ms
         n_launch = sum(r["launches_per_step"] for r in conv)
