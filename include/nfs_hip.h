@@ -62,11 +62,14 @@ int nfs_warp3d_bwd(const float* imgs, const float* coords, const float* g_out,
  * computed in-register (no mgrid tensor).  bwd: g_d [D,H,W,C] += over all views.
  * `workspace` (device, >= 64 bytes, nullable): with C == 1 and a workspace the adjoint runs
  * output-stationary (a block owns a tile of g_d, accumulates in 64-bit fixed point in LDS, no
- * global atomics, bit-reproducible); otherwise it scatters with global float atomics. */
+ * global atomics, bit-reproducible); otherwise it scatters with global float atomics.
+ * `g_max` (device, nullable): max |g_out| as produced by nfs_render_bwd(gmax_out) -- the fixed-point scale
+ * is derived from it; when NULL a streaming pre-pass over g_out computes it into the workspace. */
 int nfs_rotate_fwd(const float* d, const float* rot, float* out,
                    int V, int D, int H, int W, int C, nfs_stream_t stream);
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc,
-                   int V, int D, int H, int W, int C, float* workspace, nfs_stream_t stream);
+                   int V, int D, int H, int W, int C, float* workspace, const float* g_max,
+                   nfs_stream_t stream);
 
 /* ---- A11: advect, order 1 (transform.py:557-569) ------------------------------------
  * d [D,H,W,C], vel [D,H,W,3] normalised units (component k moves along array axis k),
@@ -91,11 +94,13 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d,
 /* ---- A4: render block (styler_3p.py:147-158) -----------------------------------------
  * d [V,D,H,W] (C=1), img [V,H,W]: smoke (liquid=0) I = sum_z d[z]*exp(-tau*sum_{z'>=z} d[z'])
  * (un-normalised; the global-max division is nfs_maxnorm_*), liquid=1: 1-exp(-tau*sum_z d).
- * raysum [V,H,W] = sum_z d is saved for the adjoint.  bwd overwrites g_d [V,D,H,W]. */
+ * raysum [V,H,W] = sum_z d is saved for the adjoint.  bwd overwrites g_d [V,D,H,W] (may alias d);
+ * gmax_out (device, nullable, 4 bytes) receives max |g_d| for nfs_rotate_bwd's fixed-point scale. */
 int nfs_render_fwd(const float* d, float* img, float* raysum,
                    int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
 int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d,
-                   int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
+                   int V, int D, int H, int W, float tau, int liquid, float* gmax_out,
+                   nfs_stream_t stream);
 
 /* fused A3+A4: d [D,H,W], rot [V,9] -> img/raysum [V,H,W] in one pass over the rays.  d_rot
  * (nullable, [V,D,H,W]) receives the rotated samples so that the adjoint can run as

@@ -36,13 +36,13 @@ SIGNATURES = {
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "nfs_rotate_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nfs_rotate_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nfs_advect_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_smooth3d_relu_fwd": [_P, _P, _I, _I, _I, _F, _P],
     "nfs_smooth3d_relu_bwd": [_P, _P, _P, _I, _I, _I, _F, _P],
     "nfs_render_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "nfs_render_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_render_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "nfs_rotate_render_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_maxnorm_fwd": [_P, _P, _P, _I, _I, _P],

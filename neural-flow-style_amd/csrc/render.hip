@@ -36,27 +36,40 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) render_bwd_kernel(const float* d,
                                                          const float* __restrict__ raysum,
                                                          const float* __restrict__ g_img, float* g_d,
-                                                         int V, int D, int HW, float tau, int liquid) {
+                                                         int V, int D, int HW, float tau, int liquid,
+                                                         unsigned* __restrict__ gmax_bits) {
+  __shared__ float red[16];
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)V * HW) return;
-  const int v = (int)(gid / HW);
-  const int px = (int)(gid - (int64_t)v * HW);
-  const int64_t base = (int64_t)v * D * HW + px;
-  const float total = raysum[gid];
-  const float g = g_img[gid];
-  if (liquid) {
-    const float gd = g * tau * expf(-total * tau);
-    for (int z = 0; z < D; ++z) g_d[base + (int64_t)z * HW] = gd;
-    return;
-  }
-  float prefix = 0.f, P = 0.f;
+  float amax = 0.f;
+  if (gid < (int64_t)V * HW) {
+    const int v = (int)(gid / HW);
+    const int px = (int)(gid - (int64_t)v * HW);
+    const int64_t base = (int64_t)v * D * HW + px;
+    const float total = raysum[gid];
+    const float g = g_img[gid];
+    const float ntau = -tau * 1.44269504088896341f;                 // exp(-tau a) = exp2(ntau a)
+    if (liquid) {
+      const float gd = g * tau * __builtin_amdgcn_exp2f(total * ntau);
+      for (int z = 0; z < D; ++z) g_d[base + (int64_t)z * HW] = gd;
+      amax = fabsf(gd);
+    } else {
+      float prefix = 0.f, P = 0.f;
 #pragma unroll 4
-  for (int z = 0; z < D; ++z) {
-    const float s = d[base + (int64_t)z * HW];
-    const float T = expf(-(total - prefix) * tau);
-    P += s * T;
-    g_d[base + (int64_t)z * HW] = g * (T - tau * P);
-    prefix += s;
+      for (int z = 0; z < D; ++z) {
+        const float s = d[base + (int64_t)z * HW];
+        const float T = __builtin_amdgcn_exp2f((total - prefix) * ntau);
+        P = fmaf(s, T, P);
+        const float o = g * (T - tau * P);
+        g_d[base + (int64_t)z * HW] = o;
+        amax = fmaxf(amax, fabsf(o));
+        prefix += s;
+      }
+    }
+  }
+  // optional by-product: max |g_d| (as float bits) for the fixed-point scale of the rotate adjoint that follows
+  if (gmax_bits) {
+    amax = block_max(amax, red);
+    if (threadIdx.x == 0 && amax > 0.f) atomicMax(gmax_bits, __float_as_uint(fminf(amax, 3.0e38f)));
   }
 }
 
@@ -354,12 +367,16 @@ int nfs_render_fwd(const float* d, float* img, float* raysum, int V, int D, int 
 }
 
 int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d, int V, int D, int H, int W,
-                   float tau, int liquid, nfs_stream_t stream) {
+                   float tau, int liquid, float* gmax_out, nfs_stream_t stream) {
   NFS_REQUIRE(d && raysum && g_img && g_d, "nfs_render_bwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_render_bwd: non-positive dimension");
   const int64_t n = (int64_t)V * H * W;
+  if (gmax_out && hipMemsetAsync(gmax_out, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
+    set_error("nfs_render_bwd: memset failed");
+    return NFS_ELAUNCH;
+  }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, raysum, g_img, g_d,
-                     V, D, H * W, tau, liquid);
+                     V, D, H * W, tau, liquid, reinterpret_cast<unsigned*>(gmax_out));
   return check_launch("nfs_render_bwd");
 }
 

@@ -514,18 +514,22 @@ int nfs_rotate_fwd(const float* d, const float* rot, float* out, int V, int D, i
 }
 
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, int D, int H, int W, int C,
-                   float* workspace, nfs_stream_t stream) {
+                   float* workspace, const float* g_max, nfs_stream_t stream) {
   NFS_REQUIRE(g_out && rot && g_d_acc, "nfs_rotate_bwd: null pointer");
   if (int e = check_dims(V, D, H, W, C)) return e;
   if (C == 1 && workspace) {
     const int tz = (D + RT_TZ - 1) / RT_TZ, ty = (H + RT_TY - 1) / RT_TY, tx = (W + RT_TX - 1) / RT_TX;
-    unsigned* gmax_bits = reinterpret_cast<unsigned*>(workspace);
-    if (hipMemsetAsync(gmax_bits, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
-      set_error("nfs_rotate_bwd: memset failed");
-      return NFS_ELAUNCH;
+    const unsigned* gmax_bits = reinterpret_cast<const unsigned*>(g_max);
+    if (!gmax_bits) {                       // no max |g_out| supplied: streaming pre-pass
+      unsigned* wb = reinterpret_cast<unsigned*>(workspace);
+      if (hipMemsetAsync(wb, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
+        set_error("nfs_rotate_bwd: memset failed");
+        return NFS_ELAUNCH;
+      }
+      const int64_t n = (int64_t)V * D * H * W;
+      hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g_out, n, wb);
+      gmax_bits = wb;
     }
-    const int64_t n = (int64_t)V * D * H * W;
-    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g_out, n, gmax_bits);
     // a voxel collects, per view, unit total weight from interior samples and at most ~max(D,H,W)
     // clamped samples per face direction; 4*nmax per view is a safe bound on the summed weights
     const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);

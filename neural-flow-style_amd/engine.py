@@ -156,8 +156,8 @@ class RenderStyleLoss(object):
         if self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
-            g_rot = ops.render_bwd(d_rot, rs, g_img, self.tau, self.liquid, g_d=d_rot)
-            ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1))
+            g_rot, g_max = ops.render_bwd(d_rot, rs, g_img, self.tau, self.liquid, g_d=d_rot, want_max=True)
+            ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1), g_max=g_max)
         elif self.rotate:
             ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
         else:

@@ -74,12 +74,14 @@ def workspace(device):
     return _workspaces[key]
 
 
-def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True):
+def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True, g_max=None):
+    """g_max: optional device scalar max|g_out| (render_bwd(..., want_max=True)): skips the pre-pass"""
     V, D, H, W, Cn = g_out.shape
     if g_d_acc is None:
         g_d_acc = _zeros((D, H, W, Cn), g_out)
     ws = workspace(g_out.device) if (tiled and Cn == 1) else None
-    _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _ptr(ws), _stream())
+    _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _ptr(ws), _ptr(g_max),
+              _stream())
     return g_d_acc
 
 
@@ -130,13 +132,15 @@ def render_fwd(d, tau, liquid=False):
     return img, rs
 
 
-def render_bwd(d, raysum, g_img, tau, liquid=False, g_d=None):
+def render_bwd(d, raysum, g_img, tau, liquid=False, g_d=None, want_max=False):
+    """want_max: also return the device scalar max|g_d| (a by-product of the same pass) for rotate_bwd(g_max=...)"""
     V, D, H, W = d.shape
     if g_d is None:
         g_d = _empty(d.shape, d)
+    gmax = _empty((1,), d) if want_max else None
     _lib.call("nfs_render_bwd", _ptr(d), _ptr(raysum), _ptr(g_img), _ptr(g_d), V, D, H, W, float(tau),
-              int(liquid), _stream())
-    return g_d
+              int(liquid), _ptr(gmax), _stream())
+    return (g_d, gmax) if want_max else g_d
 
 
 def rotate_render_fwd(d, rot, tau, liquid=False, img=None, raysum=None, d_rot=None):

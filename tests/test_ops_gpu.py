@@ -191,9 +191,12 @@ def test_rotate_render_fused(ops, liquid, D):
     d_rot = torch.empty(4, D, 12, 10, device="cuda")
     img3, rs3 = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, liquid, d_rot=d_rot)
     assert rel(img3, img) < 1e-6 and rel(d_rot, dr[..., 0]) < TOL
-    g_rot = ops.render_bwd(d_rot, rs3, gi, tau, liquid, g_d=d_rot)
+    g_rot, g_max = ops.render_bwd(d_rot, rs3, gi, tau, liquid, g_d=d_rot, want_max=True)
+    assert float(g_max) == float(g_rot.abs().max())                   # by-product of the same pass, exact
     gd_2 = ops.rotate_bwd(g_rot.unsqueeze(-1), dev(R))
     assert rel(gd_2[..., 0], gd[0, ..., 0]) < TOL
+    gd_3 = ops.rotate_bwd(g_rot.unsqueeze(-1), dev(R), g_max=g_max)    # supplied maximum: no pre-pass
+    assert torch.equal(gd_3, gd_2)
     # fused == unfused HIP
     img2, _ = ops.render_fwd(ops.rotate_fwd(dev(d[0]), dev(R))[..., 0].contiguous(), tau, liquid)
     assert rel(img2, img) < 1e-5
