@@ -248,12 +248,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # one rank per GPU; NFS_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the sharded path on a
+    # single-GPU box (functional check only: the ranks then time-share the device)
+    backend = os.environ.get("NFS_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert args.views % world == 0, "views must divide over ranks"
 
     from neural_flow_style_amd import _lib
