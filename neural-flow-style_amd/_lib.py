@@ -96,6 +96,10 @@ def lib():
             raise NfsLibraryError(
                 "libnfs_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "-- there is no CPU fallback for the product path" % LIB_PATH)
+        # PyTorch-ROCm ships its own HIP runtime; it must be the one already resident when libnfs_hip.so resolves
+        # libamdhip64 -- loading this library first leaves the process with two runtimes and every later launch
+        # fails with "no ROCm-capable device is detected" (seen when build() and smoke() shared a process)
+        import torch  # noqa: F401
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
