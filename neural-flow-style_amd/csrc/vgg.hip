@@ -302,6 +302,74 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(ConvArgs a, int64_t mn
 
 // ---- first layer (Ci = 3): direct VALU kernels; 0.5 % of the FLOPs -------------------------
 // fwd: thread = (pixel, 4 consecutive output channels); weights HWIO [9][3][Co] in LDS.
+// ---- conv1_1 (Ci = 3, Co = 64) on the f32 MFMA ------------------------------------------------------------------
+// Implicit GEMM with M = an 8 x 16 pixel tile, N = 64, K = 27 (14 k-steps of 2, the last half-step zero): the
+// 3-channel halo patch is tiny (540 floats) and lives in LDS, a lane builds its A operand by indexing it, the 27 x 64
+// weights sit in 28 registers per lane; the tile leaves through LDS as float4 rows.  The VALU version (one thread per
+// output float4, 27 global loads + 108 FMAs) was bound by vector-memory issue at 55 us for an 82 MB output.
+constexpr int C3F_TH = 8, C3F_TW = 16, C3F_PW = C3F_TW + 2, C3F_OS = 68;
+__global__ void __launch_bounds__(256) conv3x3_c3co64_fwd_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,      // [27][64]
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int B, int H, int W, int relu,
+                                                                 int tiles_x, int tiles_y) {
+  __shared__ float patch[(C3F_TH + 2) * C3F_PW * 3 + 4];
+  __shared__ __attribute__((aligned(16))) float otile[C3F_TH * C3F_TW * C3F_OS];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, i = lane & 31, h = lane >> 5;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = ty * C3F_TH, x0 = tx * C3F_TW;
+  for (int e = t; e < (C3F_TH + 2) * C3F_PW * 3; e += 256) {
+    const int r = e / (C3F_PW * 3), rem = e - r * (C3F_PW * 3);
+    const int c = rem / 3, ci = rem - c * 3;
+    const int gy_ = y0 - 1 + r, gx_ = x0 - 1 + c;
+    float v = 0.f;
+    if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) v = x[(((int64_t)b * H + gy_) * W + gx_) * 3 + ci];
+    patch[e] = v;
+  }
+  float bfr[14][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 14; ++s2) {
+    const int k = 2 * s2 + h;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bfr[s2][nt] = k < 27 ? w[k * 64 + nt * 32 + i] : 0.f;
+  }
+  __syncthreads();
+  const int m = wid * 32 + i;                       // pixel of this lane's A row
+  const int base = ((m / C3F_TW) * C3F_PW + (m % C3F_TW)) * 3;
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < 14; ++s2) {
+    const int k = 2 * s2 + h;                       // k = (ky*3 + kx)*3 + ci
+    const int ky = k / 9, kx = (k / 3) % 3, ci = k % 3;
+    const float av = k < 27 ? patch[base + (ky * C3F_PW + kx) * 3 + ci] : 0.f;
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[s2][0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfr[s2][1], acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float bv = bias ? bias[nt * 32 + i] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc[nt][r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      otile[row * C3F_OS + nt * 32 + i] = v;
+    }
+  }
+  __syncthreads();
+  for (int f = t; f < C3F_TH * C3F_TW * 16; f += 256) {
+    const int row = f >> 4, q = f & 15;
+    const int gy_ = y0 + row / C3F_TW, gx_ = x0 + row % C3F_TW;
+    if (gy_ < H && gx_ < W)
+      *reinterpret_cast<float4*>(y + (((int64_t)b * H + gy_) * W + gx_) * 64 + 4 * q) =
+          *reinterpret_cast<const float4*>(otile + row * C3F_OS + 4 * q);
+  }
+}
+
 __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              int B, int H, int W, int Co, int relu) {
@@ -337,6 +405,74 @@ __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const float* __rest
 }
 
 // dgrad to the 3-channel image: thread = pixel; packed [tap'][Co][3] (taps pre-flipped) in LDS.
+// conv1_1 data gradient (Co = 64 -> 3 channels) on the f32 MFMA, in two phases inside one block:
+//   T[q][tap*3+ci] = sum_co gy[q][co] * wd[tap][co][ci]     GEMM, M = the 10 x 18 halo'd pixels of an 8 x 16 tile
+//                                                           (192 rows), K = 64, N = 27 (-> 32)
+//   gx[p][ci]      = sum_tap T[p + d(tap)][tap*3+ci]        9-tap gather of T from LDS
+// A fragments come straight from global memory as float4 (K permuted so that a lane owns 4 consecutive channels
+// for 4 consecutive k-steps: lane (i, h) of step 4j+u multiplies channel 8j + 4h + u), the 64 x 27 weights sit
+// in 32 registers per lane.  The VALU version (one thread per pixel, 144 float4 loads at a 256-byte lane stride)
+// took 118 us for an 82 MB input.
+constexpr int C3D_TH = 8, C3D_TW = 16, C3D_PH = C3D_TH + 2, C3D_PW = C3D_TW + 2, C3D_M = 192, C3D_TS = 33;
+__global__ void __launch_bounds__(256) conv3x3_c3co64_dgrad_kernel(const float* __restrict__ gy,
+                                                                   const float* __restrict__ wd,   // [9][64][3]
+                                                                   float* __restrict__ gx, int B, int H, int W,
+                                                                   int tiles_x, int tiles_y) {
+  __shared__ float Tt[C3D_M * C3D_TS];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, i = lane & 31, h = lane >> 5;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = ty * C3D_TH, x0 = tx * C3D_TW;
+  // B operand: column n = i (tap = n / 3, ci = n % 3; columns 27..31 are zero), rows k = 8j + 4h + u
+  float bw[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bw[j][u] = i < 27 ? wd[((i / 3) * 64 + 8 * j + 4 * h + u) * 3 + i % 3] : 0.f;
+  // M tiles of 32 halo'd pixels: waves 0,1 take two, waves 2,3 one (6 tiles = 192 >= 180 rows)
+  const int ntile = wid < 2 ? 2 : 1, tile0 = wid < 2 ? 2 * wid : 2 + wid;
+  for (int mt = 0; mt < ntile; ++mt) {
+    const int q = (tile0 + mt) * 32 + i;                         // halo'd pixel index of this lane's A row
+    const int qy = y0 - 1 + q / C3D_PW, qx = x0 - 1 + q % C3D_PW;
+    const bool ok = q < C3D_PH * C3D_PW && qy >= 0 && qy < H && qx >= 0 && qx < W;
+    const float* gp = gy + (((int64_t)b * H + (ok ? qy : 0)) * W + (ok ? qx : 0)) * 64 + 4 * h;
+    float4 av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) av[j] = ok ? *reinterpret_cast<const float4*>(gp + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bw[j][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bw[j][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bw[j][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bw[j][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (tile0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      Tt[row * C3D_TS + i] = acc[r];
+    }
+  }
+  __syncthreads();
+  if (t < C3D_TH * C3D_TW) {
+    const int ly = t / C3D_TW, lx = t % C3D_TW;
+    const int py = y0 + ly, px = x0 + lx;
+    if (py < H && px < W) {
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* tp = Tt + ((ly + dy) * C3D_PW + lx + dx) * C3D_TS + (dy * 3 + dx) * 3;
+          o0 += tp[0]; o1 += tp[1]; o2 += tp[2];
+        }
+      float* o = gx + (((int64_t)b * H + py) * W + px) * 3;
+      o[0] = o0; o[1] = o1; o[2] = o2;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) conv3x3_c3_dgrad_kernel(const float* __restrict__ gy,
                                                                const float* __restrict__ wp, float* __restrict__ gx,
                                                                int B, int H, int W, int Co) {
@@ -543,6 +679,13 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_fwd: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 64 == 0, "nfs_conv3x3_fwd: Co must be a multiple of 64");
+  static const bool old_c3 = getenv("NFS_C3_OLD") != nullptr;        // timing comparisons only
+  if (Ci == 3 && Co == 64 && !old_c3) {
+    const int tiles_x = (W + C3F_TW - 1) / C3F_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
+    hipLaunchKernelGGL(conv3x3_c3co64_fwd_kernel, dim3((unsigned)((int64_t)B * tiles_x * tiles_y)), dim3(256), 0,
+                       as_stream(stream), x, packed_fwd, bias, y, B, H, W, relu, tiles_x, tiles_y);
+    return check_launch("nfs_conv3x3_fwd(c3, Co=64, MFMA)");
+  }
   if (Ci == 3) {
     const int64_t n = (int64_t)B * H * W * (Co / 4);
     hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 27 * Co * sizeof(float),
@@ -563,6 +706,13 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
   NFS_REQUIRE(Co > 0 && Co % 32 == 0, "nfs_conv3x3_dgrad: Co must be a multiple of 32");
   if (Ci == 3) {
     NFS_REQUIRE(!x_in && !addend, "nfs_conv3x3_dgrad: Ci=3 takes no mask/addend");
+    static const bool old_c3 = getenv("NFS_C3_OLD") != nullptr;      // timing comparisons only
+    if (Co == 64 && !old_c3) {
+      const int tiles_x = (W + C3D_TW - 1) / C3D_TW, tiles_y = (H + C3D_TH - 1) / C3D_TH;
+      hipLaunchKernelGGL(conv3x3_c3co64_dgrad_kernel, dim3((unsigned)((int64_t)B * tiles_x * tiles_y)), dim3(256), 0,
+                         as_stream(stream), gy, packed_dgrad, gx, B, H, W, tiles_x, tiles_y);
+      return check_launch("nfs_conv3x3_dgrad(c3, Co=64, MFMA)");
+    }
     const int64_t n = (int64_t)B * H * W;
     hipLaunchKernelGGL(conv3x3_c3_dgrad_kernel, dim3(blocks_for(n, 256)), dim3(256), 27 * Co * sizeof(float),
                        as_stream(stream), gy, packed_dgrad, gx, B, H, W, Co);
