@@ -117,11 +117,13 @@ int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,
 
 /* d /= reduce_max(d) (styler_3p.py:158): G groups of n contiguous floats, one max per
  * group (v_batch views form one group; v_batch=1 => per view).  gmax [G] is written by
- * fwd and read by bwd; the max gradient is split equally among ties like TF's. */
+ * fwd and read by bwd; the max gradient is split equally among ties like TF's.  bwd `workspace`
+ * (device, >= 64*G floats, nullable): groups of >= 16384 elements are reduced by 32 blocks each with the
+ * partial sums combined in a fixed order; without it one block per group does everything. */
 int nfs_maxnorm_fwd(const float* img, float* out, float* gmax, int G, int n,
                     nfs_stream_t stream);
 int nfs_maxnorm_bwd(const float* img, const float* gmax, const float* g_out, float* g_img,
-                    int G, int n, nfs_stream_t stream);
+                    int G, int n, float* workspace, nfs_stream_t stream);
 
 /* ---- A5: _plugin_to_loss_net + vgg.preprocess (styler_base.py:33-45, vgg.py:50-53) ---
  * img [B,H,W,Cin] in [0,1] (Cin=1 grey or 3 colour) -> d_img [B,H2,W2,3] in 0..255

@@ -312,6 +312,81 @@ __global__ void __launch_bounds__(256) rotate_render_bwd_kernel(const float* __r
 
 // ---- d /= reduce_max(d) ------------------------------------------------------------
 // one 1024-thread block per group (a group is <= a few 10^5 pixels)
+// ---- multi-block max-normalisation (groups of >= 16 k elements: one 1024-thread block per group took 20-30 us
+// on 8 of 256 CUs) -------------------------------------------------------------------------------------------
+constexpr int MN_NB = 32;          // blocks per group
+
+// float max through integer atomics: non-negative floats order like signed ints, negative ones inversely like
+// unsigned ints; the slot is initialised to -inf by the host (hipMemsetD32Async)
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+__global__ void __launch_bounds__(256) maxnorm_max_kernel(const float* __restrict__ img, float* __restrict__ gmax, int n) {
+  __shared__ float red[16];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  float m = -INFINITY;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, x[i]);
+  m = block_max(m, red);
+  if (threadIdx.x == 0) atomic_max_float(gmax + blockIdx.y, m);
+}
+
+__global__ void __launch_bounds__(256) maxnorm_div_kernel(const float* __restrict__ img, const float* __restrict__ gmax,
+                                                          float* __restrict__ out, int n) {
+  const float m = gmax[blockIdx.y];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  float* o = out + (int64_t)blockIdx.y * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = x[i] / m;
+}
+
+// adjoint, phase 1: per-block partial sums of g*x and of the tie count -> part[group][block][2]
+__global__ void __launch_bounds__(256) maxnorm_bwd_part_kernel(const float* __restrict__ img,
+                                                               const float* __restrict__ gmax,
+                                                               const float* __restrict__ g_out,
+                                                               float* __restrict__ part, int n) {
+  __shared__ float red[16];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  const float* gy = g_out + (int64_t)blockIdx.y * n;
+  const float m = gmax[blockIdx.y];
+  float s = 0.f, ties = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    s += gy[i] * xi;
+    ties += (xi == m) ? 1.f : 0.f;
+  }
+  s = block_sum(s, red);
+  ties = block_sum(ties, red);
+  if (threadIdx.x == 0) {
+    part[((int64_t)blockIdx.y * MN_NB + blockIdx.x) * 2] = s;
+    part[((int64_t)blockIdx.y * MN_NB + blockIdx.x) * 2 + 1] = ties;
+  }
+}
+
+// phase 2: every thread sums the MN_NB partials in the same order (deterministic), then applies
+__global__ void __launch_bounds__(256) maxnorm_bwd_apply_kernel(const float* __restrict__ img,
+                                                                const float* __restrict__ gmax,
+                                                                const float* __restrict__ g_out,
+                                                                const float* __restrict__ part,
+                                                                float* __restrict__ g_img, int n) {
+  const float* x = img + (int64_t)blockIdx.y * n;
+  const float* gy = g_out + (int64_t)blockIdx.y * n;
+  float* gx = g_img + (int64_t)blockIdx.y * n;
+  const float m = gmax[blockIdx.y];
+  float s = 0.f, ties = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < MN_NB; ++k) {
+    s += part[((int64_t)blockIdx.y * MN_NB + k) * 2];
+    ties += part[((int64_t)blockIdx.y * MN_NB + k) * 2 + 1];
+  }
+  const float corr = s / (m * m) / ties;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float g = gy[i] / m;
+    if (x[i] == m) g -= corr;
+    gx[i] = g;
+  }
+}
+
 __global__ void __launch_bounds__(1024) maxnorm_fwd_kernel(const float* __restrict__ img, float* __restrict__ out,
                                                            float* __restrict__ gmax, int n) {
   __shared__ float red[16];
@@ -408,14 +483,30 @@ int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,
 int nfs_maxnorm_fwd(const float* img, float* out, float* gmax, int G, int n, nfs_stream_t stream) {
   NFS_REQUIRE(img && out && gmax, "nfs_maxnorm_fwd: null pointer");
   NFS_REQUIRE(G > 0 && n > 0, "nfs_maxnorm_fwd: non-positive size");
+  if (n >= 16384) {
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gmax), (int)0xff800000, G, as_stream(stream)) != hipSuccess) {
+      set_error("nfs_maxnorm_fwd: memset failed");
+      return NFS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(maxnorm_max_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, n);
+    hipLaunchKernelGGL(maxnorm_div_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, out, n);
+    return check_launch("nfs_maxnorm_fwd(multi-block)");
+  }
   hipLaunchKernelGGL(maxnorm_fwd_kernel, dim3(G), dim3(1024), 0, as_stream(stream), img, out, gmax, n);
   return check_launch("nfs_maxnorm_fwd");
 }
 
 int nfs_maxnorm_bwd(const float* img, const float* gmax, const float* g_out, float* g_img, int G, int n,
-                    nfs_stream_t stream) {
+                    float* workspace, nfs_stream_t stream) {
   NFS_REQUIRE(img && gmax && g_out && g_img, "nfs_maxnorm_bwd: null pointer");
   NFS_REQUIRE(G > 0 && n > 0, "nfs_maxnorm_bwd: non-positive size");
+  if (workspace && n >= 16384) {   // two-phase, MN_NB blocks per group, partial sums through the workspace
+    hipLaunchKernelGGL(maxnorm_bwd_part_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, g_out,
+                       workspace, n);
+    hipLaunchKernelGGL(maxnorm_bwd_apply_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, g_out,
+                       workspace, g_img, n);
+    return check_launch("nfs_maxnorm_bwd(multi-block)");
+  }
   hipLaunchKernelGGL(maxnorm_bwd_kernel, dim3(G), dim3(1024), 0, as_stream(stream), img, gmax, g_out, g_img, n);
   return check_launch("nfs_maxnorm_bwd");
 }

@@ -182,7 +182,8 @@ def maxnorm_bwd(img, gmax, g_out, g_img=None):
     n = img.numel() // groups
     if g_img is None:
         g_img = _empty(img.shape, img)
-    _lib.call("nfs_maxnorm_bwd", _ptr(img), _ptr(gmax), _ptr(g_out), _ptr(g_img), groups, n, _stream())
+    ws = _empty((64 * groups,), img)            # partial sums of the multi-block path
+    _lib.call("nfs_maxnorm_bwd", _ptr(img), _ptr(gmax), _ptr(g_out), _ptr(g_img), groups, n, _ptr(ws), _stream())
     return g_img
 
 

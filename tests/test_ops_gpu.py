@@ -155,6 +155,24 @@ def test_render_and_maxnorm(ops, liquid):
     assert rel(gd_h, gd[..., 0]) < TOL
 
 
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_maxnorm_multiblock(ops, sign):
+    """groups of >= 16384 elements take the 32-block two-phase path: float max through integer atomics (also for
+    all-negative groups), deterministic partial sums, ties split like TF"""
+    torch.manual_seed(12)
+    x = (torch.rand(3, 150, 140) + 0.1) * sign
+    x[1, 7, 9] = x[1, 100, 3] = x[1].max() + 0.5 if sign > 0 else x[1].max() * 0.5    # a tie at the maximum
+    x = x.requires_grad_()
+    y = x / x.amax(dim=(1, 2), keepdim=True)
+    g = torch.randn_like(x)
+    (gx,) = torch.autograd.grad(y, x, g)
+    out, gmax = ops.maxnorm_fwd(dev(x), 3)
+    assert torch.equal(gmax.cpu(), x.detach().amax(dim=(1, 2))) and rel(out, y) < 1e-6
+    gx_h = ops.maxnorm_bwd(dev(x), gmax, dev(g))
+    assert rel(gx_h, gx) < 1e-5
+    assert torch.equal(gx_h, ops.maxnorm_bwd(dev(x), gmax, dev(g)))
+
+
 def test_maxnorm_ties_split_like_tf(ops):
     x = torch.tensor([[1.0, 3.0, 3.0, 2.0]]).requires_grad_()
     y = x / x.amax()
