@@ -112,6 +112,10 @@ def work_of(name, a):
     if name == "nfs_advect_bwd":
         D, H, W, C = a[5:9]
         return "B", ((12.0 if a[3] else 8.0) * C + 24.0) * D * H * W
+    if name == "nfs_advect_bwd_adam":
+        D, H, W = a[5:8]
+        # g_out 4 + gathered d 4 + vel/m/v read 36 + vel/m/v write 36 bytes per voxel
+        return "B", 80.0 * D * H * W
     if name in ("nfs_smooth3d_relu_fwd",):
         D, H, W = a[2:5]
         return "B", 8.0 * D * H * W

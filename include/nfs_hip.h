@@ -81,6 +81,13 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out,
                    float* g_d_acc, float* g_vel,
                    int D, int H, int W, int C, nfs_stream_t stream);
 
+/* advect velocity gradient fused with the TF ApplyAdam update of the velocity (styler_3p.py:320-323 on the
+ * gradient of transform.py:557-569): vel, m, v [D,H,W,3] are updated in place, the gradient is never stored.
+ * Scalar field only (C = 1), D,H,W >= 2, D*H*W % 4 == 0; same arithmetic as nfs_advect_bwd + nfs_adam_tf_step. */
+int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m, float* v,
+                        int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
+                        nfs_stream_t stream);
+
 /* ---- A9: smoothing conv + clamp (styler_3p.py:112-125) ------------------------------
  * out = max(conv3d_SAME(d, [1,k,1]^3/(k+2)^3), 0), d/out [D,H,W].  k<=0 skips the conv.
  * out stores -0.0f where the pre-activation was negative, so the TF Maximum gradient

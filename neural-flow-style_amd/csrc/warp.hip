@@ -143,10 +143,16 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
 // clamping it to [0, n-1], base cell min(floor, n-2), weight in [0,1]; the four row-pairs of the stencil are
 // dword-aligned 8-byte loads.  D, H, W >= 2.  The first form (per-corner index clamps, two runtime integer
 // divisions per voxel) spent ~150 VALU instructions per voxel on a 20-byte-per-voxel stream.
-template <bool BWD>
-__global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* __restrict__ vel,
-                                                      const float* __restrict__ g_out, float* __restrict__ out,
-                                                      int D, int H, int W) {
+struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; };
+
+// MODE 0: forward; 1: velocity gradient -> out; 2: velocity gradient consumed on the spot by the TF-Adam update of
+// the velocity itself (vel, m, v updated in place: every thread reads and writes only its own 4 voxels of them;
+// the 96 MB gradient never goes to HBM)
+template <int MODE>
+__global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* vel,
+                                                      const float* __restrict__ g_out, float* out,
+                                                      int D, int H, int W, AdamFused ad) {
+  constexpr bool BWD = MODE != 0;
   const int n = D * H * W;
   const int base = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // n % 4 == 0 (checked by the host)
   if (base >= n) return;
@@ -214,10 +220,33 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       gv[3 * j + 1] = -gg[j] * dy * my[j];
       gv[3 * j + 2] = -gg[j] * dx * mx[j];
     }
-    float4* o4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;
-    o4[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
-    o4[1] = make_float4(gv[4], gv[5], gv[6], gv[7]);
-    o4[2] = make_float4(gv[8], gv[9], gv[10], gv[11]);
+    if (MODE == 1) {
+      float4* o4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;
+      o4[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      o4[1] = make_float4(gv[4], gv[5], gv[6], gv[7]);
+      o4[2] = make_float4(gv[8], gv[9], gv[10], gv[11]);
+    } else {
+      // TF ApplyAdam, same arithmetic as adam_kernel (field.hip)
+      float4* x4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;      // out == vel
+      float4* m4 = reinterpret_cast<float4*>(ad.m) + (size_t)(base / 4) * 3;
+      float4* v4m = reinterpret_cast<float4*>(ad.v) + (size_t)(base / 4) * 3;
+      float xs[12] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w, vc.x, vc.y, vc.z, vc.w};
+      const float4 ma = m4[0], mb = m4[1], mc = m4[2], ua = v4m[0], ub = v4m[1], uc = v4m[2];
+      float ms[12] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc.x, mc.y, mc.z, mc.w};
+      float us[12] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w, uc.x, uc.y, uc.z, uc.w};
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        ms[j] = ad.b1 * ms[j] + (1.f - ad.b1) * gv[j];
+        us[j] = ad.b2 * us[j] + (1.f - ad.b2) * gv[j] * gv[j];
+        xs[j] -= ad.lr_t * ms[j] / (sqrtf(us[j]) + ad.eps);
+      }
+      x4[0] = make_float4(xs[0], xs[1], xs[2], xs[3]); x4[1] = make_float4(xs[4], xs[5], xs[6], xs[7]);
+      x4[2] = make_float4(xs[8], xs[9], xs[10], xs[11]);
+      m4[0] = make_float4(ms[0], ms[1], ms[2], ms[3]); m4[1] = make_float4(ms[4], ms[5], ms[6], ms[7]);
+      m4[2] = make_float4(ms[8], ms[9], ms[10], ms[11]);
+      v4m[0] = make_float4(us[0], us[1], us[2], us[3]); v4m[1] = make_float4(us[4], us[5], us[6], us[7]);
+      v4m[2] = make_float4(us[8], us[9], us[10], us[11]);
+    }
   }
 }
 
@@ -555,8 +584,8 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
-    hipLaunchKernelGGL(advect1_kernel<false>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
-                       (const float*)nullptr, out, D, H, W);
+    hipLaunchKernelGGL(advect1_kernel<0>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
+                       (const float*)nullptr, out, D, H, W, AdamFused{});
     return check_launch("nfs_advect_fwd(x4)");
   }
   hipLaunchKernelGGL(warp_fwd_kernel<COORD_ADVECT>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a, out);
@@ -572,13 +601,26 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* 
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && !g_d_acc && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
-    hipLaunchKernelGGL(advect1_kernel<true>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
-                       g_out, g_vel, D, H, W);
+    hipLaunchKernelGGL(advect1_kernel<1>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
+                       g_out, g_vel, D, H, W, AdamFused{});
     return check_launch("nfs_advect_bwd(x4)");
   }
   hipLaunchKernelGGL(warp_bwd_kernel<COORD_ADVECT>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a,
                      g_out, g_d_acc, g_vel);
   return check_launch("nfs_advect_bwd");
+}
+
+// velocity gradient of advect + TF ApplyAdam on the velocity in one pass (scalar field, C = 1)
+int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m, float* v, int D, int H, int W,
+                        float lr_t, float beta1, float beta2, float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v, "nfs_advect_bwd_adam: null pointer");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam: needs D, H, W >= 2 and D*H*W %% 4 == 0 (use nfs_advect_bwd + nfs_adam_tf_step)");
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps});
+  return check_launch("nfs_advect_bwd_adam");
 }
 
 }  // extern "C"

@@ -218,6 +218,18 @@ class TFAdamState(object):
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.adam_tf_step(x, self.m, self.v, g, float(lr_t), float(self.b1), float(self.b2), float(self.eps))
 
+    def step_through_advect(self, vel, d0, g_adv, lr):
+        """the same update for the velocity variable of ``advect(d0, vel)`` given dL/d(advected density): the
+        velocity gradient is formed and consumed inside one kernel (never written to HBM)"""
+        if self.m is None or self.m.shape != vel.shape:
+            self.m = torch.zeros_like(vel)
+            self.v = torch.zeros_like(vel)
+        self.b1p = np.float32(self.b1p * self.b1)
+        self.b2p = np.float32(self.b2p * self.b2)
+        lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
+        ops.advect_bwd_adam(d0, vel, g_adv, self.m, self.v, float(lr_t), float(self.b1), float(self.b2),
+                            float(self.eps))
+
 
 class GridStylizer(object):
     """TNST-style grid path assembled from the reference's operators:
@@ -235,6 +247,7 @@ class GridStylizer(object):
         self.lr = float(lr)
         self.pg = process_group
         self.adam = TFAdamState()
+        self.fuse_adam = os.environ.get("NFS_FUSE_ADAM", "1") != "0"
         D, H, W = d0.shape
         if target == "v":
             self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
@@ -280,7 +293,12 @@ class GridStylizer(object):
             # gradient, not on the 12*G^3-byte velocity gradient: everything below it is linear and
             # replicated, so reducing early moves 3x fewer bytes over the links.
             parallel.all_reduce_sum_([g_ds, total], group=self.pg)
-        self.adam.step(self.var, self.variable_gradient(g_ds), self.lr)
+        D, H, W = self.d0.shape
+        if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
+            g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
+            self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr)
+        else:
+            self.adam.step(self.var, self.variable_gradient(g_ds), self.lr)
         return total
 
 

@@ -104,6 +104,14 @@ def advect_bwd(d, vel, g_out, need_d=True, need_vel=True, g_d_acc=None, g_vel=No
     return g_d_acc, g_vel
 
 
+def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """velocity gradient of advect consumed on the spot by the TF-Adam update of vel (vel, m, v in place)"""
+    D, H, W, Cn = d.shape
+    assert Cn == 1
+    _lib.call("nfs_advect_bwd_adam", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), D, H, W, float(lr_t),
+              float(beta1), float(beta2), float(eps), _stream())
+
+
 # ---- A9 -----------------------------------------------------------------------------
 
 def smooth3d_relu_fwd(d, k, out=None):

@@ -118,3 +118,22 @@ def test_view_groups_on_streams_match_single_batch():
     for losses, g in res[1:]:
         assert rel(losses, res[0][0]) < 1e-5
         assert rel(g, res[0][1]) < 1e-5
+
+
+def test_fused_advect_adam_equals_separate_kernels():
+    """GridStylizer.step with the velocity gradient consumed inside the Adam kernel (default) follows the same
+    trajectory as advect_bwd + adam_tf_step"""
+    layers = ["conv1_1", "conv2_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 2, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    out = []
+    for fuse in (True, False):
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3)
+        gs.fuse_adam = fuse
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(4)]
+        out.append((ls, gs.var.clone(), gs.adam.m.clone(), gs.adam.v.clone()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert rel(a, b) < 1e-6
+
