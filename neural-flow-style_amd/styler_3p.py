@@ -68,13 +68,22 @@ class Styler(StylerBase):
 
     # ---- forward graph: variable -> d_out [1,D,H,W,1] (autograd) ---------------------------------
     def _field(self, p, r, var, res):
-        """p [N,3], r [N,nk] device tensors; var = the optimised tensor ([N,3] or [N,nk])"""
+        """p [N,3], r [N,nk] device tensors; var = the optimised tensor ([N,3] or [N,nk]).
+        Returns (positions, d_out, extra) with extra = the auxiliary loss terms on the field / variable
+        (pressure loss, styler_base.py:226-230; density-preservation loss, styler_base.py:215-223) or None"""
         pressure = None
+        extra = None
         p_ = p.unsqueeze(0)
         if "p" in self.target_field:
             p_ = p_ + var.unsqueeze(0)
         if "d" in self.target_field:
-            r_ = r.unsqueeze(0) + torch.clamp(var.unsqueeze(0), -1, 1)      # "necessary!" (styler_3p.py:74)
+            r_opt = torch.clamp(var.unsqueeze(0), -1, 1)                    # "necessary!" (styler_3p.py:74)
+            r_ = r.unsqueeze(0) + r_opt
+            if getattr(self, "w_density", 0) > 0:
+                # density preservation on the clipped offsets (self.d[i], styler_3p.py:75; styler_base.py:217-223)
+                d_loss = r_opt[0].sum() ** 2
+                d_pres = (-torch.log(r_opt[0].abs() + 1e-6)).sum()
+                extra = (d_loss + d_pres * 1e3) * self.w_density
             d_ = None
             for k in range(self.num_kernels):
                 support = self.support / self.kernel_scale ** k
@@ -87,19 +96,18 @@ class Styler(StylerBase):
             d_ = d_ / self.rest_density
             if self.w_pressure > 0:
                 pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
+                extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
         d_out = _SmoothRelu.apply(d_, float(self.k)) if self.k > 0 else _SmoothRelu.apply(d_, 0.0)
-        return p_[0], d_out, pressure
+        return p_[0], d_out, extra
 
     def _value_and_grad(self, p, r, var, res, rot):
         """loss (per view, device) and d loss / d var for one frame"""
         v = var.detach().clone().requires_grad_(True)
-        _, d_out, pressure = self._field(p, r, v, res)
+        _, d_out, extra = self._field(p, r, v, res)
         d3 = d_out.detach().reshape(d_out.shape[1:4]).contiguous()
         g_d = torch.zeros_like(d3)
         losses = self.loss.loss_and_grad(d3, rot, g_d)
-        extra = None
-        if pressure is not None:
-            extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
+        if extra is not None:
             losses = losses + extra.detach() / losses.numel()
         heads, grads = [d_out], [g_d.reshape(d_out.shape)]
         if extra is not None:

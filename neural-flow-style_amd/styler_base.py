@@ -43,8 +43,9 @@ class StylerBase(object):
             raise NotImplementedError("content loss is Inception-only in the reference (out of scope)")
         if getattr(self, "w_hist", 0):
             raise NotImplementedError("histogram loss is out of scope (SURVEY.md section 2 row 6)")
-        if getattr(self, "w_density", 0):
-            raise NotImplementedError("density-preservation loss is out of scope")
+        if getattr(self, "w_density", 0) and "d" not in getattr(self, "target_field", ""):
+            raise NotImplementedError("the density-preservation loss acts on the particle-density variable "
+                                      "(target_field 'd'), as in the reference (styler_3p.py:75)")
         self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123))
         self.content_img = None
         self.style_img = None

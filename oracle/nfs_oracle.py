@@ -660,14 +660,22 @@ def last_layer(layers):
 # --------------------------------------------------------------------------
 
 def particle_field(p, r, var, cfg, res):
-    """styler_3p.py:42-128: variable -> d_out [1,D,H,W,1] (and the pressure field for 'p')."""
+    """styler_3p.py:42-128: variable -> (positions, d_out [1,D,H,W,1], auxiliary loss or None).
+    Auxiliary terms: pressure loss of the 'p' field (styler_3p.py:96-98, styler_base.py:226-230) and the
+    density-preservation loss on the clipped density offsets ``self.d[i]`` of the 'd' field
+    (styler_3p.py:75, styler_base.py:217-223)."""
     tf_ = cfg["target_field"]
     p_ = p.unsqueeze(0)
-    pressure = None
+    extra = None
     if "p" in tf_:
         p_ = p_ + var.unsqueeze(0)
     if "d" in tf_:
-        r_ = r.unsqueeze(0) + torch.clamp(var.unsqueeze(0), -1, 1)
+        r_opt = torch.clamp(var.unsqueeze(0), -1, 1)
+        r_ = r.unsqueeze(0) + r_opt
+        if cfg.get("w_density", 0) > 0:
+            d_loss = r_opt[0].sum() ** 2
+            d_pres = (-torch.log(r_opt[0].abs() + 1e-6)).sum()
+            extra = (d_loss + d_pres * 1e3) * cfg["w_density"]
         d_ = 0
         for k in range(cfg["num_kernels"]):
             support = cfg["support"] / cfg["kernel_scale"] ** k
@@ -678,11 +686,12 @@ def particle_field(p, r, var, cfg, res):
                  clip=cfg["clip"], support=cfg["support"]) / cfg["rest_density"]
         if cfg.get("w_pressure", 0) > 0:
             pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
-    return p_[0], smooth3d_relu(d_, cfg["k"]), pressure
+            extra = (pressure ** 2).mean() * cfg["w_pressure"]
+    return p_[0], smooth3d_relu(d_, cfg["k"]), extra
 
 
 def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
-    _, d_out, pressure = particle_field(p, r, var, cfg, res)
+    _, d_out, extra = particle_field(p, r, var, cfg, res)
     total = 0
     for v in range(rot.shape[0]):
         dr = rotate(d_out, rot[v:v + 1]) if cfg["rotate"] else d_out
@@ -693,8 +702,8 @@ def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
         if cfg.get("w_tv", 0):
             l = l + tv_loss(d_img) * cfg["w_tv"]
         total = total + l
-    if pressure is not None:
-        total = total + (pressure ** 2).mean() * cfg["w_pressure"]
+    if extra is not None:
+        total = total + extra
     return total
 
 

@@ -36,8 +36,9 @@ def _particles(G, n, nk, rng):
     return p, r
 
 
-@pytest.mark.parametrize("target,mode", [("d", "sequential"), ("d", "sum"), ("p", "sequential")])
-def test_styler3p_matches_oracle_loop(target, mode):
+@pytest.mark.parametrize("target,mode,w_density", [("d", "sequential", 0), ("d", "sum", 0), ("p", "sequential", 0),
+                                                   ("d", "sequential", 1e-2)])   # last: + density-preservation loss
+def test_styler3p_matches_oracle_loop(target, mode, w_density):
     from neural_flow_style_amd import synthetic as S
     from neural_flow_style_amd.styler_3p import Styler
     G, n, nk, F = 16, 1500, 2, 2
@@ -51,7 +52,8 @@ def test_styler3p_matches_oracle_loop(target, mode):
                   style_layer=layers, w_style_layer=[1, 1, 1], w_style=1.0, w_content=0, transmit=0.1,
                   rotate=True, n_views=3, v_batch=1, sample_type="uniform", phi0=0, phi1=0, phi_unit=0,
                   theta0=-10, theta1=10, theta_unit=10, resize_scale=1.0, views_mode=mode,
-                  style_target=simg, num_kernels=nk, kernel_scale=2, w_pressure=1e3 if target == "p" else 0)
+                  style_target=simg, num_kernels=nk, kernel_scale=2, w_pressure=1e3 if target == "p" else 0,
+                  w_density=w_density)
     st = Styler(cfg)
     st.load_img([G, G])
     params = {"p": [f[0] for f in frames], "r": [f[1] for f in frames]}
