@@ -74,11 +74,14 @@ class Styler(StylerBase):
         g_opt = [self._dev(c_opt[i]) for i in range(self.num_frames)]
 
         loss_history, d_intm, opt_ = [], [], {}
+        style_per_octave = []
         for octave in range(self.octave_n):
             loss_history_o, d_intm_o = [], []
             res = [int(v) for v in oct_size[octave]]
             if self.style_img is not None:
-                self.loss.set_style_image(self._style_feature(self.style_img, res))
+                style_o = self._style_feature(self.style_img, res)
+                style_per_octave.append(np.asarray(style_o, np.float32))
+                self.loss.set_style_image(style_o)
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames
@@ -121,4 +124,7 @@ class Styler(StylerBase):
         result["c"] = c_sty
         result["d"] = np.array(d_sty)
         result["opt"] = [g.cpu().numpy() for g in g_opt]
+        # extras of this build (not in the reference's dict): what the run started from, for parity tests
+        result["c_init"] = c_opt
+        result["style_per_octave"] = style_per_octave
         return result

@@ -776,6 +776,79 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
     return hist, g_opt, d_fin
 
 
+def colour_field2d(p, r, var, cfg, res):
+    """styler_2p.py:42-102: d_gray = clip(p2g(p)/rho0, 0, 1) (mask, constant); d = clip(p2g(p, pc=clip(c,0,1),
+    pd=r), 0, 1) [1,H,W,3]; returns (d, d_gray, clipped colours)"""
+    pb = p.unsqueeze(0)
+    d_gray = torch.clamp(p2g(pb, cfg["domain"], res, cfg["radius"], cfg["rest_density"], cfg["nsize"], is_2d=True,
+                             clip=cfg["clip"], support=cfg["support"]) / cfg["rest_density"], 0, 1)
+    c_ = torch.clamp(var.unsqueeze(0), 0, 1)
+    d = p2g(pb, cfg["domain"], res, cfg["radius"], cfg["rest_density"], cfg["nsize"], pc=c_, pd=r.unsqueeze(0),
+            is_2d=True, clip=cfg["clip"], support=cfg["support"])
+    return torch.clamp(d, 0, 1), d_gray.detach(), c_[0]
+
+
+def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
+    """style (optionally masked by d_gray, styler_base.py:165-169) + TV (211-213) of the colour image"""
+    d, d_gray, _ = colour_field2d(p, r, var, cfg, res)
+    d_img = plugin_to_loss_net(d, cfg.get("resize_scale", 1.0), is_color=True)
+    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"]))
+    l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"],
+                      d_gray=d_gray if cfg.get("style_mask") else None)
+    if cfg.get("w_tv", 0):
+        l = l + tv_loss(d_img) * cfg["w_tv"]
+    return l
+
+
+def styler2p_run(cfg, params, weights, style_img, c_init):
+    """The reference's 2-D colour Styler.run (styler_2p.py:165-315) for batch_size 1: octaves coarse -> fine, one
+    TF-Adam state per frame group, temporal Gaussian smoothing of the per-frame updates.  ``style_img[octave]`` is
+    the style image already resized for that octave, ``c_init`` [F,N,3] the colour initialisation (189-192).
+    Returns (loss history per octave, optimised colours per frame, final uint8 images d*d_gray*255)."""
+    from scipy.ndimage import gaussian_filter
+    dt = torch.float32
+    F_ = cfg["num_frames"]
+    p = [torch.tensor(np.asarray(x), dtype=dt) for x in params["p"]]
+    r = [torch.tensor(np.asarray(x), dtype=dt) for x in params["r"]]
+    g_opt = [torch.tensor(np.asarray(c_init[i]), dtype=dt) for i in range(F_)]
+    oct_size = []
+    hw = np.array(cfg["resolution"])
+    for _ in range(cfg["octave_n"]):
+        oct_size.append(hw)
+        hw = (hw // cfg["octave_scale"]).astype(int)
+    oct_size.reverse()
+    opt_ = {}
+    hist = []
+    for octave in range(cfg["octave_n"]):
+        res = [int(v) for v in oct_size[octave]]
+        simg = torch.tensor(np.asarray(style_img[octave], np.float32))[None]
+        sfe = style_target_features(simg, weights, cfg["style_layer"])
+        lr = cfg["lr"][octave] if isinstance(cfg["lr"], (list, tuple)) else cfg["lr"]
+        h_o = []
+        for step in range(cfg["iter"]):
+            g_tmp = [None] * F_
+            for t in range(F_):
+                opt = opt_.setdefault(t // cfg["frames_per_opt"], TFAdam())
+                vv = g_opt[t].clone().requires_grad_()
+                l = colour_loss2d(p[t], r[t], vv, cfg, res, weights, sfe)
+                (g,) = torch.autograd.grad(l, vv)
+                h_o.append(float(l))
+                new = torch.nan_to_num(opt.step(g_opt[t].clone(), g, lr))
+                g_tmp[t] = new - g_opt[t]
+            if cfg["window_sigma"] > 0 and F_ > 1:
+                st = gaussian_filter(np.stack([g.numpy() for g in g_tmp]), sigma=(cfg["window_sigma"], 0, 0))
+                g_tmp = [torch.tensor(s) for s in st]
+            for t in range(F_):
+                g_opt[t] = g_opt[t] + g_tmp[t]
+        hist.append(h_o)
+    res = [int(v) for v in oct_size[-1]]
+    imgs = []
+    for t in range(F_):
+        d, d_gray, _ = colour_field2d(p[t], r[t], g_opt[t], cfg, res)
+        imgs.append(((d * d_gray)[0] * 255).numpy().astype(np.uint8))
+    return hist, g_opt, imgs
+
+
 # --------------------------------------------------------------------------
 # SURVEY 8(f)-1: grid -> particle sampling and the SimG2P resampler
 # (transform.py:771-1231, test_smokegun_resim.py:17-217).  Parity unpinned (the reference holds no

@@ -93,6 +93,37 @@ def test_styler2p_colour_runs_and_decreases_loss():
     assert l[-1] < l[0]
 
 
+def test_styler2p_matches_oracle_loop():
+    """BASELINE config 0 in miniature (dambreak2d: 2-D SPH colour splat, style mask, TV, two octaves, two frames
+    with temporal smoothing): the whole Styler.run against the oracle's restatement of styler_2p.py:165-315"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_2p import Styler
+    rng = np.random.RandomState(11)
+    F = 2
+    ps = [S.dambreak_particles(24, rng) for _ in range(F)]
+    n = ps[0].shape[0]
+    rs = [rng.uniform(900, 1100, (n, 1)).astype(np.float32) for _ in range(F)]
+    H = W = 32
+    simg = S.style_image(H, W, rng)
+    layers = ["conv2_1", "conv3_1"]
+    cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.05, nsize=2, support=4,
+                  rest_density=1000, clip=False, target_field="c", num_frames=F, batch_size=1, frames_per_opt=200,
+                  window_sigma=1.0, lr=0.01, iter=3, octave_n=2, octave_scale=1.6, style_layer=layers,
+                  w_style_layer=[0.5, 0.5], w_style=1.0, w_content=0, style_mask=True, w_tv=0.01, style_target=simg,
+                  resize_scale=1.0)
+    st = Styler(cfg)
+    st.load_img([H, W])
+    params = {"p": ps, "r": rs}
+    res = st.run(params)
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    hist, c_opt, imgs = O.styler2p_run(dict(vars(cfg)), params, w, res["style_per_octave"], res["c_init"])
+    for o in range(2):
+        np.testing.assert_allclose(res["l"][o], hist[o], rtol=2e-3)
+    for t in range(F):
+        assert rel(res["opt"][t], c_opt[t]) < 1e-3
+        assert np.abs(res["d"][t].astype(np.int32) - imgs[t].astype(np.int32)).max() <= 1     # uint8 rounding
+
+
 def test_chocolate_like_liquid_position_field():
     """BASELINE config 5 in miniature: SPH particles, position ('p') field, liquid render
     (1 - exp(-tau sum d)), pressure loss -- sum-over-views mode (the shardable one)."""
