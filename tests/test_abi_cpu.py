@@ -69,3 +69,19 @@ def test_view_sampling_shapes_and_determinism():
     pts = np.array([[v["theta"], v["phi"]] for v in T.rot_mat_poisson(-5, 5, 5, -10, 10, 10, np.random.RandomState(1))])
     dist = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(len(pts)) * 1e9
     assert dist.min() >= 5.0 - 1e-9
+
+
+def test_config_surface_matches_the_reference_defaults():
+    """every flag of the reference's config.get_config() (fixture generated from the reference itself by
+    tests/golden/make_config_fixture.py) exists with the same default; the build adds only documented extras"""
+    import json
+    import os
+    from neural_flow_style_amd.config import get_config
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_defaults.json")))
+    mine = vars(get_config([])[0])
+    assert len(ref) >= 60
+    for k, v in ref.items():
+        assert k in mine, k
+        got = mine[k]
+        assert (list(got) if isinstance(got, (list, tuple)) else got) == v, (k, got, v)
+    assert set(mine) - set(ref) == {"views_mode", "grid_variable"}
