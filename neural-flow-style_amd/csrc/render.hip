@@ -136,33 +136,114 @@ __device__ __forceinline__ float lean_sample(const float* __restrict__ vol, cons
   return fmaf(wz, b1 - b0, b0);
 }
 
+// The same sampler split in two, for the march that keeps the previous sample's four texel pairs in registers:
+// a ray moves ~1 cell in z per step and changes its (y, x) cell only every 6-60 steps, so the upper plane of
+// sample z is the lower plane of sample z+1 most of the time and only 2 of the 4 pair loads are new.
+struct LeanCoord {
+  unsigned base;
+  float wz, wy, wx;
+};
+// Batch form: sample u of a batch sits at z - u; its affine offsets (b - u a) are precomputed, and the cell
+// index uses 24-bit multiplies (full rate; exact for H W < 2^24, which the launcher's D H W < 2^30 implies)
+struct RayOff {
+  float bz, by, bx;
+};
+__device__ __forceinline__ LeanCoord lean_coord24(const VolDims& n, const RayAffine& q, const RayOff& o, float zf) {
+  const float cz = __builtin_amdgcn_fmed3f(fmaf(q.az, zf, o.bz), 0.f, n.nz1);
+  const float cy = __builtin_amdgcn_fmed3f(fmaf(q.ay, zf, o.by), 0.f, n.ny1);
+  const float cx = __builtin_amdgcn_fmed3f(fmaf(q.ax, zf, o.bx), 0.f, n.nx1);
+  const float fz = fminf(floorf(cz), n.nz2), fy = fminf(floorf(cy), n.ny2), fx = fminf(floorf(cx), n.nx2);
+  const unsigned base = __umul24((unsigned)(int)fz, n.HW) + __umul24((unsigned)(int)fy, n.W) + (unsigned)(int)fx;
+  return LeanCoord{base, cz - fz, cy - fy, cx - fx};
+}
+__device__ __forceinline__ F2u buf_load_f2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(F2u, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
+// l/u := previous sample's texel pairs on the lanes that do not load them: on `shift` lanes (plane advanced by one)
+// the new upper plane is the old lower plane; on `same` lanes everything carries over.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void masked_carry(F2u& l0, F2u& l1, F2u& u0, F2u& u1, const F2u& pl0, const F2u& pl1,
+                                             const F2u& pu0, const F2u& pu1, uint64_t shift, uint64_t same) {
+  f32x2 a = __builtin_bit_cast(f32x2, l0), b = __builtin_bit_cast(f32x2, l1), c = __builtin_bit_cast(f32x2, u0),
+        e = __builtin_bit_cast(f32x2, u1);
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_mov_b64 exec, %[msh]\n\t"
+      "v_mov_b64 %[u0], %[pl0]\n\t"
+      "v_mov_b64 %[u1], %[pl1]\n\t"
+      "s_mov_b64 exec, %[msa]\n\t"
+      "v_mov_b64 %[l0], %[pl0]\n\t"
+      "v_mov_b64 %[l1], %[pl1]\n\t"
+      "v_mov_b64 %[u0], %[pu0]\n\t"
+      "v_mov_b64 %[u1], %[pu1]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [l0] "+v"(a), [l1] "+v"(b), [u0] "+v"(c), [u1] "+v"(e), [sv] "=&s"(saved)
+      : [pl0] "v"(__builtin_bit_cast(f32x2, pl0)), [pl1] "v"(__builtin_bit_cast(f32x2, pl1)),
+        [pu0] "v"(__builtin_bit_cast(f32x2, pu0)), [pu1] "v"(__builtin_bit_cast(f32x2, pu1)), [msh] "s"(shift),
+        [msa] "s"(same));
+  l0 = __builtin_bit_cast(F2u, a);
+  l1 = __builtin_bit_cast(F2u, b);
+  u0 = __builtin_bit_cast(F2u, c);
+  u1 = __builtin_bit_cast(F2u, e);
+}
+__device__ __forceinline__ float lean_blend(const LeanCoord& c, F2u p00, F2u p01, F2u p10, F2u p11) {
+  const float a00 = fmaf(c.wx, p00.y - p00.x, p00.x), a01 = fmaf(c.wx, p01.y - p01.x, p01.x);
+  const float a10 = fmaf(c.wx, p10.y - p10.x, p10.x), a11 = fmaf(c.wx, p11.y - p11.x, p11.x);
+  const float b0 = fmaf(c.wy, a01 - a00, a00), b1 = fmaf(c.wy, a11 - a10, a10);
+  return fmaf(c.wz, b1 - b0, b0);
+}
+
 // Segmented variant (D >= 16, H, W >= 2): a block = 64 rays x 4 depth segments (one wave per segment, far
 // segment first).  One thread per ray leaves only V*H*W = 320 k threads for a 200-step serial march; splitting
 // the ray four ways quadruples the loads in flight (one view per GPU: 0.074 -> 0.041 ms).  Segments combine exactly:
 //   I = sum_s exp(-tau * P_s) * I_s,   P_s = sum of the ray sums of the segments farther than s,
 // because the transmittance of a sample is exp(-tau (P_s + local suffix sum)).
 constexpr int RR_SEG = 4;
-__global__ void __launch_bounds__(256) rotate_render_fwd_seg_kernel(const float* __restrict__ d,
+template <bool REUSE>
+__global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const float* __restrict__ d,
                                                                     const float* __restrict__ rot,
                                                                     float* __restrict__ img,
                                                                     float* __restrict__ raysum,
                                                                     float* __restrict__ d_rot, int V, int D, int H,
-                                                                    int W, float tau, int liquid) {
+                                                                    int W, float tau, int liquid, int lxb) {
   __shared__ float seg_sum[RR_SEG][64], seg_I[RR_SEG][64];
   const int HW = H * W;
-  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  // a wave is one segment: telling the compiler so keeps the depth index and the plane offsets in scalar registers
+  const int lane = threadIdx.x & 63, seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t total = (int64_t)V * HW;
   // XCD-aware order: consecutive workgroups go round-robin to the 8 XCDs; give each XCD a contiguous range of
   // rays (one view at V = 8), so that the planes its waves walk through stay in its own 4 MB L2 (with the plain
   // order every XCD sweeps all views at once: 54 % L2 hit rate, 1.2 GB fetched for a 32 MB volume)
   const unsigned per_xcd = gridDim.x / 8;
   const unsigned logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  const int64_t gid_raw = (int64_t)logical * 64 + lane;
-  const bool live = gid_raw < total;
-  const int64_t gid = live ? gid_raw : total - 1;
-  const int v = (int)(gid / HW);
-  const int px = (int)(gid - (int64_t)v * HW);
-  const int h = px / W, w = px - h * W;
+  bool live;
+  int v, h, w;
+  if (lxb == 0) {                                                 // 64 consecutive pixels (may wrap to the next row)
+    const int64_t gid_raw = (int64_t)logical * 64 + lane;
+    live = gid_raw < total;
+    const int64_t g = live ? gid_raw : total - 1;
+    v = (int)(g / HW);
+    const int p = (int)(g - (int64_t)v * HW);
+    h = p / W;
+    w = p - h * W;
+  } else {
+    // a wave is a 2^lxb x 2^(6-lxb) pixel tile: under a rotation the 64 x 1 strip spreads over ~64 sin(theta)
+    // source planes, one cache line each; a tile spreads over 2^lxb sin(theta) planes and its rows share lines
+    // (row y+1 of one lane row is row y of the next), so the gather touches ~40 % fewer lines
+    const int tw = 1 << lxb, th = 64 >> lxb;
+    const int ntx = (W + tw - 1) >> lxb, nty = (H + th - 1) / th;
+    const unsigned tiles = (unsigned)ntx * nty;
+    const unsigned vv = logical / tiles, t = logical - vv * tiles;
+    const int ty = t / ntx, tx = t - ty * ntx;
+    const int hh = ty * th + (lane >> lxb), ww = tx * tw + (lane & (tw - 1));
+    live = vv < (unsigned)V && hh < H && ww < W;
+    v = min((int)vv, V - 1);
+    h = min(hh, H - 1);
+    w = min(ww, W - 1);
+  }
+  const int px = h * W + w;
+  const int64_t gid = (int64_t)v * HW + px;
   float r[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = rot[v * 9 + i];
@@ -175,12 +256,80 @@ __global__ void __launch_bounds__(256) rotate_render_fwd_seg_kernel(const float*
   float* drow = d_rot ? d_rot + (int64_t)v * D * HW + px : nullptr;
   float acc = 0.f, I = 0.f;
   int z = zhi;
-  for (; z >= zlo + 3; z -= 4) {
-    float sv[4];
+  // REUSE path: buffer addressing (32-bit byte offsets; the launcher checks the sizes) so that the +W / +HW
+  // neighbours and the output plane cost scalar offsets instead of 64-bit vector adds
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t vol_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d), 0, 0xffffffff, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rot_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(d_rot ? d_rot : img, 0, 0xffffffff, 0x00020000);
+  [[maybe_unused]] const unsigned so_w = n.W * 4u, so_hw = n.HW * 4u, so_hww = (n.HW + n.W) * 4u;
+  [[maybe_unused]] const unsigned rot_vo = ((unsigned)v * (unsigned)D * n.HW + (unsigned)px) * 4u;
+  [[maybe_unused]] RayOff qo[4];                                  // offsets of the four samples of a batch
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sv[u] = lean_sample(d, n, q, (float)(z - u));
+  for (int u = 0; u < 4; ++u) qo[u] = RayOff{q.bz - (float)u * q.az, q.by - (float)u * q.ay, q.bx - (float)u * q.ax};
+  unsigned pbase = 0xffffffffu;                                   // previous sample's cell and its texel pairs
+  F2u L0{0.f, 0.f}, L1{0.f, 0.f}, U0{0.f, 0.f}, U1{0.f, 0.f};     // L: plane bz (rows by, by+1), U: plane bz+1
+  constexpr int NB = 4;                                           // samples per batch
+  for (; z >= zlo + NB - 1; z -= NB) {
+    float sv[NB];
+    if constexpr (REUSE) {
+      LeanCoord c[NB];
+      bool same[NB], shift[NB];
+      F2u l0[NB], l1[NB], u0[NB], u1[NB];
+      unsigned pb = pbase;
+      const float zf = (float)z;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
+        c[u] = lean_coord24(n, q, qo[u], zf);
+        same[u] = c[u].base == pb;
+        shift[u] = c[u].base + n.HW == pb;
+        pb = c[u].base;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (!same[u]) {
+          const unsigned vo = c[u].base * 4u;
+          l0[u] = buf_load_f2(vol_rsrc, vo, 0);
+          l1[u] = buf_load_f2(vol_rsrc, vo, so_w);
+          if (!shift[u]) {
+            u0[u] = buf_load_f2(vol_rsrc, vo, so_hw);
+            u1[u] = buf_load_f2(vol_rsrc, vo, so_hww);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        // the carry-over as masked register moves (2 for a plane advance, 4 for an unchanged cell); written as
+        // a branch the compiler turns it into ~23 copies per sample
+        masked_carry(l0[u], l1[u], u0[u], u1[u], L0, L1, U0, U1, __builtin_amdgcn_ballot_w64(shift[u]),
+                     __builtin_amdgcn_ballot_w64(same[u]));
+        L0 = l0[u]; L1 = l1[u]; U0 = u0[u]; U1 = u1[u];
+        sv[u] = lean_blend(c[u], l0[u], l1[u], u0[u], u1[u]);
+      }
+      pbase = pb;
+      if (d_rot && live) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {  // plane offset is wave-uniform: it rides in the scalar offset of the store
+          if (lxb && lxb < 5)           // half-line pieces: let the L2 merge them with the neighbouring tile's
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv[u]), rot_rsrc, rot_vo,
+                                                  (unsigned)(z - u) * n.HW * 4u, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv[u]), rot_rsrc, rot_vo,
+                                                  (unsigned)(z - u) * n.HW * 4u, 2 /* nt */);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        acc += sv[u];
+        I = fmaf(sv[u], __builtin_amdgcn_exp2f(acc * ntau), I);
+      }
+      continue;
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) sv[u] = lean_sample(d, n, q, (float)(z - u));
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
       // rotated volume kept for the adjoint: streaming store, must not evict the volume from L2
       if (drow && live) __builtin_nontemporal_store(sv[u], drow + (int64_t)(z - u) * HW);
       acc += sv[u];
@@ -521,10 +670,22 @@ int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* r
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_rotate_render_fwd: non-positive dimension");
   const int64_t n = (int64_t)V * H * W;
   static const bool no_seg = getenv("NFS_RR_NOSEG") != nullptr;   // timing comparisons only
-  if (W >= 2 && H >= 2 && D >= 4 * RR_SEG && (int64_t)D * H * W < (1ll << 31) && !no_seg)
-    hipLaunchKernelGGL(rotate_render_fwd_seg_kernel, dim3((blocks_for(n, 64) + 7) / 8 * 8), dim3(256), 0,
-                       as_stream(stream), d, rot, img, raysum, d_rot, V, D, H, W, tau, liquid);
-  else
+  static const bool no_reuse = getenv("NFS_RR_NOREUSE") != nullptr;   // timing comparisons only
+  static const int tile_env = getenv("NFS_RR_TILE") ? atoi(getenv("NFS_RR_TILE")) : -1;
+  if (W >= 2 && H >= 2 && D >= 4 * RR_SEG && (int64_t)D * H * W < (1ll << 31) && !no_seg) {
+    // wave footprint: 16 x 4 pixel tiles when the image has room for them, else 64 consecutive pixels
+    const int lxb = tile_env >= 0 ? tile_env : (W >= 16 && H >= 4 ? 4 : 0);
+    int64_t waves = blocks_for(n, 64);
+    if (lxb) waves = (int64_t)V * ((W + (1 << lxb) - 1) >> lxb) * ((H + (64 >> lxb) - 1) / (64 >> lxb));
+    const dim3 grid((waves + 7) / 8 * 8);
+    const bool fits32 = (int64_t)V * D * H * W < (1ll << 30);      // byte offsets of the buffer addressing
+    if (fits32 && !no_reuse)
+      hipLaunchKernelGGL(rotate_render_fwd_seg_kernel<true>, grid, dim3(256), 0, as_stream(stream), d, rot, img,
+                         raysum, d_rot, V, D, H, W, tau, liquid, lxb);
+    else
+      hipLaunchKernelGGL(rotate_render_fwd_seg_kernel<false>, grid, dim3(256), 0, as_stream(stream), d, rot, img,
+                         raysum, d_rot, V, D, H, W, tau, liquid, lxb);
+  } else
     hipLaunchKernelGGL(rotate_render_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, rot,
                        img, raysum, d_rot, V, D, H, W, tau, liquid);
   return check_launch("nfs_rotate_render_fwd");

@@ -415,6 +415,30 @@ def test_p2g_wavg_3d(ops):
     assert rel(gp_h, gp[0]) < 5e-4
 
 
+@pytest.mark.parametrize("shape", [(20, 9, 21), (33, 18, 37), (16, 4, 16)])
+@pytest.mark.parametrize("big", [False, True])
+def test_rotate_render_wave_tiles(ops, shape, big):
+    """W >= 16, H >= 4: the forward march runs on 16 x 4 pixel wave tiles with the texel carry-over between
+    samples; ragged tile edges, large rotations (no plane-advance reuse) and the kept rotated volume."""
+    D, H, W = shape
+    torch.manual_seed(9)
+    d = torch.rand(1, D, H, W, 1)
+    R = rots(5, 11, big=big)
+    tau = 0.2
+    dr = O.rotate(d, R)
+    ref = O.render_unnormalised(dr, tau)
+    d_rot = torch.empty(5, D, H, W, device="cuda")
+    img, rs = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, False, d_rot=d_rot)
+    assert rel(d_rot, dr[..., 0]) < TOL
+    assert rel(rs, dr[..., 0].sum(1)) < TOL
+    assert rel(img, ref[..., 0]) < TOL
+    img2, rs2 = ops.rotate_render_fwd(dev(d[0, ..., 0]), dev(R), tau, False)       # without the kept volume
+    assert torch.equal(img2, img) and torch.equal(rs2, rs)
+    out, _ = ops.maxnorm_fwd(img, 5)
+    ref_n = torch.cat([O.render(dr[v:v + 1], tau, False) for v in range(5)])
+    assert rel(out, ref_n[..., 0]) < TOL
+
+
 def test_error_channel(ops):
     from neural_flow_style_amd import _lib
     with pytest.raises(RuntimeError, match="null pointer"):
