@@ -53,17 +53,37 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(const float* d,
       for (int z = 0; z < D; ++z) g_d[base + (int64_t)z * HW] = gd;
       amax = fabsf(gd);
     } else {
+      // g_d may be d itself (in-place adjoint), so the compiler cannot lift a load above the store before it:
+      // batches of RB samples, the next batch's loads issued before this batch's stores, keep 8-16 loads in
+      // flight per ray (one thread per ray has only ~5 waves per SIMD to hide the HBM latency with)
+      constexpr int RB = 8;
       float prefix = 0.f, P = 0.f;
-#pragma unroll 4
-      for (int z = 0; z < D; ++z) {
-        const float s = d[base + (int64_t)z * HW];
+      auto step = [&](float s, int z) __attribute__((always_inline)) {
         const float T = __builtin_amdgcn_exp2f((total - prefix) * ntau);
         P = fmaf(s, T, P);
         const float o = g * (T - tau * P);
         g_d[base + (int64_t)z * HW] = o;
         amax = fmaxf(amax, fabsf(o));
         prefix += s;
+      };
+      const int nfull = D / RB;
+      float cur[RB], nxt[RB];
+      if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) cur[u] = d[base + (int64_t)u * HW];
       }
+      for (int b = 0; b < nfull; ++b) {
+        const int z0 = b * RB;
+        if (b + 1 < nfull) {
+#pragma unroll
+          for (int u = 0; u < RB; ++u) nxt[u] = d[base + (int64_t)(z0 + RB + u) * HW];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) step(cur[u], z0 + u);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
+      }
+      for (int z = nfull * RB; z < D; ++z) step(d[base + (int64_t)z * HW], z);
     }
   }
   // optional by-product: max |g_d| (as float bits) for the fixed-point scale of the rotate adjoint that follows

@@ -148,32 +148,52 @@ struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; };
 // MODE 0: forward; 1: velocity gradient -> out; 2: velocity gradient consumed on the spot by the TF-Adam update of
 // the velocity itself (vel, m, v updated in place: every thread reads and writes only its own 4 voxels of them;
 // the 96 MB gradient never goes to HBM)
+struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
+
 template <int MODE>
 __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* vel,
                                                       const float* __restrict__ g_out, float* out,
                                                       int D, int H, int W, AdamFused ad) {
   constexpr bool BWD = MODE != 0;
   const int n = D * H * W;
-  const int base = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // n % 4 == 0 (checked by the host)
-  if (base >= n) return;
-  const float4* v4 = reinterpret_cast<const float4*>(vel) + (size_t)(base / 4) * 3;
-  const float4 va = v4[0], vb = v4[1], vc = v4[2];
-  const float vv[12] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w, vc.x, vc.y, vc.z, vc.w};
-  float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (BWD) go = *reinterpret_cast<const float4*>(g_out + base);
-  const float gg[4] = {go.x, go.y, go.z, go.w};
+  // a wave owns 256 consecutive voxels and lane l takes l, l+64, l+128, l+192: every streamed access (the
+  // 12-byte velocity / moment vectors, g_out, out) is then one contiguous 768- or 256-byte run per instruction.
+  // (Four consecutive voxels per lane with float4 accesses put the lanes 48 bytes apart: 24 cache lines per
+  // instruction, a third of each used.)
+  const int lane = threadIdx.x & 63;
+  const int first = (blockIdx.x * blockDim.x + (threadIdx.x - lane)) * 4 + lane;
+  if (first - lane >= n) return;
+  const F3u* v3 = reinterpret_cast<const F3u*>(vel);
+  const F3u* m3 = reinterpret_cast<const F3u*>(ad.m);
+  const F3u* u3 = reinterpret_cast<const F3u*>(ad.v);
+  F3u vv[4], mm[4], uu[4];
+  float gg[4];
+  bool ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = first + 64 * j;
+    ok[j] = idx < n;
+    const int ic = ok[j] ? idx : n - 1;
+    vv[j] = v3[ic];
+    if (BWD) gg[j] = g_out[ic];
+    if (MODE == 2) {   // the Adam moments are streamed: ask for them with the velocity, before the gather
+      mm[j] = m3[ic];
+      uu[j] = u3[ic];
+    }
+  }
   const float hz = 0.5f * (float)(D - 1), hy = 0.5f * (float)(H - 1), hx = 0.5f * (float)(W - 1);
   const float nz1 = (float)(D - 1), ny1 = (float)(H - 1), nx1 = (float)(W - 1);
   const unsigned uW = (unsigned)W, uHW = (unsigned)(H * W);
-  int w = base % W;
-  const int t2 = base / W;
+  const int f0 = min(first, n - 1);
+  int w = f0 % W;
+  const int t2 = f0 / W;
   int h = t2 % H, z = t2 / H;
   F2u p[4][4];
   float wz[4], wy[4], wx[4], mz[4], my[4], mx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float xz = fmaf(-vv[3 * j], hz, (float)z), xy = fmaf(-vv[3 * j + 1], hy, (float)h),
-                xx = fmaf(-vv[3 * j + 2], hx, (float)w);
+    const float xz = fmaf(-vv[j].x, hz, (float)z), xy = fmaf(-vv[j].y, hy, (float)h),
+                xx = fmaf(-vv[j].z, hx, (float)w);
     const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
                 cx = __builtin_amdgcn_fmed3f(xx, 0.f, nx1);
     const float bz = fminf(floorf(cz), nz1 - 1.f), by = fminf(floorf(cy), ny1 - 1.f), bx = fminf(floorf(cx), nx1 - 1.f);
@@ -188,20 +208,19 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
     p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
     p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
     p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
-    if (++w == W) { w = 0; if (++h == H) { h = 0; ++z; } }
+    // next voxel of this lane: 64 further on (clamped at the end of the volume; those results are not stored)
+    w += 64;
+    while (w >= W) { w -= W; if (++h == H) { h = 0; if (z < D - 1) ++z; } }
   }
   if (!BWD) {
-    float r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float a00 = fmaf(wx[j], p[j][0].y - p[j][0].x, p[j][0].x), a01 = fmaf(wx[j], p[j][1].y - p[j][1].x, p[j][1].x);
       const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
       const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
-      r[j] = fmaf(wz[j], b1 - b0, b0);
+      if (ok[j]) out[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
     }
-    *reinterpret_cast<float4*>(out + base) = make_float4(r[0], r[1], r[2], r[3]);
   } else {
-    float gv[12];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float e00 = p[j][0].y - p[j][0].x, e01 = p[j][1].y - p[j][1].x, e10 = p[j][2].y - p[j][2].x,
@@ -216,36 +235,25 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       const float b0 = fmaf(wy[j], g0, a00), b1 = fmaf(wy[j], g1, a10);
       const float dz = b1 - b0;
       // coordinate = index - vel * (n-1)/2  =>  d/dvel = -(n-1)/2 * d/dcoordinate (mz/my/mx carry the factor)
-      gv[3 * j] = -gg[j] * dz * mz[j];
-      gv[3 * j + 1] = -gg[j] * dy * my[j];
-      gv[3 * j + 2] = -gg[j] * dx * mx[j];
-    }
-    if (MODE == 1) {
-      float4* o4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;
-      o4[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
-      o4[1] = make_float4(gv[4], gv[5], gv[6], gv[7]);
-      o4[2] = make_float4(gv[8], gv[9], gv[10], gv[11]);
-    } else {
-      // TF ApplyAdam, same arithmetic as adam_kernel (field.hip)
-      float4* x4 = reinterpret_cast<float4*>(out) + (size_t)(base / 4) * 3;      // out == vel
-      float4* m4 = reinterpret_cast<float4*>(ad.m) + (size_t)(base / 4) * 3;
-      float4* v4m = reinterpret_cast<float4*>(ad.v) + (size_t)(base / 4) * 3;
-      float xs[12] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w, vc.x, vc.y, vc.z, vc.w};
-      const float4 ma = m4[0], mb = m4[1], mc = m4[2], ua = v4m[0], ub = v4m[1], uc = v4m[2];
-      float ms[12] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc.x, mc.y, mc.z, mc.w};
-      float us[12] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w, uc.x, uc.y, uc.z, uc.w};
+      const float gv[3] = {-gg[j] * dz * mz[j], -gg[j] * dy * my[j], -gg[j] * dx * mx[j]};
+      if (!ok[j]) continue;
+      const int idx = first + 64 * j;
+      if (MODE == 1) {
+        reinterpret_cast<F3u*>(out)[idx] = F3u{gv[0], gv[1], gv[2]};
+      } else {
+        // TF ApplyAdam, same arithmetic as adam_kernel (field.hip); out == vel
+        float xs[3] = {vv[j].x, vv[j].y, vv[j].z}, ms[3] = {mm[j].x, mm[j].y, mm[j].z},
+              us[3] = {uu[j].x, uu[j].y, uu[j].z};
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        ms[j] = ad.b1 * ms[j] + (1.f - ad.b1) * gv[j];
-        us[j] = ad.b2 * us[j] + (1.f - ad.b2) * gv[j] * gv[j];
-        xs[j] -= ad.lr_t * ms[j] / (sqrtf(us[j]) + ad.eps);
+        for (int c = 0; c < 3; ++c) {
+          ms[c] = ad.b1 * ms[c] + (1.f - ad.b1) * gv[c];
+          us[c] = ad.b2 * us[c] + (1.f - ad.b2) * gv[c] * gv[c];
+          xs[c] -= ad.lr_t * ms[c] / (sqrtf(us[c]) + ad.eps);
+        }
+        reinterpret_cast<F3u*>(out)[idx] = F3u{xs[0], xs[1], xs[2]};
+        reinterpret_cast<F3u*>(ad.m)[idx] = F3u{ms[0], ms[1], ms[2]};
+        reinterpret_cast<F3u*>(ad.v)[idx] = F3u{us[0], us[1], us[2]};
       }
-      x4[0] = make_float4(xs[0], xs[1], xs[2], xs[3]); x4[1] = make_float4(xs[4], xs[5], xs[6], xs[7]);
-      x4[2] = make_float4(xs[8], xs[9], xs[10], xs[11]);
-      m4[0] = make_float4(ms[0], ms[1], ms[2], ms[3]); m4[1] = make_float4(ms[4], ms[5], ms[6], ms[7]);
-      m4[2] = make_float4(ms[8], ms[9], ms[10], ms[11]);
-      v4m[0] = make_float4(us[0], us[1], us[2], us[3]); v4m[1] = make_float4(us[4], us[5], us[6], us[7]);
-      v4m[2] = make_float4(us[8], us[9], us[10], us[11]);
     }
   }
 }
@@ -584,7 +592,7 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
-    hipLaunchKernelGGL(advect1_kernel<0>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
+    hipLaunchKernelGGL(advect1_kernel<0>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel,
                        (const float*)nullptr, out, D, H, W, AdamFused{});
     return check_launch("nfs_advect_fwd(x4)");
   }
@@ -601,7 +609,7 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* 
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && !g_d_acc && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
-    hipLaunchKernelGGL(advect1_kernel<1>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel,
+    hipLaunchKernelGGL(advect1_kernel<1>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel,
                        g_out, g_vel, D, H, W, AdamFused{});
     return check_launch("nfs_advect_bwd(x4)");
   }
@@ -618,7 +626,7 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
   const int64_t n = (int64_t)D * H * W;
   NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
               "nfs_advect_bwd_adam: needs D, H, W >= 2 and D*H*W %% 4 == 0 (use nfs_advect_bwd + nfs_adam_tf_step)");
-  hipLaunchKernelGGL(advect1_kernel<2>, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps});
   return check_launch("nfs_advect_bwd_adam");
 }
