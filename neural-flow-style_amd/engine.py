@@ -125,10 +125,13 @@ class RenderStyleLoss(object):
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-            F.record_stream(side)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:                       # a captured step owns its buffers: nothing to tell the allocator
+                F.record_stream(side)
             with torch.cuda.stream(side):
                 sg[name] = self._gram_job(name, F, loss)
-            sg[name].record_stream(main)
+            if not capturing:
+                sg[name].record_stream(main)
 
         acts = self.net.forward(x, self.top, on_layer=on_layer)
         main.wait_stream(side)
@@ -239,7 +242,7 @@ class GridStylizer(object):
     of the rotation matrices, the field gradient is all-reduced (sum) and every rank applies the
     identical Adam step."""
 
-    def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None):
+    def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None, graph=None):
         self.loss = loss
         self.d0 = d0.contiguous()
         self.k = float(k)
@@ -248,6 +251,13 @@ class GridStylizer(object):
         self.pg = process_group
         self.adam = TFAdamState()
         self.fuse_adam = os.environ.get("NFS_FUSE_ADAM", "1") != "0"
+        # hipGraph replay of the forward + adjoint (about 130 launches a step; the host needs 1.25 ms to issue
+        # them one by one, which is the whole step at one view per rank)
+        self.use_graph = os.environ.get("NFS_GRAPH", "0") == "1" if graph is None else bool(graph)
+        self._graph = None
+        self._graph_rot = None
+        self._graph_total = None
+        self._graph_warm = 0
         D, H, W = d0.shape
         if target == "v":
             self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
@@ -285,9 +295,33 @@ class GridStylizer(object):
         losses, g_ds = self.field_gradient(rot_local)
         return losses, self.variable_gradient(g_ds)
 
+    def _field_gradient_graphed(self, rot_local):
+        """field_gradient as one hipGraph: the first call runs eagerly (lazy state: packed Winograd filters, side
+        streams, workspaces), the second is captured, later ones replay.  Shapes, the variable, d0 and the style
+        targets are fixed for the life of the capture; the view matrices are copied into a static buffer."""
+        if self._graph is None:
+            if self._graph_warm < 1:
+                self._graph_warm += 1
+                losses, g_ds = self.field_gradient(rot_local)
+                return losses.sum(), g_ds
+            self._graph_rot = rot_local.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                losses, _ = self.field_gradient(self._graph_rot)
+                self._graph_total = losses.sum()
+            self._graph = g
+        elif rot_local.data_ptr() != self._graph_rot.data_ptr():
+            self._graph_rot.copy_(rot_local)
+        self._graph.replay()
+        return self._graph_total, self.g_ds
+
     def step(self, rot_local):
-        losses, g_ds = self.field_gradient(rot_local)
-        total = losses.sum()
+        if self.use_graph:
+            total, g_ds = self._field_gradient_graphed(rot_local)
+        else:
+            losses, g_ds = self.field_gradient(rot_local)
+            total = losses.sum()
         if self.pg is not None:
             # The one exchange step (RCCL over xGMI).  The reduction is placed on the 4*G^3-byte density
             # gradient, not on the 12*G^3-byte velocity gradient: everything below it is linear and

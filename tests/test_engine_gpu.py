@@ -137,3 +137,22 @@ def test_fused_advect_adam_equals_separate_kernels():
     for a, b in zip(out[0][1:], out[1][1:]):
         assert rel(a, b) < 1e-6
 
+
+
+def test_graph_replay_equals_eager_steps():
+    """GridStylizer(graph=True): forward + adjoint replayed as one hipGraph (eager warm-up step, capture, replays)
+    follows the eager trajectory; a different view tensor is copied into the captured buffer."""
+    layers = ["conv1_1", "conv2_1", "conv3_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 3, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    out = []
+    for graph in (False, True):
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3, graph=graph)
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(5)]
+        ls.append(float(gs.step(rot.clone())))                      # not the captured tensor: copied in
+        assert (gs._graph is not None) == graph
+        out.append((ls, gs.var.clone(), gs.adam.m.clone(), gs.adam.v.clone()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert rel(a, b) < 1e-6

@@ -4,8 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
-for V in (1, 2, 8):
+for V, graph in ((1, False), (1, True), (2, True), (8, False), (8, True)):
     gs, rot, data = bench.build_problem(200, V, torch.device("cuda", 0), 0, 1)
+    gs.use_graph = graph
     for _ in range(3):
         gs.step(rot)
     torch.cuda.synchronize()
@@ -15,4 +16,4 @@ for V in (1, 2, 8):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print("views %d: host issue %.3f ms/step, total %.3f ms/step" % (V, 1e3 * (t1 - t0) / 20, 1e3 * (t2 - t0) / 20))
+    print("graph", graph, "views %d: host issue %.3f ms/step, total %.3f ms/step" % (V, 1e3 * (t1 - t0) / 20, 1e3 * (t2 - t0) / 20))
