@@ -206,6 +206,16 @@ int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* 
 int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, int C,
                  const float* scale_dev, float scale, int relu_mask, nfs_stream_t stream);
 
+/* ---- content loss on a layer of the loss network (styler_base.py:135-150) ---------------
+ * F [B,HW,C] is a post-ReLU activation.  loss_acc[b] += image b's share of weight * L, g_acc [B,HW,C] +=
+ * dL/d(pre-activation) = weight * dL/dF * (F > 0), with L (means over the whole batch, as reduce_mean):
+ *   mode 0: -mean(F[...,channel]) + mean|F[...,:channel]| + mean|F[...,channel+1:]|   (0 < channel < C;
+ *           an empty upper slice contributes nothing, where TF's reduce_mean of an empty tensor is NaN)
+ *   mode 1: -mean(F)                                   (content_channel == 0 in the reference)
+ *   mode 2: mean((F - amp * target[b % Bt])^2)         (content image; target [Bt,HW,C], amp = w_content_amp) */
+int nfs_content_loss(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt,
+                     int HW, int C, int channel, int mode, float weight, float amp, nfs_stream_t stream);
+
 /* ---- A12: TV loss (styler_base.py:211-213) --------------------------------------------
  * loss_acc[0] += weight * mean_b(sum|dh| + sum|dw|) on d_img [B,H,W,3]; g_acc (nullable) +=. */
 int nfs_tv_loss(const float* d_img, float* loss_acc, float* g_acc, int B, int H, int W, int C,

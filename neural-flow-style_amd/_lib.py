@@ -62,6 +62,7 @@ SIGNATURES = {
     "nfs_gram_workspace_floats": [_I, _I, _I],
     "nfs_gram_fwd": [_P, _P, _I, _I, _I, _P, _F, _P, _L, _P],
     "nfs_style_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_tv_loss": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "nfs_p2g_fwd": [_P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],

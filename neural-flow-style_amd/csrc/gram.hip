@@ -230,6 +230,47 @@ __global__ void __launch_bounds__(256) style_loss_kernel(const float* __restrict
   if (threadIdx.x == 0) atomicAdd(loss + b, part);
 }
 
+// Content loss on a post-ReLU activation F [B,HW,C] (styler_base.py:135-150); the terms are means over the whole
+// batch, image b contributes its own partial sum to loss[b].  g_acc += dL/d(pre-activation) = dL/dF * (F > 0).
+//   mode 0 (content_channel c != 0): -mean(F[...,c]) + mean|F[...,:c]| + mean|F[...,c+1:]|
+//   mode 1 (no channel):             -mean(F)
+//   mode 2 (content image):          mean((F - amp * target)^2), target [Bt,HW,C] with bt = b % Bt
+__global__ void __launch_bounds__(256) content_loss_kernel(const float* __restrict__ F, const float* __restrict__ target,
+                                                           float* __restrict__ loss, float* __restrict__ g_acc,
+                                                           int B, int Bt, int64_t HWC, int C, int channel, int mode,
+                                                           float weight, float amp) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const float n_all = (float)B * (float)HWC;
+  const float n_pix = n_all / (float)C;
+  const float c_on = -weight / n_pix;                                          // the maximised channel
+  const float c_lo = channel > 0 ? weight / (n_pix * (float)channel) : 0.f;     // channels below / above it
+  const float c_hi = channel + 1 < C ? weight / (n_pix * (float)(C - channel - 1)) : 0.f;
+  float part = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < HWC; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = (int64_t)b * HWC + e;
+    const float f = F[i];
+    float l, g;
+    if (mode == 0) {
+      const int ch = (int)(e % C);
+      const float k = ch == channel ? c_on : (ch < channel ? c_lo : c_hi);
+      l = k * f;                                   // f >= 0 (post-ReLU): |f| = f
+      g = k;
+    } else if (mode == 1) {
+      l = -weight / n_all * f;
+      g = -weight / n_all;
+    } else {
+      const float diff = f - amp * target[(int64_t)(b % Bt) * HWC + e];
+      l = weight / n_all * diff * diff;
+      g = 2.f * weight / n_all * diff;
+    }
+    part += l;
+    if (f > 0.f) g_acc[i] += g;
+  }
+  part = block_sum(part, red);
+  if (threadIdx.x == 0) atomicAdd(loss + b, part);
+}
+
 // winograd.hip: batched f32-MFMA GEMM (LDS-staged, double-buffered) shared with the Winograd convolution
 int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
                   int relu_mask, int cus, hipStream_t s);
@@ -301,6 +342,20 @@ int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* 
   hipLaunchKernelGGL(style_loss_kernel, dim3(nb, B), dim3(256), 0, as_stream(stream), G, Gs, loss_acc, Dmat, B, Bs,
                      CC, weight);
   return check_launch("nfs_style_loss_fwd");
+}
+
+int nfs_content_loss(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt, int HW, int C,
+                     int channel, int mode, float weight, float amp, nfs_stream_t stream) {
+  NFS_REQUIRE(F && loss_acc && g_acc, "nfs_content_loss: null pointer");
+  NFS_REQUIRE(B > 0 && HW > 0 && C > 0, "nfs_content_loss: non-positive dimension");
+  NFS_REQUIRE(mode >= 0 && mode <= 2, "nfs_content_loss: mode must be 0 (channel), 1 (all) or 2 (target)");
+  NFS_REQUIRE(mode != 0 || (channel > 0 && channel < C), "nfs_content_loss: channel out of range");
+  NFS_REQUIRE(mode != 2 || (target && Bt > 0), "nfs_content_loss: mode 2 needs the target features");
+  const int64_t HWC = (int64_t)HW * C;
+  const unsigned nb = blocks_for(HWC, 256) < 64u ? blocks_for(HWC, 256) : 64u;
+  hipLaunchKernelGGL(content_loss_kernel, dim3(nb, B), dim3(256), 0, as_stream(stream), F, target, loss_acc, g_acc, B,
+                     Bt > 0 ? Bt : 1, HWC, C, channel, mode, weight, amp);
+  return check_launch("nfs_content_loss");
 }
 
 int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, int C, const float* scale_dev,

@@ -20,7 +20,8 @@ class RenderStyleLoss(object):
     (+ w_tv * TV).  ``loss_and_grad`` returns the per-view losses and ADDS dL/dd to ``g_d``."""
 
     def __init__(self, net, style_layer, w_style_layer, w_style=1.0, transmit=0.01, render_liquid=False,
-                 resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1):
+                 resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1, w_content=0.0, content_layer=None,
+                 content_channel=0, w_content_amp=100.0):
         self.net = net
         self.layers = list(style_layer)
         self.w_layers = [float(w) for w in w_style_layer]
@@ -43,8 +44,31 @@ class RenderStyleLoss(object):
         self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "1"))
         self._streams = []
         order = [s[0] for s in net.seq]
-        self.top = max(self.layers, key=order.index)
+        # content term on a layer of the same network (styler_base.py:135-150): channel maximisation, -mean, or the
+        # distance to a content image's features (set_content_image)
+        self.w_content = float(w_content) if content_layer else 0.0
+        self.content_layer = content_layer if self.w_content else None
+        self.content_channel = int(content_channel or 0)
+        self.w_content_amp = float(w_content_amp)
+        self.content_feature = None
+        if self.content_layer is not None:
+            kinds = dict((s[0], s[1]) for s in net.seq)
+            if kinds.get(self.content_layer) != "conv":
+                raise KeyError("content_layer %r is not a conv layer of the loss network" % (self.content_layer,))
+        self.top = max(self.layers + ([self.content_layer] if self.content_layer else []), key=order.index)
         self.style_grams = None
+
+    def set_content_image(self, content_img):
+        """content_img: float32 [h,w,3] in 0..255 at the loss-net input size, or None (styler_base.py:232-247)"""
+        if content_img is None or self.content_layer is None:
+            self.content_feature = None
+            return None
+        dev = self.net.device
+        s = torch.as_tensor(np.asarray(content_img, np.float32)).to(dev)
+        mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255], dtype=torch.float32, device=dev)
+        acts = self.net.forward((s - mean).unsqueeze(0).contiguous(), self.content_layer)
+        self.content_feature = acts[self.content_layer].clone()
+        return self.content_feature
 
     # -- style targets (styler_base.py:249-278: the style image enters at d_img) -------------
     def out_hw(self, H, W):
@@ -112,6 +136,7 @@ class RenderStyleLoss(object):
             acts = self.net.forward(x, self.top)
             for name in self.layers:
                 sg[name] = self._gram_job(name, acts[name], loss)
+            self._content_job(acts, sg, loss)
             return self.net.backward(acts, sg, self.top)
         main = torch.cuda.current_stream(x.device)
         if self._side is None:
@@ -135,7 +160,22 @@ class RenderStyleLoss(object):
 
         acts = self.net.forward(x, self.top, on_layer=on_layer)
         main.wait_stream(side)
+        self._content_job(acts, sg, loss)
         return self.net.backward(acts, sg, self.top)
+
+    def _content_job(self, acts, sg, loss):
+        """adds the content term's per-view losses into ``loss`` and its gradient into the layer's entry of ``sg``"""
+        if self.content_layer is None:
+            return
+        F = acts[self.content_layer]
+        V = F.shape[0]
+        # the reference's means run over one loss-net batch (v_batch views); here all V views share the batch
+        w = self.w_content * V / float(min(max(self.v_batch, 1), V))
+        g = sg.get(self.content_layer)
+        if g is None:
+            g = sg[self.content_layer] = torch.zeros_like(F)
+        ops.content_loss(F, w, loss, g, channel=self.content_channel, target=self.content_feature,
+                         amp=self.w_content_amp)
 
     # -- the hot step -----------------------------------------------------------------------
     def _chain(self, d, rot, g_d):

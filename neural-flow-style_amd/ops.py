@@ -334,6 +334,19 @@ def style_loss_fwd(G, Gs, weight, loss_acc, Dmat=None):
     return Dmat
 
 
+def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
+    """content loss of the post-ReLU activation F [B,h,w,C] (styler_base.py:135-150): with ``target`` [Bt,h,w,C]
+    mean((F - amp*target)^2), else channel maximisation (channel != 0) or -mean(F); loss_acc [B] and
+    g_acc [B,h,w,C] (gradient wrt the pre-activation) are accumulated into"""
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    mode = 2 if target is not None else (0 if channel else 1)
+    Bt = target.shape[0] if target is not None else 0
+    _lib.call("nfs_content_loss", _ptr(F), _ptr(target), _ptr(loss_acc), _ptr(g_acc), B, Bt, HW, Cn, int(channel or 0),
+              mode, float(weight), float(amp), _stream())
+    return g_acc
+
+
 def gram_bwd(F, Dmat, scale, scale_dev=None, relu_mask=True, out=None):
     B, Cn = F.shape[0], F.shape[-1]
     HW = F.numel() // (B * Cn)

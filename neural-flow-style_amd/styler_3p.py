@@ -166,6 +166,8 @@ class Styler(StylerBase):
             res = [int(v) for v in oct_size[octave]]
             if self.style_img is not None:
                 self.loss.set_style_image(self._style_feature(self.style_img, res[1:]))
+            if self.content_img is not None:                     # styler_3p.py:277-279
+                self.loss.set_content_image(self._content_feature(self.content_img, res[1:]))
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
 
             for step in range(self.iter):

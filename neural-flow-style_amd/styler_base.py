@@ -4,8 +4,9 @@ Same attribute surface: every ``config`` attribute is copied onto the object
 (styler_base.py:14-15); ``load_img(hw)`` loads / tiles / crops the style image
 (311-346); the loss terms of ``_loss`` that the BASELINE configurations use (style
 152-185, TV 211-213, pressure 228-230) are evaluated by ``engine.RenderStyleLoss`` on
-the HIP kernels.  The Inception-pb network, content / histogram / density-preservation
-losses are out of scope and raise.
+the HIP kernels, and so is the content term (135-150) on a layer of the same VGG network.
+The Inception-pb network and the histogram loss are out of scope (SURVEY.md section 2,
+rows 6 and 18) and raise.
 """
 from __future__ import annotations
 
@@ -39,14 +40,19 @@ class StylerBase(object):
             raise NotImplementedError(
                 "network=%r: only the VGG loss network (vgg_19.ckpt) is on the MI355X hot path; the "
                 "Inception-v1 graph (tensorflow_inception_graph.pb) is out of scope" % self.network)
-        if getattr(self, "w_content", 0) and getattr(self, "content_target", ""):
-            raise NotImplementedError("content loss is Inception-only in the reference (out of scope)")
         if getattr(self, "w_hist", 0):
             raise NotImplementedError("histogram loss is out of scope (SURVEY.md section 2 row 6)")
         if getattr(self, "w_density", 0) and "d" not in getattr(self, "target_field", ""):
             raise NotImplementedError("the density-preservation loss acts on the particle-density variable "
                                       "(target_field 'd'), as in the reference (styler_3p.py:75)")
         self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123))
+        if getattr(self, "w_content", 0):
+            # _layer(content_layer) is a dict lookup on the VGG end points (styler_base.py:91-94): an Inception
+            # layer name (the config default) is a KeyError there too
+            names = [s_[0] for s_ in self.net.seq if s_[1] == "conv"]
+            if self.content_layer not in names:
+                raise KeyError("content_layer %r is not a layer of %s (w_content=%g; pass --w_content 0 for pure "
+                               "style transfer as run.bat does)" % (self.content_layer, self.network, self.w_content))
         self.content_img = None
         self.style_img = None
 
@@ -58,7 +64,22 @@ class StylerBase(object):
         return engine.RenderStyleLoss(
             self.net, self.style_layer, w_layers, self.w_style, transmit=self.transmit,
             render_liquid=self.render_liquid if render_liquid is None else render_liquid,
-            resize_scale=self.resize_scale, rotate=rotate, w_tv=self.w_tv, v_batch=self.v_batch)
+            resize_scale=self.resize_scale, rotate=rotate, w_tv=self.w_tv, v_batch=self.v_batch,
+            w_content=getattr(self, "w_content", 0), content_layer=getattr(self, "content_layer", None),
+            content_channel=getattr(self, "content_channel", 0), w_content_amp=getattr(self, "w_content_amp", 100))
+
+    # -- _content_feature (styler_base.py:232-247): the content image at the loss-net input size -------------------
+    def _content_feature(self, content_target, content_shp):
+        # top_k > 0 keeps the k strongest classes of Inception's softmax2_pre_activation (styler_base.py:240-245);
+        # on any other layer the reference asserts
+        assert getattr(self, "top_k", 0) <= 0 or "softmax2_pre_activation" in self.content_layer, \
+            "top_k > 0 needs content_layer softmax2_pre_activation (pass --top_k 0 with a VGG content layer)"
+        content_target = np.array(content_target, np.float32)
+        if not np.isclose(self.resize_scale, 1):
+            content_shp = [int(s * self.resize_scale) for s in content_shp]
+        if tuple(content_target.shape[:2]) != tuple(int(s) for s in content_shp):
+            content_target = util.resize(content_target, content_shp, order=3)
+        return content_target
 
     # -- _style_feature (styler_base.py:249-278) -----------------------------------------------------
     def _style_feature(self, style_target, style_shp=None):
@@ -78,6 +99,17 @@ class StylerBase(object):
         from PIL import Image
         self.content_img = None
         self.style_img = None
+        content_target = getattr(self, "content_target", "")
+        if getattr(self, "w_content", 0) > 0 and (isinstance(content_target, np.ndarray) or bool(content_target)):
+            img = np.float32(content_target) if isinstance(content_target, np.ndarray) \
+                else np.float32(Image.open(content_target))
+            if img.ndim == 2:
+                img = np.stack([img] * 3, -1)
+            if img.shape[-1] == 4:                           # remove the alpha channel (styler_base.py:317-318)
+                img = img[..., :-1]
+            if hw is not None:
+                img = util.crop_ratio(img, hw[1] / hw[0])
+            self.content_img = img
         has_style = isinstance(self.style_target, np.ndarray) or bool(self.style_target)
         if self.w_style > 0 and has_style:
             if isinstance(self.style_target, np.ndarray):

@@ -431,6 +431,25 @@ def style_loss(feats, style_feats, layers, w_layers, w_style=1.0, batch_size=Non
     return total * w_style, per_layer
 
 
+def content_loss(feature, content_channel=0, content_feature=None, w_content_amp=100.0):
+    """content term of _loss (styler_base.py:135-150), before the w_content factor:
+    with a content image  mean((feature - content_feature*amp)^2)  (139-142);
+    else with content_channel c != 0  -mean(f[...,c]) + mean|f[...,:c]| + mean|f[...,c+1:]|  (144-147)
+    (an empty slice is skipped here; TF's reduce_mean of it is NaN);
+    else  -mean(feature)  (149).  ``feature`` [B,h,w,C] is one layer of the loss network."""
+    if content_feature is not None:
+        return ((feature - content_feature * w_content_amp) ** 2).mean()
+    if content_channel:
+        c = int(content_channel)
+        loss = -feature[..., c].mean()
+        if c > 0:
+            loss = loss + feature[..., :c].abs().mean()
+        if c + 1 < feature.shape[-1]:
+            loss = loss + feature[..., c + 1:].abs().mean()
+        return loss
+    return -feature.mean()
+
+
 # --------------------------------------------------------------------------
 # A12  TV loss                                            styler_base.py:211-213
 # --------------------------------------------------------------------------
@@ -638,6 +657,10 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
         feats = vgg19_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"])
         l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
+        if cfg.get("w_content", 0):
+            # one view per loss-net batch here (v_batch = 1): the content means are per view
+            l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
+                                                    cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
         per_view.append(l)
         total = total + l
     return total, per_view, d_out
@@ -697,8 +720,13 @@ def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
         dr = rotate(d_out, rot[v:v + 1]) if cfg["rotate"] else d_out
         img = render(dr, cfg["transmit"], cfg.get("render_liquid", False))
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
-        feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"]))
+        use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
+        feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] +
+                                                          ([cfg["content_layer"]] if use_content else [])))
         l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"])
+        if use_content:                                           # styler_base.py:135-150, total_loss order: content first
+            l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
+                                                    cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
         if cfg.get("w_tv", 0):
             l = l + tv_loss(d_img) * cfg["w_tv"]
         total = total + l

@@ -100,7 +100,8 @@ def main(config):
     if config.style_layer == ["conv3_1"]:
         config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
         config.w_style_layer = [1, 1, 1, 1, 1]
-    config.w_content = 0
+    if not str(config.content_layer).startswith("conv"):
+        config.w_content = 0          # the default content layer is an Inception-v1 name: style transfer only
     config.octave_n = 1
     config.transmit = 0.01
     config.rotate = True

@@ -156,3 +156,43 @@ def test_graph_replay_equals_eager_steps():
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
     for a, b in zip(out[0][1:], out[1][1:]):
         assert rel(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["channel", "all", "image", "content_only"])
+def test_gradient_parity_with_content_loss(variant):
+    """the content term of _loss (styler_base.py:135-150) on a VGG layer, added to the style loss:
+    channel maximisation, -mean(feature), distance to a content image's features; and alone on a layer above the
+    style layers (the gradient then enters the adjoint chain at the content layer only)."""
+    import neural_flow_style_amd.vgg as vgg
+    G, V = 24, 2
+    layers = ["conv1_1", "conv2_1"]
+    clayer = "conv3_1" if variant == "content_only" else "conv2_1"
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(G, V, layers + (["conv3_1"] if variant == "content_only" else []))
+    net = loss.net
+    w_content = 3.0e4                                   # comparable to the style term for this synthetic network
+    kw = dict(w_content=w_content, content_layer=clayer, content_channel=0 if variant == "all" else 37,
+              w_content_amp=1.5)
+    loss = eng.RenderStyleLoss(net, layers, [1.0] * len(layers), 1.0, transmit=cfg["transmit"], **kw)
+    simg = style_image(G, G, np.random.RandomState(123 + 1))
+    loss.set_style_image(simg)
+    cfg = dict(cfg, style_layer=layers, w_style_layer=[1.0] * len(layers), upto=O.last_layer(layers + [clayer]), **kw)
+    sfe = O.style_target_features(torch.tensor(simg)[None], w_or, layers, upto=cfg["upto"])
+    if variant == "image":
+        cimg = style_image(G, G, np.random.RandomState(7))
+        cf = loss.set_content_image(cimg)
+        cfg["content_feature"] = O.vgg19_features(torch.tensor(cimg)[None], w_or, clayer)[clayer].detach()
+        assert rel(cf, cfg["content_feature"]) < 1e-5
+    d0_o = torch.tensor(d0)[None, ..., None]
+    vel_o = torch.tensor(vel0)[None].requires_grad_()
+    rot_o = torch.tensor(np.asarray(mats, np.float32))
+    total, per_view, _ = O.grid_forward(d0_o, vel_o, rot_o, cfg, w_or, sfe)
+    (g_o,) = torch.autograd.grad(total, vel_o)
+    # the content term must matter in this comparison
+    cfg0 = dict(cfg, w_content=0)
+    total0, _, _ = O.grid_forward(d0_o, vel_o, rot_o, cfg0, w_or, sfe)
+    assert abs(float(total.detach() - total0.detach())) > 1e-2 * abs(float(total0.detach()))
+    gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v")
+    gs.var.copy_(torch.tensor(vel0))
+    losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
+    assert rel(losses, torch.stack(per_view)) < 1e-4
+    assert rel(g_h, g_o[0]) < 1e-3

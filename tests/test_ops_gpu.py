@@ -459,3 +459,24 @@ def test_g2p(ops, nd, C, linear):
     ref = O.g2p(g, p, is_2d=(nd == 2), is_linear=linear)[0]
     out = ops.g2p_fwd(dev(g[0]), dev(p[0]), cubic=not linear)
     assert rel(out, ref) < TOL
+
+
+@pytest.mark.parametrize("mode", ["channel", "last_channel", "all", "target"])
+def test_content_loss(ops, mode):
+    """nfs_content_loss vs autograd of the oracle's restatement of styler_base.py:135-150 on a post-ReLU feature"""
+    torch.manual_seed(17)
+    B, h, w, C = 3, 5, 7, 64
+    pre = torch.randn(B, h, w, C).requires_grad_()
+    f = torch.relu(pre)
+    ch = {"channel": 11, "last_channel": C - 1, "all": 0, "target": 5}[mode]
+    tgt = torch.rand(2, h, w, C) if mode == "target" else None
+    t_full = tgt[torch.arange(B) % 2] if tgt is not None else None
+    wgt, amp = 2.5, 1.7
+    ref = wgt * O.content_loss(f, ch, t_full, amp)
+    (g_ref,) = torch.autograd.grad(ref, pre)
+    loss = torch.zeros(B, device="cuda")
+    g0 = torch.randn(B, h, w, C, device="cuda") * 1e-4  # accumulated into, not overwritten (same scale: no cancellation)
+    g = g0.clone()
+    ops.content_loss(dev(f), wgt, loss, g, channel=ch, target=dev(tgt) if tgt is not None else None, amp=amp)
+    assert abs(float(loss.sum()) - float(ref)) < 1e-5 * max(abs(float(ref)), 1.0)
+    assert rel(g - g0, g_ref) < 2e-5

@@ -176,3 +176,16 @@ def test_mac_to_centered_and_rk4_advect():
     u = torch.zeros(6, 6, 6, 3, dtype=torch.float64) + torch.tensor([0.01, -0.02, 0.03], dtype=torch.float64)
     x = torch.rand(10, 3, dtype=torch.float64) * 0.5 + 0.25
     assert torch.allclose(O.simg2p_advect(x, u), x + 0.5 * u[0, 0, 0])
+
+
+def test_content_loss_known_answers():
+    """styler_base.py:135-150 on a 1x1x2x4 feature, by hand"""
+    f = torch.tensor([[[[1.0, 2.0, 3.0, 4.0], [0.0, 6.0, 1.0, 2.0]]]])
+    # channel 2: -mean([3,1]) + mean|[1,2,0,6]| + mean|[4,2]| = -2 + 2.25 + 3
+    assert abs(float(O.content_loss(f, 2)) - 3.25) < 1e-6
+    # channel falsy: -mean(all) = -19/8
+    assert abs(float(O.content_loss(f, 0)) + 19.0 / 8.0) < 1e-6
+    # content image: mean((f - 2*t)^2) with t = f/2 + 1/2 -> (f - f - 1)^2 = 1
+    assert abs(float(O.content_loss(f, 0, f / 2 + 0.5, 2.0)) - 1.0) < 1e-6
+    # the last channel has no upper slice
+    assert abs(float(O.content_loss(f, 3)) - (-3.0 + 13.0 / 6.0)) < 1e-6

@@ -70,6 +70,42 @@ def test_styler3p_matches_oracle_loop(target, mode, w_density):
     assert len(res["p"]) == F and res["p"][0].shape == (n, 3)
 
 
+def test_styler3p_semantic_transfer_on_a_vgg_layer():
+    """run.bat:14-20 style 'semantic' runs (w_content 1, w_style 0 there; both here) with the content term on a layer
+    of the VGG network: Styler(config).run vs the oracle loop with the same content term"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_3p import Styler
+    G, n, nk, F = 16, 1500, 2, 1
+    rng = np.random.RandomState(9)
+    frames = [_particles(G, n, nk, rng) for _ in range(F)]
+    simg = S.style_image(G, G, rng)
+    layers = ["conv1_1", "conv2_1"]
+    cfg = _config(resolution=[G, G, G], domain=[G, G, G], radius=0.5, nsize=1, support=4, rest_density=1000, k=3,
+                  clip=False, target_field="d", num_frames=F, batch_size=1, frames_per_opt=1, window_sigma=1.0,
+                  interp=1, lr=0.05, iter=3, octave_n=1, octave_scale=1.8,
+                  style_layer=layers, w_style_layer=[1, 1], w_style=1.0, w_content=2e4, content_layer="conv3_1",
+                  content_channel=44, transmit=0.1,
+                  rotate=True, n_views=2, v_batch=1, sample_type="uniform", phi0=0, phi1=0, phi_unit=0,
+                  theta0=-10, theta1=10, theta_unit=20, resize_scale=1.0, views_mode="sequential",
+                  style_target=simg, num_kernels=nk, kernel_scale=2, w_pressure=0, w_density=0)
+    st = Styler(cfg)
+    st.load_img([G, G])
+    params = {"p": [f[0] for f in frames], "r": [f[1] for f in frames]}
+    res = st.run(params)
+    ocfg = dict(vars(cfg))
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    hist, g_opt, d_fin = O.styler3p_run(ocfg, params, w, [simg], st.rot_mat_, views_mode="sequential")
+    hist0, _, _ = O.styler3p_run(dict(ocfg, w_content=0), params, w, [simg], st.rot_mat_, views_mode="sequential")
+    assert abs(hist[0][0] - hist0[0][0]) > 1e-2 * abs(hist0[0][0])       # the content term is not negligible
+    np.testing.assert_allclose(res["l"][0], hist[0], rtol=2e-3)
+    assert rel(res["opt"][0], g_opt[0]) < 2e-3
+    assert rel(res["d"][0], d_fin[0]) < 1e-3
+    # an Inception layer name (the config default) is a KeyError, as the reference's end-point lookup is
+    bad = _config(**dict(vars(cfg), content_layer="mixed4d_3x3_bottleneck_pre_relu"))
+    with pytest.raises(KeyError):
+        Styler(bad)
+
+
 def test_styler2p_colour_runs_and_decreases_loss():
     from neural_flow_style_amd import synthetic as S
     from neural_flow_style_amd.styler_2p import Styler
