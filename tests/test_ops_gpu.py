@@ -480,3 +480,39 @@ def test_content_loss(ops, mode):
     ops.content_loss(dev(f), wgt, loss, g, channel=ch, target=dev(tgt) if tgt is not None else None, amp=amp)
     assert abs(float(loss.sum()) - float(ref)) < 1e-5 * max(abs(float(ref)), 1.0)
     assert rel(g - g0, g_ref) < 2e-5
+
+
+_RR_VARIANT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import neural_flow_style_amd.ops as ops
+import neural_flow_style_amd.transform as T
+rng = np.random.RandomState(3)
+D, H, W = 40, 22, 37
+d = torch.tensor(rng.rand(D, H, W).astype(np.float32), device="cuda")
+mats = [T.rot_y_3d(t) @ T.rot_z_3d(p) for t, p in ((0, 0), (9, -4), (-35, 20), (80, 5))]
+rot = T.rot_to_device(mats, "cuda")
+d_rot = torch.empty(4, D, H, W, device="cuda")
+img, rs = ops.rotate_render_fwd(d, rot, 0.07, False, d_rot=d_rot)
+np.save(sys.argv[1], np.concatenate([img.cpu().numpy().ravel(), rs.cpu().numpy().ravel(), d_rot.cpu().numpy().ravel()]))
+"""
+
+
+def test_rotate_render_march_variants_agree(ops, tmp_path):
+    """the ablation switches of the forward march (read once per process, hence subprocesses): plain reload of all
+    four texel pairs (also the path of volumes beyond the 32-bit buffer offsets), 64 x 1 / 32 x 2 / 8 x 8 wave
+    footprints -- all within f32 rounding of the default (16 x 4 tiles + carry-over)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("default", {}), ("noreuse", {"NFS_RR_NOREUSE": "1"}), ("strip", {"NFS_RR_TILE": "0"}),
+                     ("noreuse_strip", {"NFS_RR_NOREUSE": "1", "NFS_RR_TILE": "0"}), ("t32x2", {"NFS_RR_TILE": "5"}),
+                     ("t8x8", {"NFS_RR_TILE": "3"}), ("noseg", {"NFS_RR_NOSEG": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _RR_VARIANT_SCRIPT % root, f], check=True, env=e, timeout=300)
+        outs[tag] = np.load(f)
+    ref = outs["default"]
+    for tag, o in outs.items():
+        err = np.linalg.norm(o.astype(np.float64) - ref) / np.linalg.norm(ref)
+        assert err < 2e-6, (tag, err)
