@@ -36,10 +36,15 @@ __device__ __forceinline__ float smooth_fetch(const float* __restrict__ in, cons
 template <bool BWD>
 __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ act, float* __restrict__ out,
-                                                              int D, int H, int W, float k, int txe, int ntx, int nty) {
+                                                              int D, int H, int W, float k, int txe, int ntx, int nty, int nz) {
   __shared__ float tile[2][SM_TY + 2][SM_TXMAX + 2];
   const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-  const int bx = blockIdx.x % ntx, by = (blockIdx.x / ntx) % nty, bz = blockIdx.x / (ntx * nty);
+  // consecutive workgroups go round-robin to the 8 XCDs: give each XCD a contiguous range of tiles, so that x / y
+  // neighbours (which share halo lines, and 128-byte lines at 50-column tile edges) meet in one L2
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lb >= (unsigned)(ntx * nty * nz)) return;
+  const int bx = lb % ntx, by = (lb / ntx) % nty, bz = lb / (ntx * nty);
   const int x0 = bx * txe, y0 = by * SM_TY, z0 = bz * SM_ZCHUNK, z1 = min(z0 + SM_ZCHUNK, D);
   const int x = x0 + tx, y = y0 + ty;
   const bool owner = tx < txe && x < W && y < H;
@@ -289,8 +294,8 @@ int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_fwd: non-positive dimension");
   const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;   // balanced column tiles
   const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
-  hipLaunchKernelGGL(smooth3d_kernel<false>, dim3(ntx * nty * nz), dim3(SM_THREADS), 0, as_stream(stream), d,
-                     (const float*)nullptr, out, D, H, W, k, txe, ntx, nty);
+  hipLaunchKernelGGL(smooth3d_kernel<false>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
+                     d, (const float*)nullptr, out, D, H, W, k, txe, ntx, nty, nz);
   return check_launch("nfs_smooth3d_relu_fwd");
 }
 
@@ -300,8 +305,8 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d, int 
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_bwd: non-positive dimension");
   const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;
   const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
-  hipLaunchKernelGGL(smooth3d_kernel<true>, dim3(ntx * nty * nz), dim3(SM_THREADS), 0, as_stream(stream), g_out, out,
-                     g_d, D, H, W, k, txe, ntx, nty);
+  hipLaunchKernelGGL(smooth3d_kernel<true>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
+                     g_out, out, g_d, D, H, W, k, txe, ntx, nty, nz);
   return check_launch("nfs_smooth3d_relu_bwd");
 }
 

@@ -45,12 +45,17 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
   // G is symmetric: only the tile pairs t1 <= t2 are computed
   const int npair = a.ntile * (a.ntile + 1) / 2;
-  int64_t unit = blockIdx.x;
+  // unit order (image, slab, tile pair) with the pair fastest, and a contiguous range of units per XCD (workgroups
+  // are dealt round-robin to the 8 XCDs): the npair blocks that read the same 512-pixel slab of F then run together
+  // behind one L2, and each 64-channel strip comes from HBM once instead of once per pair it takes part in
+  const int64_t per_xcd = gridDim.x / 8;
+  int64_t unit = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const int64_t per_img = (int64_t)a.nslab * npair;
+  if (unit >= per_img * a.B) return;
   const int b = (int)(unit / per_img);
   unit -= (int64_t)b * per_img;
-  const int pair = (int)(unit / a.nslab);
-  const int sl = (int)(unit - (int64_t)pair * a.nslab);
+  const int sl = (int)(unit / npair);
+  const int pair = (int)(unit - (int64_t)sl * npair);
   int t1 = 0, t2 = pair;
   while (t2 >= a.ntile - t1) { t2 -= a.ntile - t1; ++t1; }
   t2 += t1;
@@ -149,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
     }
   __syncthreads();
   if (a.ws) {
-    float* wt = a.ws + (int64_t)blockIdx.x * TS * TS;
+    float* wt = a.ws + (((int64_t)b * npair + pair) * a.nslab + sl) * TS * TS;
 #pragma unroll
     for (int e = 0; e < (TS * R4) / 256; ++e) {
       const int f = t + 256 * e;
@@ -325,7 +330,7 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
   const int64_t units = (int64_t)B * (a.ntile * (a.ntile + 1) / 2) * a.nslab;
   a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
   const size_t lds = 4 * GR_KC * 64 * sizeof(float);            // 32 KB (>= the 64 x 68 epilogue tile)
-  hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)units), dim3(256), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)((units + 7) / 8 * 8)), dim3(256), lds, as_stream(stream), a);
   if (a.ws) {
     const unsigned rb = (unsigned)((int64_t)B * (a.ntile * (a.ntile + 1) / 2) * (64 / GRD_ROWS));
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(rb), dim3(256), 0, as_stream(stream), a);
