@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const flo
                                                                     float* __restrict__ img,
                                                                     float* __restrict__ raysum,
                                                                     float* __restrict__ d_rot, int V, int D, int H,
-                                                                    int W, float tau, int liquid, int lxb) {
+                                                                    int W, float tau, int liquid, int lxb, int band) {
   __shared__ float seg_sum[RR_SEG][64], seg_I[RR_SEG][64];
   const int HW = H * W;
   // a wave is one segment: telling the compiler so keeps the depth index and the plane offsets in scalar registers
@@ -254,10 +254,20 @@ __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const flo
     const int tw = 1 << lxb, th = 64 >> lxb;
     const int ntx = (W + tw - 1) >> lxb, nty = (H + th - 1) / th;
     const unsigned tiles = (unsigned)ntx * nty;
-    const unsigned vv = logical / tiles, t = logical - vv * tiles;
+    unsigned vv, t;
+    if (band) {
+      // all XCDs on the same view at the same time, XCD k on the k-th band of its tiles: every L2 serves a
+      // 1/8 band of the volume instead of the whole of it, and the kept-volume stores form one front
+      const unsigned per_band = (tiles + 7) / 8, s_ = blockIdx.x / 8;
+      vv = s_ / per_band;
+      t = (blockIdx.x % 8) * per_band + (s_ - vv * per_band);
+    } else {
+      vv = logical / tiles;
+      t = logical - vv * tiles;
+    }
     const int ty = t / ntx, tx = t - ty * ntx;
     const int hh = ty * th + (lane >> lxb), ww = tx * tw + (lane & (tw - 1));
-    live = vv < (unsigned)V && hh < H && ww < W;
+    live = vv < (unsigned)V && t < tiles && hh < H && ww < W;
     v = min((int)vv, V - 1);
     h = min(hh, H - 1);
     w = min(ww, W - 1);
@@ -695,16 +705,19 @@ int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* r
   if (W >= 2 && H >= 2 && D >= 4 * RR_SEG && (int64_t)D * H * W < (1ll << 31) && !no_seg) {
     // wave footprint: 16 x 4 pixel tiles when the image has room for them, else 64 consecutive pixels
     const int lxb = tile_env >= 0 ? tile_env : (W >= 16 && H >= 4 ? 4 : 0);
+    static const int band = getenv("NFS_RR_BAND") ? atoi(getenv("NFS_RR_BAND")) : 1;   // 0: one view per XCD
     int64_t waves = blocks_for(n, 64);
-    if (lxb) waves = (int64_t)V * ((W + (1 << lxb) - 1) >> lxb) * ((H + (64 >> lxb) - 1) / (64 >> lxb));
+    const int64_t tiles_v = (int64_t)((W + (1 << lxb) - 1) >> lxb) * ((H + (64 >> lxb) - 1) / (64 >> lxb));
+    if (lxb) waves = (int64_t)V * tiles_v;
+    if (lxb && band) waves = (int64_t)V * ((tiles_v + 7) / 8) * 8;
     const dim3 grid((waves + 7) / 8 * 8);
     const bool fits32 = (int64_t)V * D * H * W < (1ll << 30);      // byte offsets of the buffer addressing
     if (fits32 && !no_reuse)
       hipLaunchKernelGGL(rotate_render_fwd_seg_kernel<true>, grid, dim3(256), 0, as_stream(stream), d, rot, img,
-                         raysum, d_rot, V, D, H, W, tau, liquid, lxb);
+                         raysum, d_rot, V, D, H, W, tau, liquid, lxb, lxb ? band : 0);
     else
       hipLaunchKernelGGL(rotate_render_fwd_seg_kernel<false>, grid, dim3(256), 0, as_stream(stream), d, rot, img,
-                         raysum, d_rot, V, D, H, W, tau, liquid, lxb);
+                         raysum, d_rot, V, D, H, W, tau, liquid, lxb, lxb ? band : 0);
   } else
     hipLaunchKernelGGL(rotate_render_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, rot,
                        img, raysum, d_rot, V, D, H, W, tau, liquid);

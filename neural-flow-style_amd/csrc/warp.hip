@@ -161,7 +161,13 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   // (Four consecutive voxels per lane with float4 accesses put the lanes 48 bytes apart: 24 cache lines per
   // instruction, a third of each used.)
   const int lane = threadIdx.x & 63;
-  const int first = (blockIdx.x * blockDim.x + (threadIdx.x - lane)) * 4 + lane;
+  // contiguous z-slab per XCD (workgroups are dealt round-robin to the 8 XCDs): the gathered density planes of
+  // neighbouring rows then come through one L2 instead of being fetched into all eight
+  // (not for the fused Adam variant: it is dominated by the streamed moments, and eight distant streams measured
+  // slower than one front, 0.128 vs 0.112 ms)
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = MODE == 2 ? blockIdx.x : (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int first = (lb * blockDim.x + (threadIdx.x - lane)) * 4 + lane;
   if (first - lane >= n) return;
   const F3u* v3 = reinterpret_cast<const F3u*>(vel);
   const F3u* m3 = reinterpret_cast<const F3u*>(ad.m);
@@ -592,7 +598,7 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
-    hipLaunchKernelGGL(advect1_kernel<0>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel,
+    hipLaunchKernelGGL(advect1_kernel<0>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
                        (const float*)nullptr, out, D, H, W, AdamFused{});
     return check_launch("nfs_advect_fwd(x4)");
   }
@@ -609,7 +615,7 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* 
   WarpArgs a{d, vel, 1, D, H, W, C, 0};
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && !g_d_acc && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
-    hipLaunchKernelGGL(advect1_kernel<1>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel,
+    hipLaunchKernelGGL(advect1_kernel<1>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
                        g_out, g_vel, D, H, W, AdamFused{});
     return check_launch("nfs_advect_bwd(x4)");
   }
@@ -626,7 +632,7 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
   const int64_t n = (int64_t)D * H * W;
   NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
               "nfs_advect_bwd_adam: needs D, H, W >= 2 and D*H*W %% 4 == 0 (use nfs_advect_bwd + nfs_adam_tf_step)");
-  hipLaunchKernelGGL(advect1_kernel<2>, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps});
   return check_launch("nfs_advect_bwd_adam");
 }

@@ -507,7 +507,7 @@ def test_rotate_render_march_variants_agree(ops, tmp_path):
     outs = {}
     for tag, env in (("default", {}), ("noreuse", {"NFS_RR_NOREUSE": "1"}), ("strip", {"NFS_RR_TILE": "0"}),
                      ("noreuse_strip", {"NFS_RR_NOREUSE": "1", "NFS_RR_TILE": "0"}), ("t32x2", {"NFS_RR_TILE": "5"}),
-                     ("t8x8", {"NFS_RR_TILE": "3"}), ("noseg", {"NFS_RR_NOSEG": "1"})):
+                     ("t8x8", {"NFS_RR_TILE": "3"}), ("noseg", {"NFS_RR_NOSEG": "1"}), ("view_per_xcd", {"NFS_RR_BAND": "0"})):
         f = str(tmp_path / (tag + ".npy"))
         e = dict(os.environ); e.update(env)
         subprocess.run([sys.executable, "-c", _RR_VARIANT_SCRIPT % root, f], check=True, env=e, timeout=300)
