@@ -414,7 +414,8 @@ class ImageStyleLoss(object):
     density mask and the Gram denominator becomes 2*area*C (styler_base.py:165-169)."""
 
     def __init__(self, net, style_layer, w_style_layer, w_style=1.0, w_tv=0.0, resize_scale=1.0,
-                 style_mask=False, style_mask_on_ref=False):
+                 style_mask=False, style_mask_on_ref=False, w_content=0.0, content_layer=None, content_channel=0,
+                 w_content_amp=100.0):
         assert not style_mask_on_ref, "style_mask_on_ref is not used by any reference driver"
         self.net = net
         self.layers = list(style_layer)
@@ -423,10 +424,20 @@ class ImageStyleLoss(object):
         self.resize_scale = float(resize_scale)
         self.style_mask = bool(style_mask)
         order = [s[0] for s in net.seq]
-        self.top = max(self.layers, key=order.index)
+        self.w_content = float(w_content) if content_layer else 0.0
+        self.content_layer = content_layer if self.w_content else None
+        self.content_channel = int(content_channel or 0)
+        self.w_content_amp = float(w_content_amp)
+        self.content_feature = None
+        if self.content_layer is not None and dict((s[0], s[1]) for s in net.seq).get(self.content_layer) != "conv":
+            raise KeyError("content_layer %r is not a conv layer of the loss network" % (self.content_layer,))
+        self.v_batch = 1 << 30                      # the content means run over the whole image batch (one sess.run)
+        self.top = max(self.layers + ([self.content_layer] if self.content_layer else []), key=order.index)
         self.style_grams = None
 
     set_style_image = RenderStyleLoss.set_style_image
+    set_content_image = RenderStyleLoss.set_content_image
+    _content_job = RenderStyleLoss._content_job
     out_hw = RenderStyleLoss.out_hw
 
     def d_img(self, d):
@@ -460,6 +471,7 @@ class ImageStyleLoss(object):
                 G = ops.gram_fwd(F, scale)
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
                 sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        self._content_job(acts, sg, loss)
         g_x = self.net.backward(acts, sg, self.top)
         if self.w_tv > 0:
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)

@@ -29,7 +29,11 @@ class Styler(StylerBase):
             w_layers = w_layers * len(self.style_layer)
         self.loss = engine.ImageStyleLoss(self.net, self.style_layer, w_layers, self.w_style, w_tv=self.w_tv,
                                           resize_scale=self.resize_scale, style_mask=self.style_mask,
-                                          style_mask_on_ref=self.style_mask_on_ref)
+                                          style_mask_on_ref=self.style_mask_on_ref,
+                                          w_content=getattr(self, "w_content", 0),
+                                          content_layer=getattr(self, "content_layer", None),
+                                          content_channel=getattr(self, "content_channel", 0),
+                                          w_content_amp=getattr(self, "w_content_amp", 100))
 
     def _dev(self, a):
         return torch.as_tensor(np.asarray(a, np.float32)).to(self.device).contiguous()
@@ -82,6 +86,8 @@ class Styler(StylerBase):
                 style_o = self._style_feature(self.style_img, res)
                 style_per_octave.append(np.asarray(style_o, np.float32))
                 self.loss.set_style_image(style_o)
+            if self.content_img is not None:                     # styler_2p.py:209-211
+                self.loss.set_content_image(self._content_feature(self.content_img, res))
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames

@@ -785,7 +785,7 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
                 else:
                     l, g = grad_at(var, rot_all)
                     var = opt.step(var, g, cfg["lr"])
-                    h_o.append(float(l))
+                    h_o.append(float(l.detach()))
                     new = torch.nan_to_num(var)
                 upd = new - g_opt[t]
                 if "d" in cfg["target_field"]:
@@ -820,9 +820,14 @@ def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
     """style (optionally masked by d_gray, styler_base.py:165-169) + TV (211-213) of the colour image"""
     d, d_gray, _ = colour_field2d(p, r, var, cfg, res)
     d_img = plugin_to_loss_net(d, cfg.get("resize_scale", 1.0), is_color=True)
-    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"]))
+    use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
+    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] +
+                                                      ([cfg["content_layer"]] if use_content else [])))
     l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"],
                       d_gray=d_gray if cfg.get("style_mask") else None)
+    if use_content:
+        l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
+                                                cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
     if cfg.get("w_tv", 0):
         l = l + tv_loss(d_img) * cfg["w_tv"]
     return l
@@ -860,7 +865,7 @@ def styler2p_run(cfg, params, weights, style_img, c_init):
                 vv = g_opt[t].clone().requires_grad_()
                 l = colour_loss2d(p[t], r[t], vv, cfg, res, weights, sfe)
                 (g,) = torch.autograd.grad(l, vv)
-                h_o.append(float(l))
+                h_o.append(float(l.detach()))
                 new = torch.nan_to_num(opt.step(g_opt[t].clone(), g, lr))
                 g_tmp[t] = new - g_opt[t]
             if cfg["window_sigma"] > 0 and F_ > 1:

@@ -160,6 +160,34 @@ def test_styler2p_matches_oracle_loop():
         assert np.abs(res["d"][t].astype(np.int32) - imgs[t].astype(np.int32)).max() <= 1     # uint8 rounding
 
 
+def test_styler2p_with_content_channel():
+    """the 2-D colour stylizer with the content term (channel maximisation on conv3_1) next to the masked style loss"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_2p import Styler
+    rng = np.random.RandomState(13)
+    ps = [S.dambreak_particles(24, rng)]
+    n = ps[0].shape[0]
+    rs = [rng.uniform(900, 1100, (n, 1)).astype(np.float32)]
+    H = W = 32
+    simg = S.style_image(H, W, rng)
+    layers = ["conv2_1"]
+    cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.05, nsize=2, support=4,
+                  rest_density=1000, clip=False, target_field="c", num_frames=1, batch_size=1, frames_per_opt=200,
+                  window_sigma=1.0, lr=0.01, iter=3, octave_n=1, octave_scale=1.6, style_layer=layers,
+                  w_style_layer=[1.0], w_style=1.0, w_content=1e3, content_layer="conv3_1", content_channel=65,
+                  style_mask=True, w_tv=0.01, style_target=simg, resize_scale=1.0)
+    st = Styler(cfg)
+    st.load_img([H, W])
+    params = {"p": ps, "r": rs}
+    res = st.run(params)
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    hist, c_opt, _ = O.styler2p_run(dict(vars(cfg)), params, w, res["style_per_octave"], res["c_init"])
+    hist0, _, _ = O.styler2p_run(dict(vars(cfg), w_content=0), params, w, res["style_per_octave"], res["c_init"])
+    assert abs(hist[0][0] - hist0[0][0]) > 1e-2 * abs(hist0[0][0])
+    np.testing.assert_allclose(res["l"][0], hist[0], rtol=2e-3)
+    assert rel(res["opt"][0], c_opt[0]) < 1e-3
+
+
 def test_chocolate_like_liquid_position_field():
     """BASELINE config 5 in miniature: SPH particles, position ('p') field, liquid render
     (1 - exp(-tau sum d)), pressure loss -- sum-over-views mode (the shardable one)."""
