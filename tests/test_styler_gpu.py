@@ -70,6 +70,37 @@ def test_styler3p_matches_oracle_loop(target, mode, w_density):
     assert len(res["p"]) == F and res["p"][0].shape == (n, 3)
 
 
+def test_styler3p_cell_ordered_particles_return_in_caller_order():
+    """run() processes the particles in grid-cell order (splat atomics then share cache lines) and must hand every
+    per-particle output back in the caller's order: same results as with sort_particles=False up to the float
+    atomics' summation order, two frames with the temporal filter on"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_3p import Styler
+    G, n, nk, F = 16, 1200, 1, 2
+    rng = np.random.RandomState(21)
+    frames = [_particles(G, n, nk, rng) for _ in range(F)]
+    simg = S.style_image(G, G, rng)
+    out = []
+    for sort in (False, True):
+        cfg = _config(resolution=[G, G, G], domain=[G, G, G], radius=0.5, nsize=1, support=4, rest_density=1000, k=3,
+                      clip=False, target_field="p", num_frames=F, batch_size=1, frames_per_opt=1, window_sigma=1.0,
+                      interp=1, lr=0.002, iter=2, octave_n=1, octave_scale=1.8, style_layer=["conv1_1", "conv2_1"],
+                      w_style_layer=[1, 1], w_style=1.0, w_content=0, transmit=0.1, rotate=True, n_views=2, v_batch=1,
+                      sample_type="uniform", phi0=0, phi1=0, phi_unit=0, theta0=-10, theta1=10, theta_unit=20,
+                      resize_scale=1.0, views_mode="sequential", style_target=simg, num_kernels=nk, kernel_scale=2,
+                      w_pressure=1e3, w_density=0, sort_particles=sort)
+        st = Styler(cfg)
+        st.load_img([G, G])
+        out.append(st.run({"p": [f[0] for f in frames], "r": [f[1] for f in frames]}))
+    a, b = out
+    np.testing.assert_allclose(a["l"][0], b["l"][0], rtol=1e-4)
+    for t in range(F):
+        assert rel(b["opt"][t], a["opt"][t]) < 1e-3
+        assert rel(b["p"][t], a["p"][t]) < 1e-5
+        assert rel(b["v"][t], a["v"][t]) < 1e-3
+        assert rel(b["d"][t], a["d"][t]) < 1e-4
+
+
 def test_styler3p_semantic_transfer_on_a_vgg_layer():
     """run.bat:14-20 style 'semantic' runs (w_content 1, w_style 0 there; both here) with the content term on a layer
     of the VGG network: Styler(config).run vs the oracle loop with the same content term"""
