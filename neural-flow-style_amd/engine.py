@@ -144,8 +144,15 @@ class RenderStyleLoss(object):
         side = self._side
         side.wait_stream(main)                      # ``loss`` / style targets were produced on the main stream
 
+        top_inline = os.environ.get("NFS_GRAM_TOP_INLINE", "1") != "0"
+
         def on_layer(name, F):
             if name not in self.layers:
+                return
+            if name == self.top and top_inline:
+                # nothing follows the top layer on the main stream: its Gram work is the critical path, run it in
+                # place (no event hand-over to the side stream and back)
+                sg[name] = self._gram_job(name, F, loss)
                 return
             ev = torch.cuda.Event()
             ev.record(main)
