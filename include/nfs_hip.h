@@ -158,16 +158,26 @@ int nfs_conv3x3_pack(const float* w_hwio, float* packed, int Ci, int Co, int kin
  * partial sums when a layer gives too few M x N tiles to fill 256 CUs.  Without a workspace (NULL)
  * or with one smaller than nfs_conv3x3_workspace_floats the layer runs direct and unsplit. */
 int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co);
-/* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable */
+/* ReLU bit cache of a layer (optional, Winograd F(4x4) path only).  The forward pass can record the two masks
+ * its data gradient needs -- (x > 0) of its input and, for a pooled layer, (y > 0) of its output -- as one bit
+ * per element (a uint32 word = one 4x4 tile x one channel pair), so that the backward pass never re-reads the
+ * activations for them: pass the same `relu_bits` buffer of nfs_conv3x3_relu_bits_words(...) words to the
+ * layer's fwd / fwd_pool and later to its dgrad / dgrad_pool.  Layout [in: T*Ci/2][out (pooled): T*Co/2],
+ * T = B*ceil(H/4)*ceil(W/4).  The query returns 0 for a layer that does not keep the cache (pass NULL then;
+ * x_in / x_out are still required arguments and are what a NULL cache falls back to). */
+int64_t nfs_conv3x3_relu_bits_words(int B, int H, int W, int Ci, int Co, int pooled);
+/* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable; relu_bits nullable (written) */
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y,
                     int B, int H, int W, int Ci, int Co, int relu,
-                    float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+                    float* workspace, int64_t workspace_floats, uint32_t* relu_bits,
+                    nfs_stream_t stream);
 /* gx = dgrad(gy) * (x_in > 0 if x_in) + (addend if addend); gy [B,H,W,Co] is the gradient
- * wrt the conv's pre-activation, gx [B,H,W,Ci]. */
+ * wrt the conv's pre-activation, gx [B,H,W,Ci]; relu_bits nullable (read instead of x_in). */
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in,
                       const float* addend, float* gx,
                       int B, int H, int W, int Ci, int Co,
-                      float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+                      float* workspace, int64_t workspace_floats, const uint32_t* relu_bits,
+                      nfs_stream_t stream);
 /* Fused forms for a conv that is followed by the 2x2 average pool (conv1_2, conv2_2, conv3_4, conv4_4):
  * fwd_pool also writes y_pool [B,H/2,W/2,Co] = avg_pool2d(y); dgrad_pool takes the gradient at the POOLED
  * resolution gy_pool [B,H/2,W/2,Co] plus the conv's own output x_out [B,H,W,Co] and forms
@@ -176,11 +186,13 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
  * they run the separate kernels (dgrad_pool then needs >= B*H*W*Co workspace floats). */
 int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y,
                          float* y_pool, int B, int H, int W, int Ci, int Co, int relu,
-                         float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+                         float* workspace, int64_t workspace_floats, uint32_t* relu_bits,
+                         nfs_stream_t stream);
 int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad,
                            const float* x_in, const float* addend, float* gx,
                            int B, int H, int W, int Ci, int Co,
-                           float* workspace, int64_t workspace_floats, nfs_stream_t stream);
+                           float* workspace, int64_t workspace_floats, const uint32_t* relu_bits,
+                           nfs_stream_t stream);
 /* slim.avg_pool2d [2,2]: stride 2, VALID (odd sizes floor).  x [B,H,W,C] -> y [B,H/2,W/2,C].
  * bwd: gx = 0.25*gy[h/2,w/2] (0 outside the pooled area) * (x > 0 if x) + (addend if addend) */
 int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream);

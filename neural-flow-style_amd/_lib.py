@@ -53,10 +53,11 @@ SIGNATURES = {
     "nfs_conv3x3_packed_floats": [_I, _I, _I],
     "nfs_conv3x3_pack": [_P, _P, _I, _I, _I, _P],
     "nfs_conv3x3_workspace_floats": [_I, _I, _I, _I, _I],
-    "nfs_conv3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
-    "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
-    "nfs_conv3x3_fwd_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
-    "nfs_conv3x3_dgrad_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
+    "nfs_conv3x3_relu_bits_words": [_I, _I, _I, _I, _I, _I],
+    "nfs_conv3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "nfs_conv3x3_fwd_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "nfs_conv3x3_dgrad_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P],
     "nfs_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "nfs_avgpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_gram_workspace_floats": [_I, _I, _I],
@@ -75,7 +76,8 @@ SIGNATURES = {
     "nfs_axpy": [_P, _P, _F, _L, _P],
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
-            "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64}
+            "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
+            "nfs_conv3x3_relu_bits_words": C.c_int64}
 
 _lib = None
 

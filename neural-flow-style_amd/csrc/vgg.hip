@@ -27,7 +27,7 @@ int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
-                  const float* xmask);
+                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits);
 // layers with >= 64 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops); only the
 // 3-channel conv1_1 stays direct.  NFS_WINOGRAD_MIN_CH raises the threshold (timing comparisons).
 static inline bool winograd_eligible(int K, int N) {
@@ -595,12 +595,13 @@ static bool takes_fused_pool(const ConvArgs& a, const float* ws, int64_t ws_floa
 
 template <int MODE>
 static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s, float* ypool = nullptr,
-                       const float* xmask = nullptr) {
+                       const float* xmask = nullptr, uint32_t* in_bits = nullptr, uint32_t* out_bits = nullptr) {
   ConvArgs a = base;
   if (takes_winograd(a, ws, ws_floats)) {
     const float* U = a.wp + (int64_t)9 * a.Kc * a.Nc;               // Winograd weights follow the direct packing
+    const bool cache = takes_fused_pool(a, ws, ws_floats);           // the bit cache lives in the F(4x4) transforms
     return winograd_conv(a.x, U, a.aux0, a.aux1, a.y, ws, a.B, a.H, a.W, a.Kc, a.Nc, MODE, a.relu, device_cus(), s,
-                         ypool, xmask);
+                         ypool, xmask, cache ? in_bits : nullptr, cache ? out_bits : nullptr);
   }
   NFS_REQUIRE(!ypool && !xmask, "conv3x3: fused pooling needs the Winograd path");
   int tiles_r = 0;
@@ -673,8 +674,25 @@ int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co) {
   return want < ((int64_t)32 << 20) ? want : ((int64_t)32 << 20);
 }
 
+// words of a layer's ReLU bit cache: [in: T*Ci/2][out (pooled layers): T*Co/2], T = B*ceil(H/4)*ceil(W/4); 0 when the
+// layer does not run the F(4x4) Winograd transforms that keep it (the caller then passes NULL and the float masks)
+int64_t nfs_conv3x3_relu_bits_words(int B, int H, int W, int Ci, int Co, int pooled) {
+  if (B <= 0 || H < 2 || W < 2 || Ci <= 0 || Co <= 0 || Ci % 64 || Co % 64) return 0;
+  static const bool off = getenv("NFS_NO_RELU_BITS") != nullptr;    // timing comparisons only
+  ConvArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Ci, Co, 0, 0, 0, 1, 1, 0};
+  float dummy = 0.f;
+  if (off || !takes_fused_pool(a, &dummy, INT64_MAX)) return 0;
+  const int64_t T = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+  return T * (Ci / 2) + (pooled ? T * (Co / 2) : 0);
+}
+
+static inline uint32_t* out_bits_of(uint32_t* relu_bits, int B, int H, int W, int Ci) {
+  return relu_bits ? relu_bits + (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (Ci / 2) : nullptr;
+}
+
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y, int B, int H, int W, int Ci,
-                    int Co, int relu, float* workspace, int64_t workspace_floats, nfs_stream_t stream) {
+                    int Co, int relu, float* workspace, int64_t workspace_floats, uint32_t* relu_bits,
+                    nfs_stream_t stream) {
   NFS_REQUIRE(x && packed_fwd && y, "nfs_conv3x3_fwd: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_fwd: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd: too many pixels");
@@ -694,12 +712,12 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
   }
   NFS_REQUIRE(Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd: Ci must be 3 or a multiple of 32");
   ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1, 0};
-  return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream));
+  return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream), nullptr, nullptr, relu_bits, nullptr);
 }
 
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in, const float* addend, float* gx,
                       int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_floats,
-                      nfs_stream_t stream) {
+                      const uint32_t* relu_bits, nfs_stream_t stream) {
   NFS_REQUIRE(gy && packed_dgrad && gx, "nfs_conv3x3_dgrad: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_dgrad: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad: too many pixels");
@@ -720,20 +738,24 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
   }
   NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
   ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
-  return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream));
+  return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, nullptr,
+                        const_cast<uint32_t*>(relu_bits), nullptr);
 }
 
 // conv + bias + ReLU that also emits the 2x2 VALID average pool of its output (vgg.py: conv*_2/_4 -> pool*).
 int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y, float* y_pool, int B, int H,
                          int W, int Ci, int Co, int relu, float* workspace, int64_t workspace_floats,
-                         nfs_stream_t stream) {
+                         uint32_t* relu_bits, nfs_stream_t stream) {
   NFS_REQUIRE(x && packed_fwd && y && y_pool, "nfs_conv3x3_fwd_pool: null pointer");
   NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_fwd_pool: need H, W >= 2");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd_pool: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd_pool: Ci %% 32, Co %% 64 required");
   ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1, 0};
   if (takes_fused_pool(a, workspace, workspace_floats))
-    return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream), y_pool, nullptr);
+    return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream), y_pool, nullptr, relu_bits,
+                          out_bits_of(relu_bits, B, H, W, Ci));
+  NFS_REQUIRE(!relu_bits, "nfs_conv3x3_fwd_pool: the ReLU bit cache needs the fused Winograd path "
+                          "(nfs_conv3x3_relu_bits_words returned 0 for this layer)");
   if (int e = launch_conv<0>(a, workspace, workspace_floats, as_stream(stream))) return e;
   return nfs_avgpool2_fwd(y, y_pool, B, H, W, Co, stream);
 }
@@ -742,14 +764,17 @@ int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* b
 // g_y = 0.25 * gy_pool[h/2, w/2] * (x_out > 0) (0 outside the pooled area) is formed inside the input transform.
 int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad, const float* x_in,
                            const float* addend, float* gx, int B, int H, int W, int Ci, int Co, float* workspace,
-                           int64_t workspace_floats, nfs_stream_t stream) {
+                           int64_t workspace_floats, const uint32_t* relu_bits, nfs_stream_t stream) {
   NFS_REQUIRE(gy_pool && x_out && packed_dgrad && gx, "nfs_conv3x3_dgrad_pool: null pointer");
   NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_dgrad_pool: need H, W >= 2");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad_pool: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 32 == 0 && Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad_pool: Co %% 32, Ci %% 64 required");
   ConvArgs a{gy_pool, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
-  if (takes_fused_pool(a, workspace, workspace_floats))
-    return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, x_out);
+  if (takes_fused_pool(a, workspace, workspace_floats)) {
+    uint32_t* rb = const_cast<uint32_t*>(relu_bits);
+    return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, x_out, rb,
+                          out_bits_of(rb, B, H, W, Ci));
+  }
   // unfused: full-resolution gradient through the head of the workspace, conv on the rest
   const int64_t n = (int64_t)B * H * W * Co;
   NFS_REQUIRE(workspace && workspace_floats >= n, "nfs_conv3x3_dgrad_pool: workspace of >= B*H*W*Co floats required");

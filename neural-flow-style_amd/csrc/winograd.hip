@@ -171,7 +171,12 @@ __device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
 template <bool POOLED>
 __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                               int B, int H, int W, int K, int TH, int TW,
-                                                              const float* __restrict__ xmask) {
+                                                              const float* __restrict__ xmask,
+                                                              uint32_t* __restrict__ bits) {
+  // ReLU bit cache (word = one 4x4 tile x one channel pair, bit ((row*4 + col)*2 + channel) = value > 0):
+  //   !POOLED: `bits` (nullable) is WRITTEN with the mask of the tile's own 4x4 input pixels -- the forward pass of a
+  //            layer records (x > 0) for its data gradient, which then never reads x again;
+  //   POOLED:  `bits` (nullable) is READ instead of xmask (recorded by the forward output transform of this layer).
   const int K2 = K >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   // 6x6 input patches of neighbouring tiles overlap by two pixels: give each XCD a contiguous range of tiles
@@ -186,6 +191,18 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
   float2 t[6][6];   // t[s][r]: column s after the vertical pass
+  uint32_t word = 0u;
+  uint32_t nb[3][3];      // POOLED with bits: the words of the 3 x 3 tiles the 6 x 6 patch reaches into
+  if (POOLED && bits) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ny = ty + dy - 1, nx = tx + dx - 1;
+        nb[dy][dx] = (ny >= 0 && ny < TH && nx >= 0 && nx < TW)
+                         ? bits[(((int64_t)b * TH + ny) * TW + nx) * K2 + c2] : 0u;
+      }
+  }
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     float2 d[6];
@@ -197,17 +214,32 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
       if (!POOLED) {
         if (yy >= 0 && yy < H && xx >= 0 && xx < W)
           d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+        if (r >= 1 && r <= 4 && s >= 1 && s <= 4)
+          word |= ((d[r].x > 0.f ? 1u : 0u) | (d[r].y > 0.f ? 2u : 0u)) << (((r - 1) * 4 + (s - 1)) * 2);
       } else {
         const int PH = H >> 1, PW = W >> 1;
         if (yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW) {
           const float2 g = *reinterpret_cast<const float2*>(x + (((int64_t)b * PH + (yy >> 1)) * PW + (xx >> 1)) * K + 2 * c2);
-          const float2 m = *reinterpret_cast<const float2*>(xmask + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
-          d[r] = make_float2(m.x > 0.f ? 0.25f * g.x : 0.f, m.y > 0.f ? 0.25f * g.y : 0.f);
+          bool mx, my;
+          if (bits) {
+            // patch row r: tile offset / row inside that tile (row 0 = last row of the tile above, 5 = first below)
+            const int dy = r == 0 ? 0 : (r == 5 ? 2 : 1), ir = r == 0 ? 3 : (r == 5 ? 0 : r - 1);
+            const int dx = s == 0 ? 0 : (s == 5 ? 2 : 1), is = s == 0 ? 3 : (s == 5 ? 0 : s - 1);
+            const uint32_t wv = nb[dy][dx] >> ((ir * 4 + is) * 2);
+            mx = wv & 1u;
+            my = wv & 2u;
+          } else {
+            const float2 m = *reinterpret_cast<const float2*>(xmask + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+            mx = m.x > 0.f;
+            my = m.y > 0.f;
+          }
+          d[r] = make_float2(mx ? 0.25f * g.x : 0.f, my ? 0.25f * g.y : 0.f);
         }
       }
     }
     wg4_bt(d, t[s]);
   }
+  if (!POOLED && bits) bits[gid] = word;
   const int64_t comp_stride = T * K;
   float* vo = V + tile * K + 2 * c2;
 #pragma unroll
@@ -235,7 +267,9 @@ template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
 __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
                                                                int B, int H, int W, int N, int TH, int TW, int relu,
-                                                               float* __restrict__ ypool) {
+                                                               float* __restrict__ ypool, uint32_t* __restrict__ bits) {
+  // ReLU bit cache (layout as in winograd_input4_kernel): MODE 0 WRITES the mask of its own output (read back by the
+  // pooled data gradient of this layer), MODE 1 READS the mask of x_in instead of aux0 (both nullable)
   const int N2 = N >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,6 +290,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
   }
   float2 bias = make_float2(0.f, 0.f);
   if (MODE == 0 && aux0) bias = *reinterpret_cast<const float2*>(aux0 + 2 * c2);
+  uint32_t word = (MODE == 1 && bits) ? bits[gid] : 0u;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int yy = 4 * ty + a;
@@ -272,8 +307,12 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
       if (MODE == 0) {
         v.x += bias.x; v.y += bias.y;
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        word |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u)) << ((a * 4 + c) * 2);
       } else {
-        if (aux0) {
+        if (bits) {
+          const uint32_t wv = word >> ((a * 4 + c) * 2);
+          v.x = (wv & 1u) ? v.x : 0.f; v.y = (wv & 2u) ? v.y : 0.f;
+        } else if (aux0) {
           const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
           v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
         }
@@ -286,6 +325,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
       if (MODE == 0) { pool[a >> 1][c >> 1].x += v.x; pool[a >> 1][c >> 1].y += v.y; }
     }
   }
+  if (MODE == 0 && bits) bits[gid] = word;
   // slim.avg_pool2d [2,2] VALID of the layer output: a 4x4 output tile holds 2x2 complete pooling windows
   if (MODE == 0 && ypool) {
     const int PH = H >> 1, PW = W >> 1;
@@ -659,20 +699,23 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
 // x [B,H,W,K] -> y [B,H,W,N]; U packed by winograd_pack; ws >= winograd_workspace_floats
 // ypool (mode 0, nullable): also write the 2x2 average pool of y.  xmask (mode 1, nullable): x is a POOLED gradient
 // [B,H/2,W/2,K] that reaches the conv through the ReLU of xmask [B,H,W,K] (see winograd_input4_kernel<true>).
+// ReLU bit cache (m == 4 only; see winograd_input4_kernel): mode 0 writes in_bits (mask of x) and out_bits (mask of y),
+// mode 1 reads in_bits instead of aux0 (the x_in mask of the result) and out_bits instead of xmask.  All nullable.
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
-                  const float* xmask) {
+                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits) {
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
   float* M = ws + comps * T * K;
-  if (m == 4 && xmask)
-    hipLaunchKernelGGL(winograd_input4_kernel<true>, dim3((blocks_for(T * (K / 2), 256) + 7) / 8 * 8), dim3(256), 0, s, x, V, B, H, W,
-                       K, TH, TW, xmask);
+  const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
+  if (m == 4 && xmask)     // pooled data gradient: the mask of the layer's own output, from the bit cache if there is one
+    hipLaunchKernelGGL(winograd_input4_kernel<true>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask,
+                       mode == 1 ? out_bits : nullptr);
   else if (m == 4)
-    hipLaunchKernelGGL(winograd_input4_kernel<false>, dim3((blocks_for(T * (K / 2), 256) + 7) / 8 * 8), dim3(256), 0, s, x, V, B, H, W,
-                       K, TH, TW, (const float*)nullptr);
+    hipLaunchKernelGGL(winograd_input4_kernel<false>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
+                       (const float*)nullptr, mode == 0 ? in_bits : nullptr);
   else
     hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
                        TW);
@@ -682,10 +725,10 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
     const unsigned ob = blocks_for(T * (N / 2), 256);
     if (mode == 0)
       hipLaunchKernelGGL(winograd_output4_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                         ypool);
+                         ypool, out_bits);
     else
       hipLaunchKernelGGL(winograd_output4_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                         (float*)nullptr);
+                         (float*)nullptr, aux0 ? in_bits : nullptr);       // a mask only where the caller asks for one
   } else {
     const unsigned ob = blocks_for(T * (N / 4), 256);
     if (mode == 0)

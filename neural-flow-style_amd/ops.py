@@ -248,45 +248,52 @@ def _conv_ws_for(B, H, W, Ci, Co, device, splitk):
     return ws, ws.numel()
 
 
-def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None, splitk=True):
+def conv3x3_relu_bits(B, H, W, Ci, Co, pooled, device):
+    """buffer for a layer's ReLU bit cache (raw 32-bit words, held in a float32 tensor), or None when the layer does
+    not keep one: pass it to the layer's conv3x3_fwd / conv3x3_fwd_pool and later to its conv3x3_dgrad / _pool"""
+    n = _lib.lib().nfs_conv3x3_relu_bits_words(B, H, W, Ci, Co, int(bool(pooled)))
+    return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+
+
+def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None, splitk=True, relu_bits=None):
     B, H, W, Ci = x.shape
     if out is None:
         out = _empty((B, H, W, Co), x)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, x.device, splitk)
     _lib.call("nfs_conv3x3_fwd", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), B, H, W, Ci, Co, int(relu),
-              _ptr(ws), nws, _stream())
+              _ptr(ws), nws, _ptr(relu_bits if splitk else None), _stream())
     return out
 
 
-def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True):
+def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True, relu_bits=None):
     B, H, W, Co = gy.shape
     if out is None:
         out = _empty((B, H, W, Ci), gy)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, gy.device, splitk)
     _lib.call("nfs_conv3x3_dgrad", _ptr(gy), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out), B, H, W, Ci, Co,
-              _ptr(ws), nws, _stream())
+              _ptr(ws), nws, _ptr(relu_bits if (splitk and x_in is not None) else None), _stream())
     return out
 
 
-def conv3x3_fwd_pool(x, packed, bias, Co, relu=True):
+def conv3x3_fwd_pool(x, packed, bias, Co, relu=True, relu_bits=None):
     """conv + bias + ReLU and its 2x2 VALID average pool in one pass -> (y [B,H,W,Co], y_pool [B,H/2,W/2,Co])"""
     B, H, W, Ci = x.shape
     out = _empty((B, H, W, Co), x)
     pooled = _empty((B, H // 2, W // 2, Co), x)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, x.device, True)
     _lib.call("nfs_conv3x3_fwd_pool", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), _ptr(pooled), B, H, W, Ci, Co,
-              int(relu), _ptr(ws), nws, _stream())
+              int(relu), _ptr(ws), nws, _ptr(relu_bits), _stream())
     return out, pooled
 
 
-def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None):
+def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_bits=None):
     """data gradient of a conv followed by ReLU + 2x2 average pool, from the gradient at the POOLED resolution
     gy_pool [B,H/2,W/2,Co] and the conv's own output x_out [B,H,W,Co] -> gx [B,H,W,Ci]"""
     B, H, W, Co = x_out.shape
     out = _empty((B, H, W, Ci), x_out)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, x_out.device, True)
     _lib.call("nfs_conv3x3_dgrad_pool", _ptr(gy_pool), _ptr(x_out), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out),
-              B, H, W, Ci, Co, _ptr(ws), nws, _stream())
+              B, H, W, Ci, Co, _ptr(ws), nws, _ptr(relu_bits), _stream())
     return out
 
 

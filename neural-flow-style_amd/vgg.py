@@ -70,6 +70,14 @@ def load_npz_weights(path, blocks=VGG19_BLOCKS):
     return out
 
 
+class _Activations(OrderedDict):
+    """name -> activation of one forward pass, plus that pass's per-layer ReLU bit caches"""
+
+    def __init__(self):
+        OrderedDict.__init__(self)
+        self.relu_bits = {}
+
+
 class VGG(object):
     """Forward caches the post-ReLU activations (end points, vgg.py:55-66); backward is
     data-gradient only (weights frozen)."""
@@ -100,19 +108,26 @@ class VGG(object):
         """x [B,H,W,3] (mean-subtracted) -> OrderedDict name -> [B,h,w,C] post-ReLU / pooled.
         ``on_layer(name, tensor)`` is called right after a layer has been enqueued (the style loss uses it to
         start that layer's Gram work on a second stream while the next convolutions run)."""
-        acts = OrderedDict()
+        acts = _Activations()
         cur = x
         plan = self.plan(upto)
         pooled = None
+        bits = acts.relu_bits           # name -> the layer's ReLU bit cache (masks for its data gradient), if it keeps one
         for li, (name, kind, cin, cout) in enumerate(plan):
             if kind == "conv":
                 p = self.params[name]
                 nxt_pool = li + 1 < len(plan) and plan[li + 1][1] == "pool"
+                B_, H_, W_ = cur.shape[0], cur.shape[1], cur.shape[2]
+                below_conv = li > 0 and plan[li - 1][1] == "conv"          # the data gradient masks with (x > 0)
                 if nxt_pool and cin % 32 == 0 and cur.shape[1] >= 2 and cur.shape[2] >= 2:
                     # the conv feeds a 2x2 average pool: both outputs from one pass (pool folded into the transform)
-                    cur, pooled = ops.conv3x3_fwd_pool(cur, p["fwd"], p["bias"], cout, relu=True)
+                    rb = ops.conv3x3_relu_bits(B_, H_, W_, cin, cout, True, cur.device) if below_conv else None
+                    cur, pooled = ops.conv3x3_fwd_pool(cur, p["fwd"], p["bias"], cout, relu=True, relu_bits=rb)
                 else:
-                    cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True)
+                    rb = ops.conv3x3_relu_bits(B_, H_, W_, cin, cout, False, cur.device) if below_conv else None
+                    cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True, relu_bits=rb)
+                if rb is not None:
+                    bits[name] = rb
             else:
                 cur = pooled if pooled is not None else ops.avgpool2_fwd(cur)
                 pooled = None
@@ -138,7 +153,7 @@ class VGG(object):
                 bname, bkind = below[0], below[1]
                 assert bkind == "conv"
                 g = ops.conv3x3_dgrad_pool(g, acts[name], p["dgrad"], cin, x_in=acts[bname],
-                                           addend=style_grads.get(bname))
+                                           addend=style_grads.get(bname), relu_bits=getattr(acts, "relu_bits", {}).get(name))
                 continue
             if kind == "conv":
                 p = self.params[name]
@@ -147,7 +162,8 @@ class VGG(object):
                 bname, bkind = below[0], below[1]
                 if bkind == "conv":
                     # below is a post-ReLU conv output: fold its ReLU mask and its style gradient
-                    g = ops.conv3x3_dgrad(g, p["dgrad"], cin, x_in=acts[bname], addend=style_grads.get(bname))
+                    g = ops.conv3x3_dgrad(g, p["dgrad"], cin, x_in=acts[bname], addend=style_grads.get(bname),
+                                          relu_bits=getattr(acts, "relu_bits", {}).get(name))
                 else:
                     g = ops.conv3x3_dgrad(g, p["dgrad"], cin)   # gradient wrt the pooled tensor
             else:

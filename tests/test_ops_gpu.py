@@ -516,3 +516,37 @@ def test_rotate_render_march_variants_agree(ops, tmp_path):
     for tag, o in outs.items():
         err = np.linalg.norm(o.astype(np.float64) - ref) / np.linalg.norm(ref)
         assert err < 2e-6, (tag, err)
+
+
+@pytest.mark.parametrize("shape", [(2, 18, 21, 64, 128), (1, 8, 8, 128, 64), (3, 13, 30, 64, 64)])
+def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
+    """a layer's ReLU bit cache (recorded by its forward transforms) must reproduce, bit for bit, the data gradient
+    computed with the float masks x_in > 0 / x_out > 0 -- plain and pooled forms, ragged tile edges, odd sizes"""
+    B, H, W, Ci, Co = shape
+    torch.manual_seed(41)
+    x = torch.relu(torch.randn(B, H, W, Ci, device="cuda"))               # a post-ReLU activation (zeros included)
+    w = torch.randn(3, 3, Ci, Co) * 0.05
+    b = torch.randn(Co, device="cuda") * 0.1
+    wf, wd = ops.conv3x3_pack(dev(w), 0), ops.conv3x3_pack(dev(w), 1)
+    # plain layer
+    rb = ops.conv3x3_relu_bits(B, H, W, Ci, Co, False, x.device)
+    assert rb is not None
+    y0 = ops.conv3x3_fwd(x, wf, b, Co, True)
+    y1 = ops.conv3x3_fwd(x, wf, b, Co, True, relu_bits=rb)
+    assert torch.equal(y0, y1)
+    gy = torch.randn(B, H, W, Co, device="cuda")
+    add = torch.randn(B, H, W, Ci, device="cuda")
+    g0 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add)
+    g1 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add, relu_bits=rb)
+    assert torch.equal(g0, g1)
+    g2 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=None, addend=add, relu_bits=rb)    # no mask asked for: the cache is ignored
+    assert torch.equal(g2, ops.conv3x3_dgrad(gy, wd, Ci, x_in=None, addend=add))
+    # pooled layer
+    rbp = ops.conv3x3_relu_bits(B, H, W, Ci, Co, True, x.device)
+    yp0, p0 = ops.conv3x3_fwd_pool(x, wf, b, Co, True)
+    yp1, p1 = ops.conv3x3_fwd_pool(x, wf, b, Co, True, relu_bits=rbp)
+    assert torch.equal(yp0, yp1) and torch.equal(p0, p1)
+    gp = torch.randn(B, H // 2, W // 2, Co, device="cuda")
+    q0 = ops.conv3x3_dgrad_pool(gp, yp0, wd, Ci, x_in=x, addend=add)
+    q1 = ops.conv3x3_dgrad_pool(gp, yp1, wd, Ci, x_in=x, addend=add, relu_bits=rbp)
+    assert torch.equal(q0, q1)
