@@ -183,7 +183,9 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
  * resolution gy_pool [B,H/2,W/2,Co] plus the conv's own output x_out [B,H,W,Co] and forms
  * 0.25*gy_pool[h/2,w/2]*(x_out>0) on the fly (x_in / addend as in nfs_conv3x3_dgrad).  On the Winograd path
  * both are folded into the transforms (no separate pool kernels, no full-resolution round trip); otherwise
- * they run the separate kernels (dgrad_pool then needs >= B*H*W*Co workspace floats). */
+ * they run the separate kernels (dgrad_pool then needs >= B*H*W*Co workspace floats).  With a ReLU bit cache on the
+ * fused path the full-resolution tensor is optional on both sides: fwd_pool accepts y = NULL (only the pool and the
+ * cache are written), dgrad_pool accepts x_out = NULL. */
 int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y,
                          float* y_pool, int B, int H, int W, int Ci, int Co, int relu,
                          float* workspace, int64_t workspace_floats, uint32_t* relu_bits,

@@ -27,7 +27,7 @@ int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
-                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits);
+                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad);
 // layers with >= 64 channels on both sides take the Winograd path (F(4x4,3x3): 4x fewer MFMA flops); only the
 // 3-channel conv1_1 stays direct.  NFS_WINOGRAD_MIN_CH raises the threshold (timing comparisons).
 static inline bool winograd_eligible(int K, int N) {
@@ -595,15 +595,16 @@ static bool takes_fused_pool(const ConvArgs& a, const float* ws, int64_t ws_floa
 
 template <int MODE>
 static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipStream_t s, float* ypool = nullptr,
-                       const float* xmask = nullptr, uint32_t* in_bits = nullptr, uint32_t* out_bits = nullptr) {
+                       const float* xmask = nullptr, uint32_t* in_bits = nullptr, uint32_t* out_bits = nullptr,
+                       bool pooled_grad = false) {
   ConvArgs a = base;
   if (takes_winograd(a, ws, ws_floats)) {
     const float* U = a.wp + (int64_t)9 * a.Kc * a.Nc;               // Winograd weights follow the direct packing
     const bool cache = takes_fused_pool(a, ws, ws_floats);           // the bit cache lives in the F(4x4) transforms
     return winograd_conv(a.x, U, a.aux0, a.aux1, a.y, ws, a.B, a.H, a.W, a.Kc, a.Nc, MODE, a.relu, device_cus(), s,
-                         ypool, xmask, cache ? in_bits : nullptr, cache ? out_bits : nullptr);
+                         ypool, xmask, cache ? in_bits : nullptr, cache ? out_bits : nullptr, pooled_grad);
   }
-  NFS_REQUIRE(!ypool && !xmask, "conv3x3: fused pooling needs the Winograd path");
+  NFS_REQUIRE(!ypool && !xmask && !pooled_grad, "conv3x3: fused pooling needs the Winograd path");
   int tiles_r = 0;
   a.TH = 0;
   pick_tile(a.B, a.H, a.W, a.TH, a.TW, tiles_r, a.tiles_c);
@@ -746,16 +747,19 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
 int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* bias, float* y, float* y_pool, int B, int H,
                          int W, int Ci, int Co, int relu, float* workspace, int64_t workspace_floats,
                          uint32_t* relu_bits, nfs_stream_t stream) {
-  NFS_REQUIRE(x && packed_fwd && y && y_pool, "nfs_conv3x3_fwd_pool: null pointer");
+  NFS_REQUIRE(x && packed_fwd && y_pool, "nfs_conv3x3_fwd_pool: null pointer");
   NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_fwd_pool: need H, W >= 2");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_fwd_pool: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % 32 == 0, "nfs_conv3x3_fwd_pool: Ci %% 32, Co %% 64 required");
   ConvArgs a{x, packed_fwd, bias, nullptr, y, nullptr, B, H, W, Ci, Co, 0, 0, 0, relu, 1, 0};
-  if (takes_fused_pool(a, workspace, workspace_floats))
+  if (takes_fused_pool(a, workspace, workspace_floats)) {
+    NFS_REQUIRE(y || relu_bits, "nfs_conv3x3_fwd_pool: without y the ReLU bit cache must be recorded");
     return launch_conv<0>(a, workspace, workspace_floats, as_stream(stream), y_pool, nullptr, relu_bits,
                           out_bits_of(relu_bits, B, H, W, Ci));
+  }
   NFS_REQUIRE(!relu_bits, "nfs_conv3x3_fwd_pool: the ReLU bit cache needs the fused Winograd path "
                           "(nfs_conv3x3_relu_bits_words returned 0 for this layer)");
+  NFS_REQUIRE(y, "nfs_conv3x3_fwd_pool: y may only be NULL on the fused Winograd path with a ReLU bit cache");
   if (int e = launch_conv<0>(a, workspace, workspace_floats, as_stream(stream))) return e;
   return nfs_avgpool2_fwd(y, y_pool, B, H, W, Co, stream);
 }
@@ -765,7 +769,8 @@ int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* b
 int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad, const float* x_in,
                            const float* addend, float* gx, int B, int H, int W, int Ci, int Co, float* workspace,
                            int64_t workspace_floats, const uint32_t* relu_bits, nfs_stream_t stream) {
-  NFS_REQUIRE(gy_pool && x_out && packed_dgrad && gx, "nfs_conv3x3_dgrad_pool: null pointer");
+  NFS_REQUIRE(gy_pool && packed_dgrad && gx, "nfs_conv3x3_dgrad_pool: null pointer");
+  NFS_REQUIRE(x_out || relu_bits, "nfs_conv3x3_dgrad_pool: x_out or the layer's ReLU bit cache is required");
   NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_dgrad_pool: need H, W >= 2");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad_pool: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 32 == 0 && Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad_pool: Co %% 32, Ci %% 64 required");
@@ -773,8 +778,9 @@ int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float
   if (takes_fused_pool(a, workspace, workspace_floats)) {
     uint32_t* rb = const_cast<uint32_t*>(relu_bits);
     return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, x_out, rb,
-                          out_bits_of(rb, B, H, W, Ci));
+                          out_bits_of(rb, B, H, W, Ci), true);
   }
+  NFS_REQUIRE(x_out, "nfs_conv3x3_dgrad_pool: x_out may only be NULL on the fused Winograd path");
   // unfused: full-resolution gradient through the head of the workspace, conv on the rest
   const int64_t n = (int64_t)B * H * W * Co;
   NFS_REQUIRE(workspace && workspace_floats >= n, "nfs_conv3x3_dgrad_pool: workspace of >= B*H*W*Co floats required");

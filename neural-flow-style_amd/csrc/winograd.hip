@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
           v.x += ad.x; v.y += ad.y;
         }
       }
-      *reinterpret_cast<float2*>(y + idx) = v;
+      if (MODE != 0 || y) *reinterpret_cast<float2*>(y + idx) = v;   // MODE 0: y is optional when only the pool is wanted
       if (MODE == 0) { pool[a >> 1][c >> 1].x += v.x; pool[a >> 1][c >> 1].y += v.y; }
     }
   }
@@ -697,20 +697,20 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
 }
 
 // x [B,H,W,K] -> y [B,H,W,N]; U packed by winograd_pack; ws >= winograd_workspace_floats
-// ypool (mode 0, nullable): also write the 2x2 average pool of y.  xmask (mode 1, nullable): x is a POOLED gradient
+// ypool (mode 0, nullable): also write the 2x2 average pool of y (y itself is then optional).  pooled_grad (mode 1): x is a POOLED gradient
 // [B,H/2,W/2,K] that reaches the conv through the ReLU of xmask [B,H,W,K] (see winograd_input4_kernel<true>).
 // ReLU bit cache (m == 4 only; see winograd_input4_kernel): mode 0 writes in_bits (mask of x) and out_bits (mask of y),
 // mode 1 reads in_bits instead of aux0 (the x_in mask of the result) and out_bits instead of xmask.  All nullable.
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
-                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits) {
+                  const float* xmask, uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad) {
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
   float* M = ws + comps * T * K;
   const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
-  if (m == 4 && xmask)     // pooled data gradient: the mask of the layer's own output, from the bit cache if there is one
+  if (m == 4 && pooled_grad)   // pooled data gradient: the mask of the layer's own output, from the bit cache if there is one
     hipLaunchKernelGGL(winograd_input4_kernel<true>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask,
                        mode == 1 ? out_bits : nullptr);
   else if (m == 4)

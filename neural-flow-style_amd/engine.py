@@ -133,7 +133,7 @@ class RenderStyleLoss(object):
         MFMA kernels that fill the launch tails of the conv GEMMs); the backward chain waits for it once."""
         sg = {}
         if not self.gram_side_stream:
-            acts = self.net.forward(x, self.top)
+            acts = self.net.forward(x, self.top, keep=self._keep())
             for name in self.layers:
                 sg[name] = self._gram_job(name, acts[name], loss)
             self._content_job(acts, sg, loss)
@@ -165,10 +165,15 @@ class RenderStyleLoss(object):
             if not capturing:
                 sg[name].record_stream(main)
 
-        acts = self.net.forward(x, self.top, on_layer=on_layer)
+        acts = self.net.forward(x, self.top, on_layer=on_layer, keep=self._keep())
         main.wait_stream(side)
         self._content_job(acts, sg, loss)
         return self.net.backward(acts, sg, self.top)
+
+    def _keep(self):
+        """the activations the loss itself reads: the forward pass need not materialise the full-resolution output
+        of a pooled layer that is not among them"""
+        return set(self.layers) | ({self.content_layer} if self.content_layer else set())
 
     def _content_job(self, acts, sg, loss):
         """adds the content term's per-view losses into ``loss`` and its gradient into the layer's entry of ``sg``"""
@@ -445,6 +450,7 @@ class ImageStyleLoss(object):
     set_style_image = RenderStyleLoss.set_style_image
     set_content_image = RenderStyleLoss.set_content_image
     _content_job = RenderStyleLoss._content_job
+    _keep = RenderStyleLoss._keep
     out_hw = RenderStyleLoss.out_hw
 
     def d_img(self, d):
@@ -458,7 +464,7 @@ class ImageStyleLoss(object):
         B, H, W, _ = d.shape
         H2, W2 = self.out_hw(H, W)
         dimg, x = ops.loss_net_input_fwd(d.contiguous(), H2, W2, want_d_img=self.w_tv > 0)
-        acts = self.net.forward(x, self.top)
+        acts = self.net.forward(x, self.top, keep=self._keep())
         loss = torch.zeros(B, dtype=torch.float32, device=d.device)
         sg = {}
         for name, wl in zip(self.layers, self.w_layers):

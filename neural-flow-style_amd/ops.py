@@ -275,10 +275,11 @@ def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True,
     return out
 
 
-def conv3x3_fwd_pool(x, packed, bias, Co, relu=True, relu_bits=None):
-    """conv + bias + ReLU and its 2x2 VALID average pool in one pass -> (y [B,H,W,Co], y_pool [B,H/2,W/2,Co])"""
+def conv3x3_fwd_pool(x, packed, bias, Co, relu=True, relu_bits=None, want_y=True):
+    """conv + bias + ReLU and its 2x2 VALID average pool in one pass -> (y [B,H,W,Co], y_pool [B,H/2,W/2,Co]);
+    with a ReLU bit cache and want_y=False the full-resolution output is not written at all (y = None)"""
     B, H, W, Ci = x.shape
-    out = _empty((B, H, W, Co), x)
+    out = _empty((B, H, W, Co), x) if (want_y or relu_bits is None) else None
     pooled = _empty((B, H // 2, W // 2, Co), x)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, x.device, True)
     _lib.call("nfs_conv3x3_fwd_pool", _ptr(x), _ptr(packed), _ptr(bias), _ptr(out), _ptr(pooled), B, H, W, Ci, Co,
@@ -286,12 +287,18 @@ def conv3x3_fwd_pool(x, packed, bias, Co, relu=True, relu_bits=None):
     return out, pooled
 
 
-def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_bits=None):
+def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_bits=None, hw=None):
     """data gradient of a conv followed by ReLU + 2x2 average pool, from the gradient at the POOLED resolution
-    gy_pool [B,H/2,W/2,Co] and the conv's own output x_out [B,H,W,Co] -> gx [B,H,W,Ci]"""
-    B, H, W, Co = x_out.shape
-    out = _empty((B, H, W, Ci), x_out)
-    ws, nws = _conv_ws_for(B, H, W, Ci, Co, x_out.device, True)
+    gy_pool [B,H/2,W/2,Co] and the conv's own output x_out [B,H,W,Co] -> gx [B,H,W,Ci]; x_out may be None when the
+    layer's ReLU bit cache is given (``hw`` = its (H, W) then)"""
+    if x_out is not None:
+        B, H, W, Co = x_out.shape
+    else:
+        assert relu_bits is not None and hw is not None
+        B, Co = gy_pool.shape[0], gy_pool.shape[-1]
+        H, W = hw
+    out = _empty((B, H, W, Ci), gy_pool)
+    ws, nws = _conv_ws_for(B, H, W, Ci, Co, gy_pool.device, True)
     _lib.call("nfs_conv3x3_dgrad_pool", _ptr(gy_pool), _ptr(x_out), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out),
               B, H, W, Ci, Co, _ptr(ws), nws, _ptr(relu_bits), _stream())
     return out

@@ -76,6 +76,7 @@ class _Activations(OrderedDict):
     def __init__(self):
         OrderedDict.__init__(self)
         self.relu_bits = {}
+        self.hw = {}                    # (H, W) of pooled layers whose full-resolution output was not materialised
 
 
 class VGG(object):
@@ -104,7 +105,7 @@ class VGG(object):
                 raise KeyError("no weights for %s" % name)
         return plan
 
-    def forward(self, x, upto, on_layer=None):
+    def forward(self, x, upto, on_layer=None, keep=None):
         """x [B,H,W,3] (mean-subtracted) -> OrderedDict name -> [B,h,w,C] post-ReLU / pooled.
         ``on_layer(name, tensor)`` is called right after a layer has been enqueued (the style loss uses it to
         start that layer's Gram work on a second stream while the next convolutions run)."""
@@ -122,7 +123,12 @@ class VGG(object):
                 if nxt_pool and cin % 32 == 0 and cur.shape[1] >= 2 and cur.shape[2] >= 2:
                     # the conv feeds a 2x2 average pool: both outputs from one pass (pool folded into the transform)
                     rb = ops.conv3x3_relu_bits(B_, H_, W_, cin, cout, True, cur.device) if below_conv else None
-                    cur, pooled = ops.conv3x3_fwd_pool(cur, p["fwd"], p["bias"], cout, relu=True, relu_bits=rb)
+                    # nothing but the pool and this layer's own data gradient (served by the bit cache) reads the
+                    # full-resolution output of a pooled layer, unless the caller wants it (``keep``)
+                    want_y = rb is None or keep is None or name in keep
+                    acts.hw[name] = (H_, W_)
+                    cur, pooled = ops.conv3x3_fwd_pool(cur, p["fwd"], p["bias"], cout, relu=True, relu_bits=rb,
+                                                       want_y=want_y)
                 else:
                     rb = ops.conv3x3_relu_bits(B_, H_, W_, cin, cout, False, cur.device) if below_conv else None
                     cur = ops.conv3x3_fwd(cur, p["fwd"], p["bias"], cout, relu=True, relu_bits=rb)
@@ -153,7 +159,8 @@ class VGG(object):
                 bname, bkind = below[0], below[1]
                 assert bkind == "conv"
                 g = ops.conv3x3_dgrad_pool(g, acts[name], p["dgrad"], cin, x_in=acts[bname],
-                                           addend=style_grads.get(bname), relu_bits=getattr(acts, "relu_bits", {}).get(name))
+                                           addend=style_grads.get(bname), relu_bits=getattr(acts, "relu_bits", {}).get(name),
+                                           hw=getattr(acts, "hw", {}).get(name))
                 continue
             if kind == "conv":
                 p = self.params[name]
@@ -168,12 +175,14 @@ class VGG(object):
                     g = ops.conv3x3_dgrad(g, p["dgrad"], cin)   # gradient wrt the pooled tensor
             else:
                 bname = below[0]                                 # the conv feeding this pool
-                xb = acts[bname]
+                xb = acts[bname]                                 # None: a pooled layer whose output was not kept
+                hw = (xb.shape[1], xb.shape[2]) if xb is not None else getattr(acts, "hw", {})[bname]
                 b2 = plan[li - 2] if li > 1 else None
                 if (style_grads.get(bname) is None and b2 is not None and b2[1] == "conv" and below[2] % 64 == 0
-                        and xb.shape[1] >= 2 and xb.shape[2] >= 2):
+                        and hw[0] >= 2 and hw[1] >= 2):
                     pooled_from = bname                          # keep g pooled; fused into the conv below
                 else:
+                    assert xb is not None, "the output of %s is needed here: list it in ``keep``" % bname
                     g = ops.avgpool2_bwd(g, xb.shape, x=xb, addend=style_grads.get(bname))
         raise AssertionError("unreachable")
 

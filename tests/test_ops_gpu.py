@@ -550,3 +550,26 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     q0 = ops.conv3x3_dgrad_pool(gp, yp0, wd, Ci, x_in=x, addend=add)
     q1 = ops.conv3x3_dgrad_pool(gp, yp1, wd, Ci, x_in=x, addend=add, relu_bits=rbp)
     assert torch.equal(q0, q1)
+
+
+def test_pooled_layer_without_full_resolution_output(ops):
+    """with the bit cache a pooled layer need not write its full-resolution output: forward (pool only) and data
+    gradient (x_out = None) agree bit for bit with the materialised form"""
+    B, H, W, Ci, Co = 2, 18, 22, 64, 128
+    torch.manual_seed(43)
+    x = torch.relu(torch.randn(B, H, W, Ci, device="cuda"))
+    w = torch.randn(3, 3, Ci, Co) * 0.05
+    b = torch.randn(Co, device="cuda") * 0.1
+    wf, wd = ops.conv3x3_pack(dev(w), 0), ops.conv3x3_pack(dev(w), 1)
+    rb0 = ops.conv3x3_relu_bits(B, H, W, Ci, Co, True, x.device)
+    rb1 = ops.conv3x3_relu_bits(B, H, W, Ci, Co, True, x.device)
+    y0, p0 = ops.conv3x3_fwd_pool(x, wf, b, Co, True, relu_bits=rb0)
+    y1, p1 = ops.conv3x3_fwd_pool(x, wf, b, Co, True, relu_bits=rb1, want_y=False)
+    assert y1 is None and torch.equal(p0, p1)
+    assert torch.equal(rb0.view(torch.int32), rb1.view(torch.int32))
+    gp = torch.randn(B, H // 2, W // 2, Co, device="cuda")
+    q0 = ops.conv3x3_dgrad_pool(gp, y0, wd, Ci, x_in=x, relu_bits=rb0)
+    q1 = ops.conv3x3_dgrad_pool(gp, None, wd, Ci, x_in=x, relu_bits=rb1, hw=(H, W))
+    assert torch.equal(q0, q1)
+    with pytest.raises(AssertionError):                           # neither the output nor the cache: refused by the binding
+        ops.conv3x3_dgrad_pool(gp, None, wd, Ci, x_in=x, relu_bits=None, hw=(H, W))
