@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
-for V, graph in ((1, False), (1, True), (2, True), (8, False), (8, True)):
+for V, graph in ((1, False), (2, False), (4, False), (8, False), (1, True), (8, True)):
     gs, rot, data = bench.build_problem(200, V, torch.device("cuda", 0), 0, 1)
     gs.use_graph = graph
     for _ in range(3):
