@@ -196,3 +196,38 @@ def test_gradient_parity_with_content_loss(variant):
     losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
     assert rel(losses, torch.stack(per_view)) < 1e-4
     assert rel(g_h, g_o[0]) < 1e-3
+
+
+def test_gradient_parity_non_cubic_grid():
+    """D != H != W (and a non-square image through the loss network): every tile / wave mapping on the path takes its
+    extents from the right axis"""
+    import neural_flow_style_amd.vgg as vgg
+    import neural_flow_style_amd.engine as eng
+    import neural_flow_style_amd.transform as T
+    D, H, W, V = 20, 28, 36, 3
+    layers = ["conv1_1", "conv2_1", "conv3_1"]
+    rng = np.random.RandomState(77)
+    big = blob_density(40, rng)
+    d0 = np.ascontiguousarray(big[4:4 + D, 6:6 + H, 2:2 + W])
+    vel0 = (rng.randn(D, H, W, 3) * 0.3 / 30).astype(np.float32)
+    mats = uniform_views(V)
+    simg = style_image(H, W, rng)
+    w_np = vgg.synthetic_weights(123, upto="conv3_1")
+    w_or = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    net = vgg.VGG(w_np, "cuda")
+    tau = 0.05
+    loss = eng.RenderStyleLoss(net, layers, [1.0] * 3, 1.0, transmit=tau)
+    loss.set_style_image(simg)
+    cfg = dict(k=3, transmit=tau, style_layer=layers, w_style_layer=[1.0] * 3, w_style=1.0, upto="conv3_1")
+    sfe = O.style_target_features(torch.tensor(simg)[None], w_or, layers, upto="conv3_1")
+    d0_o = torch.tensor(d0)[None, ..., None]
+    vel_o = torch.tensor(vel0)[None].requires_grad_()
+    rot_o = torch.tensor(np.asarray(mats, np.float32))
+    total, per_view, d_out = O.grid_forward(d0_o, vel_o, rot_o, cfg, w_or, sfe)
+    (g_o,) = torch.autograd.grad(total, vel_o)
+    gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v")
+    gs.var.copy_(torch.tensor(vel0))
+    losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
+    assert rel(gs.d_s, d_out[0, ..., 0]) < 1e-5
+    assert rel(losses, torch.stack(per_view)) < 1e-4
+    assert rel(g_h, g_o[0]) < 1e-3
