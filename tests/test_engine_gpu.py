@@ -198,13 +198,14 @@ def test_gradient_parity_with_content_loss(variant):
     assert rel(g_h, g_o[0]) < 1e-3
 
 
-def test_gradient_parity_non_cubic_grid():
+@pytest.mark.parametrize("dims", [(20, 28, 36), (18, 25, 27)])
+def test_gradient_parity_non_cubic_grid(dims):
     """D != H != W (and a non-square image through the loss network): every tile / wave mapping on the path takes its
-    extents from the right axis"""
+    extents from the right axis; odd H, W: VALID pools floor, ragged Winograd tiles and bit-cache words at the edges"""
     import neural_flow_style_amd.vgg as vgg
     import neural_flow_style_amd.engine as eng
     import neural_flow_style_amd.transform as T
-    D, H, W, V = 20, 28, 36, 3
+    (D, H, W), V = dims, 3
     layers = ["conv1_1", "conv2_1", "conv3_1"]
     rng = np.random.RandomState(77)
     big = blob_density(40, rng)
