@@ -172,12 +172,14 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
                     float* workspace, int64_t workspace_floats, uint32_t* relu_bits,
                     nfs_stream_t stream);
 /* gx = dgrad(gy) * (x_in > 0 if x_in) + (addend if addend); gy [B,H,W,Co] is the gradient
- * wrt the conv's pre-activation, gx [B,H,W,Ci]; relu_bits nullable (read instead of x_in). */
+ * wrt the conv's pre-activation, gx [B,H,W,Ci]; relu_bits nullable (read instead of x_in).
+ * addend_unmasked != 0 (F(4x4) Winograd path with x_in only): the addend is a gradient wrt the OUTPUT of the
+ * layer below that has not been through that layer's ReLU mask yet: gx = (dgrad(gy) + addend) * (x_in > 0). */
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in,
                       const float* addend, float* gx,
                       int B, int H, int W, int Ci, int Co,
                       float* workspace, int64_t workspace_floats, const uint32_t* relu_bits,
-                      nfs_stream_t stream);
+                      int addend_unmasked, nfs_stream_t stream);
 /* Fused forms for a conv that is followed by the 2x2 average pool (conv1_2, conv2_2, conv3_4, conv4_4):
  * fwd_pool also writes y_pool [B,H/2,W/2,Co] = avg_pool2d(y); dgrad_pool takes the gradient at the POOLED
  * resolution gy_pool [B,H/2,W/2,Co] plus the conv's own output x_out [B,H,W,Co] and forms
@@ -194,7 +196,7 @@ int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float
                            const float* x_in, const float* addend, float* gx,
                            int B, int H, int W, int Ci, int Co,
                            float* workspace, int64_t workspace_floats, const uint32_t* relu_bits,
-                           nfs_stream_t stream);
+                           int addend_unmasked, nfs_stream_t stream);
 /* slim.avg_pool2d [2,2]: stride 2, VALID (odd sizes floor).  x [B,H,W,C] -> y [B,H/2,W/2,C].
  * bwd: gx = 0.25*gy[h/2,w/2] (0 outside the pooled area) * (x > 0 if x) + (addend if addend) */
 int nfs_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, nfs_stream_t stream);

@@ -55,9 +55,9 @@ SIGNATURES = {
     "nfs_conv3x3_workspace_floats": [_I, _I, _I, _I, _I],
     "nfs_conv3x3_relu_bits_words": [_I, _I, _I, _I, _I, _I],
     "nfs_conv3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
-    "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "nfs_conv3x3_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P],
     "nfs_conv3x3_fwd_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P],
-    "nfs_conv3x3_dgrad_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P],
+    "nfs_conv3x3_dgrad_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P],
     "nfs_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "nfs_avgpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_gram_workspace_floats": [_I, _I, _I],

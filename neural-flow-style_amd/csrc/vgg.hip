@@ -718,7 +718,7 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
 
 int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x_in, const float* addend, float* gx,
                       int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_floats,
-                      const uint32_t* relu_bits, nfs_stream_t stream) {
+                      const uint32_t* relu_bits, int addend_unmasked, nfs_stream_t stream) {
   NFS_REQUIRE(gy && packed_dgrad && gx, "nfs_conv3x3_dgrad: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0, "nfs_conv3x3_dgrad: non-positive dimension");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad: too many pixels");
@@ -738,7 +738,9 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
     return check_launch("nfs_conv3x3_dgrad(c3)");
   }
   NFS_REQUIRE(Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad: Ci must be 3 or a multiple of 64");
-  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
+  ConvArgs a{gy, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, addend_unmasked ? 1 : 0, 1, 0};
+  NFS_REQUIRE(!addend_unmasked || (x_in && takes_fused_pool(a, workspace, workspace_floats)),
+              "nfs_conv3x3_dgrad: addend_unmasked needs x_in and the F(4x4) Winograd path");
   return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, nullptr,
                         const_cast<uint32_t*>(relu_bits), nullptr);
 }
@@ -768,13 +770,16 @@ int nfs_conv3x3_fwd_pool(const float* x, const float* packed_fwd, const float* b
 // g_y = 0.25 * gy_pool[h/2, w/2] * (x_out > 0) (0 outside the pooled area) is formed inside the input transform.
 int nfs_conv3x3_dgrad_pool(const float* gy_pool, const float* x_out, const float* packed_dgrad, const float* x_in,
                            const float* addend, float* gx, int B, int H, int W, int Ci, int Co, float* workspace,
-                           int64_t workspace_floats, const uint32_t* relu_bits, nfs_stream_t stream) {
+                           int64_t workspace_floats, const uint32_t* relu_bits, int addend_unmasked,
+                           nfs_stream_t stream) {
   NFS_REQUIRE(gy_pool && packed_dgrad && gx, "nfs_conv3x3_dgrad_pool: null pointer");
   NFS_REQUIRE(x_out || relu_bits, "nfs_conv3x3_dgrad_pool: x_out or the layer's ReLU bit cache is required");
   NFS_REQUIRE(B > 0 && H > 1 && W > 1, "nfs_conv3x3_dgrad_pool: need H, W >= 2");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31) / 4, "nfs_conv3x3_dgrad_pool: too many pixels");
   NFS_REQUIRE(Co > 0 && Co % 32 == 0 && Ci > 0 && Ci % 64 == 0, "nfs_conv3x3_dgrad_pool: Co %% 32, Ci %% 64 required");
-  ConvArgs a{gy_pool, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, 0, 1, 0};
+  ConvArgs a{gy_pool, packed_dgrad, x_in, addend, gx, nullptr, B, H, W, Co, Ci, 0, 0, 0, addend_unmasked ? 1 : 0, 1, 0};
+  NFS_REQUIRE(!addend_unmasked || (x_in && takes_fused_pool(a, workspace, workspace_floats)),
+              "nfs_conv3x3_dgrad_pool: addend_unmasked needs x_in and the F(4x4) Winograd path");
   if (takes_fused_pool(a, workspace, workspace_floats)) {
     uint32_t* rb = const_cast<uint32_t*>(relu_bits);
     return launch_conv<1>(a, workspace, workspace_floats, as_stream(stream), nullptr, x_out, rb,

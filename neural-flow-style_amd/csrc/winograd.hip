@@ -309,6 +309,12 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
         word |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u)) << ((a * 4 + c) * 2);
       } else {
+        // relu != 0 in this mode: the addend has NOT been through the ReLU mask yet (same mask: both are gradients
+        // wrt the output of the layer below), so it is added first and masked with the rest
+        if (relu && aux1) {
+          const float2 ad = *reinterpret_cast<const float2*>(aux1 + idx);
+          v.x += ad.x; v.y += ad.y;
+        }
         if (bits) {
           const uint32_t wv = word >> ((a * 4 + c) * 2);
           v.x = (wv & 1u) ? v.x : 0.f; v.y = (wv & 2u) ? v.y : 0.f;
@@ -316,7 +322,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
           const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
           v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
         }
-        if (aux1) {
+        if (!relu && aux1) {
           const float2 ad = *reinterpret_cast<const float2*>(aux1 + idx);
           v.x += ad.x; v.y += ad.y;
         }

@@ -116,14 +116,20 @@ class RenderStyleLoss(object):
         dimg, _ = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_x=False)
         return dimg
 
-    def _gram_job(self, name, F, loss):
-        """Gram matrix, style loss and the Gram gradient dF (ReLU-masked) of one style layer"""
+    def _gram_job(self, name, F, loss, unmasked=None):
+        """Gram matrix, style loss and the Gram gradient dF of one style layer.  dF carries the layer's ReLU mask unless
+        the data gradient that will add it applies that mask anyway (then the name is recorded in ``unmasked`` and the
+        GEMM epilogue does not read F a second time)."""
         wl = self.w_layers[self.layers.index(name)]
         _, h, w, c = F.shape
         scale = 1.0 / (2.0 * h * w * c)
         G = ops.gram_fwd(F, scale)
         Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
-        return ops.gram_bwd(F, Dm, scale, relu_mask=True)
+        defer = (unmasked is not None and name != self.top and name != self.content_layer
+                 and os.environ.get("NFS_NO_DEFER_MASK") is None and self.net.masks_addend_of(name, F.shape))
+        if defer:
+            unmasked.add(name)
+        return ops.gram_bwd(F, Dm, scale, relu_mask=not defer)
 
     def _vgg_loss_grad(self, x, loss):
         """x [B,h,w,3] (mean-subtracted) -> dL/dx; adds the per-image style losses into ``loss`` [B].
@@ -132,12 +138,13 @@ class RenderStyleLoss(object):
         is enqueued on a side stream as soon as the layer exists and overlaps the following convolutions (short
         MFMA kernels that fill the launch tails of the conv GEMMs); the backward chain waits for it once."""
         sg = {}
+        unmasked = set()                            # style layers whose dF is handed over without its ReLU mask
         if not self.gram_side_stream:
             acts = self.net.forward(x, self.top, keep=self._keep())
             for name in self.layers:
-                sg[name] = self._gram_job(name, acts[name], loss)
+                sg[name] = self._gram_job(name, acts[name], loss, unmasked)
             self._content_job(acts, sg, loss)
-            return self.net.backward(acts, sg, self.top)
+            return self.net.backward(acts, sg, self.top, unmasked=unmasked)
         main = torch.cuda.current_stream(x.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=x.device)
@@ -152,7 +159,7 @@ class RenderStyleLoss(object):
             if name == self.top and top_inline:
                 # nothing follows the top layer on the main stream: its Gram work is the critical path, run it in
                 # place (no event hand-over to the side stream and back)
-                sg[name] = self._gram_job(name, F, loss)
+                sg[name] = self._gram_job(name, F, loss, unmasked)
                 return
             ev = torch.cuda.Event()
             ev.record(main)
@@ -161,14 +168,14 @@ class RenderStyleLoss(object):
             if not capturing:                       # a captured step owns its buffers: nothing to tell the allocator
                 F.record_stream(side)
             with torch.cuda.stream(side):
-                sg[name] = self._gram_job(name, F, loss)
+                sg[name] = self._gram_job(name, F, loss, unmasked)
             if not capturing:
                 sg[name].record_stream(main)
 
         acts = self.net.forward(x, self.top, on_layer=on_layer, keep=self._keep())
         main.wait_stream(side)
         self._content_job(acts, sg, loss)
-        return self.net.backward(acts, sg, self.top)
+        return self.net.backward(acts, sg, self.top, unmasked=unmasked)
 
     def _keep(self):
         """the activations the loss itself reads: the forward pass need not materialise the full-resolution output

@@ -248,6 +248,10 @@ def _conv_ws_for(B, H, W, Ci, Co, device, splitk):
     return ws, ws.numel()
 
 
+def conv3x3_relu_bits_words(B, H, W, Ci, Co, pooled):
+    return int(_lib.lib().nfs_conv3x3_relu_bits_words(B, H, W, Ci, Co, int(bool(pooled))))
+
+
 def conv3x3_relu_bits(B, H, W, Ci, Co, pooled, device):
     """buffer for a layer's ReLU bit cache (raw 32-bit words, held in a float32 tensor), or None when the layer does
     not keep one: pass it to the layer's conv3x3_fwd / conv3x3_fwd_pool and later to its conv3x3_dgrad / _pool"""
@@ -265,13 +269,15 @@ def conv3x3_fwd(x, packed, bias, Co, relu=True, out=None, splitk=True, relu_bits
     return out
 
 
-def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True, relu_bits=None):
+def conv3x3_dgrad(gy, packed, Ci, x_in=None, addend=None, out=None, splitk=True, relu_bits=None,
+                  addend_unmasked=False):
     B, H, W, Co = gy.shape
     if out is None:
         out = _empty((B, H, W, Ci), gy)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, gy.device, splitk)
     _lib.call("nfs_conv3x3_dgrad", _ptr(gy), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out), B, H, W, Ci, Co,
-              _ptr(ws), nws, _ptr(relu_bits if (splitk and x_in is not None) else None), _stream())
+              _ptr(ws), nws, _ptr(relu_bits if (splitk and x_in is not None) else None), int(bool(addend_unmasked)),
+              _stream())
     return out
 
 
@@ -287,7 +293,8 @@ def conv3x3_fwd_pool(x, packed, bias, Co, relu=True, relu_bits=None, want_y=True
     return out, pooled
 
 
-def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_bits=None, hw=None):
+def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_bits=None, hw=None,
+                       addend_unmasked=False):
     """data gradient of a conv followed by ReLU + 2x2 average pool, from the gradient at the POOLED resolution
     gy_pool [B,H/2,W/2,Co] and the conv's own output x_out [B,H,W,Co] -> gx [B,H,W,Ci]; x_out may be None when the
     layer's ReLU bit cache is given (``hw`` = its (H, W) then)"""
@@ -300,7 +307,7 @@ def conv3x3_dgrad_pool(gy_pool, x_out, packed, Ci, x_in=None, addend=None, relu_
     out = _empty((B, H, W, Ci), gy_pool)
     ws, nws = _conv_ws_for(B, H, W, Ci, Co, gy_pool.device, True)
     _lib.call("nfs_conv3x3_dgrad_pool", _ptr(gy_pool), _ptr(x_out), _ptr(packed), _ptr(x_in), _ptr(addend), _ptr(out),
-              B, H, W, Ci, Co, _ptr(ws), nws, _ptr(relu_bits), _stream())
+              B, H, W, Ci, Co, _ptr(ws), nws, _ptr(relu_bits), int(bool(addend_unmasked)), _stream())
     return out
 
 

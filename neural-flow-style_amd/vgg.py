@@ -142,9 +142,24 @@ class VGG(object):
                 on_layer(name, cur)
         return acts
 
-    def backward(self, acts, style_grads, upto):
+    def masks_addend_of(self, name, acts_shape):
+        """True when the gradient injected at conv layer ``name`` (a style / content gradient) may be handed over
+        WITHOUT its ReLU mask: the data gradient of the conv above adds it before applying that same mask (Winograd
+        F(4x4) path with the ReLU bit cache).  ``acts_shape`` = [B,h,w,C] of the layer's activation."""
+        names = [s_[0] for s_ in self.seq]
+        i = names.index(name)
+        if i + 1 >= len(self.seq) or self.seq[i + 1][1] != "conv":
+            return False
+        _, _, cin, cout = self.seq[i + 1]
+        B, h, w, _ = acts_shape
+        nxt_pool = i + 2 < len(self.seq) and self.seq[i + 2][1] == "pool"
+        return ops.conv3x3_relu_bits_words(B, h, w, cin, cout, nxt_pool) > 0
+
+    def backward(self, acts, style_grads, upto, unmasked=()):
         """style_grads: name -> dL/d(pre-activation contribution) already masked by (act > 0)
-        (ops.gram_bwd(relu_mask=True)).  Returns dL/dx [B,H,W,3]."""
+        (ops.gram_bwd(relu_mask=True)), except the names in ``unmasked`` (see masks_addend_of), whose mask is applied
+        by the data gradient that adds them.  Returns dL/dx [B,H,W,3]."""
+        assert upto not in unmasked, "the top layer's gradient enters the chain directly: it must be masked"
         plan = self.plan(upto)
         g = style_grads[upto]           # gradient wrt the pre-activation of the top conv
         pooled_from = None              # set when g is still at the pooled resolution below conv `pooled_from`
@@ -160,7 +175,8 @@ class VGG(object):
                 assert bkind == "conv"
                 g = ops.conv3x3_dgrad_pool(g, acts[name], p["dgrad"], cin, x_in=acts[bname],
                                            addend=style_grads.get(bname), relu_bits=getattr(acts, "relu_bits", {}).get(name),
-                                           hw=getattr(acts, "hw", {}).get(name))
+                                           hw=getattr(acts, "hw", {}).get(name),
+                                           addend_unmasked=bname in unmasked and bname in style_grads)
                 continue
             if kind == "conv":
                 p = self.params[name]
@@ -170,7 +186,8 @@ class VGG(object):
                 if bkind == "conv":
                     # below is a post-ReLU conv output: fold its ReLU mask and its style gradient
                     g = ops.conv3x3_dgrad(g, p["dgrad"], cin, x_in=acts[bname], addend=style_grads.get(bname),
-                                          relu_bits=getattr(acts, "relu_bits", {}).get(name))
+                                          relu_bits=getattr(acts, "relu_bits", {}).get(name),
+                                          addend_unmasked=bname in unmasked and bname in style_grads)
                 else:
                     g = ops.conv3x3_dgrad(g, p["dgrad"], cin)   # gradient wrt the pooled tensor
             else:

@@ -539,6 +539,10 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     g0 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add)
     g1 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add, relu_bits=rb)
     assert torch.equal(g0, g1)
+    # an addend that has not been through the mask yet: (dgrad + addend) * mask == dgrad * mask + addend * mask
+    g3 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add, relu_bits=rb, addend_unmasked=True)
+    g3_ref = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=(add * (x > 0)).contiguous(), relu_bits=rb)
+    assert torch.equal(g3, g3_ref)
     g2 = ops.conv3x3_dgrad(gy, wd, Ci, x_in=None, addend=add, relu_bits=rb)    # no mask asked for: the cache is ignored
     assert torch.equal(g2, ops.conv3x3_dgrad(gy, wd, Ci, x_in=None, addend=add))
     # pooled layer
@@ -550,6 +554,9 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     q0 = ops.conv3x3_dgrad_pool(gp, yp0, wd, Ci, x_in=x, addend=add)
     q1 = ops.conv3x3_dgrad_pool(gp, yp1, wd, Ci, x_in=x, addend=add, relu_bits=rbp)
     assert torch.equal(q0, q1)
+    q3 = ops.conv3x3_dgrad_pool(gp, yp1, wd, Ci, x_in=x, addend=add, relu_bits=rbp, addend_unmasked=True)
+    q3_ref = ops.conv3x3_dgrad_pool(gp, yp1, wd, Ci, x_in=x, addend=(add * (x > 0)).contiguous(), relu_bits=rbp)
+    assert torch.equal(q3, q3_ref)
 
 
 def test_pooled_layer_without_full_resolution_output(ops):
