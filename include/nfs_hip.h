@@ -64,12 +64,14 @@ int nfs_warp3d_bwd(const float* imgs, const float* coords, const float* g_out,
  * output-stationary (a block owns a tile of g_d, accumulates in 64-bit fixed point in LDS, no
  * global atomics, bit-reproducible); otherwise it scatters with global float atomics.
  * `g_max` (device, nullable): max |g_out| as produced by nfs_render_bwd(gmax_out) -- the fixed-point scale
- * is derived from it; when NULL a streaming pre-pass over g_out computes it into the workspace. */
+ * is derived from it; when NULL a streaming pre-pass over g_out computes it into the workspace.
+ * `overwrite` != 0 (tiled adjoint only): g_d = sum over the views instead of +=; the tiles partition the volume, so
+ * the caller needs no zero fill and the kernel no read of g_d. */
 int nfs_rotate_fwd(const float* d, const float* rot, float* out,
                    int V, int D, int H, int W, int C, nfs_stream_t stream);
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc,
                    int V, int D, int H, int W, int C, float* workspace, const float* g_max,
-                   nfs_stream_t stream);
+                   int overwrite, nfs_stream_t stream);
 
 /* ---- A11: advect, order 1 (transform.py:557-569) ------------------------------------
  * d [D,H,W,C], vel [D,H,W,3] normalised units (component k moves along array axis k),

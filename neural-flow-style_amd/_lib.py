@@ -36,7 +36,7 @@ SIGNATURES = {
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "nfs_rotate_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "nfs_rotate_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "nfs_advect_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect_bwd_adam": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],

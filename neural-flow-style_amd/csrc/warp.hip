@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
                                                                          float* __restrict__ g_d,
                                                                          const unsigned* __restrict__ gmax_bits,
                                                                          float bound_factor, int V, int D, int H,
-                                                                         int W, int tiles_y, int tiles_x) {
+                                                                         int W, int tiles_y, int tiles_x, int overwrite) {
   __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
   __shared__ ViewRows vrows[RT_VMAX];
   const int t = threadIdx.x;
@@ -408,7 +408,15 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
   // fixed-point scale 2^k: |any voxel sum| <= bound_factor * max|g_out| must stay below 2^62
   const float gmax = __uint_as_float(*gmax_bits);
-  if (!(gmax > 0.f)) return;                      // all-zero gradient: nothing to add
+  if (!(gmax > 0.f)) {                            // all-zero gradient: nothing to add
+    if (overwrite)
+      for (int i = t; i < RT_TZ * RT_TY * RT_TX; i += RT_THREADS) {
+        const int lx_ = i % RT_TX, ly_ = (i / RT_TX) % RT_TY, lz_ = i / (RT_TX * RT_TY);
+        const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
+        if (z < D && y < H && x < W) g_d[((int64_t)z * H + y) * W + x] = 0.f;
+      }
+    return;
+  }
   int ebound;
   frexpf(gmax * bound_factor, &ebound);           // gmax*bound_factor < 2^ebound
   const int kexp = 62 - ebound;
@@ -507,7 +515,9 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
     const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
     if (z < D && y < H && x < W) {
       const long long q = (long long)acc[((lz_ + 1) * RT_LY + ly_ + 1) * RT_LX + lx_ + 1];
-      if (q != 0) g_d[((int64_t)z * H + y) * W + x] += (float)ldexp((double)q, -kexp);
+      // the tiles partition the volume: with `overwrite` every voxel is written exactly once (no zero fill before)
+      if (overwrite) g_d[((int64_t)z * H + y) * W + x] = q != 0 ? (float)ldexp((double)q, -kexp) : 0.f;
+      else if (q != 0) g_d[((int64_t)z * H + y) * W + x] += (float)ldexp((double)q, -kexp);
     }
   }
 }
@@ -557,7 +567,7 @@ int nfs_rotate_fwd(const float* d, const float* rot, float* out, int V, int D, i
 }
 
 int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, int D, int H, int W, int C,
-                   float* workspace, const float* g_max, nfs_stream_t stream) {
+                   float* workspace, const float* g_max, int overwrite, nfs_stream_t stream) {
   NFS_REQUIRE(g_out && rot && g_d_acc, "nfs_rotate_bwd: null pointer");
   if (int e = check_dims(V, D, H, W, C)) return e;
   if (C == 1 && workspace) {
@@ -581,10 +591,11 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
       const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
       hipLaunchKernelGGL(rotate_bwd_tiled_kernel, dim3(tz * ty * tx), dim3(RT_THREADS), 0, as_stream(stream),
                          g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
-                         ty, tx);
+                         ty, tx, (overwrite && v0 == 0) ? 1 : 0);
     }
     return check_launch("nfs_rotate_bwd(tiled)");
   }
+  NFS_REQUIRE(!overwrite, "nfs_rotate_bwd: overwrite needs the tiled adjoint (C == 1 and a workspace)");
   WarpArgs a{nullptr, rot, V, D, H, W, C, 0};
   const int64_t n = (int64_t)V * D * H * W;
   hipLaunchKernelGGL(warp_bwd_kernel<COORD_ROTATE>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a,

@@ -197,9 +197,9 @@ class RenderStyleLoss(object):
                          amp=self.w_content_amp)
 
     # -- the hot step -----------------------------------------------------------------------
-    def _chain(self, d, rot, g_d):
+    def _chain(self, d, rot, g_d, overwrite=False):
         """render -> loss net -> Gram losses -> full adjoint for the views ``rot`` on the CURRENT stream;
-        g_d [D,H,W] += dL/dd; returns the per-view losses"""
+        g_d [D,H,W] += dL/dd (= with ``overwrite``, two-pass rotate adjoint only); returns the per-view losses"""
         D, H, W = d.shape
         img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint)
         d_rot = self.d_rot
@@ -219,14 +219,20 @@ class RenderStyleLoss(object):
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
             g_rot, g_max = ops.render_bwd(d_rot, rs, g_img, self.tau, self.liquid, g_d=d_rot, want_max=True)
-            ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1), g_max=g_max)
+            ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1), g_max=g_max, overwrite=overwrite)
         elif self.rotate:
             ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
         else:
             g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.liquid)[0])
         return loss
 
-    def loss_and_grad(self, d, rot, g_d):
+    def writes_gradient(self, V):
+        """True when loss_and_grad(..., overwrite=True) can write g_d without a zero fill: one view batch through the
+        tiled rotate adjoint, whose tiles partition the volume"""
+        ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
+        return bool(self.rotate and self.two_pass_adjoint and min(ngroups, V) <= 1)
+
+    def loss_and_grad(self, d, rot, g_d, overwrite=False):
         """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
         Returns loss per view [V] (device tensor).
 
@@ -238,7 +244,8 @@ class RenderStyleLoss(object):
         ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
         ngroups = min(ngroups, V)
         if ngroups <= 1:
-            return self._chain(d, rot, g_d)
+            return self._chain(d, rot, g_d, overwrite=overwrite and self.writes_gradient(V))
+        assert not overwrite, "overwrite needs a single view batch (see writes_gradient)"
         nst = min(self.vgg_streams, ngroups)
         main = torch.cuda.current_stream(d.device)
         if len(self._streams) < nst:
@@ -335,8 +342,11 @@ class GridStylizer(object):
     def field_gradient(self, rot_local):
         """forward + adjoint down to the smoothed density: (loss_per_view, dL/d d_s of the LOCAL views)"""
         d_s = self.forward_field()
-        self.g_ds.zero_()
-        losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds)
+        V = rot_local.shape[0]
+        fresh = hasattr(self.loss, "writes_gradient") and self.loss.writes_gradient(V)
+        if not fresh:
+            self.g_ds.zero_()
+        losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds, **({"overwrite": True} if fresh else {}))
         return losses, self.g_ds
 
     def variable_gradient(self, g_ds):

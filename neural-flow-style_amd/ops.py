@@ -74,14 +74,16 @@ def workspace(device):
     return _workspaces[key]
 
 
-def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True, g_max=None):
-    """g_max: optional device scalar max|g_out| (render_bwd(..., want_max=True)): skips the pre-pass"""
+def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True, g_max=None, overwrite=False):
+    """g_max: optional device scalar max|g_out| (render_bwd(..., want_max=True)): skips the pre-pass.
+    overwrite (tiled adjoint, C == 1): g_d_acc is written, not accumulated into (no zero fill needed)"""
     V, D, H, W, Cn = g_out.shape
-    if g_d_acc is None:
-        g_d_acc = _zeros((D, H, W, Cn), g_out)
     ws = workspace(g_out.device) if (tiled and Cn == 1) else None
+    if g_d_acc is None:
+        overwrite = ws is not None                 # a fresh buffer: let the kernel write every voxel
+        g_d_acc = _empty((D, H, W, Cn), g_out) if overwrite else _zeros((D, H, W, Cn), g_out)
     _lib.call("nfs_rotate_bwd", _ptr(g_out), _ptr(rot), _ptr(g_d_acc), V, D, H, W, Cn, _ptr(ws), _ptr(g_max),
-              _stream())
+              int(bool(overwrite)), _stream())
     return g_d_acc
 
 
