@@ -1,0 +1,47 @@
+"""BASELINE configs[0] in wall-clock terms: dambreak2d 128 x 128, single frame, one style layer (conv3_1), 50 Adam
+iterations of the 2-D colour stylizer (Styler(config).run) on the GPU, next to the CPU oracle's loop for the same
+inputs (PyTorch-CPU restatement; pass --cpu for a bounded 5-iteration sample of it)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from neural_flow_style_amd import synthetic as S
+from neural_flow_style_amd.config import get_config
+from neural_flow_style_amd.styler_2p import Styler
+
+rng = np.random.RandomState(7)
+p = S.dambreak_particles(80, rng)
+n = p.shape[0]
+r = rng.uniform(900, 1100, (n, 1)).astype(np.float32)
+H = W = 128
+simg = S.style_image(H, W, rng)
+cfg, _ = get_config([])
+for k, v in dict(network="vgg_19.ckpt", data_dir="/nonexistent", resolution=[H, W], domain=[3.2, 3.2], radius=0.0125,
+                 nsize=2, support=4, rest_density=1000, clip=False, target_field="c", num_frames=1, batch_size=1,
+                 frames_per_opt=200, window_sigma=3, lr=0.01, iter=50, octave_n=1, octave_scale=1.7,
+                 style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0, w_content=0, style_mask=True, w_tv=0.01,
+                 style_target=simg, resize_scale=1.0).items():
+    setattr(cfg, k, v)
+cfg.rng = np.random.RandomState(cfg.seed)
+st = Styler(cfg)
+st.load_img([H, W])
+params = {"p": [p], "r": [r]}
+st.run(params)                                    # warm-up (weight packing, workspaces)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = st.run(params)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("GPU: %d particles, %dx%d, %d iterations: %.3f s  (%.2f ms / iteration), loss %.4g -> %.4g"
+      % (n, H, W, cfg.iter, dt, 1e3 * dt / cfg.iter, res["l"][0][0], res["l"][0][-1]))
+if "--cpu" in sys.argv:
+    # bounded sample: 5 iterations on at most 32 threads (more threads make the small CPU tensors slower, not faster)
+    from oracle import nfs_oracle as O
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    nthr = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(nthr)
+    ocfg = dict(vars(cfg), iter=5)
+    t0 = time.perf_counter()
+    hist, _, _ = O.styler2p_run(ocfg, params, w, res["style_per_octave"], res["c_init"])
+    dtc = (time.perf_counter() - t0) / 5
+    print("CPU oracle (%d threads): %.1f ms / iteration (5 iterations), loss %.4g -> %.4g; GPU/CPU = %.0fx"
+          % (nthr, 1e3 * dtc, hist[0][0], hist[0][-1], dtc / (dt / cfg.iter)))
