@@ -309,6 +309,7 @@ def main():
     # ---- per-kernel live measurement (extra profiled steps, after the headline timing) -----------
     if not args.no_kernel_profile:
         psteps = max(2, min(args.steps, 5))
+        gs.use_graph = False          # the per-call timers hook the C-ABI calls: a graph replay would bypass them
         # clean per-kernel timings need a single stream (with two concurrent view groups the event pairs of one
         # stream also count the other stream's kernels sharing the chip); the headline above uses the default
         gs.loss.vgg_streams = 1

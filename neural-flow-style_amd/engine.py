@@ -319,7 +319,11 @@ class GridStylizer(object):
         self.fuse_adam = os.environ.get("NFS_FUSE_ADAM", "1") != "0"
         # hipGraph replay of the forward + adjoint (about 130 launches a step; the host needs 1.25 ms to issue
         # them one by one, which is the whole step at one view per rank)
-        self.use_graph = os.environ.get("NFS_GRAPH", "0") == "1" if graph is None else bool(graph)
+        # (measured: 200^3 x 8 views 3.98 -> 3.90 ms, 200^3 x 1 view 1.35 -> 1.41 ms, 100^3 x 1 view 1.20 -> 1.06 ms:
+        # it pays where the step is shorter than the 1.15 ms the host needs to issue it).  None = decide at the first
+        # step from the problem size; NFS_GRAPH=0/1 or the constructor argument override.
+        env = os.environ.get("NFS_GRAPH")
+        self.use_graph = (None if env is None else env == "1") if graph is None else bool(graph)
         self._graph = None
         self._graph_rot = None
         self._graph_total = None
@@ -386,6 +390,8 @@ class GridStylizer(object):
         return self._graph_total, self.g_ds
 
     def step(self, rot_local):
+        if self.use_graph is None:                  # host-bound regime only: small volumes, few views
+            self.use_graph = self.d0.numel() * max(int(rot_local.shape[0]), 1) <= (2 << 20)
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)
         else:
