@@ -90,6 +90,14 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
                         int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
                         nfs_stream_t stream);
 
+/* ---- A11': one step of StylerBase._transport (styler_base.py:59-89: g <- advect(g, +-v[i]) per frame crossed, or
+ * advect(g, +-v[a]*|b-a|) in its one-step form) for a C-channel grid field, with the weighted accumulation of the
+ * temporal filter (styler_3p.py:380-386 applied to grid fields, see styler_grid.py) fused in:
+ *   out [D,H,W,C] = w_g * advect(g, scale * u) + w_addend * addend   (addend nullable; out must not alias g)
+ * g [D,H,W,C], u [D,H,W,3] in advect units, same border-replicating trilinear stencil as nfs_advect_fwd. */
+int nfs_transport_step(const float* g, const float* u, float scale, float w_g, const float* addend,
+                       float w_addend, float* out, int D, int H, int W, int C, nfs_stream_t stream);
+
 /* ---- A9: smoothing conv + clamp (styler_3p.py:112-125) ------------------------------
  * out = max(conv3d_SAME(d, [1,k,1]^3/(k+2)^3), 0), d/out [D,H,W].  k<=0 skips the conv.
  * out stores -0.0f where the pre-activation was negative, so the TF Maximum gradient

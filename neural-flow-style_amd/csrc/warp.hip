@@ -264,6 +264,97 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---- one step of _transport (styler_base.py:59-89) fused with the temporal filter's accumulation -------------------
+// out = w_g * advect(g, scale * u) + w_add * addend   for a C-channel grid field g [D,H,W,C] (C = 3: the stylisation
+// velocity, C = 1: a density), u [D,H,W,3] the simulation velocity of the frame being crossed (scale = +1 forwards,
+// -1 backwards, +-|b-a| for the one-step form).  HBM-bound: reads u (12 B), gathers g (4C B compulsory), reads the
+// addend (4C B), writes out (4C B) per voxel.  A wave owns 128 consecutive voxels, lane l takes l and l+64 (every
+// streamed 12-byte vector access is one contiguous run per instruction); lean stencil as in advect1_kernel; the two
+// W-adjacent corners of a row come from one 8C-byte access (dword-aligned dwordx2 / two dwordx3).
+template <int C> struct __attribute__((packed, aligned(4))) Vec { float v[C]; };
+
+template <int C>
+__global__ void __launch_bounds__(256) transport_step_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                             const float* __restrict__ addend, float* __restrict__ out,
+                                                             int D, int H, int W, float scale, float w_g, float w_add) {
+  constexpr int NV = 2;
+  const int n = D * H * W;
+  const int lane = threadIdx.x & 63;
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;     // contiguous z-slab per XCD (shared planes)
+  const int first = (lb * blockDim.x + (threadIdx.x - lane)) * NV + lane;
+  if (first - lane >= n) return;
+  const F3u* u3 = reinterpret_cast<const F3u*>(u);
+  const Vec<C>* gC = reinterpret_cast<const Vec<C>*>(g);
+  F3u vv[NV];
+  Vec<C> add[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = first + 64 * j;
+    ok[j] = idx < n;
+    const int ic = ok[j] ? idx : n - 1;
+    vv[j] = u3[ic];
+    if (addend) add[j] = reinterpret_cast<const Vec<C>*>(addend)[ic];
+  }
+  const float hz = 0.5f * (float)(D - 1) * scale, hy = 0.5f * (float)(H - 1) * scale, hx = 0.5f * (float)(W - 1) * scale;
+  const float nz1 = (float)(D - 1), ny1 = (float)(H - 1), nx1 = (float)(W - 1);
+  const unsigned uW = (unsigned)W, uHW = (unsigned)(H * W);
+  const int f0 = min(first, n - 1);
+  int w = f0 % W;
+  const int t2 = f0 / W;
+  int h = t2 % H, z = t2 / H;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float xz = fmaf(-vv[j].x, hz, (float)z), xy = fmaf(-vv[j].y, hy, (float)h), xx = fmaf(-vv[j].z, hx, (float)w);
+    const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
+                cx = __builtin_amdgcn_fmed3f(xx, 0.f, nx1);
+    const float bz = fminf(floorf(cz), nz1 - 1.f), by = fminf(floorf(cy), ny1 - 1.f), bx = fminf(floorf(cx), nx1 - 1.f);
+    const float wz = cz - bz, wy = cy - by, wx = cx - bx;
+    const unsigned o = (unsigned)(int)bz * uHW + (unsigned)(int)by * uW + (unsigned)(int)bx;
+    const Vec<C> p00a = gC[o], p00b = gC[o + 1], p01a = gC[o + uW], p01b = gC[o + uW + 1];
+    const Vec<C> p10a = gC[o + uHW], p10b = gC[o + uHW + 1], p11a = gC[o + uHW + uW], p11b = gC[o + uHW + uW + 1];
+    Vec<C> r;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float a00 = fmaf(wx, p00b.v[c] - p00a.v[c], p00a.v[c]), a01 = fmaf(wx, p01b.v[c] - p01a.v[c], p01a.v[c]);
+      const float a10 = fmaf(wx, p10b.v[c] - p10a.v[c], p10a.v[c]), a11 = fmaf(wx, p11b.v[c] - p11a.v[c], p11a.v[c]);
+      const float b0 = fmaf(wy, a01 - a00, a00), b1 = fmaf(wy, a11 - a10, a10);
+      float s = w_g * fmaf(wz, b1 - b0, b0);
+      if (addend) s = fmaf(w_add, add[j].v[c], s);
+      r.v[c] = s;
+    }
+    if (ok[j]) reinterpret_cast<Vec<C>*>(out)[first + 64 * j] = r;
+    w += 64;
+    while (w >= W) { w -= W; if (++h == H) { h = 0; if (z < D - 1) ++z; } }
+  }
+}
+
+// generic channel count (and degenerate volumes): one thread per voxel on the exact reference stencil
+__global__ void __launch_bounds__(256) transport_step_generic_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ u,
+                                                                     const float* __restrict__ addend,
+                                                                     float* __restrict__ out, int D, int H, int W, int C,
+                                                                     float scale, float w_g, float w_add) {
+  const int64_t n = (int64_t)D * H * W;
+  const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= n) return;
+  const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)(vox / ((int64_t)W * H));
+  const float* v = u + vox * 3;
+  Tri t; Axis az, ay, ax;
+  tri_setup(lin_coord(z, D) - scale * v[0], lin_coord(y, H) - scale * v[1], lin_coord(x, W) - scale * v[2], D, H, W, t,
+            az, ay, ax);
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += t.w[k] * g[t.o[k] * C + c];
+    s *= w_g;
+    if (addend) s = fmaf(w_add, addend[vox * C + c], s);
+    out[vox * C + c] = s;
+  }
+}
+
 // ---- output-stationary adjoint of rotate for C = 1 -------------------------------------------
 // Global float atomics cap the scatter at ~90 G atomics/s (5.6 ms for 8 views of 200^3), and LDS float
 // atomics are no better: measured on gfx950 (tools/lds_atomic_bench.hip) ds_add_f32 sustains 0.33
@@ -646,6 +737,28 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
   hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps});
   return check_launch("nfs_advect_bwd_adam");
+}
+
+// one step of StylerBase._transport (styler_base.py:59-89) with the temporal filter's weighted accumulation fused in
+int nfs_transport_step(const float* g, const float* u, float scale, float w_g, const float* addend, float w_addend,
+                       float* out, int D, int H, int W, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(g && u && out, "nfs_transport_step: null pointer");
+  NFS_REQUIRE(g != out, "nfs_transport_step: out must not alias g (it is a gather)");
+  if (int e = check_dims(1, D, H, W, C)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  if ((C == 1 || C == 3) && W >= 2 && H >= 2 && D >= 2 && n < ((int64_t)1 << 29)) {
+    const unsigned blocks = (blocks_for(n, 512) + 7) / 8 * 8;
+    if (C == 3)
+      hipLaunchKernelGGL(transport_step_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(stream), g, u, addend, out, D, H,
+                         W, scale, w_g, w_addend);
+    else
+      hipLaunchKernelGGL(transport_step_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), g, u, addend, out, D, H,
+                         W, scale, w_g, w_addend);
+    return check_launch("nfs_transport_step");
+  }
+  hipLaunchKernelGGL(transport_step_generic_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g, u,
+                     addend, out, D, H, W, C, scale, w_g, w_addend);
+  return check_launch("nfs_transport_step(generic)");
 }
 
 }  // extern "C"

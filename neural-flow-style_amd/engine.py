@@ -210,8 +210,11 @@ class RenderStyleLoss(object):
         loss = torch.zeros(V, dtype=torch.float32, device=d.device)
         g_x = self._vgg_loss_grad(x, loss)
         if self.w_tv > 0:
+            # the reference's batch mean runs over one loss-net batch (v_batch views, styler_base.py:211-213); with
+            # all V local views in one batch the weight is rescaled so that the term is w_tv * sum_v TV_v / v_batch
+            # whatever the number of views this rank holds (sharded runs then sum to the single-rank value)
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
-            ops.tv_loss(dimg, self.w_tv, tv, g_x)
+            ops.tv_loss(dimg, self.w_tv * V / float(min(max(self.v_batch, 1), V)), tv, g_x)
             loss = loss + tv / V
         g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
         g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
@@ -306,7 +309,8 @@ class GridStylizer(object):
     with the velocity field ``vel`` [D,H,W,3] (target 'v') or the density itself (target 'd')
     as the Adam variable.  Views shard over ranks (``views=sum``): each rank evaluates its slice
     of the rotation matrices, the field gradient is all-reduced (sum) and every rank applies the
-    identical Adam step."""
+    identical Adam step.  ``bind`` swaps the frame (density, variable, Adam state) under the same
+    stylizer: the frame loop of a sequence (styler_grid.py) re-uses one instance."""
 
     def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None, graph=None):
         self.loss = loss
@@ -325,17 +329,52 @@ class GridStylizer(object):
         env = os.environ.get("NFS_GRAPH")
         self.use_graph = (None if env is None else env == "1") if graph is None else bool(graph)
         self._graph = None
+        self._graph_key = None
         self._graph_rot = None
         self._graph_total = None
         self._graph_warm = 0
+        self._pending = None
+        self._owns_buffers = False
         D, H, W = d0.shape
         if target == "v":
             self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
         else:
             self.var = d0.clone()
-        self.g_ds = torch.zeros_like(d0)
+        # field gradient and the summed loss share one buffer: the multi-rank exchange is ONE all-reduce
+        # (the loss rides in the slot behind the gradient)
+        n = D * H * W
+        self._gbuf = torch.zeros(n + 4, dtype=torch.float32, device=d0.device)
+        self.g_ds = self._gbuf[:n].view(D, H, W)
+        self._loss_slot = self._gbuf[n:n + 1]
+
+    def bind(self, d0, var=None, adam=None):
+        """Re-point the stylizer at another frame of the same shape (takes effect at the next step / gradient).
+        Without hipGraph replay this is a pointer swap; a captured graph has the addresses of ``d0`` and ``var`` baked
+        in, so there the stylizer keeps private buffers and the frame's data is copied into them."""
+        assert tuple(d0.shape) == tuple(self.d0.shape)
+        self._pending = (d0, var)
+        if adam is not None:
+            self.adam = adam
+
+    def _apply_binding(self):
+        if self._pending is None:
+            return
+        d0, var = self._pending
+        self._pending = None
+        if self.use_graph:
+            if not self._owns_buffers:
+                self.d0, self.var = self.d0.clone(), self.var.clone()
+                self._owns_buffers = True
+            self.d0.copy_(d0)
+            if var is not None:
+                self.var.copy_(var.reshape(self.var.shape))
+        else:
+            self.d0 = d0.contiguous()
+            if var is not None:
+                self.var = var
 
     def forward_field(self):
+        self._apply_binding()
         if self.target == "v":
             self.d_adv = ops.advect_fwd(self.d0.unsqueeze(-1), self.var).squeeze(-1)
         else:
@@ -368,40 +407,63 @@ class GridStylizer(object):
         losses, g_ds = self.field_gradient(rot_local)
         return losses, self.variable_gradient(g_ds)
 
+    def _capture_key(self, rot_local):
+        """everything a captured graph has baked in by address or by value: a mismatch forces a re-capture
+        (set_style_image / set_content_image allocate new targets; loss weights are kernel arguments)"""
+        L = self.loss
+        grams = tuple(int(t.data_ptr()) for t in (L.style_grams or {}).values())
+        cf = getattr(L, "content_feature", None)
+        hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "liquid", "resize_scale", "rotate", "w_tv",
+                                                    "v_batch", "w_content", "content_layer", "content_channel",
+                                                    "w_content_amp"))
+        return (grams, tuple(getattr(L, "w_layers", ())), hyper, None if cf is None else int(cf.data_ptr()),
+                int(self.d0.data_ptr()), int(self.var.data_ptr()), tuple(rot_local.shape), self.k, self.target)
+
     def _field_gradient_graphed(self, rot_local):
         """field_gradient as one hipGraph: the first call runs eagerly (lazy state: packed Winograd filters, side
-        streams, workspaces), the second is captured, later ones replay.  Shapes, the variable, d0 and the style
-        targets are fixed for the life of the capture; the view matrices are copied into a static buffer."""
+        streams, workspaces), the second is captured, later ones replay.  The capture is keyed on what it bakes in
+        (style / content targets, loss hyper-parameters, the addresses of d0 and the variable, the number of views):
+        when any of that changes the graph is dropped and captured again.  The view matrices are copied into a
+        static buffer."""
+        key = self._capture_key(rot_local)
+        if self._graph is not None and key != self._graph_key:
+            self._graph = None
+            self._graph_warm = 0
         if self._graph is None:
             if self._graph_warm < 1:
                 self._graph_warm += 1
                 losses, g_ds = self.field_gradient(rot_local)
-                return losses.sum(), g_ds
+                self._loss_slot.copy_(losses.sum().reshape(1))
+                return self._loss_slot, g_ds
             self._graph_rot = rot_local.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 losses, _ = self.field_gradient(self._graph_rot)
-                self._graph_total = losses.sum()
+                self._loss_slot.copy_(losses.sum().reshape(1))
             self._graph = g
+            self._graph_key = key
         elif rot_local.data_ptr() != self._graph_rot.data_ptr():
             self._graph_rot.copy_(rot_local)
         self._graph.replay()
-        return self._graph_total, self.g_ds
+        return self._loss_slot, self.g_ds
 
     def step(self, rot_local):
         if self.use_graph is None:                  # host-bound regime only: small volumes, few views
             self.use_graph = self.d0.numel() * max(int(rot_local.shape[0]), 1) <= (2 << 20)
+        self._apply_binding()
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)
         else:
             losses, g_ds = self.field_gradient(rot_local)
-            total = losses.sum()
+            self._loss_slot.copy_(losses.sum().reshape(1))
+            total = self._loss_slot
         if self.pg is not None:
-            # The one exchange step (RCCL over xGMI).  The reduction is placed on the 4*G^3-byte density
-            # gradient, not on the 12*G^3-byte velocity gradient: everything below it is linear and
-            # replicated, so reducing early moves 3x fewer bytes over the links.
-            parallel.all_reduce_sum_([g_ds, total], group=self.pg)
+            # The one exchange step (RCCL over xGMI): ONE all-reduce of gradient + loss.  The reduction is placed on
+            # the 4*G^3-byte density gradient, not on the 12*G^3-byte velocity gradient: everything below it is
+            # linear and replicated, so reducing early moves 3x fewer bytes over the links.
+            parallel.all_reduce_sum_([self._gbuf], group=self.pg)
+        total = total[0].clone()
         D, H, W = self.d0.shape
         if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)

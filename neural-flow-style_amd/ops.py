@@ -114,6 +114,18 @@ def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8)
               float(beta1), float(beta2), float(eps), _stream())
 
 
+def transport_step(g, u, scale=1.0, w_g=1.0, addend=None, w_addend=0.0, out=None):
+    """out = w_g*advect(g, scale*u) + w_addend*addend: one frame crossing of ``_transport`` (styler_base.py:59-89) for the
+    C-channel field g [D,H,W,C] with the temporal filter's accumulation fused in"""
+    D, H, W, Cn = g.shape
+    if out is None:
+        out = _empty(g.shape, g)
+    _lib.call("nfs_transport_step", _ptr(g), _ptr(u), float(scale), float(w_g), _ptr(addend), float(w_addend), _ptr(out),
+              D, H, W,
+              Cn, _stream())
+    return out
+
+
 # ---- A9 -----------------------------------------------------------------------------
 
 def smooth3d_relu_fwd(d, k, out=None):

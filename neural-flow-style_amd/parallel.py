@@ -43,3 +43,84 @@ def replicas_identical(t, group=None, atol=0.0):
     diff = (t - ref).abs().max()
     dist.all_reduce(diff, op=dist.ReduceOp.MAX, group=group)
     return float(diff) <= atol
+
+
+# ---- frame sharding of a sequence ("Frames") ------------------------------------------------
+
+def plan_frames(num_frames, interp=1, frames_per_opt=1, world=1):
+    """Contiguous blocks of key frames per rank.  Key frames are 0, interp, 2*interp, ... (styler_3p.py:304); frames
+    of one optimiser group ``t // frames_per_opt`` (styler_3p.py:315) stay on one rank because their Adam state is
+    updated sequentially.  Returns a list (per rank) of lists of key-frame indices; blocks differ by at most one
+    group."""
+    keys = list(range(0, num_frames, max(int(interp), 1)))
+    groups = {}
+    for t in keys:
+        groups.setdefault(t // max(int(frames_per_opt), 1), []).append(t)
+    gids = sorted(groups)
+    out = []
+    for rnk in range(world):
+        lo = len(gids) * rnk // world
+        hi = len(gids) * (rnk + 1) // world
+        out.append([t for g in gids[lo:hi] for t in groups[g]])
+    return out
+
+
+def _is_gloo(group=None):
+    return dist.get_backend(group) == "gloo"
+
+
+def exchange_frames(have, need, owner, like, group=None):
+    """Point-to-point exchange of per-frame tensors (the temporal filter's halo): ``have`` {frame: tensor} are this
+    rank's frames, ``need`` the frames this rank wants, ``owner`` {frame: rank} (identical on all ranks, as is
+    ``need_of(rank)`` below).  Every rank calls with the same ``owner`` and its own ``need``; what the others need is
+    derived from the all-gathered need lists (a few integers).  Returns {frame: tensor} for every frame of ``need``.
+    gloo has no GPU point-to-point: tensors are staged through the host there (CPU tests / one-GPU functional
+    checks); under nccl (RCCL) the device buffers go over xGMI directly."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return {t: have[t] for t in need}
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    needs = [None] * world
+    dist.all_gather_object(needs, sorted(int(t) for t in need), group=group)
+    stage = _is_gloo(group) and like.is_cuda
+    out, ops_, keep = {}, [], []
+    for t in sorted(int(t) for t in need):
+        if owner[t] == rank:
+            out[t] = have[t]
+    # a fixed global order of (src, dst, frame) triples keeps the send/recv pairing identical on both ends
+    for src in range(world):
+        for dst in range(world):
+            if src == dst:
+                continue
+            for t in needs[dst]:
+                if owner[t] != src:
+                    continue
+                if rank == src:
+                    buf = have[t].detach().contiguous()
+                    buf = buf.cpu() if stage else buf
+                    keep.append(buf)
+                    ops_.append(dist.P2POp(dist.isend, buf, dst, group=group))
+                elif rank == dst:
+                    buf = torch.empty(like.shape, dtype=like.dtype, device="cpu" if stage else like.device)
+                    out[t] = buf
+                    ops_.append(dist.P2POp(dist.irecv, buf, src, group=group))
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+    if stage:
+        out = {t: (v.to(like.device) if not v.is_cuda else v) for t, v in out.items()}
+    return out
+
+
+def all_reduce_sum_coalesced_(tensors, group=None):
+    """one collective for several tensors of one dtype/device (field gradient + loss): flattened into one buffer,
+    reduced, copied back"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[o:o + n].view_as(t))
+        o += n
+    return tensors

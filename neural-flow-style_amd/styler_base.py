@@ -30,7 +30,8 @@ class StylerBase(object):
             raise RuntimeError("the stylizer runs on the HIP kernels only (no CPU fallback): no GPU visible")
         gpu = 0
         if "LOCAL_RANK" in os.environ:
-            gpu = int(os.environ["LOCAL_RANK"])
+            # one rank per GPU; ranks beyond the device count wrap (gloo functional checks on a one-GPU box)
+            gpu = int(os.environ["LOCAL_RANK"]) % max(torch.cuda.device_count(), 1)
         elif str(getattr(self, "gpu_id", "0")).lstrip("-").isdigit() and int(self.gpu_id) >= 0:
             gpu = int(self.gpu_id) % max(torch.cuda.device_count(), 1)
         self.device = torch.device("cuda", gpu)

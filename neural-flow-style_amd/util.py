@@ -77,3 +77,27 @@ def prepare_dirs_and_logger(config):
     with open(os.path.join(config.log_dir, "params.json"), "w") as fp:
         json.dump(params, fp, indent=4, sort_keys=True)
     return config.log_dir
+
+
+def temporal_weights(n, sigma, truncate=4.0):
+    """The frame-axis Gaussian of ``denoise`` (util.py:169-170 -> scipy.ndimage.gaussian_filter, defaults: mode
+    'reflect', truncate 4 sigma) written out as the n x n matrix it is: ``denoise(x, (sigma,0,..))[t] = sum_s
+    W[t,s] x[s]``.  Kernel: w_k = exp(-k^2 / 2 sigma^2) / sum, |k| <= int(truncate*sigma + 0.5); 'reflect' maps an
+    index outside [0,n) as (d c b a | a b c d | d c b a).  The grid-sequence stylizer needs the matrix form because
+    it transports x[s] to frame t before adding it (an Eulerian field cannot be filtered in place the way
+    per-particle attributes can)."""
+    n = int(n)
+    W = np.zeros((n, n), np.float64)
+    if sigma <= 0 or n <= 1:
+        return np.eye(n)
+    radius = int(truncate * float(sigma) + 0.5)
+    k = np.arange(-radius, radius + 1)
+    w = np.exp(-0.5 / (float(sigma) ** 2) * k ** 2)
+    w /= w.sum()
+    for t in range(n):
+        for kk, wk in zip(k, w):
+            s = (t + int(kk)) % (2 * n)
+            if s >= n:
+                s = 2 * n - 1 - s
+            W[t, s] += wk
+    return W

@@ -804,6 +804,98 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
     return hist, g_opt, d_fin
 
 
+def temporal_filter_matrix(n, sigma):
+    """The frame-axis filter of ``denoise`` (util.py:169-170) as a matrix, obtained by pushing the identity through
+    SciPy's own gaussian_filter (defaults: reflect, truncate 4 sigma): column s = response to a unit update of frame s."""
+    from scipy.ndimage import gaussian_filter
+    if sigma <= 0 or n <= 1:
+        return np.eye(n)
+    return gaussian_filter(np.eye(n), sigma=(sigma, 0))
+
+
+def grid_sequence_run(cfg, d_frames, u_frames, weights, style_img, rot_mats, v_init=None):
+    """Grid counterpart of Styler.run (styler_3p.py:300-397) assembled from the reference's grid leftovers -- the
+    restatement the HIP grid-sequence stylizer (styler_grid.py) is checked against.
+
+    Per key frame t (304): variable re-assigned from g_opt[t] (312), TFAdam per ``t // frames_per_opt`` (315-323), one
+    step on the summed view losses of grid_forward (advect 557-569 -> smooth 112-125 -> rotate 611-628 -> render
+    147-158 -> style loss); update = new - old (359-360), 'd' masked by the original density (361-363).  Gradient
+    alignment (380-386): the per-frame updates are Gaussian-filtered along the frame axis; a grid field is first
+    carried to the receiving frame by ``transport`` (= StylerBase._transport, styler_base.py:59-89), each source frame
+    separately (no Horner form here).  Then g_opt[t] += (386) and the frame interpolation (392-397).
+    d_frames [F,D,H,W], u_frames [F,D,H,W,3] (advect units).  Returns (loss history [iter][key frame], list of
+    variables per frame [D,H,W,C], list of final d_out per frame)."""
+    F_ = cfg["num_frames"]
+    interp = cfg.get("interp", 1)
+    target = cfg.get("grid_variable", "v")
+    dt = torch.float32
+    d = [torch.tensor(np.asarray(x), dtype=dt)[None, ..., None] for x in d_frames]
+    u = torch.tensor(np.asarray(u_frames), dtype=dt) if u_frames is not None else None
+    rot = torch.tensor(np.asarray(rot_mats, np.float32)) if cfg.get("rotate", True) else torch.eye(3)[None]
+    sfe = style_target_features(torch.tensor(np.asarray(style_img, np.float32))[None], weights, cfg["style_layer"],
+                                upto=cfg.get("upto"))
+    keys = list(range(0, F_, interp))
+    g_opt = {}
+    for t in keys:
+        if target == "d":
+            g_opt[t] = d[t].clone()
+        elif v_init is not None:
+            g_opt[t] = torch.tensor(np.asarray(v_init[t]), dtype=dt)[None]
+        else:
+            g_opt[t] = torch.zeros(d[t].shape[:-1] + (3,), dtype=dt)
+    Wm = temporal_filter_matrix(len(keys), cfg["window_sigma"]) if (cfg["window_sigma"] > 0 and F_ > 1) else None
+    opt_ = {}
+    hist = []
+    for step in range(cfg["iter"]):
+        upd, h = {}, []
+        for t in keys:
+            var = g_opt[t].clone().requires_grad_()
+            opt = opt_.setdefault(t // cfg["frames_per_opt"], TFAdam())
+            if target == "v":
+                total, _, _ = grid_forward(d[t], var, rot, cfg, weights, sfe)
+            else:
+                total, _, _ = grid_forward(var, None, rot, cfg, weights, sfe)
+            (g,) = torch.autograd.grad(total, var)
+            new = torch.nan_to_num(opt.step(var.detach(), g, cfg["lr"]))
+            dl = new - g_opt[t]
+            if target == "d":
+                dl = dl * d[t]
+            upd[t] = dl
+            h.append(float(total))
+        hist.append(h)
+        for j, t in enumerate(keys):
+            if Wm is None:
+                g_opt[t] = g_opt[t] + upd[t]
+                continue
+            acc = torch.zeros_like(upd[t])
+            for jj, s in enumerate(keys):
+                if Wm[j, jj] == 0.0:
+                    continue
+                acc = acc + float(Wm[j, jj]) * transport(upd[s], u, s, t, recursive=cfg.get("transport_recursive", True))
+            g_opt[t] = g_opt[t] + acc
+    full = dict(g_opt)
+    if interp > 1:
+        w = np.linspace(0, 1, interp + 1)
+        for t in range(0, F_ - 1, interp):
+            for i in range(1, interp):
+                if t + interp < F_:
+                    full[t + i] = full[t] * float(1 - w[i]) + full[t + interp] * float(w[i])
+    outs, d_fin = [], []
+    for t in range(F_):
+        var = full.get(t)
+        if var is None:
+            if target == "d":
+                var = d[t].clone()
+            elif v_init is not None:
+                var = torch.tensor(np.asarray(v_init[t]), dtype=dt)[None]
+            else:
+                var = torch.zeros(d[t].shape[:-1] + (3,), dtype=dt)
+        d_adv = advect(d[t], var) if target == "v" else var
+        d_fin.append(smooth3d_relu(d_adv, cfg["k"])[0])
+        outs.append(var[0])
+    return hist, outs, d_fin
+
+
 def colour_field2d(p, r, var, cfg, res):
     """styler_2p.py:42-102: d_gray = clip(p2g(p)/rho0, 0, 1) (mask, constant); d = clip(p2g(p, pc=clip(c,0,1),
     pd=r), 0, 1) [1,H,W,3]; returns (d, d_gray, clipped colours)"""

@@ -83,3 +83,84 @@ def test_shard_is_a_partition_for_any_world():
         got = sum((parallel.shard(list(range(8)), r, world) for r in range(world)), [])
         assert sorted(got) == list(range(8))
         assert len({len(parallel.shard(list(range(8)), r, world)) for r in range(world)}) == 1
+
+
+# ---- frame sharding of a sequence (configs[3]) ----------------------------------------------------------------------
+
+def test_plan_frames_is_a_partition_and_keeps_optimiser_groups_whole():
+    from neural_flow_style_amd import parallel
+    for F, interp, fpo in ((60, 1, 1), (60, 1, 10), (61, 2, 4), (7, 1, 3), (5, 2, 1), (3, 1, 1)):
+        keys = list(range(0, F, interp))
+        for world in (1, 2, 3, 8):
+            plan = parallel.plan_frames(F, interp, fpo, world)
+            assert len(plan) == world
+            assert sum(plan, []) == keys                               # contiguous blocks in frame order
+            owner = {t: r for r, ts in enumerate(plan) for t in ts}
+            for t in keys:                                             # one Adam state never straddles ranks
+                assert all(owner[s] == owner[t] for s in keys if s // fpo == t // fpo)
+            n_groups = [len({t // fpo for t in ts}) for ts in plan]
+            assert max(n_groups) - min(n_groups) <= 1
+
+
+def test_temporal_weights_is_the_matrix_of_denoise():
+    """W @ x == util.denoise(x, (sigma,0,..)) -- the function pinned to the reference's own util.denoise by
+    tests/golden/util_reference.npz; rows sum to one; non-zero band <= 4 sigma"""
+    from neural_flow_style_amd.util import denoise, temporal_weights
+    rng = np.random.RandomState(0)
+    for n, sg in ((1, 2.0), (2, 2.0), (6, 0.8), (9, 3.0), (60, 2.0)):
+        x = rng.randn(n, 4, 3).astype(np.float32)
+        W = temporal_weights(n, sg)
+        np.testing.assert_allclose(np.einsum("ts,sij->tij", W, x.astype(np.float64)), denoise(x, (sg, 0, 0)), atol=2e-7)
+        np.testing.assert_allclose(W.sum(1), 1.0, atol=1e-12)
+        r = int(4 * sg + 0.5)
+        assert all(W[t, s] == 0 for t in range(n) for s in range(n) if abs(t - s) > r)
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_flow_style_amd import parallel
+    from neural_flow_style_amd.util import temporal_weights
+    F, sigma = 11, 0.9
+    plan = parallel.plan_frames(F, 1, 2, world)
+    owner = {t: r for r, ts in enumerate(plan) for t in ts}
+    W = temporal_weights(F, sigma)
+    have = {t: torch.full((3, 2), float(t)) + torch.arange(6.).view(3, 2) * 0.01 for t in plan[rank]}
+    need = set(plan[rank])
+    for t in plan[rank]:
+        need |= set(int(s) for s in np.nonzero(W[t])[0])
+    got = parallel.exchange_frames(have, need, owner, torch.zeros(3, 2))
+    # the filtered value of my frames, computed from what arrived
+    mine = {t: sum(float(W[t, s]) * got[s] for s in sorted(need) if W[t, s] != 0).numpy() for t in plan[rank]}
+    q.put((rank, sorted(need), {t: v.numpy() for t, v in got.items()}, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_of_frame_updates_world3():
+    """three gloo ranks: every rank receives exactly the frames its temporal filter reaches, bit-identical to the
+    owner's tensors, and the filtered updates equal the single-process denoise"""
+    from neural_flow_style_amd.util import denoise
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F = 11
+    full = np.stack([(torch.full((3, 2), float(t)) + torch.arange(6.).view(3, 2) * 0.01).numpy() for t in range(F)])
+    want = denoise(full, (0.9, 0, 0))
+    seen = set()
+    for rank, need, got, mine in outs:
+        assert sorted(got) == need
+        for t, v in got.items():
+            assert np.array_equal(v, full[t])
+        for t, v in mine.items():
+            np.testing.assert_allclose(v, want[t], atol=1e-6)
+            seen.add(t)
+    assert seen == set(range(F))
