@@ -4,8 +4,9 @@ defaults, so a reference driver's ``config`` Namespace drops in.  ``get_config()
 ``kernel_scale``; test_smokegun.py:22,117-120) -- ``complete()`` fills their defaults.
 
 Build-specific additions (not in the reference): ``--views_mode`` (``sequential`` = the reference's
-one-Adam-step-per-view loop, ``sum`` = gradient of the summed view losses, shardable over GPUs) and
-``--grid_variable`` for the grid (TNST-style) path.
+one-Adam-step-per-view loop, ``sum`` = gradient of the summed view losses, shardable over GPUs),
+``--grid_variable`` / ``--transport_recursive`` for the grid (TNST-style) path and ``--synthetic_weights`` (explicit
+opt-in to seeded synthetic VGG filters when no converted checkpoint exists).
 """
 from __future__ import annotations
 
@@ -92,6 +93,8 @@ _FLAGS = [
     # ---- build-specific -------------------------------------------------------------------
     ("MI355X", "views_mode", dict(type=str, default="sequential", choices=["sequential", "sum"])),
     ("MI355X", "grid_variable", dict(type=str, default="", choices=["", "v", "d"])),
+    ("MI355X", "synthetic_weights", dict(type=str2bool, default=False)),
+    ("MI355X", "transport_recursive", dict(type=str2bool, default=True)),
 ]
 
 
@@ -126,4 +129,8 @@ def complete(config):
         config.views_mode = "sequential"
     if not hasattr(config, "grid_variable"):
         config.grid_variable = ""
+    if not hasattr(config, "synthetic_weights"):
+        config.synthetic_weights = False
+    if not hasattr(config, "transport_recursive"):
+        config.transport_recursive = True
     return config

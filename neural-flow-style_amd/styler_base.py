@@ -46,7 +46,8 @@ class StylerBase(object):
         if getattr(self, "w_density", 0) and "d" not in getattr(self, "target_field", ""):
             raise NotImplementedError("the density-preservation loss acts on the particle-density variable "
                                       "(target_field 'd'), as in the reference (styler_3p.py:75)")
-        self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123))
+        self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123),
+                                   synthetic=True if getattr(self, "synthetic_weights", False) else None)
         if getattr(self, "w_content", 0):
             # _layer(content_layer) is a dict lookup on the VGG end points (styler_base.py:91-94): an Inception
             # layer name (the config default) is a KeyError there too

@@ -119,103 +119,124 @@ class Styler(StylerBase):
             out, w_out = S, 1.0
         return out if w_out == 1.0 else out * w_out
 
-    # ---- the optimisation loop ---------------------------------------------------------------------------------------
-    def run(self, params):
+    # ---- the optimisation loop: prepare -> iterate x iter -> finish ------------------------------------------------------
+    def _frames(self, x, wanted):
+        """params entry (list indexed by frame, or {frame: array}) -> {frame: device tensor} for the wanted frames"""
+        if x is None:
+            return None
+        get = (lambda t: x[t]) if not isinstance(x, dict) else (lambda t: x.get(t))
+        return {t: self._dev(get(t)) for t in wanted if get(t) is not None}
+
+    def prepare(self, params, frames_on_device=None):
+        """Put this rank's share of the sequence on the device and set up the loop state.  ``params['d']`` /
+        ``params['v']`` / ``params['v_init']``: list over frames or {frame: array}; a sharded run only needs the
+        frames this rank touches (``frames_needed(rank)``)."""
         assert self.octave_n == 1, "the grid path has one octave (the reference's octaves resize the SPLAT target, " \
                                    "styler_3p.py:241-247; a grid sequence comes at its own resolution)"
         F_ = int(self.num_frames)
         rank, world = self._rank_world()
-        d = [self._dev(x).reshape(tuple(self.resolution)) for x in params["d"]]
-        u = {i: self._dev(params["v"][i]) for i in range(F_)} if ("v" in params and params["v"] is not None) else None
-        D, H, W_ = d[0].shape
-        C = 3 if self.target == "v" else 1
-        shape = (D, H, W_, C)
-        keys = list(range(0, F_, self.interp))
-        plan = parallel.plan_frames(F_, self.interp, self.frames_per_opt, world)
-        owner = {t: r for r, ts in enumerate(plan) for t in ts}
-        mine = plan[rank]
-        Wt = temporal_weights(len(keys), self.window_sigma) if (self.window_sigma > 0 and F_ > 1) else None
-        if Wt is not None and u is None:
+        st = self._st = argparse_ns()
+        st.F, st.rank, st.world = F_, rank, world
+        st.keys = list(range(0, F_, self.interp))
+        st.plan = parallel.plan_frames(F_, self.interp, self.frames_per_opt, world)
+        st.owner = {t: r for r, ts in enumerate(st.plan) for t in ts}
+        st.mine = st.plan[rank]
+        st.Wt = temporal_weights(len(st.keys), self.window_sigma) if (self.window_sigma > 0 and F_ > 1) else None
+        # which frames' updates this rank's filter reaches (non-zero weights only), and the velocities in between
+        st.need = set(st.mine)
+        if st.Wt is not None:
+            for t in st.mine:
+                j = st.keys.index(t)
+                st.need |= set(st.keys[jj] for jj in np.nonzero(st.Wt[j])[0])
+        want_d = set(range(F_)) if frames_on_device is None else set(frames_on_device) | set(st.mine)
+        want_u = set(range(F_)) if frames_on_device is None else \
+            set(range(max(min(st.need) - 1, 0), min(max(st.need) + 1, F_))) if st.need else set()
+        st.d = {t: x.reshape(tuple(self.resolution)) for t, x in self._frames(params["d"], sorted(want_d)).items()}
+        st.u = self._frames(params.get("v"), sorted(want_u))
+        if st.Wt is not None and not st.u:
             raise ValueError("params['v'] (simulation velocities) is needed to align the updates of a sequence")
-
+        D, H, W_ = tuple(self.resolution)
+        st.C = 3 if self.target == "v" else 1
+        st.shape = (D, H, W_, st.C)
         if self.style_img is not None:
             self.loss.set_style_image(self._style_feature(self.style_img, [H, W_]))
         if self.content_img is not None:
             self.loss.set_content_image(self._content_feature(self.content_img, [H, W_]))
-        lr = self.lr[0] if isinstance(self.lr, list) else self.lr
-
+        st.lr = self.lr[0] if isinstance(self.lr, list) else self.lr
         # the variable per key frame: stylisation velocity (zero, or params['v_init'][t]) / the density itself.
         # NOTE: at velocity == 0 every back-traced point sits exactly on a grid node, where the trilinear stencil has a
         # kink -- the first gradient is a one-sided derivative whose side depends on float rounding (DESIGN.md section 5)
-        v_init = params.get("v_init")
-        g_opt = {}
-        for t in mine:
-            if self.target == "d":
-                g_opt[t] = d[t].reshape(shape).clone()
-            elif v_init is not None:
-                g_opt[t] = self._dev(v_init[t]).reshape(shape).clone()
-            else:
-                g_opt[t] = torch.zeros(shape, device=self.device)
-        work = torch.zeros(shape, device=self.device)            # the variable (re-assigned per frame, 312)
-        gs = engine.GridStylizer(self.loss, d[mine[0]] if mine else d[0], k=self.k, target=self.target, lr=lr)
-        opt_ = {}
-        # which frames' updates this rank's filter reaches (non-zero weights only)
-        need = set(mine)
-        if Wt is not None:
-            for t in mine:
-                j = keys.index(t)
-                need |= set(keys[jj] for jj in np.nonzero(Wt[j])[0])
+        st.v_init = params.get("v_init")
+        st.g_opt = {t: self._initial(t) for t in st.mine}
+        st.work = torch.zeros(st.shape, device=self.device)     # the variable (re-assigned per frame, 312)
+        first = st.d[st.mine[0]] if st.mine else next(iter(st.d.values()))
+        st.gs = engine.GridStylizer(self.loss, first, k=self.k, target=self.target, lr=st.lr)
+        st.opt_ = {}
+        st.hist = []
+        return st
 
-        loss_history = []
-        for step in range(self.iter):
-            losses = torch.zeros(len(keys), device=self.device)
-            upd = {}
-            for j, t in enumerate(keys):
-                if owner[t] == rank:
-                    opt_id = t // self.frames_per_opt
-                    adam = opt_.setdefault(opt_id, engine.TFAdamState())
-                    work.copy_(g_opt[t])
-                    gs.bind(d[t], work.view(D, H, W_, 3) if self.target == "v" else work.view(D, H, W_), adam)
-                    losses[j] = gs.step(self._rot())
-                    new = torch.nan_to_num(gs.var.reshape(shape))
-                    dlt = new - g_opt[t]
-                    if self.target == "d":
-                        dlt = dlt * d[t].reshape(shape)             # masking by original density (361-363)
-                    upd[t] = dlt
-                # every rank draws the same view sequence whoever owns the frame (344-349)
-                self._resample_views()
-            if world > 1:
-                parallel.all_reduce_sum_([losses], group=self.pg)
-            loss_history.append([float(x) for x in losses.cpu()])
-            if Wt is not None:
-                got = parallel.exchange_frames(upd, need, owner, work, group=self.pg)
-                aligned = {t: self.aligned_update(t, got, u, Wt, keys) for t in mine}
-            else:
-                aligned = upd
-            for t in mine:
-                g_opt[t] = g_opt[t] + aligned[t]
+    def _initial(self, t):
+        st = self._st
+        if self.target == "d":
+            return st.d[t].reshape(st.shape).clone()
+        if st.v_init is not None:
+            vi = st.v_init[t] if not isinstance(st.v_init, dict) else st.v_init.get(t)
+            if vi is not None:
+                return self._dev(vi).reshape(st.shape).clone()
+        return torch.zeros(st.shape, device=self.device)
 
-        # ---- frame interpolation (392-397) + final inference, gathered on every rank ------------------------------------
-        allv = parallel.exchange_frames(g_opt, set(keys), owner, work, group=self.pg) if world > 1 else g_opt
-        full = {t: allv[t] for t in keys}
+    def iterate(self):
+        """one iteration of the frame loop (styler_3p.py:301-386): a stylisation step per own key frame, the halo
+        exchange of the updates, their temporal alignment, ``g_opt += `` -- returns the per-key-frame losses (device
+        tensor, summed over ranks)"""
+        st = self._st
+        D, H, W_, _ = st.shape
+        losses = torch.zeros(len(st.keys), device=self.device)
+        upd = {}
+        for j, t in enumerate(st.keys):
+            if st.owner[t] == st.rank:
+                adam = st.opt_.setdefault(t // self.frames_per_opt, engine.TFAdamState())
+                st.work.copy_(st.g_opt[t])
+                st.gs.bind(st.d[t], st.work.view(D, H, W_, 3) if self.target == "v" else st.work.view(D, H, W_), adam)
+                losses[j] = st.gs.step(self._rot())
+                dlt = torch.nan_to_num(st.gs.var.reshape(st.shape)) - st.g_opt[t]
+                if self.target == "d":
+                    dlt = dlt * st.d[t].reshape(st.shape)          # masking by original density (361-363)
+                upd[t] = dlt
+            # every rank draws the same view sequence whoever owns the frame (344-349)
+            self._resample_views()
+        if st.world > 1:
+            parallel.all_reduce_sum_([losses], group=self.pg)
+        if st.Wt is not None:
+            got = parallel.exchange_frames(upd, st.need, st.owner, st.work, group=self.pg)
+            for t in st.mine:
+                st.g_opt[t] = st.g_opt[t] + self.aligned_update(t, got, st.u, st.Wt, st.keys)
+        else:
+            for t in st.mine:
+                st.g_opt[t] = st.g_opt[t] + upd[t]
+        st.hist.append(losses)
+        return losses
+
+    def finish(self):
+        """frame interpolation (392-397) + final inference of every frame, on every rank"""
+        st = self._st
+        D, H, W_, _ = st.shape
+        allv = parallel.exchange_frames(st.g_opt, set(st.keys), st.owner, st.work, group=self.pg) \
+            if st.world > 1 else st.g_opt
+        full = {t: allv[t] for t in st.keys}
         if self.interp > 1:
             w = np.linspace(0, 1, self.interp + 1)
-            for t in range(0, F_ - 1, self.interp):
+            for t in range(0, st.F - 1, self.interp):
                 for i in range(1, self.interp):
-                    if t + self.interp < F_:
+                    if t + self.interp < st.F:
                         full[t + i] = full[t] * float(1 - w[i]) + full[t + self.interp] * float(w[i])
         d_sty, r_sty, v_sty = [], [], []
-        for t in range(F_):
+        for t in range(st.F):
             var = full.get(t)
             if var is None:                                        # trailing frames past the last key frame
-                if self.target == "d":
-                    var = d[t].reshape(shape).clone()
-                elif v_init is not None:
-                    var = self._dev(v_init[t]).reshape(shape)
-                else:
-                    var = torch.zeros(shape, device=self.device)
+                var = self._initial(t)
             if self.target == "v":
-                d_adv = ops.advect_fwd(d[t].unsqueeze(-1), var).squeeze(-1)
+                d_adv = ops.advect_fwd(st.d[t].unsqueeze(-1), var).squeeze(-1)
             else:
                 d_adv = var.reshape(D, H, W_)
             d_out = ops.smooth3d_relu_fwd(d_adv.contiguous(), float(self.k))
@@ -223,6 +244,17 @@ class Styler(StylerBase):
             d_sty.append(torch.abs(d_out).unsqueeze(-1).cpu().numpy())   # abs(): drop the sign-bit mask of -0.0
             r_sty.append(dimg[0].cpu().numpy().astype(np.uint8))
             v_sty.append(var.cpu().numpy())
-        return {"l": [[x for l_ in loss_history for x in l_]], "l_frames": loss_history, "d_intm": [],
+        hist = [[float(x) for x in l_.cpu()] for l_ in st.hist]
+        return {"l": [[x for l_ in hist for x in l_]], "l_frames": hist, "d_intm": [],
                 "d": np.array(d_sty), "r": np.array(r_sty), "v": v_sty if self.target == "v" else None,
                 "opt": v_sty, "p": None, "c": None}
+
+    def run(self, params):
+        self.prepare(params)
+        for _ in range(self.iter):
+            self.iterate()
+        return self.finish()
+
+
+class argparse_ns(object):
+    """plain attribute bag for the loop state"""

@@ -52,21 +52,32 @@ def synthetic_weights(seed=123, blocks=VGG19_BLOCKS, upto=None):
     return out
 
 
-def load_npz_weights(path, blocks=VGG19_BLOCKS):
+def load_npz_weights(path, blocks=VGG19_BLOCKS, scope="vgg_19", upto=None):
+    """Weights converted offline from the slim checkpoint (``vgg_19_2016_08_28``).  Accepted key forms per layer:
+    ``conv1_1/weights`` + ``conv1_1/biases``, the checkpoint's own ``<scope>/conv1/conv1_1/weights`` (+ ``biases``; scope
+    = model name, vgg.py:89,119) or ``conv1_1_w`` + ``conv1_1_b``.  Every conv layer of the network (down to ``upto``
+    if given) must be present with shape [3,3,Cin,Cout] HWIO: a missing layer raises instead of silently truncating
+    the network."""
     z = np.load(path)
     out = OrderedDict()
     for name, kind, cin, cout in layer_sequence(blocks):
         if kind != "conv":
             continue
-        for wk in ("%s/weights" % name, "vgg_19/%s/%s/weights" % (name[:5], name), name + "_w"):
-            if wk in z:
+        forms = (("%s/weights" % name, "%s/biases" % name),
+                 ("%s/%s/%s/weights" % (scope, name[:5], name), "%s/%s/%s/biases" % (scope, name[:5], name)),
+                 (name + "_w", name + "_b"))
+        for wk, bk in forms:
+            if wk in z and bk in z:
                 break
         else:
-            break
-        bk = wk.replace("weights", "biases").replace("_w", "_b")
+            raise KeyError("%s: no weights for layer %s (looked for %s)" % (path, name, ", ".join(f[0] for f in forms)))
         w, b = np.asarray(z[wk], np.float32), np.asarray(z[bk], np.float32)
-        assert w.shape == (3, 3, cin, cout), (name, w.shape)
+        if w.shape != (3, 3, cin, cout) or b.shape != (cout,):
+            raise ValueError("%s: layer %s has shapes %s / %s, expected (3,3,%d,%d) HWIO / (%d,)"
+                             % (path, name, w.shape, b.shape, cin, cout, cout))
         out[name] = (w, b)
+        if name == upto:
+            break
     return out
 
 
@@ -204,18 +215,32 @@ class VGG(object):
         raise AssertionError("unreachable")
 
 
-def load_vgg(model_path, device, seed=123):
-    """Counterpart of vgg.load_vgg (vgg.py:110-120): ``model_path`` 'vgg_19.ckpt' -> looks for a
-    converted 'vgg_19.npz' next to it; falls back to the seeded synthetic weights (stated in logs)."""
+def load_vgg(model_path, device, seed=123, synthetic=None):
+    """Counterpart of vgg.load_vgg (vgg.py:110-120).  ``model_path`` '.../vgg_19.ckpt' -> the weights converted
+    offline to '.../vgg_19.npz' (TensorFlow checkpoints cannot be read here).  Without that file the loader RAISES --
+    a stylisation against random filters looks plausible and means nothing -- unless seeded synthetic He-normal
+    weights are asked for explicitly: ``synthetic=True`` (config.synthetic_weights) or NFS_SYNTHETIC_VGG=1 (what the
+    tests and the benchmark use: no checkpoint exists offline).  ``net.source`` names what was loaded."""
     name = os.path.basename(model_path).split(".")[0]
     blocks = VGG16_BLOCKS if "16" in name else VGG19_BLOCKS
+    scope = "vgg_16" if "16" in name else "vgg_19"
     npz = os.path.splitext(model_path)[0] + ".npz"
+    if synthetic is None:
+        synthetic = os.environ.get("NFS_SYNTHETIC_VGG", "0") == "1"
     if os.path.exists(npz):
-        w = load_npz_weights(npz, blocks)
+        w = load_npz_weights(npz, blocks, scope)
         src = npz
-    else:
+    elif synthetic:
         w = synthetic_weights(seed, blocks)
         src = "synthetic(seed=%d)" % seed
+    else:
+        raise FileNotFoundError(
+            "%s not found%s.  Convert the slim checkpoint to an .npz with keys 'conv1_1/weights' [3,3,Cin,Cout], "
+            "'conv1_1/biases', ... (INTEGRATION.md), or opt in to seeded SYNTHETIC weights with config.synthetic_weights"
+            "=True / NFS_SYNTHETIC_VGG=1 (results are then not a stylisation by VGG-19)"
+            % (npz, " (a TensorFlow checkpoint %s is present but cannot be read without TensorFlow)" % model_path
+               if os.path.exists(model_path) or os.path.exists(model_path + ".index") else ""))
     net = VGG(w, device, blocks)
     net.source = src
+    print("loss network: %s weights from %s" % (scope, src))
     return net

@@ -52,10 +52,15 @@ def run(config):
     prepare_dirs_and_logger(config)
     config.rng = np.random.RandomState(config.seed)
     if not config.style_target:
+        # demo mode: no style image given -> seeded synthetic style image AND (explicitly) synthetic VGG filters; a real
+        # run needs --style_target and data/model/vgg_19.npz (vgg.load_vgg raises without it)
         from neural_flow_style_amd import synthetic as S
+        print("DEMO MODE: synthetic style image and synthetic (random) VGG-19 filters -- not a stylisation by VGG-19")
         config.style_target = S.style_image(256, 256, np.random.RandomState(config.seed))
         config.w_style = 1
+        config.synthetic_weights = True
     styler = Styler(config)
+    print("loss network weights:", styler.net.source)
     styler.load_img(config.resolution[1:])
     params = load_frames(config) or synthetic_frames(config)
     result = styler.run(params)
@@ -75,23 +80,44 @@ def run(config):
         Image.fromarray(img).save(os.path.join(config.log_dir, "%03d.png" % (config.target_frame + i)))
     for i, d in enumerate(result["d"]):
         np.savez_compressed(os.path.join(config.log_dir, "%03d.npz" % (config.target_frame + i)), x=d[:, ::-1])
+    for o, d_intm_o in enumerate(result["d_intm"]):          # intermediate octave images (test_smokegun.py:103-109)
+        for i, img in enumerate(d_intm_o):
+            if img is None:
+                continue
+            Image.fromarray(img).save(os.path.join(config.log_dir, "o%02d_%03d.png" % (o, config.target_frame + i)))
     return result
 
 
 def main(config):
+    """The reference's main() (test_smokegun.py:111-197) sets these unconditionally; kept verbatim:
+    dataset, num_kernels 2, kernel_scale 2, support 4, disc 1, radius 0.5, nsize 1, rest_density 1000, clip False,
+    w_density 0, k 3, window_sigma 3, batch_size 1, frames_per_opt 1, target_field 'd', lr 0.1, octave_n 1,
+    octave_scale 1.8, transmit 0.01, iter 20, interp 1.
+    Deliberate differences (each because the reference's value cannot run here):
+      * d_path 'pt_low_o2/%03d.npz' instead of '.bgeo' (io_bgeo reads .bgeo too when the file exists);
+      * network 'vgg_19.ckpt' with style layers conv1_1..conv5_1 instead of the Inception graph ('conv2d2','mixed3b',
+        'mixed4b': weights not available), w_content 0 unless a VGG content layer is named;
+      * rotate True with 8 views instead of False (the benchmark's multi-view path); pass --rotate false to get the
+        reference's single view;
+      * resolution/domain [200,300,200] and resize_scale 300/resolution[0] are applied only when --resolution is left
+        at its flag default (so that a smaller grid can be asked for on the command line)."""
     config.dataset = "smokegun"
     config.d_path = "pt_low_o2/%03d.npz"
     config.num_kernels = 2
     config.kernel_scale = 2
     config.support = 4
-    config.radius = 0.5
+    config.disc = 1
+    config.radius = 1 / config.disc / 2
     config.nsize = 1
     config.rest_density = 1000
     if config.resolution == [384, 288]:          # flag default -> the driver's grid (test_smokegun.py:128)
-        config.resolution = [100, 150, 100]
+        config.resolution = [200, 300, 200]
+        config.resize_scale = 300 / config.resolution[0]
     config.domain = list(config.resolution)
     config.clip = False
+    config.w_density = 0
     config.k = 3
+    config.window_sigma = 3
     config.batch_size = 1
     config.frames_per_opt = 1
     config.target_field = "d"
@@ -103,10 +129,14 @@ def main(config):
     if not str(config.content_layer).startswith("conv"):
         config.w_content = 0          # the default content layer is an Inception-v1 name: style transfer only
     config.octave_n = 1
+    config.octave_scale = 1.8
     config.transmit = 0.01
-    config.rotate = True
-    config.n_views = 8
-    config.resize_scale = 1.0
+    config.iter = 20
+    config.interp = 1
+    import sys
+    if not any(a.startswith("--rotate") for a in sys.argv[1:]):
+        config.rotate = True
+        config.n_views = 8
     return run(config)
 
 

@@ -34,13 +34,38 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
     args = ["--steps", "3", "--warmup", "1", "--grid", "64", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py"] + args)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "parity"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "parity", "sustained", "other_configs",
+              "scaling_by"):
         assert k in one, k
     assert one["n_gpus"] == 1 and one["dtype"] == "f32" and one["scaling"] == "strong" and one["vs_baseline"] is None
     assert one["roofline"]["bound"] == "mfma" and 0 < one["roofline"]["frac"] < 1.2
     assert one["parity"]["grad_rel_l2"] < one["parity"]["tolerance"]
+    assert "64^3" in one["metric"] and one["sustained"]["windows"] >= 3
+    assert len(one["other_configs"]) == 4 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
+    fast = args + ["--no-kernel-profile", "--no-other-configs", "--no-sustained"]
+    # (a) the launcher form the driver uses, views sharded (strong scaling): 2 ranks share the GPU over gloo
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--no-kernel-profile"] + args,
-               env={"NFS_DIST_BACKEND": "gloo"})
-    assert two["n_gpus"] == 2 and two["config"]["views_per_rank"] == 4
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--scaling-by", "views"]
+               + fast, env={"NFS_DIST_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["config"]["views_per_rank"] == 4 and two["scaling"] == "strong"
     assert abs(two["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"])
+    # (b) ``python bench.py --gpus 2`` WITHOUT a launcher must become two ranks by itself; default sharding for N > 1
+    # is by frames (weak scaling), with the view-sharded number of the same box beside it
+    env = {"NFS_DIST_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    seq2 = _run([sys.executable, "bench.py", "--gpus", "2"] + fast, env=env)
+    assert seq2["n_gpus"] == 2 and seq2["world_size_seen"] == 2 and seq2["scaling"] == "weak"
+    assert seq2["scaling_by"] == "frames" and seq2["config"]["frames"] == 2
+    assert abs(seq2["views_strong"]["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"])
+    # the same two-frame sequence on one rank: identical trajectory (frame sharding + halo exchange are exact)
+    seq1 = _run([sys.executable, "bench.py", "--scaling-by", "frames", "--frames-per-rank", "2"] + fast)
+    assert seq1["n_gpus"] == 1 and seq1["config"]["frames"] == 2
+    assert abs(seq2["final_loss"] - seq1["final_loss"]) <= 1e-5 * abs(seq1["final_loss"])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1"], cwd=ROOT, capture_output=True,
+                       text=True, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -27,6 +27,7 @@ def _config(**over):
     cfg, _ = get_config([])
     cfg.network = "vgg_19.ckpt"
     cfg.data_dir = "/nonexistent"
+    cfg.synthetic_weights = True      # no converted checkpoint offline: explicit opt-in (vgg.load_vgg raises otherwise)
     for k, v in over.items():
         setattr(cfg, k, v)
     cfg.rng = np.random.RandomState(cfg.seed)

@@ -15,7 +15,7 @@ r = rng.uniform(900, 1100, (n, 1)).astype(np.float32)
 H = W = 128
 simg = S.style_image(H, W, rng)
 cfg, _ = get_config([])
-for k, v in dict(network="vgg_19.ckpt", data_dir="/nonexistent", resolution=[H, W], domain=[3.2, 3.2], radius=0.0125,
+for k, v in dict(network="vgg_19.ckpt", data_dir="/nonexistent", synthetic_weights=True, resolution=[H, W], domain=[3.2, 3.2], radius=0.0125,
                  nsize=2, support=4, rest_density=1000, clip=False, target_field="c", num_frames=1, batch_size=1,
                  frames_per_opt=200, window_sigma=3, lr=0.01, iter=50, octave_n=1, octave_scale=1.7,
                  style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0, w_content=0, style_mask=True, w_tv=0.01,
