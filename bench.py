@@ -439,7 +439,8 @@ def other_configs(device, base):
     # configs[3]: the sequence loop on 4 frames of 200^3 (one GPU): frame-iterations/s incl. temporal alignment, and
     # the transport step kernel against its HBM roofline
     try:
-        ns = argparse.Namespace(grid=200, views=8, window_sigma=2.0)
+        G3 = int(base["d0"].shape[0])
+        ns = argparse.Namespace(grid=G3, views=len(base["mats"]), window_sigma=2.0)
         st = build_sequence(ns, device, 0, 1, 4, base, None)
         for _ in range(2):
             st.iterate()
@@ -449,11 +450,12 @@ def other_configs(device, base):
             st.iterate()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
-        gq = torch.randn(200, 200, 200, 3, device=device); uq = torch.tensor(base["vel"], device=device)
+        gq = torch.randn(G3, G3, G3, 3, device=device); uq = torch.tensor(base["vel"], device=device)
         oq = torch.empty_like(gq)
         ms = ev_time(lambda: ops.transport_step(gq, uq, 1.0, 0.5, gq, 0.5, out=oq), 20)
-        bytes_ = (12.0 + 36.0) * 200 ** 3
-        out.append({"config": "configs[3] smokegun 200^3 sequence, 4 frames x 8 views, window_sigma 2 (one GPU)",
+        bytes_ = (12.0 + 36.0) * G3 ** 3
+        out.append({"config": "configs[3] smokegun %d^3 sequence, 4 frames x %d views, window_sigma 2 (one GPU)"
+                              % (G3, ns.views),
                     "value": 4 / dt, "unit": "frame-iters/s", "ms_per_iteration": 1e3 * dt,
                     "transport_step_ms": ms, "transport_step_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         del st
