@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -242,5 +243,5 @@ def load_vgg(model_path, device, seed=123, synthetic=None):
                if os.path.exists(model_path) or os.path.exists(model_path + ".index") else ""))
     net = VGG(w, device, blocks)
     net.source = src
-    print("loss network: %s weights from %s" % (scope, src))
+    print("loss network: %s weights from %s" % (scope, src), file=sys.stderr)
     return net
