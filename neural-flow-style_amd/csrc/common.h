@@ -30,6 +30,15 @@ inline int check_launch(const char* what) {
     }                                 \
   } while (0)
 
+// Timing-only ablation branches (they skip loads / stores / MFMAs: WRONG RESULTS by construction) exist only in builds
+// made with -DNFS_ABLATE (make ABLATE=1); in the product library NFS_DBG() is the constant 0 and the branches, the
+// environment reads that set them (NFS_GEMM_DBG, NFS_CONV_DBG) and the `dbg` argument fields compile away.
+#ifdef NFS_ABLATE
+#define NFS_DBG(args, bit) ((args).dbg & (bit))
+#else
+#define NFS_DBG(args, bit) 0
+#endif
+
 inline unsigned blocks_for(int64_t n, int threads) {
   return (unsigned)((n + threads - 1) / threads);
 }

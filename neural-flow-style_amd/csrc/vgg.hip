@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
   for (int it = it0; it < it1; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
     if (tap == 0) {
-      if (!(a.dbg & 2)) __syncthreads();  // every wave is done with the previous chunk's patch
+      if (!NFS_DBG(a, 2)) __syncthreads();  // every wave is done with the previous chunk's patch
       float* pdst = patch + (t >> 3) * LDS_STRIDE + q4;
       *reinterpret_cast<float4*>(pdst) = p0;
       *reinterpret_cast<float4*>(pdst + 32 * LDS_STRIDE) = p1;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
       *reinterpret_cast<float4*>(pdst + 160 * LDS_STRIDE) = p5;
     }
     float* wcur = wl + (it & 1) * BN * LDS_STRIDE;
-    if (!(a.dbg & 4) || it == it0) {
+    if (!NFS_DBG(a, 4) || it == it0) {
       float* wdst = wcur + (t >> 3) * LDS_STRIDE + q4;   // f = t + 256 r -> row (f>>3) = (t>>3) + 32 r
       *reinterpret_cast<float4*>(wdst) = w0;
       *reinterpret_cast<float4*>(wdst + 32 * LDS_STRIDE) = w1;
@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
         *reinterpret_cast<float4*>(wdst + 96 * LDS_STRIDE) = w3;
       }
     }
-    if (!(a.dbg & 2)) __syncthreads();
-    if (it + 1 < it1 && !(a.dbg & 4)) {
+    if (!NFS_DBG(a, 2)) __syncthreads();
+    if (it + 1 < it1 && !NFS_DBG(a, 4)) {
       const float4* wn = wp4 + (int64_t)(it + 1) * slab4;
       w0 = wn[0]; w1 = wn[256];
       if (WREG > 2) { w2 = wn[512]; w3 = wn[768]; }
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(ConvArgs a) {
     const bool z1 = (dy == 0 && !up_ok[1]) || (dy == 2 && !dn_ok[1]);
 #pragma unroll
     for (int c = 0; c < KC / 8; ++c) {
-      if (!(a.dbg & 1) || it == it0) {
+      if (!NFS_DBG(a, 1) || it == it0) {
       float4 a0 = *reinterpret_cast<const float4*>(patch + abase[0] + tapoff + 8 * c);
       float4 a1 = *reinterpret_cast<const float4*>(patch + abase[1] + tapoff + 8 * c);
       if (z0) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -614,8 +614,10 @@ static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipSt
   const ConvPlan plan = plan_conv(mtiles, a.Nc, a.Kc / KC, mn, ws ? ws_floats : 0);
   a.ksplit = plan.ksplit;
   a.ws = ws;
+#ifdef NFS_ABLATE
   static const int dbg = getenv("NFS_CONV_DBG") ? atoi(getenv("NFS_CONV_DBG")) : 0;
   a.dbg = dbg;
+#endif
   const dim3 grid(mtiles, a.Nc / plan.bn, plan.ksplit);
   if (plan.bn == 128) {
     constexpr int BN = 128;

@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     float* Ac = As + (NBUF == 2 ? (c & 1) : 0) * BM * WG_LS;
     float* Bc = Bs + (NBUF == 2 ? (c & 1) : 0) * BN * WG_LS;
     if (NBUF == 1 && c > 0) __syncthreads();          // single buffer: everyone is done reading chunk c-1
-    if (!(a.dbg & 8)) {
+    if (!NFS_DBG(a, 8)) {
       float* ad = Ac + r0 * WG_LS + q4;
       *reinterpret_cast<float4*>(ad) = a0;
       *reinterpret_cast<float4*>(ad + 32 * WG_LS) = a1;
@@ -460,9 +460,9 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
         *reinterpret_cast<float4*>(bd + 96 * WG_LS) = b3;
       }
     }
-    if (!(a.dbg & 16)) __syncthreads();    // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
-    if (c + 1 < nchunks && !(a.dbg & 4)) NFS_WG_LOAD(c + 1)
-    if (!(a.dbg & 1))
+    if (!NFS_DBG(a, 16)) __syncthreads();    // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    if (c + 1 < nchunks && !NFS_DBG(a, 4)) NFS_WG_LOAD(c + 1)
+    if (!NFS_DBG(a, 1))
 #pragma unroll
     for (int s = 0; s < WG_KC / 8; ++s) {
       float af[MT][4], bf[NT][4];
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
       v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
       v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
     }
-    if (!(a.dbg & 2) || v.x == 12345.f) *reinterpret_cast<float4*>(Mc + idx) = v;
+    if (!NFS_DBG(a, 2) || v.x == 12345.f) *reinterpret_cast<float4*>(Mc + idx) = v;
   }
 }
 
@@ -651,10 +651,12 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   a.mt = (int)((a.T + bm - 1) / bm);
   a.nt = a.N / bn;
   a.Z = Z;
-  // timing-only ablations (wrong results by construction): 1 no MFMA / operand reads, 2 no stores of C, 4 no global
+  // timing-only ablations, -DNFS_ABLATE builds only (wrong results by construction): 1 no MFMA / operand reads, 2 no stores of C, 4 no global
   // loads after the first chunk, 8 no LDS staging, 16 no barrier in the K loop
+#ifdef NFS_ABLATE
   static const int dbg = getenv("NFS_GEMM_DBG") ? atoi(getenv("NFS_GEMM_DBG")) : 0;
   a.dbg = dbg;
+#endif
   // K = 64 (two chunks): nothing to double-buffer; a single LDS buffer doubles the co-resident blocks of this
   // bandwidth-bound shape (conv1_2: 0.103 -> 0.093 ms)
   if (nbuf == 2 && (a.K > 64 || nbuf_env == 2)) {

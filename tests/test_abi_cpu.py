@@ -85,3 +85,15 @@ def test_config_surface_matches_the_reference_defaults():
         got = mine[k]
         assert (list(got) if isinstance(got, (list, tuple)) else got) == v, (k, got, v)
     assert set(mine) - set(ref) == {"views_mode", "grid_variable", "synthetic_weights", "transport_recursive"}
+
+
+def test_product_library_has_no_wrong_result_ablation_switches():
+    """the timing-only ablation branches (NFS_GEMM_DBG / NFS_CONV_DBG: skip loads, stores or MFMAs, wrong results by
+    construction) exist only in ``make ABLATE=1`` builds: the product library must not even contain the variable names"""
+    import os
+    from neural_flow_style_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"NFS_GEMM_DBG", b"NFS_CONV_DBG"):
+        assert name not in blob, name
