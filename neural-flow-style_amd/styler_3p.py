@@ -107,6 +107,11 @@ class Styler(StylerBase):
         d3 = d_out.detach().reshape(d_out.shape[1:4]).contiguous()
         g_d = torch.zeros_like(d3)
         losses = self.loss.loss_and_grad(d3, rot, g_d)
+        # view-independent terms (pressure / density preservation) belong to the iteration, not to a view: with the
+        # views sharded over ranks (views=sum) only rank 0 adds them, so that the all-reduced loss and gradient
+        # contain them ONCE (every rank would otherwise contribute a copy: world x the single-rank weight)
+        if extra is not None and self._rank_world()[0] != 0:
+            extra = None
         if extra is not None:
             losses = losses + extra.detach() / losses.numel()
         heads, grads = [d_out], [g_d.reshape(d_out.shape)]

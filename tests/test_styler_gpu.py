@@ -261,3 +261,96 @@ def test_transport_matches_oracle():
         out = sb._transport(g.cuda(), v.cuda(), a, b, recursive=rec)
         ref = O.transport(g[None], v, a, b, recursive=rec)[0]
         assert rel(out.cpu(), ref) < 1e-4
+
+
+_SUM_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from tests.test_styler_gpu import _config, _particles
+from neural_flow_style_amd import synthetic as S
+from neural_flow_style_amd.styler_3p import Styler
+world = int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(0)
+if world > 1:
+    dist.init_process_group("gloo")
+G, n, nk, F = 16, 1200, 1, 1
+rng = np.random.RandomState(31)
+frames = [_particles(G, n, nk, rng) for _ in range(F)]
+simg = S.style_image(G, G, rng)
+cfg = _config(resolution=[G, G, G], domain=[G, G, G], radius=0.5, nsize=1, support=4, rest_density=1000, k=3,
+              clip=False, target_field="p", num_frames=F, batch_size=1, frames_per_opt=1, window_sigma=0, interp=1,
+              lr=0.002, iter=3, octave_n=1, octave_scale=1.8, style_layer=["conv1_1", "conv2_1"], w_style_layer=[1, 1],
+              w_style=1.0, w_content=0, transmit=0.1, rotate=True, n_views=4, v_batch=1, sample_type="uniform",
+              phi0=-5, phi1=5, phi_unit=10, theta0=-10, theta1=10, theta_unit=20, resize_scale=1.0, views_mode="sum",
+              style_target=simg, num_kernels=nk, kernel_scale=2, w_pressure=1e3, w_density=0, w_tv=0.05)
+st = Styler(cfg)
+if world > 1:
+    st.pg = dist.group.WORLD
+st.load_img([G, G])
+res = st.run({"p": [f[0] for f in frames], "r": [f[1] for f in frames]})
+if int(os.environ.get("RANK", "0")) == 0:
+    np.savez(sys.argv[1], l=np.asarray(res["l"][0]), opt=np.stack(res["opt"]), d=res["d"])
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_views_sum_two_ranks_match_single_rank_with_tv_and_pressure(tmp_path):
+    """views=sum with the views sharded over two ranks (sharing the GPU over gloo): the view-independent pressure term
+    and the TV term (normalised per loss-net batch, not per local view count) must enter the all-reduced loss and
+    gradient exactly once -- identical trajectory to the single-rank run"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_SUM_SCRIPT % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    one, two = tmp_path / "one.npz", tmp_path / "two.npz"
+    subprocess.run([sys.executable, str(script), str(one)], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29741", str(script), str(two)],
+                   check=True, env=env, timeout=900)
+    a, b = np.load(one), np.load(two)
+    np.testing.assert_allclose(b["l"], a["l"], rtol=2e-5)
+    assert rel(b["opt"], a["opt"]) < 1e-4
+    assert rel(b["d"], a["d"]) < 1e-5
+
+
+def test_particle_sum_mode_tv_weight_matches_the_oracle_per_view_sum():
+    """engine TV term with several views in one batch = w_tv * sum over views of TV(view) (v_batch = 1), as the
+    oracle's per-view loop adds it"""
+    import torch
+    from neural_flow_style_amd import engine, vgg
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd import transform as T
+    G, V = 16, 3
+    rng = np.random.RandomState(3)
+    d = torch.tensor(S.blob_density(G, rng)).cuda()
+    simg = S.style_image(G, G, rng)
+    layers = ["conv1_1", "conv2_1"]
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv2_1"), "cuda")
+    mats = S.uniform_views(V)
+    w = O.synthetic_vgg19_weights(123, upto="conv2_1")
+    sfe = O.style_target_features(torch.tensor(simg)[None], w, layers, upto="conv2_1")
+    ocfg = dict(k=3, transmit=0.1, style_layer=layers, w_style_layer=[1.0, 1.0], w_style=1.0, upto="conv2_1",
+                rotate=True, target_field="d", w_tv=0.05)
+    dd = d.cpu()[None, ..., None].clone().requires_grad_()
+    tot = 0
+    for v in range(V):
+        dr = O.rotate(dd, torch.tensor(np.asarray(mats[v:v + 1], np.float32)))
+        img = O.render(dr, 0.1)
+        dimg = O.plugin_to_loss_net(img)
+        feats = O.vgg19_features(dimg, w, "conv2_1")
+        l, _ = O.style_loss(feats, sfe, layers, [1.0, 1.0], 1.0)
+        tot = tot + l + O.tv_loss(dimg) * 0.05
+    (go,) = torch.autograd.grad(tot, dd)
+    loss = engine.RenderStyleLoss(net, layers, [1.0, 1.0], 1.0, transmit=0.1, w_tv=0.05)
+    loss.set_style_image(simg)
+    g = torch.zeros_like(d)
+    losses = loss.loss_and_grad(d, T.rot_to_device(mats, "cuda"), g)
+    assert abs(float(losses.sum()) - float(tot)) < 1e-4 * abs(float(tot))
+    assert rel(g.cpu(), go[0, ..., 0]) < 1e-4
