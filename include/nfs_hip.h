@@ -90,6 +90,36 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
                         int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
                         nfs_stream_t stream);
 
+/* ---- A2 (2-D twin): batch_warp2d / _interpolate2d (transform.py:206-236, 280-341) ---------------------------
+ * imgs [B,X,Y,C], coords [B,2,X,Y] normalised [-1,1], out [B,X,Y,C]; border-replicating bilinear gather (the
+ * reference's only known-answer vector, transform.py:1859-1885, pins this stencil).  bwd: g_imgs_acc (nullable) +=
+ * scatter, g_coords (nullable) overwritten. */
+int nfs_warp2d_fwd(const float* imgs, const float* coords, float* out, int B, int X, int Y, int C,
+                   nfs_stream_t stream);
+int nfs_warp2d_bwd(const float* imgs, const float* coords, const float* g_out, float* g_imgs_acc,
+                   float* g_coords, int B, int X, int Y, int C, nfs_stream_t stream);
+
+/* ---- A11 (2-D branch): advect order 1 (transform.py:583-588) ---------------------------------------------------
+ * d [H,W,C], vel [H,W,2] normalised units (component k moves along array axis k), out = bilinear(d, mgrid - vel). */
+int nfs_advect2d_fwd(const float* d, const float* vel, float* out, int H, int W, int C, nfs_stream_t stream);
+int nfs_advect2d_bwd(const float* d, const float* vel, const float* g_out, float* g_d_acc, float* g_vel,
+                     int H, int W, int C, nfs_stream_t stream);
+
+/* ---- advect order 2, MacCormack (transform.py:570-582 3-D, 590-607 2-D) ---------------------------
+ * Second pass of the scheme on top of d_fwd = advect(d, vel) (nfs_advect_fwd / nfs_advect2d_fwd):
+ *   d_bwd = advect(d_fwd, -vel);  d_adv = d_fwd + (d - d_bwd)/2;  where d_adv leaves the range of d over the corners
+ *   of the back-traced interpolation cell, d_fwd is kept (the reference's "soft clamp").  The reference's own limiter
+ *   is broken (tf.to_int32 of [-1,1] coordinates; d_max[grids]); this is the scheme it transcribes, done as intended.
+ * d, d_fwd, out [D,H,W,C] (2-D: D = 1), vel [D,H,W,nd], nd = 2 | 3.  Forward only (as its uses: transport of results). */
+int nfs_advect_maccormack(const float* d, const float* vel, const float* d_fwd, float* out,
+                          int D, int H, int W, int C, int nd, nfs_stream_t stream);
+
+/* ---- curl of a stream function (transform.py:517-555) -------------------------------------------
+ * nd = 2: s [H,W] -> out [H,W,2] = (ds/dy, -ds/dx);  nd = 3: s [D,H,W,3] -> out [D,H,W,3] (forward differences, last
+ * slice replicated).  bwd: g_s = curl^T g_out (gather form, deterministic).  2-D: D = 1. */
+int nfs_curl_fwd(const float* s, float* out, int D, int H, int W, int nd, nfs_stream_t stream);
+int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nfs_stream_t stream);
+
 /* ---- A11': one step of StylerBase._transport (styler_base.py:59-89: g <- advect(g, +-v[i]) per frame crossed, or
  * advect(g, +-v[a]*|b-a|) in its one-step form) for a C-channel grid field, with the weighted accumulation of the
  * temporal filter (styler_3p.py:380-386 applied to grid fields, see styler_grid.py) fused in:

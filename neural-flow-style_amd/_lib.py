@@ -40,6 +40,13 @@ SIGNATURES = {
     "nfs_advect_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect_bwd_adam": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "nfs_warp2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "nfs_warp2d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "nfs_advect2d_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "nfs_advect2d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "nfs_advect_maccormack": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_curl_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "nfs_curl_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "nfs_transport_step": [_P, _P, _F, _F, _P, _F, _P, _I, _I, _I, _I, _P],
     "nfs_smooth3d_relu_fwd": [_P, _P, _I, _I, _I, _F, _P],
     "nfs_smooth3d_relu_bwd": [_P, _P, _P, _I, _I, _I, _F, _P],

@@ -1,0 +1,299 @@
+// 2-D twins of the resampling family and the remaining TNST grid operators:
+//   batch_warp2d / _interpolate2d      transform.py:206-236, 280-341   (A2, 2-D; pins the reference's only KAT)
+//   advect, 2-D branch, order 1        transform.py:583-588            (A11, 2-D)
+//   advect order 2 (MacCormack)        transform.py:570-582 / 590-607  (the reference's clamp is broken
+//                                      -- tf.to_int32 of [-1,1] coordinates, d_max[grids] -- here done as intended)
+//   curl of a stream function          transform.py:517-555            (SURVEY 8(f)-4), forward and adjoint
+// Images are small (128^2 ... 512 x 1024) next to the volumes: one thread per output element, exact reference stencil
+// (x0 = floor, x1 = x0 + 1, both clipped to [0, n-1], weight dx = x - float(clipped x0)).
+#include "common.h"
+
+namespace nfs {
+
+enum Coord2 { C2_EXPLICIT = 0, C2_ADVECT = 1 };
+
+struct Warp2Args {
+  const float* src;     // [B,X,Y,C] (explicit: batched; advect: B = 1)
+  const float* coords;  // explicit [B,2,X,Y] | vel [X,Y,2]
+  int B, X, Y, C;
+};
+
+template <int KIND>
+__device__ __forceinline__ void coords2_at(const Warp2Args& a, int b, int x, int y, int64_t pix, float& cx, float& cy) {
+  if (KIND == C2_EXPLICIT) {
+    const int64_t n = (int64_t)a.X * a.Y;
+    const float* c = a.coords + (int64_t)b * 2 * n;
+    cx = c[pix];
+    cy = c[n + pix];
+  } else {
+    const float* v = a.coords + pix * 2;
+    cx = lin_coord(x, a.X) - v[0];
+    cy = lin_coord(y, a.Y) - v[1];
+  }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) warp2d_fwd_kernel(Warp2Args a, float* __restrict__ out) {
+  const int64_t n = (int64_t)a.X * a.Y;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * a.B) return;
+  const int b = (int)(gid / n);
+  const int64_t pix = gid - (int64_t)b * n;
+  const int y = (int)(pix % a.Y), x = (int)(pix / a.Y);
+  float cx, cy;
+  coords2_at<KIND>(a, b, x, y, pix, cx, cy);
+  const Axis ax = axis_setup(cx, a.X), ay = axis_setup(cy, a.Y);
+  const float* src = a.src + (int64_t)b * n * a.C;
+  const float w00 = (1.f - ax.w1) * (1.f - ay.w1), w01 = (1.f - ax.w1) * ay.w1, w10 = ax.w1 * (1.f - ay.w1),
+              w11 = ax.w1 * ay.w1;
+  const int64_t o00 = ((int64_t)ax.i0 * a.Y + ay.i0) * a.C, o01 = ((int64_t)ax.i0 * a.Y + ay.i1) * a.C,
+                o10 = ((int64_t)ax.i1 * a.Y + ay.i0) * a.C, o11 = ((int64_t)ax.i1 * a.Y + ay.i1) * a.C;
+  float* o = out + gid * a.C;
+  for (int c = 0; c < a.C; ++c)   // add_n order of the reference: w00 I00 + w01 I01 + w10 I10 + w11 I11
+    o[c] = ((w00 * src[o00 + c] + w01 * src[o01 + c]) + w10 * src[o10 + c]) + w11 * src[o11 + c];
+}
+
+// adjoint: g_src += scatter(g_out) (float atomics), g_coord overwritten (explicit [B,2,X,Y]; advect: g_vel = -g_coord)
+template <int KIND>
+__global__ void __launch_bounds__(256) warp2d_bwd_kernel(Warp2Args a, const float* __restrict__ g_out,
+                                                         float* __restrict__ g_src, float* __restrict__ g_coord) {
+  const int64_t n = (int64_t)a.X * a.Y;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * a.B) return;
+  const int b = (int)(gid / n);
+  const int64_t pix = gid - (int64_t)b * n;
+  const int y = (int)(pix % a.Y), x = (int)(pix / a.Y);
+  float cx, cy;
+  coords2_at<KIND>(a, b, x, y, pix, cx, cy);
+  const Axis ax = axis_setup(cx, a.X), ay = axis_setup(cy, a.Y);
+  const int64_t boff = (int64_t)b * n * a.C;
+  const float wx[2] = {1.f - ax.w1, ax.w1}, wy[2] = {1.f - ay.w1, ay.w1};
+  const int ix[2] = {ax.i0, ax.i1}, iy[2] = {ay.i0, ay.i1};
+  const float* go = g_out + gid * a.C;
+  float gx = 0.f, gy = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    const float g = go[c];
+    float v[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t o = boff + ((int64_t)ix[p] * a.Y + iy[q]) * a.C + c;
+        if (g_src) {
+          const float contrib = wx[p] * wy[q] * g;
+          if (contrib != 0.f) atomicAdd(g_src + o, contrib);
+        }
+        if (g_coord) v[p][q] = a.src[o];
+      }
+    if (g_coord) {
+      gx += g * (wy[0] * (v[1][0] - v[0][0]) + wy[1] * (v[1][1] - v[0][1]));
+      gy += g * (wx[0] * (v[0][1] - v[0][0]) + wx[1] * (v[1][1] - v[1][0]));
+    }
+  }
+  if (g_coord) {
+    gx *= (float)(a.X - 1) * 0.5f;
+    gy *= (float)(a.Y - 1) * 0.5f;
+    if (KIND == C2_ADVECT) {
+      g_coord[pix * 2] = -gx;
+      g_coord[pix * 2 + 1] = -gy;
+    } else {
+      float* gc = g_coord + (int64_t)b * 2 * n;
+      gc[pix] = gx;
+      gc[n + pix] = gy;
+    }
+  }
+}
+
+// ---- MacCormack (order 2), 2-D (D == 1) and 3-D ------------------------------------------------------------------
+//   d_fwd = advect(d, v)                         (given: nfs_advect_fwd / nfs_advect2d_fwd)
+//   d_bwd = advect(d_fwd, -v)                    (grids_ = mgrid + vel)
+//   d_adv = d_fwd + (d - d_bwd) / 2
+//   limiter: d_min / d_max = extrema of d over the corners of the back-traced interpolation stencil (what the
+//   reference's 2x2(x2) max-pool sampled at the back-traced cell means); where d_adv leaves [d_min, d_max] the
+//   first-order value d_fwd is kept ("soft clamp", transform.py:578-582 / 604-607).
+__global__ void __launch_bounds__(256) maccormack_kernel(const float* __restrict__ d, const float* __restrict__ vel,
+                                                         const float* __restrict__ d_fwd, float* __restrict__ out,
+                                                         int D, int H, int W, int C, int nd) {
+  const int64_t n = (int64_t)D * H * W;
+  const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= n) return;
+  const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)(vox / ((int64_t)W * H));
+  const float* v = vel + vox * nd;
+  const float vz = nd == 3 ? v[0] : 0.f, vy = v[nd - 2], vx = v[nd - 1];
+  const float gz = lin_coord(z, D), gy = lin_coord(y, H), gx = lin_coord(x, W);
+  Tri tb, tf;
+  Axis az, ay, ax;
+  tri_setup(gz - vz, gy - vy, gx - vx, D, H, W, tb, az, ay, ax);     // back-trace (stencil of d_fwd; the limiter's cell)
+  tri_setup(gz + vz, gy + vy, gx + vx, D, H, W, tf, az, ay, ax);     // forward trace of d_fwd
+  for (int c = 0; c < C; ++c) {
+    float lo = d[tb.o[0] * C + c], hi = lo, bwd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dv = d[tb.o[k] * C + c];
+      lo = fminf(lo, dv);
+      hi = fmaxf(hi, dv);
+      bwd += tf.w[k] * d_fwd[tf.o[k] * C + c];
+    }
+    const float f = d_fwd[vox * C + c];
+    const float adv = f + (d[vox * C + c] - bwd) * 0.5f;
+    out[vox * C + c] = (adv > hi || lo > adv) ? f : adv;
+  }
+}
+
+// ---- curl of a stream function (forward differences, last slice replicated; transform.py:517-555) ------------------
+// 2-D: s [H,W] -> [H,W,2]: u = ds/dy (axis 0), v = -ds/dx (axis 1).  3-D: s [D,H,W,3] -> [D,H,W,3]:
+//   u = dw/dy - dv/dz, v = du/dz - dw/dx, w = dv/dx - du/dy   with x = axis W, y = axis H, z = axis D.
+__device__ __forceinline__ int fd_lo(int i, int n) { return i < n - 1 ? i : (n >= 2 ? n - 2 : 0); }
+
+__global__ void __launch_bounds__(256) curl_fwd_kernel(const float* __restrict__ s, float* __restrict__ out, int D, int H,
+                                                       int W, int nd) {
+  const int64_t n = (int64_t)D * H * W;
+  const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= n) return;
+  const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)(vox / ((int64_t)W * H));
+  const int xl = fd_lo(x, W), yl = fd_lo(y, H), zl = fd_lo(z, D);
+  const int dxs = W >= 2, dys = H >= 2, dzs = D >= 2;
+  if (nd == 2) {
+    // u = s[y+1,x] - s[y,x] at row yl;  v = s[y,x] - s[y,x+1] at column xl
+    const float u = dys ? s[(int64_t)(yl + 1) * W + x] - s[(int64_t)yl * W + x] : 0.f;
+    const float v = dxs ? s[(int64_t)y * W + xl] - s[(int64_t)y * W + xl + 1] : 0.f;
+    out[vox * 2] = u;
+    out[vox * 2 + 1] = v;
+    return;
+  }
+  auto at = [&](int zz, int yy, int xx, int c) { return s[(((int64_t)zz * H + yy) * W + xx) * 3 + c]; };
+  const float dvdx = dxs ? at(z, y, xl + 1, 1) - at(z, y, xl, 1) : 0.f, dwdx = dxs ? at(z, y, xl + 1, 2) - at(z, y, xl, 2) : 0.f;
+  const float dudy = dys ? at(z, yl + 1, x, 0) - at(z, yl, x, 0) : 0.f, dwdy = dys ? at(z, yl + 1, x, 2) - at(z, yl, x, 2) : 0.f;
+  const float dudz = dzs ? at(zl + 1, y, x, 0) - at(zl, y, x, 0) : 0.f, dvdz = dzs ? at(zl + 1, y, x, 1) - at(zl, y, x, 1) : 0.f;
+  out[vox * 3] = dwdy - dvdz;
+  out[vox * 3 + 1] = dudz - dwdx;
+  out[vox * 3 + 2] = dvdx - dudy;
+}
+
+// adjoint: g_s = curl^T g.  A forward difference taken at cell l = fd_lo(i) contributes +g to s[l+1] and -g to s[l];
+// cell i receives from the outputs whose l equals i (outputs i, and n-1 as well when i == n-2) and whose l+1 equals i.
+// Written as a gather over the (at most three) contributing outputs per axis: no atomics, deterministic.
+__device__ __forceinline__ float fd_adj(const float* __restrict__ g, int64_t base, int64_t stride, int i, int n, int ch,
+                                        int nch) {
+  // sum over outputs o along this axis: coefficient of s[i] in (s[lo(o)+1] - s[lo(o)])
+  if (n < 2) return 0.f;
+  float r = 0.f;
+  if (i >= 1) {                       // s[i] is the upper sample of outputs with lo == i-1
+    r += g[(base + (int64_t)(i - 1) * stride) * nch + ch];
+    if (i == n - 1) r += g[(base + (int64_t)(n - 1) * stride) * nch + ch];   // replicated last slice (lo = n-2)
+  }
+  if (i <= n - 2) {                   // s[i] is the lower sample of outputs with lo == i
+    r -= g[(base + (int64_t)i * stride) * nch + ch];
+    if (i == n - 2) r -= g[(base + (int64_t)(n - 1) * stride) * nch + ch];
+  }
+  return r;
+}
+
+__global__ void __launch_bounds__(256) curl_bwd_kernel(const float* __restrict__ g, float* __restrict__ gs, int D, int H,
+                                                       int W, int nd) {
+  const int64_t n = (int64_t)D * H * W;
+  const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= n) return;
+  const int x = (int)(vox % W), y = (int)((vox / W) % H), z = (int)(vox / ((int64_t)W * H));
+  const int64_t bx = (int64_t)z * H * W + (int64_t)y * W;     // base with x = 0, stride 1
+  const int64_t by = (int64_t)z * H * W + x;                  // base with y = 0, stride W
+  const int64_t bz = (int64_t)y * W + x;                      // base with z = 0, stride H*W
+  if (nd == 2) {
+    // u = +d/dy s, v = -d/dx s
+    gs[vox] = fd_adj(g, by, W, y, H, 0, 2) - fd_adj(g, bx, 1, x, W, 1, 2);
+    return;
+  }
+  // u = dw/dy - dv/dz ; v = du/dz - dw/dx ; w = dv/dx - du/dy      (channels of s: 0 = u-, 1 = v-, 2 = w-potential)
+  // d/ds0: +d/dz (into v) - d/dy (into w);  d/ds1: -d/dz (into u) + d/dx (into w);  d/ds2: +d/dy (into u) - d/dx (into v)
+  gs[vox * 3] = fd_adj(g, bz, (int64_t)H * W, z, D, 1, 3) - fd_adj(g, by, W, y, H, 2, 3);
+  gs[vox * 3 + 1] = fd_adj(g, bx, 1, x, W, 2, 3) - fd_adj(g, bz, (int64_t)H * W, z, D, 0, 3);
+  gs[vox * 3 + 2] = fd_adj(g, by, W, y, H, 0, 3) - fd_adj(g, bx, 1, x, W, 1, 3);
+}
+
+static int check_dims2(int B, int X, int Y, int C) {
+  NFS_REQUIRE(B > 0 && X > 0 && Y > 0 && C > 0, "warp2d: non-positive dimension");
+  NFS_REQUIRE((int64_t)B * X * Y * C < (int64_t)1 << 40, "warp2d: tensor too large");
+  return NFS_OK;
+}
+
+}  // namespace nfs
+
+using namespace nfs;
+
+extern "C" {
+
+int nfs_warp2d_fwd(const float* imgs, const float* coords, float* out, int B, int X, int Y, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(imgs && coords && out, "nfs_warp2d_fwd: null pointer");
+  if (int e = check_dims2(B, X, Y, C)) return e;
+  Warp2Args a{imgs, coords, B, X, Y, C};
+  hipLaunchKernelGGL(warp2d_fwd_kernel<C2_EXPLICIT>, dim3(blocks_for((int64_t)B * X * Y, 256)), dim3(256), 0,
+                     as_stream(stream), a, out);
+  return check_launch("nfs_warp2d_fwd");
+}
+
+int nfs_warp2d_bwd(const float* imgs, const float* coords, const float* g_out, float* g_imgs_acc, float* g_coords, int B,
+                   int X, int Y, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(coords && g_out, "nfs_warp2d_bwd: null pointer");
+  NFS_REQUIRE(!g_coords || imgs, "nfs_warp2d_bwd: g_coords needs imgs");
+  NFS_REQUIRE(g_imgs_acc || g_coords, "nfs_warp2d_bwd: nothing to compute");
+  if (int e = check_dims2(B, X, Y, C)) return e;
+  Warp2Args a{imgs, coords, B, X, Y, C};
+  hipLaunchKernelGGL(warp2d_bwd_kernel<C2_EXPLICIT>, dim3(blocks_for((int64_t)B * X * Y, 256)), dim3(256), 0,
+                     as_stream(stream), a, g_out, g_imgs_acc, g_coords);
+  return check_launch("nfs_warp2d_bwd");
+}
+
+int nfs_advect2d_fwd(const float* d, const float* vel, float* out, int H, int W, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && out, "nfs_advect2d_fwd: null pointer");
+  if (int e = check_dims2(1, H, W, C)) return e;
+  Warp2Args a{d, vel, 1, H, W, C};
+  hipLaunchKernelGGL(warp2d_fwd_kernel<C2_ADVECT>, dim3(blocks_for((int64_t)H * W, 256)), dim3(256), 0, as_stream(stream),
+                     a, out);
+  return check_launch("nfs_advect2d_fwd");
+}
+
+int nfs_advect2d_bwd(const float* d, const float* vel, const float* g_out, float* g_d_acc, float* g_vel, int H, int W,
+                     int C, nfs_stream_t stream) {
+  NFS_REQUIRE(vel && g_out, "nfs_advect2d_bwd: null pointer");
+  NFS_REQUIRE(!g_vel || d, "nfs_advect2d_bwd: g_vel needs d");
+  NFS_REQUIRE(g_d_acc || g_vel, "nfs_advect2d_bwd: nothing to compute");
+  if (int e = check_dims2(1, H, W, C)) return e;
+  Warp2Args a{d, vel, 1, H, W, C};
+  hipLaunchKernelGGL(warp2d_bwd_kernel<C2_ADVECT>, dim3(blocks_for((int64_t)H * W, 256)), dim3(256), 0, as_stream(stream),
+                     a, g_out, g_d_acc, g_vel);
+  return check_launch("nfs_advect2d_bwd");
+}
+
+int nfs_advect_maccormack(const float* d, const float* vel, const float* d_fwd, float* out, int D, int H, int W, int C,
+                          int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && d_fwd && out, "nfs_advect_maccormack: null pointer");
+  NFS_REQUIRE(nd == 2 || nd == 3, "nfs_advect_maccormack: nd must be 2 or 3");
+  NFS_REQUIRE(nd == 3 || D == 1, "nfs_advect_maccormack: a 2-D field has D == 1");
+  NFS_REQUIRE(out != d_fwd && out != d, "nfs_advect_maccormack: out must not alias d or d_fwd");
+  if (int e = check_dims2(D, H, W, C)) return e;
+  hipLaunchKernelGGL(maccormack_kernel, dim3(blocks_for((int64_t)D * H * W, 256)), dim3(256), 0, as_stream(stream), d, vel,
+                     d_fwd, out, D, H, W, C, nd);
+  return check_launch("nfs_advect_maccormack");
+}
+
+int nfs_curl_fwd(const float* s, float* out, int D, int H, int W, int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(s && out, "nfs_curl_fwd: null pointer");
+  NFS_REQUIRE(nd == 2 || nd == 3, "nfs_curl_fwd: nd must be 2 or 3");
+  NFS_REQUIRE(nd == 3 || D == 1, "nfs_curl_fwd: a 2-D stream function has D == 1");
+  if (int e = check_dims2(D, H, W, 1)) return e;
+  hipLaunchKernelGGL(curl_fwd_kernel, dim3(blocks_for((int64_t)D * H * W, 256)), dim3(256), 0, as_stream(stream), s, out, D,
+                     H, W, nd);
+  return check_launch("nfs_curl_fwd");
+}
+
+int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(g_out && g_s, "nfs_curl_bwd: null pointer");
+  NFS_REQUIRE(nd == 2 || nd == 3, "nfs_curl_bwd: nd must be 2 or 3");
+  NFS_REQUIRE(nd == 3 || D == 1, "nfs_curl_bwd: a 2-D stream function has D == 1");
+  if (int e = check_dims2(D, H, W, 1)) return e;
+  hipLaunchKernelGGL(curl_bwd_kernel, dim3(blocks_for((int64_t)D * H * W, 256)), dim3(256), 0, as_stream(stream), g_out,
+                     g_s, D, H, W, nd);
+  return check_launch("nfs_curl_bwd");
+}
+
+}  // extern "C"

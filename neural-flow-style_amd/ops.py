@@ -114,6 +114,77 @@ def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8)
               float(beta1), float(beta2), float(eps), _stream())
 
 
+def warp2d_fwd(imgs, coords):
+    """imgs [B,X,Y,C], coords [B,2,X,Y] -> [B,X,Y,C]  (transform.py:206-236, 280-341)"""
+    B, X, Y, Cn = imgs.shape
+    out = _empty(imgs.shape, imgs)
+    _lib.call("nfs_warp2d_fwd", _ptr(imgs), _ptr(coords), _ptr(out), B, X, Y, Cn, _stream())
+    return out
+
+
+def warp2d_bwd(imgs, coords, g_out, need_imgs=True, need_coords=True):
+    B, X, Y, Cn = imgs.shape
+    g_imgs = _zeros(imgs.shape, imgs) if need_imgs else None
+    g_coords = _empty(coords.shape, imgs) if need_coords else None
+    _lib.call("nfs_warp2d_bwd", _ptr(imgs), _ptr(coords), _ptr(g_out), _ptr(g_imgs), _ptr(g_coords), B, X, Y, Cn,
+              _stream())
+    return g_imgs, g_coords
+
+
+def advect2d_fwd(d, vel):
+    """d [H,W,C], vel [H,W,2] -> [H,W,C]  (transform.py:583-588)"""
+    H, W, Cn = d.shape
+    out = _empty(d.shape, d)
+    _lib.call("nfs_advect2d_fwd", _ptr(d), _ptr(vel), _ptr(out), H, W, Cn, _stream())
+    return out
+
+
+def advect2d_bwd(d, vel, g_out, need_d=True, need_vel=True):
+    H, W, Cn = d.shape
+    g_d = _zeros(d.shape, d) if need_d else None
+    g_vel = _empty(vel.shape, d) if need_vel else None
+    _lib.call("nfs_advect2d_bwd", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(g_d), _ptr(g_vel), H, W, Cn, _stream())
+    return g_d, g_vel
+
+
+def advect_maccormack(d, vel):
+    """order-2 (MacCormack) advection with the extrema limiter (transform.py:570-582, 590-607 as intended);
+    d [D,H,W,C] + vel [D,H,W,3], or d [H,W,C] + vel [H,W,2].  Forward only."""
+    nd = vel.shape[-1]
+    if nd == 3:
+        D, H, W, Cn = d.shape
+        d_fwd = advect_fwd(d, vel)
+    else:
+        (H, W, Cn), D = d.shape, 1
+        d_fwd = advect2d_fwd(d, vel)
+    out = _empty(d.shape, d)
+    _lib.call("nfs_advect_maccormack", _ptr(d), _ptr(vel), _ptr(d_fwd), _ptr(out), D, H, W, Cn, nd, _stream())
+    return out
+
+
+def curl_fwd(s):
+    """s [H,W] -> [H,W,2] or s [D,H,W,3] -> [D,H,W,3]  (transform.py:517-555)"""
+    if s.dim() == 2:
+        (H, W), D, nd = s.shape, 1, 2
+        out = _empty((H, W, 2), s)
+    else:
+        (D, H, W, _), nd = s.shape, 3
+        out = _empty(s.shape, s)
+    _lib.call("nfs_curl_fwd", _ptr(s), _ptr(out), D, H, W, nd, _stream())
+    return out
+
+
+def curl_bwd(g_out):
+    if g_out.shape[-1] == 2:
+        (H, W, _), D, nd = g_out.shape, 1, 2
+        g_s = _empty((H, W), g_out)
+    else:
+        (D, H, W, _), nd = g_out.shape, 3
+        g_s = _empty(g_out.shape, g_out)
+    _lib.call("nfs_curl_bwd", _ptr(g_out), _ptr(g_s), D, H, W, nd, _stream())
+    return g_s
+
+
 def transport_step(g, u, scale=1.0, w_g=1.0, addend=None, w_addend=0.0, out=None):
     """out = w_g*advect(g, scale*u) + w_addend*addend: one frame crossing of ``_transport`` (styler_base.py:59-89) for the
     C-channel field g [D,H,W,C] with the temporal filter's accumulation fused in"""

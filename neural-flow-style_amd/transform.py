@@ -212,13 +212,69 @@ class _Advect(torch.autograd.Function):
         return (None if gd is None else gd.unsqueeze(0)), (None if gv is None else gv.unsqueeze(0))
 
 
-def advect(d, vel, order=1, is_3d=True):
-    """semi-Lagrangian step d(x - v) (transform.py:557-569).  order 2 (MacCormack) is
-    broken in the reference (570-582) and not provided."""
-    if order != 1 or not is_3d:
-        raise NotImplementedError("only the 3-D order-1 branch of the reference is functional")
+class _Advect2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, vel):
+        d = d.contiguous(); vel = vel.contiguous()
+        ctx.save_for_backward(d, vel)
+        return ops.advect2d_fwd(d[0], vel[0]).unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        d, vel = ctx.saved_tensors
+        gd, gv = ops.advect2d_bwd(d[0], vel[0], g.contiguous()[0], need_d=ctx.needs_input_grad[0],
+                                  need_vel=ctx.needs_input_grad[1])
+        return (None if gd is None else gd.unsqueeze(0)), (None if gv is None else gv.unsqueeze(0))
+
+
+def advect(d, vel, order=1, is_3d=False):
+    """semi-Lagrangian step d(x - v) (transform.py:557-609): 3-D d [1,D,H,W,C] + vel [1,D,H,W,3], or 2-D d [1,H,W,C]
+    + vel [1,H,W,2] (``is_3d=False``, the reference's default).  order 1 is differentiable in d and vel; order 2 is
+    the MacCormack scheme with its extrema limiter done as intended (the reference's limiter lines do not run,
+    transform.py:577,598-601), forward only."""
     assert d.shape[0] == 1
-    return _Advect.apply(d, vel)
+    is_3d = bool(is_3d) or d.dim() == 5
+    if order == 1:
+        return _Advect.apply(d, vel) if is_3d else _Advect2d.apply(d, vel)
+    return ops.advect_maccormack(d.detach()[0].contiguous(), vel.detach()[0].contiguous()).unsqueeze(0)
+
+
+class _Warp2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, imgs, coords):
+        imgs = imgs.contiguous(); coords = coords.contiguous()
+        ctx.save_for_backward(imgs, coords)
+        return ops.warp2d_fwd(imgs, coords)
+
+    @staticmethod
+    def backward(ctx, g):
+        imgs, coords = ctx.saved_tensors
+        gi, gc = ops.warp2d_bwd(imgs, coords, g.contiguous(), need_imgs=ctx.needs_input_grad[0],
+                                need_coords=ctx.needs_input_grad[1])
+        return gi, gc
+
+
+def batch_warp2d(imgs, mappings, sample_shape=None):
+    """imgs [B,X,Y,C], mappings [B,2,X,Y] -> [B,X,Y,C]   (transform.py:206-236)"""
+    return _Warp2d.apply(imgs, mappings)
+
+
+class _Curl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s):
+        return ops.curl_fwd(s.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.curl_bwd(g.contiguous())
+
+
+def curl(s, is_2d=True):
+    """velocity of a stream function (transform.py:517-555): 2-D s [B,H,W,1] -> [B,H,W,2] = (ds/dy, -ds/dx);
+    3-D s [B,D,H,W,3] -> [B,D,H,W,3].  Differentiable (the TNST parametrisation optimises s)."""
+    if is_2d:
+        return torch.stack([_Curl.apply(s[b, ..., 0]) for b in range(s.shape[0])])
+    return torch.stack([_Curl.apply(s[b]) for b in range(s.shape[0])])
 
 
 class _P2G(torch.autograd.Function):

@@ -173,6 +173,72 @@ def advect2d(d, vel):
     return batch_warp2d(d, g, [1, H, W])
 
 
+def _stencil_extrema(d, coords):
+    """min / max of d over the (clipped) corners of the interpolation cell of each coordinate -- what the reference's
+    2x2(x2) max-pool of d sampled at the back-traced cell stands for (transform.py:574-579, 594-601).
+    d [1,*dims,C], coords [1,nd,*dims] normalised."""
+    dims = d.shape[1:-1]
+    nd = len(dims)
+    idx = []
+    for k in range(nd):
+        x = (coords[0, k] + 1.0) * (dims[k] - 1.0) * 0.5
+        x0 = torch.floor(x).long()
+        idx.append((x0.clamp(0, dims[k] - 1), (x0 + 1).clamp(0, dims[k] - 1)))
+    lo = hi = None
+    import itertools
+    for corner in itertools.product((0, 1), repeat=nd):
+        v = d[0][tuple(idx[k][corner[k]] for k in range(nd))]
+        lo = v if lo is None else torch.minimum(lo, v)
+        hi = v if hi is None else torch.maximum(hi, v)
+    return lo[None], hi[None]
+
+
+def advect_maccormack(d, vel):
+    """advect order 2 (transform.py:570-582 3-D, 590-607 2-D), the scheme those lines transcribe with the limiter done
+    as intended (the reference's own limiter cannot run: tf.to_int32 of [-1,1] coordinates, ``d_max[grids]``):
+    d_fwd = SL(d, v); d_bwd = SL(d_fwd, -v) (grids_ = mgrid + vel); d_adv = d_fwd + (d - d_bwd)/2; soft clamp: where
+    d_adv > max or < min of d over the back-traced cell's corners, keep d_fwd."""
+    is_3d = d.dim() == 5
+    if is_3d:
+        _, D, H, W, _ = d.shape
+        g = mgrid(D, H, W, dtype=d.dtype).unsqueeze(0)
+        vp = vel.permute(0, 4, 1, 2, 3)
+        d_fwd = batch_warp3d(d, g - vp, [1, D, H, W])
+        d_bwd = batch_warp3d(d_fwd, g + vp, [1, D, H, W])
+    else:
+        _, H, W, _ = d.shape
+        g = mgrid(H, W, dtype=d.dtype).unsqueeze(0)
+        vp = vel.permute(0, 3, 1, 2)
+        d_fwd = batch_warp2d(d, g - vp, [1, H, W])
+        d_bwd = batch_warp2d(d_fwd, g + vp, [1, H, W])
+    d_adv = d_fwd + (d - d_bwd) * 0.5
+    lo, hi = _stencil_extrema(d, g - vp)
+    return torch.where((d_adv > hi) | (lo > d_adv), d_fwd, d_adv)
+
+
+def curl(s, is_2d=True):
+    """transform.py:517-555, line by line (forward differences, last slice repeated)."""
+    if is_2d:
+        u = s[:, 1:, :, 0] - s[:, :-1, :, 0]
+        v = s[:, :, :-1, 0] - s[:, :, 1:, 0]
+        u = torch.cat([u, u[:, -1:, :]], dim=1)
+        v = torch.cat([v, v[:, :, -1:]], dim=2)
+        return torch.stack([u, v], dim=-1)
+    dvdx = s[:, :, :, 1:, 1] - s[:, :, :, :-1, 1]
+    dwdx = s[:, :, :, 1:, 2] - s[:, :, :, :-1, 2]
+    dudy = s[:, :, 1:, :, 0] - s[:, :, :-1, :, 0]
+    dwdy = s[:, :, 1:, :, 2] - s[:, :, :-1, :, 2]
+    dudz = s[:, 1:, :, :, 0] - s[:, :-1, :, :, 0]
+    dvdz = s[:, 1:, :, :, 1] - s[:, :-1, :, :, 1]
+    dvdx = torch.cat((dvdx, dvdx[:, :, :, -1:]), dim=3)
+    dwdx = torch.cat((dwdx, dwdx[:, :, :, -1:]), dim=3)
+    dudy = torch.cat((dudy, dudy[:, :, -1:, :]), dim=2)
+    dwdy = torch.cat((dwdy, dwdy[:, :, -1:, :]), dim=2)
+    dudz = torch.cat((dudz, dudz[:, -1:, :, :]), dim=1)
+    dvdz = torch.cat((dvdz, dvdz[:, -1:, :, :]), dim=1)
+    return torch.stack([dwdy - dvdz, dudz - dwdx, dvdx - dudy], dim=-1)
+
+
 def transport(g, v, a, b, recursive=True):
     """StylerBase._transport_tf (styler_base.py:76-89): move field g from frame
     a to frame b through the per-frame velocities v[F,D,H,W,3]."""
