@@ -232,3 +232,48 @@ def test_gradient_parity_non_cubic_grid(dims):
     assert rel(gs.d_s, d_out[0, ..., 0]) < 1e-5
     assert rel(losses, torch.stack(per_view)) < 1e-4
     assert rel(g_h, g_o[0]) < 1e-3
+
+
+def test_gradient_parity_at_real_vgg_dynamic_range():
+    """f32 Winograd F(4x4,3x3) at the dynamic range of the REAL vgg_19 checkpoint (which cannot be loaded here):
+    conv1_1 filters of O(0.5) on 0..255 inputs and biases of O(1) give activations of O(10^2..10^3) through the net --
+    the seeded filters are rescaled to reach that range.  Reference = the oracle in float64 on the same float32
+    weights.  Error budget, stated: activations <= 2e-5 relative L2 per style layer (Winograd's interpolation points
+    0, +-1, +-2 amplify f32 rounding by ~10x over a direct f32 convolution), field gradient <= 2e-4 -- a factor 5
+    inside the 1e-3 bar of the metric."""
+    import neural_flow_style_amd.vgg as vgg
+    import neural_flow_style_amd.engine as eng
+    import neural_flow_style_amd.transform as T
+    G, V = 32, 2
+    layers = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
+    rng = np.random.RandomState(77)
+    d0 = blob_density(G, rng)
+    simg = style_image(G, G, rng)
+    mats = uniform_views(V)
+    w = vgg.synthetic_weights(123, upto="conv5_1")
+    w["conv1_1"] = ((w["conv1_1"][0] * 8.0).astype(np.float32), (w["conv1_1"][1] * 100.0).astype(np.float32))
+    for k in list(w)[1:]:
+        w[k] = (w[k][0], (w[k][1] * 100.0).astype(np.float32))           # biases of O(1)
+    net = vgg.VGG(w, "cuda")
+    # activations: HIP f32 vs oracle f64
+    dimg = torch.tensor(simg)[None]
+    fo = O.vgg19_features(dimg.double(), {k: (v[0].astype(np.float64), v[1].astype(np.float64)) for k, v in w.items()},
+                          "conv5_1")
+    mean = torch.tensor(O.VGG_MEAN, dtype=torch.float32)
+    acts = net.forward((dimg - mean).cuda().contiguous(), "conv5_1")
+    assert float(fo["conv1_1"].max()) > 500 and float(fo["conv3_1"].max()) > 200
+    for name in layers:
+        assert rel(acts[name], fo[name]) < 2e-5, name
+    # field gradient through render -> VGG -> Gram -> adjoints
+    loss = eng.RenderStyleLoss(net, layers, [1.0] * 5, 1.0, transmit=0.05)
+    loss.set_style_image(simg)
+    cfg = dict(k=3, transmit=0.05, style_layer=layers, w_style_layer=[1.0] * 5, w_style=1.0, upto="conv5_1")
+    w64 = {k: (v[0].astype(np.float64), v[1].astype(np.float64)) for k, v in w.items()}
+    sfe = O.style_target_features(dimg.double(), w64, layers, upto="conv5_1")
+    d_o = torch.tensor(d0, dtype=torch.float64)[None, ..., None].requires_grad_()
+    total, per_view, _ = O.grid_forward(d_o, None, torch.tensor(np.asarray(mats, np.float64)), cfg, w64, sfe)
+    (g_o,) = torch.autograd.grad(total, d_o)
+    gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="d")
+    losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
+    assert rel(losses, torch.stack(per_view).detach()) < 1e-4
+    assert rel(g_h, g_o[0, ..., 0]) < 2e-4
