@@ -44,6 +44,14 @@ int nfs_device_cus(void);
  * summed kernel time [ms], the summed executed MFMA flops (2*Z*T*K*N per launch) and the launch count, and
  * clears the record.  Disabled by default; no effect on results. */
 int nfs_gemm_timer(int enable);
+
+/* Arithmetic of the batched Winograd GEMMs (process-wide; returns the previous mode; any other value only queries):
+ *   0  float32-input MFMA (v_mfma_f32_32x32x2_f32), the default;
+ *   1  split-limb form: every float32 operand is written exactly as three bf16 limbs and the six leading limb
+ *      products run on v_mfma_f32_32x32x16_bf16 with float32 accumulation -- inputs, outputs and accumulation stay
+ *      float32, each product is carried to within 2^-26 (float32-equivalent accuracy, 2.67x the MFMA rate).
+ * NFS_GEMM_MODE presets it. */
+int nfs_gemm_mode(int mode);
 int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
 
 /* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------

@@ -580,3 +580,60 @@ def test_pooled_layer_without_full_resolution_output(ops):
     assert torch.equal(q0, q1)
     with pytest.raises(AssertionError):                           # neither the output nor the cache: refused by the binding
         ops.conv3x3_dgrad_pool(gp, None, wd, Ci, x_in=x, relu_bits=None, hw=(H, W))
+
+
+def test_split_limb_gemm_is_float32_accurate():
+    """The split-limb GEMM mode (nfs_gemm_mode(1): every float32 operand written exactly as three bf16 limbs, six limb
+    products on the bf16 MFMA, float32 accumulation) against a float64 convolution, next to the float32-input MFMA
+    (mode 0) on the same inputs: same accuracy class -- each product is carried to 2^-26, below float32's rounding unit.
+    Inputs span 10 orders of magnitude per tensor (the limb split must be exact at every scale)."""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(12)
+    B, H, W, Ci, Co = 2, 24, 20, 64, 128
+    x = (rng.randn(B, H, W, Ci) * np.exp(rng.uniform(-11, 11, (B, H, W, Ci)))).astype(np.float32)
+    x = np.maximum(x, 0)
+    w = (rng.randn(3, 3, Ci, Co) * 0.05 * np.exp(rng.uniform(-3, 3, (3, 3, Ci, Co)))).astype(np.float32)
+    b = rng.randn(Co).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.tensor(x).double().permute(0, 3, 1, 2),
+                                     torch.tensor(w).double().permute(3, 2, 0, 1), torch.tensor(b).double(),
+                                     padding=1).permute(0, 2, 3, 1)
+    scale = torch.nn.functional.conv2d(torch.tensor(x).double().abs().permute(0, 3, 1, 2),
+                                       torch.tensor(w).double().abs().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    xd, wd, bd = torch.tensor(x).cuda(), torch.tensor(w).cuda(), torch.tensor(b).cuda()
+    pk = ops.conv3x3_pack(wd, 0)
+    errs = {}
+    prev = ops.gemm_mode(None)
+    try:
+        for mode in (0, 1):
+            ops.gemm_mode(mode)
+            y = ops.conv3x3_fwd(xd, pk, bd, Co, relu=False).double().cpu()
+            # error relative to the magnitude of the terms summed (the natural scale of float32 rounding)
+            errs[mode] = float(((y - ref).abs() / (scale + 1e-300)).max())
+    finally:
+        ops.gemm_mode(prev)
+    # the error floor here is Winograd's, not the GEMM's: F(4x4)'s transforms mix pixels whose magnitudes differ by
+    # orders of magnitude in this input (measured 1.1e-4 for the float32-input MFMA); the point is that the split-limb
+    # arithmetic lands on the SAME floor
+    assert errs[0] < 5e-4 and errs[1] < 5e-4, errs
+    assert errs[1] < 1.5 * errs[0] + 1e-7, errs
+
+
+def test_gradient_chain_identical_in_both_gemm_modes():
+    """VGG forward + data-gradient chain with the Winograd GEMMs in split-limb mode vs float32-input MFMA mode: the
+    two float32-equivalent arithmetics agree to float32 rounding (1e-5), far inside the 1e-3 bar"""
+    from neural_flow_style_amd import ops, vgg
+    rng = np.random.RandomState(13)
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv4_1"), "cuda")
+    x = torch.tensor(rng.uniform(-120, 130, (2, 40, 40, 3)).astype(np.float32)).cuda()
+    out = {}
+    prev = ops.gemm_mode(None)
+    try:
+        for mode in (0, 1):
+            ops.gemm_mode(mode)
+            acts = net.forward(x, "conv4_1")
+            g_top = torch.ones_like(acts["conv4_1"]) * (acts["conv4_1"] > 0)
+            gx = net.backward(acts, {"conv4_1": g_top.contiguous()}, "conv4_1")
+            out[mode] = (acts["conv4_1"].clone(), gx.clone())
+    finally:
+        ops.gemm_mode(prev)
+    assert rel(out[1][0], out[0][0]) < 1e-5 and rel(out[1][1], out[0][1]) < 1e-5
