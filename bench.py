@@ -568,6 +568,24 @@ def main():
     if not args.no_sustained:
         out["sustained"] = dict(sustained(step_fn, barrier, units, device, world), unit=out["unit"])
 
+    # ---- the same workload with the Winograd GEMMs in split-limb arithmetic (float32-equivalent, see nfs_gemm_mode) -----
+    if gs is not None and mode == "views":
+        from neural_flow_style_amd import ops
+        prev = ops.gemm_mode(1)
+        try:
+            gs.use_graph = False
+            dts, lasts = time_steps(views_step, barrier, max(args.warmup, 2), args.steps, device, world)
+            out["split_limb_gemm"] = {
+                "value": args.steps / dts, "unit": "iters/s", "ms_per_step": 1e3 * dts / args.steps,
+                "final_loss": float(lasts),
+                "note": "NOT the headline: same step with nfs_gemm_mode(1) -- every float32 GEMM operand written exactly "
+                        "as three bf16 limbs, the six leading limb products on v_mfma_f32_32x32x16_bf16, float32 "
+                        "accumulation; inputs/outputs/accumulators float32, per-product error <= 2^-26 (parity tests: "
+                        "same error against float64 as the float32-input MFMA).  The headline `value` uses the "
+                        "float32-input MFMA."}
+        finally:
+            ops.gemm_mode(prev)
+
     # ---- per-kernel live measurement (extra profiled steps, after the headline timing) -----------
     if not args.no_kernel_profile and gs is not None:
         import ctypes

@@ -98,6 +98,15 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
                         int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
                         nfs_stream_t stream);
 
+/* ---- histogram loss (styler_base.py:187-209 + util.histogram_match_tf, util.py:317-399) -------------
+ * feat [B,HW,C] (a layer of the loss network, or d_img for hist_layer 'input'), templ [Bt,HWt,C] (the same layer of
+ * the style image; image b uses template min(b, Bt-1)).  Per (image, channel): 255-bin histogram matching of feat to
+ * templ over their joint range, matched values = bin centres; loss_acc[b] += weight * sum((feat - matched)^2) and
+ * g_acc (nullable) += 2 weight (feat - matched) [only where feat > 0 when relu_mask: gradient wrt the pre-activation
+ * of a post-ReLU layer].  `matched` is piecewise constant in feat (no gradient through it, as in the TF graph). */
+int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc,
+                  int B, int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream);
+
 /* ---- A2 (2-D twin): batch_warp2d / _interpolate2d (transform.py:206-236, 280-341) ---------------------------
  * imgs [B,X,Y,C], coords [B,2,X,Y] normalised [-1,1], out [B,X,Y,C]; border-replicating bilinear gather (the
  * reference's only known-answer vector, transform.py:1859-1885, pins this stencil).  bwd: g_imgs_acc (nullable) +=

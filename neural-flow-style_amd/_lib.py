@@ -74,6 +74,7 @@ SIGNATURES = {
     "nfs_style_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
+    "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "nfs_tv_loss": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "nfs_p2g_fwd": [_P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],
     "nfs_p2g_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],

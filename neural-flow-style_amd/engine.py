@@ -21,7 +21,7 @@ class RenderStyleLoss(object):
 
     def __init__(self, net, style_layer, w_style_layer, w_style=1.0, transmit=0.01, render_liquid=False,
                  resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1, w_content=0.0, content_layer=None,
-                 content_channel=0, w_content_amp=100.0):
+                 content_channel=0, w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=()):
         self.net = net
         self.layers = list(style_layer)
         self.w_layers = [float(w) for w in w_style_layer]
@@ -55,8 +55,57 @@ class RenderStyleLoss(object):
             kinds = dict((s[0], s[1]) for s in net.seq)
             if kinds.get(self.content_layer) != "conv":
                 raise KeyError("content_layer %r is not a conv layer of the loss network" % (self.content_layer,))
-        self.top = max(self.layers + ([self.content_layer] if self.content_layer else []), key=order.index)
+        # histogram term (styler_base.py:187-209): layers of the loss network and / or 'input' (= d_img)
+        self.w_hist = float(w_hist)
+        self.hist_layers = list(hist_layer) if self.w_hist else []
+        self.w_hist_layers = [float(w) for w in w_hist_layer] if self.w_hist else []
+        if len(self.w_hist_layers) == 1 and len(self.hist_layers) > 1:
+            self.w_hist_layers = self.w_hist_layers * len(self.hist_layers)
+        for name in self.hist_layers:
+            if "input" not in name and name not in order:
+                raise KeyError("hist_layer %r is not a layer of the loss network" % (name,))
+        self.hist_targets = None
+        vgg_hist = [n for n in self.hist_layers if "input" not in n]
+        self.top = max(self.layers + vgg_hist + ([self.content_layer] if self.content_layer else []), key=order.index)
         self.style_grams = None
+
+    def set_hist_image(self, style_img):
+        """template features of the histogram term: style_img float32 [h,w,3] in 0..255 at the loss-net input size
+        (styler_base.py:280-309: the style image fed at d_img, each hist layer fetched)"""
+        if not self.hist_layers:
+            self.hist_targets = None
+            return None
+        dev = self.net.device
+        s = torch.as_tensor(np.asarray(style_img, np.float32)).to(dev)
+        mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255], dtype=torch.float32, device=dev)
+        vgg_hist = [n for n in self.hist_layers if "input" not in n]
+        acts = {}
+        if vgg_hist:
+            order = [q[0] for q in self.net.seq]
+            acts = self.net.forward((s - mean).unsqueeze(0).contiguous(), max(vgg_hist, key=order.index))
+        self.hist_targets = {n: (s.unsqueeze(0).contiguous() if "input" in n else acts[n].clone())
+                             for n in self.hist_layers}
+        return self.hist_targets
+
+    def _hist_job(self, acts, sg, loss):
+        """histogram losses on layers of the loss network: per-view losses into ``loss``, gradients (ReLU-masked) into
+        the layers' entries of ``sg``"""
+        for name, wl in zip(self.hist_layers, self.w_hist_layers):
+            if "input" in name:
+                continue
+            assert self.hist_targets is not None, "call set_hist_image first"
+            F = acts[name]
+            g = sg.get(name)
+            if g is None:
+                g = sg[name] = torch.zeros_like(F)
+            ops.hist_loss(F, self.hist_targets[name], wl * self.w_hist, loss, g, relu_mask=True)
+
+    def _hist_input(self, dimg, loss, g_x):
+        """hist_layer 'input': the term on d_img itself (gradient wrt d_img = gradient wrt the mean-subtracted x)"""
+        for name, wl in zip(self.hist_layers, self.w_hist_layers):
+            if "input" in name:
+                assert self.hist_targets is not None, "call set_hist_image first"
+                ops.hist_loss(dimg, self.hist_targets[name], wl * self.w_hist, loss, g_x, relu_mask=False)
 
     def set_content_image(self, content_img):
         """content_img: float32 [h,w,3] in 0..255 at the loss-net input size, or None (styler_base.py:232-247)"""
@@ -144,6 +193,7 @@ class RenderStyleLoss(object):
             for name in self.layers:
                 sg[name] = self._gram_job(name, acts[name], loss, unmasked)
             self._content_job(acts, sg, loss)
+            self._hist_job(acts, sg, loss)
             return self.net.backward(acts, sg, self.top, unmasked=unmasked)
         main = torch.cuda.current_stream(x.device)
         if self._side is None:
@@ -175,12 +225,14 @@ class RenderStyleLoss(object):
         acts = self.net.forward(x, self.top, on_layer=on_layer, keep=self._keep())
         main.wait_stream(side)
         self._content_job(acts, sg, loss)
+        self._hist_job(acts, sg, loss)
         return self.net.backward(acts, sg, self.top, unmasked=unmasked)
 
     def _keep(self):
         """the activations the loss itself reads: the forward pass need not materialise the full-resolution output
         of a pooled layer that is not among them"""
-        return set(self.layers) | ({self.content_layer} if self.content_layer else set())
+        return (set(self.layers) | ({self.content_layer} if self.content_layer else set())
+                | set(n for n in getattr(self, "hist_layers", []) if "input" not in n))
 
     def _content_job(self, acts, sg, loss):
         """adds the content term's per-view losses into ``loss`` and its gradient into the layer's entry of ``sg``"""
@@ -206,9 +258,12 @@ class RenderStyleLoss(object):
         self.d_rot = None
         V = img.shape[0]
         H2, W2 = self.out_hw(H, W)
-        dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0)
+        hist_in = any("input" in n for n in self.hist_layers)
+        dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
         loss = torch.zeros(V, dtype=torch.float32, device=d.device)
         g_x = self._vgg_loss_grad(x, loss)
+        if hist_in:
+            self._hist_input(dimg, loss, g_x)
         if self.w_tv > 0:
             # the reference's batch mean runs over one loss-net batch (v_batch views, styler_base.py:211-213); with
             # all V local views in one batch the weight is rescaled so that the term is w_tv * sum_v TV_v / v_batch
@@ -512,7 +567,7 @@ class ImageStyleLoss(object):
 
     def __init__(self, net, style_layer, w_style_layer, w_style=1.0, w_tv=0.0, resize_scale=1.0,
                  style_mask=False, style_mask_on_ref=False, w_content=0.0, content_layer=None, content_channel=0,
-                 w_content_amp=100.0):
+                 w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=()):
         assert not style_mask_on_ref, "style_mask_on_ref is not used by any reference driver"
         self.net = net
         self.layers = list(style_layer)
@@ -529,11 +584,22 @@ class ImageStyleLoss(object):
         if self.content_layer is not None and dict((s[0], s[1]) for s in net.seq).get(self.content_layer) != "conv":
             raise KeyError("content_layer %r is not a conv layer of the loss network" % (self.content_layer,))
         self.v_batch = 1 << 30                      # the content means run over the whole image batch (one sess.run)
-        self.top = max(self.layers + ([self.content_layer] if self.content_layer else []), key=order.index)
+        self.w_hist = float(w_hist)
+        self.hist_layers = list(hist_layer) if self.w_hist else []
+        self.w_hist_layers = [float(w) for w in w_hist_layer] if self.w_hist else []
+        if len(self.w_hist_layers) == 1 and len(self.hist_layers) > 1:
+            self.w_hist_layers = self.w_hist_layers * len(self.hist_layers)
+        assert not (self.hist_layers and style_mask), "the masked histogram branch (styler_base.py:196-201) is not built"
+        self.hist_targets = None
+        vgg_hist = [n for n in self.hist_layers if "input" not in n]
+        self.top = max(self.layers + vgg_hist + ([self.content_layer] if self.content_layer else []), key=order.index)
         self.style_grams = None
 
     set_style_image = RenderStyleLoss.set_style_image
     set_content_image = RenderStyleLoss.set_content_image
+    set_hist_image = RenderStyleLoss.set_hist_image
+    _hist_job = RenderStyleLoss._hist_job
+    _hist_input = RenderStyleLoss._hist_input
     _content_job = RenderStyleLoss._content_job
     _keep = RenderStyleLoss._keep
     out_hw = RenderStyleLoss.out_hw
@@ -548,7 +614,8 @@ class ImageStyleLoss(object):
         """d [B,H,W,3]; d_gray [B,H,W,1] (mask, constant).  Returns (loss per image [B], dL/dd)."""
         B, H, W, _ = d.shape
         H2, W2 = self.out_hw(H, W)
-        dimg, x = ops.loss_net_input_fwd(d.contiguous(), H2, W2, want_d_img=self.w_tv > 0)
+        hist_in = any("input" in n for n in self.hist_layers)
+        dimg, x = ops.loss_net_input_fwd(d.contiguous(), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
         acts = self.net.forward(x, self.top, keep=self._keep())
         loss = torch.zeros(B, dtype=torch.float32, device=d.device)
         sg = {}
@@ -570,7 +637,10 @@ class ImageStyleLoss(object):
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
                 sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
         self._content_job(acts, sg, loss)
+        self._hist_job(acts, sg, loss)
         g_x = self.net.backward(acts, sg, self.top)
+        if hist_in:
+            self._hist_input(dimg, loss, g_x)
         if self.w_tv > 0:
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
             ops.tv_loss(dimg, self.w_tv, tv, g_x)

@@ -460,6 +460,19 @@ def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
     return g_acc
 
 
+def hist_loss(F, templ, weight, loss_acc, g_acc=None, relu_mask=False):
+    """histogram loss of F [B,h,w,C] against the template features templ [Bt,ht,wt,C] (styler_base.py:187-209,
+    util.py:317-399): loss_acc [B] += weight * sum((F - matched)^2); g_acc [B,h,w,C] += 2 weight (F - matched)"""
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    Bt = templ.shape[0]
+    HWt = templ.numel() // (Bt * Cn)
+    assert templ.shape[-1] == Cn
+    _lib.call("nfs_hist_loss", _ptr(F), _ptr(templ), _ptr(loss_acc), _ptr(g_acc), B, Bt, HW, HWt, Cn, float(weight),
+              int(bool(relu_mask)), _stream())
+    return g_acc
+
+
 def gram_bwd(F, Dmat, scale, scale_dev=None, relu_mask=True, out=None):
     B, Cn = F.shape[0], F.shape[-1]
     HW = F.numel() // (B * Cn)

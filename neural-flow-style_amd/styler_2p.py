@@ -33,7 +33,9 @@ class Styler(StylerBase):
                                           w_content=getattr(self, "w_content", 0),
                                           content_layer=getattr(self, "content_layer", None),
                                           content_channel=getattr(self, "content_channel", 0),
-                                          w_content_amp=getattr(self, "w_content_amp", 100))
+                                          w_content_amp=getattr(self, "w_content_amp", 100),
+                                          w_hist=getattr(self, "w_hist", 0), hist_layer=getattr(self, "hist_layer", ()),
+                                          w_hist_layer=getattr(self, "w_hist_layer", ()))
 
     def _dev(self, a):
         return torch.as_tensor(np.asarray(a, np.float32)).to(self.device).contiguous()
@@ -86,6 +88,8 @@ class Styler(StylerBase):
                 style_o = self._style_feature(self.style_img, res)
                 style_per_octave.append(np.asarray(style_o, np.float32))
                 self.loss.set_style_image(style_o)
+                if getattr(self, "w_hist", 0) > 0:               # styler_2p.py:220-225
+                    self.loss.set_hist_image(self._hist_feature(self.style_img, res))
             if self.content_img is not None:                     # styler_2p.py:209-211
                 self.loss.set_content_image(self._content_feature(self.content_img, res))
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr

@@ -185,6 +185,8 @@ class Styler(StylerBase):
             res = [int(v) for v in oct_size[octave]]
             if self.style_img is not None:
                 self.loss.set_style_image(self._style_feature(self.style_img, res[1:]))
+                if getattr(self, "w_hist", 0) > 0:                # styler_3p.py:288-293
+                    self.loss.set_hist_image(self._hist_feature(self.style_img, res[1:]))
             if self.content_img is not None:                     # styler_3p.py:277-279
                 self.loss.set_content_image(self._content_feature(self.content_img, res[1:]))
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr

@@ -5,8 +5,8 @@ Same attribute surface: every ``config`` attribute is copied onto the object
 (311-346); the loss terms of ``_loss`` that the BASELINE configurations use (style
 152-185, TV 211-213, pressure 228-230) are evaluated by ``engine.RenderStyleLoss`` on
 the HIP kernels, and so is the content term (135-150) on a layer of the same VGG network.
-The Inception-pb network and the histogram loss are out of scope (SURVEY.md section 2,
-rows 6 and 18) and raise.
+The histogram term (187-209, util.histogram_match_tf) runs on ``nfs_hist_loss``.  The Inception-pb network is out
+of scope (its weights are not available) and raises.
 """
 from __future__ import annotations
 
@@ -41,8 +41,6 @@ class StylerBase(object):
             raise NotImplementedError(
                 "network=%r: only the VGG loss network (vgg_19.ckpt) is on the MI355X hot path; the "
                 "Inception-v1 graph (tensorflow_inception_graph.pb) is out of scope" % self.network)
-        if getattr(self, "w_hist", 0):
-            raise NotImplementedError("histogram loss is out of scope (SURVEY.md section 2 row 6)")
         if getattr(self, "w_density", 0) and "d" not in getattr(self, "target_field", ""):
             raise NotImplementedError("the density-preservation loss acts on the particle-density variable "
                                       "(target_field 'd'), as in the reference (styler_3p.py:75)")
@@ -68,7 +66,16 @@ class StylerBase(object):
             render_liquid=self.render_liquid if render_liquid is None else render_liquid,
             resize_scale=self.resize_scale, rotate=rotate, w_tv=self.w_tv, v_batch=self.v_batch,
             w_content=getattr(self, "w_content", 0), content_layer=getattr(self, "content_layer", None),
-            content_channel=getattr(self, "content_channel", 0), w_content_amp=getattr(self, "w_content_amp", 100))
+            content_channel=getattr(self, "content_channel", 0), w_content_amp=getattr(self, "w_content_amp", 100),
+            w_hist=getattr(self, "w_hist", 0), hist_layer=getattr(self, "hist_layer", ()),
+            w_hist_layer=getattr(self, "w_hist_layer", ()))
+
+    # -- _hist_feature (styler_base.py:280-309): the style image at the loss-net input size -------------------------
+    def _hist_feature(self, style_target, style_shp=None):
+        """RGBA style images are premultiplied by alpha (283-286); the reference's further masking of the fetched
+        features by the resized alpha (299-303) multiplies the graph TENSOR, not the fetched array, i.e. has no effect
+        on what is returned -- as with _style_feature."""
+        return self._style_feature(style_target, style_shp)
 
     # -- _content_feature (styler_base.py:232-247): the content image at the loss-net input size -------------------
     def _content_feature(self, content_target, content_shp):

@@ -160,6 +160,8 @@ class Styler(StylerBase):
         st.shape = (D, H, W_, st.C)
         if self.style_img is not None:
             self.loss.set_style_image(self._style_feature(self.style_img, [H, W_]))
+            if getattr(self, "w_hist", 0) > 0:
+                self.loss.set_hist_image(self._hist_feature(self.style_img, [H, W_]))
         if self.content_img is not None:
             self.loss.set_content_image(self._content_feature(self.content_img, [H, W_]))
         st.lr = self.lr[0] if isinstance(self.lr, list) else self.lr

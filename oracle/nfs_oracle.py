@@ -520,6 +520,51 @@ def content_loss(feature, content_channel=0, content_feature=None, w_content_amp
 # A12  TV loss                                            styler_base.py:211-213
 # --------------------------------------------------------------------------
 
+def histogram_match(source, template, hist_bins=255):
+    """util.histogram_match_tf (util.py:317-399) for one channel, restated in NumPy float32 (the graph dtype):
+    255 fixed-width bins over [min, max] of source AND template (323-327); hist_range = bin centres
+    range(min, max, delta) + delta/2 (329-334); s_hist / t_hist = tf.histogram_fixed_width (337-347:
+    index = floor(nbins * (v - min) / (max - min)) clipped to nbins-1); quantiles = cumsum / total (352-356);
+    nearest_indices = round(interp1d(t_quantiles, arange(nbins), fill (0, nbins-1))(s_quantiles)) (358-362);
+    matched = hist_range[nearest_indices[clip(int((source - min) / delta), 0, nbins-1)]] (370-379).
+    Returns the matched array (same shape as source).  No gradient flows through it (py_func / integer casts /
+    tf.range): d loss / d source = 2 (source - matched)."""
+    from scipy.interpolate import interp1d
+    src = np.asarray(source, np.float32).reshape(-1)
+    tpl = np.asarray(template, np.float32).reshape(-1)
+    vmax = np.float32(max(src.max(), tpl.max()))
+    vmin = np.float32(min(src.min(), tpl.min()))
+    delta = np.float32((vmax - vmin) / np.float32(hist_bins))
+    hist_range = (vmin + delta * np.arange(hist_bins, dtype=np.float32)).astype(np.float32) + delta / np.float32(2)
+
+    def fixed_width(v):
+        scaled = (v - vmin) / (vmax - vmin)
+        idx = np.floor(np.float32(hist_bins) * scaled).astype(np.int64)
+        return np.bincount(np.clip(idx, 0, hist_bins - 1), minlength=hist_bins)
+
+    s_q = np.cumsum(fixed_width(src)).astype(np.float64); s_q /= s_q[-1]
+    t_q = np.cumsum(fixed_width(tpl)).astype(np.float64); t_q /= t_q[-1]
+    f = interp1d(t_q, np.arange(hist_bins), bounds_error=False, fill_value=(0, hist_bins - 1))
+    nearest = np.round(np.nan_to_num(f(s_q))).astype(np.int64)   # 0/0 at a flat start of the template CDF -> bin 0
+    s_bin = np.clip(((src - vmin) / delta).astype(np.int64), 0, hist_bins - 1)
+    return hist_range[nearest[s_bin]].reshape(np.shape(source))
+
+
+def hist_loss(feature, hist_feature):
+    """histogram term of _loss (styler_base.py:187-209, the non-mask branch as intended: the template is the fed
+    ``hist_feature`` of the same layer -- the mounted line 203 reads the stale ``style_feature`` of the style loop):
+    sum over images i < batch and channels j of sum((feature[i,...,j] - matched)^2) with
+    matched = histogram_match(feature[i,...,j], hist_feature[i,...,j]) held constant.  feature [B,h,w,C] torch tensor
+    (differentiable), hist_feature [Bt,ht,wt,C]."""
+    f = feature.detach().cpu().numpy()
+    t = np.asarray(hist_feature.detach().cpu().numpy() if torch.is_tensor(hist_feature) else hist_feature)
+    m = np.empty_like(f)
+    for i in range(f.shape[0]):
+        for j in range(f.shape[-1]):
+            m[i, ..., j] = histogram_match(f[i, ..., j], t[min(i, t.shape[0] - 1), ..., j])
+    return ((feature - torch.as_tensor(m, dtype=feature.dtype)) ** 2).sum()
+
+
 def tv_loss(d_img):
     """reduce_mean over batch of tf.image.total_variation: sum|dh| + sum|dw|."""
     dh = (d_img[:, 1:] - d_img[:, :-1]).abs().sum(dim=(1, 2, 3))
@@ -727,6 +772,11 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
             # one view per loss-net batch here (v_batch = 1): the content means are per view
             l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
                                                     cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
+        if cfg.get("w_hist", 0):
+            # histogram term (styler_base.py:187-209): 'input' = d_img, otherwise a layer of the loss network
+            for name, wl in zip(cfg["hist_layer"], cfg["w_hist_layer"]):
+                f = d_img if "input" in name else feats[name]
+                l = l + cfg["w_hist"] * wl * hist_loss(f, cfg["hist_feature"][name])
         per_view.append(l)
         total = total + l
     return total, per_view, d_out

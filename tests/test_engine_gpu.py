@@ -277,3 +277,32 @@ def test_gradient_parity_at_real_vgg_dynamic_range():
     losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
     assert rel(losses, torch.stack(per_view).detach()) < 1e-4
     assert rel(g_h, g_o[0, ..., 0]) < 2e-4
+
+
+def test_gradient_parity_with_histogram_loss():
+    """style + histogram terms (styler_base.py:187-209; hist layers 'input' and conv2_1) through the whole chain vs the
+    oracle.  The matching is a staircase in the feature values, so single pixels may sit on the other side of a bin
+    edge in float32: the gradient is held to 2e-2, the loss to 2e-3"""
+    G, V = 24, 2
+    layers = ["conv1_1", "conv2_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(G, V, layers)
+    import neural_flow_style_amd.vgg as vgg
+    rng = np.random.RandomState(4)
+    simg = style_image(G, G, rng)
+    net = loss.net
+    hl, hw = ["input", "conv2_1"], [1.0, 0.5]
+    loss2 = eng.RenderStyleLoss(net, layers, [1.0, 1.0], 1.0, transmit=0.05, w_hist=0.3, hist_layer=hl, w_hist_layer=hw)
+    loss2.set_style_image(simg)
+    targets = loss2.set_hist_image(simg)
+    feats_s = O.vgg19_features(torch.tensor(simg)[None], w_or, "conv2_1")
+    assert rel(targets["conv2_1"], feats_s["conv2_1"]) < 1e-5
+    sfe = O.style_target_features(torch.tensor(simg)[None], w_or, layers, upto="conv2_1")
+    cfg = dict(cfg, w_hist=0.3, hist_layer=hl, w_hist_layer=hw, upto="conv2_1",
+               hist_feature={"input": torch.tensor(simg)[None], "conv2_1": feats_s["conv2_1"]})
+    d_o = torch.tensor(d0)[None, ..., None].requires_grad_()
+    total, per_view, _ = O.grid_forward(d_o, None, torch.tensor(np.asarray(mats, np.float32)), cfg, w_or, sfe)
+    (g_o,) = torch.autograd.grad(total, d_o)
+    gs = eng.GridStylizer(loss2, torch.tensor(d0).cuda(), k=3, target="d")
+    losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
+    assert rel(losses, torch.stack(per_view).detach()) < 2e-3
+    assert rel(g_h, g_o[0, ..., 0]) < 2e-2

@@ -637,3 +637,28 @@ def test_gradient_chain_identical_in_both_gemm_modes():
     finally:
         ops.gemm_mode(prev)
     assert rel(out[1][0], out[0][0]) < 1e-5 and rel(out[1][1], out[0][1]) < 1e-5
+
+
+def test_hist_loss_matches_the_oracle_restatement():
+    """nfs_hist_loss vs oracle.hist_loss (util.histogram_match_tf restated in NumPy with SciPy's interp1d): loss and
+    gradient for a post-ReLU-like feature (many exact zeros) and for an image-like 'input' layer; the matching is a
+    staircase, so a value within float rounding of a bin edge may take the neighbouring step: a handful of elements"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(21)
+    for (B, h, w, C, Bt, ht, wt, relu) in ((2, 13, 11, 5, 1, 9, 14, True), (1, 20, 20, 3, 1, 20, 20, False)):
+        f = rng.gamma(2.0, 15.0, (B, h, w, C)).astype(np.float32)
+        t = (rng.rand(Bt, ht, wt, C) * 180 + rng.rand(1, 1, 1, C) * 40).astype(np.float32)
+        if relu:
+            f[rng.rand(*f.shape) < 0.3] = 0.0
+        ft = torch.tensor(f, requires_grad=True)
+        lo = O.hist_loss(ft, torch.tensor(t))
+        (go,) = torch.autograd.grad(lo * 0.7, ft)
+        if relu:
+            go = go * (ft.detach() > 0)
+        loss = torch.zeros(B, device="cuda")
+        g = torch.zeros(B, h, w, C, device="cuda")
+        ops.hist_loss(torch.tensor(f).cuda(), torch.tensor(t).cuda(), 0.7, loss, g, relu_mask=relu)
+        assert abs(float(loss.sum()) - 0.7 * float(lo)) < 2e-3 * 0.7 * float(lo)
+        d = (g.cpu() - go).abs()
+        assert float((d > 1e-3 * go.abs().max()).float().mean()) < 5e-3
+        assert rel(g.cpu(), go) < 3e-2
