@@ -23,6 +23,16 @@ def load_frames(config):
     raw = []
     for i in range(config.num_frames):
         path = os.path.join(config.data_dir, config.dataset, config.d_path % (config.target_frame + i))
+        bgeo = os.path.splitext(path)[0] + ".bgeo"
+        if path.endswith(".bgeo") or (not os.path.exists(path) and os.path.exists(bgeo)):
+            # the reference's own format (test_smokegun.py:41-56): partio particle file; particle j reads the
+            # position / density stored at index id[j]
+            import io_bgeo as partio
+            pt = partio.read(bgeo if not path.endswith(".bgeo") else path)
+            ids = pt.array("id")[:, 0]
+            raw.append((pt.array("position")[ids], pt.array("density")[ids]))
+            nmax = max(nmax, raw[-1][0].shape[0])
+            continue
         if not os.path.exists(path):
             return None
         z = np.load(path)

@@ -80,6 +80,15 @@ def run(config):
         np.savez_compressed(os.path.join(config.log_dir, "%03d.npz" % (config.target_frame + t)),
                             id=np.asarray(p_id, np.int64), position=p_, density=np.asarray(p_den, np.float32),
                             radius=np.float32(config.radius))
+        # ... and as the reference writes it (test_smokegun_resim.py:295-319): partio .bgeo with id, position, density,
+        # Cd (the first density channel three times) and radius
+        import io_bgeo as partio
+        pt = partio.from_arrays({"id": np.asarray(p_id, np.int32), "position": p_,
+                                 "density": np.asarray(p_den, np.float32),
+                                 "Cd": np.repeat(np.asarray(p_den, np.float32)[:, :1], 3, axis=1),
+                                 "radius": np.full((p_.shape[0], 1), config.radius, np.float32)},
+                                types={"density": partio.VECTOR if np.asarray(p_den).shape[1] > 1 else partio.FLOAT})
+        partio.write(os.path.join(config.log_dir, "%03d.bgeo" % (config.target_frame + t)), pt)
         # density preview, same transmittance render as the reference (326-331)
         transmit = np.exp(-np.cumsum(d_smp[::-1], axis=0) * config.transmit)
         d_img = np.sum(d_smp * transmit, axis=0)

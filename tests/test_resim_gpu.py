@@ -94,3 +94,10 @@ def test_resim_driver_writes_particle_sets_the_styler_driver_reads(tmp_path):
     params = test_smokegun.load_frames(cfg2)
     assert params is not None and params["p"][1].shape[1] == 3 and params["r"][1].shape[1] == 2
     assert float(params["p"][1].max()) <= 1.0
+    # ... and the partio .bgeo twins the reference itself exchanges (test_smokegun.py:41-56 reads id / position / density)
+    cfg2.d_path = "%03d.bgeo"
+    pb = test_smokegun.load_frames(cfg2)
+    assert pb is not None
+    for t in range(2):
+        assert np.allclose(np.sort(pb["p"][t], axis=0), np.sort(params["p"][t], axis=0), atol=1e-6)
+        assert np.allclose(np.sort(pb["r"][t], axis=0), np.sort(params["r"][t], axis=0), atol=1e-6)
