@@ -137,6 +137,19 @@ int nfs_advect_maccormack(const float* d, const float* vel, const float* d_fwd, 
 int nfs_curl_fwd(const float* s, float* out, int D, int H, int W, int nd, nfs_stream_t stream);
 int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nfs_stream_t stream);
 
+/* ---- Laplacian-pyramid gradient normalisation (util.py:57-110) -------------------------------------
+ * nfs_lap_down: out [ceil(D/2),ceil(H/2),ceil(W/2),C] = conv(x [D,H,W,C], k, stride 2, 'SAME') (tf.nn.conv3d / conv2d of
+ *   lap_split, 60-66); k = k5x5x5 [5][5][5] (nd = 3) or k5x5 [5][5] (nd = 2, D = 1), the same for every channel.
+ * nfs_lap_up: out [D,H,W,C] = scale * conv_transpose(lo, k, output shape [D,H,W], stride 2) + addend (nullable):
+ *   lo2 of lap_split (scale 5 in 3-D, 4 in 2-D, hi = img - lo2 via scale < 0) and the merge step (80-83).
+ * nfs_normalize_mean: out = x / max(m, eps), m = sqrt(mean(x^2)) (normalize_std, 86-90) or mean|x| (use_abs: the
+ *   scale_n = 0 branch, 97-99); workspace >= 64 floats; deterministic (fixed partial-sum order). */
+int nfs_lap_down(const float* x, const float* k, float* out, int D, int H, int W, int C, int nd, nfs_stream_t stream);
+int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend, float* out,
+               int D, int H, int W, int C, int nd, nfs_stream_t stream);
+int nfs_normalize_mean(const float* x, float* out, int64_t n, int use_abs, float eps, float* workspace, int ws_floats,
+                       nfs_stream_t stream);
+
 /* ---- A11': one step of StylerBase._transport (styler_base.py:59-89: g <- advect(g, +-v[i]) per frame crossed, or
  * advect(g, +-v[a]*|b-a|) in its one-step form) for a C-channel grid field, with the weighted accumulation of the
  * temporal filter (styler_3p.py:380-386 applied to grid fields, see styler_grid.py) fused in:

@@ -297,3 +297,160 @@ int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nf
 }
 
 }  // extern "C"
+
+// ---- Laplacian-pyramid gradient normalisation (util.py:57-110) -----------------------------------------
+// lap_split: lo = conv(img, k, stride 2, SAME); lo2 = conv_transpose(lo, k * s, shape(img), stride 2); hi = img - lo2
+// (s = 5 in 3-D, 4 in 2-D); lap_merge: img = conv_transpose(img, k * s, shape(hi)) + hi; every level is divided by its
+// RMS (normalize_std).  k is the 5-tap-per-axis kernel k5x5 / k5x5x5 (util.py:27-46), the same for every channel.
+// TF 'SAME' geometry for stride 2, window 5, input n: out = ceil(n / 2), pad_before = (max((out-1)*2 + 5 - n, 0)) / 2.
+namespace nfs {
+
+__device__ __forceinline__ int same_pad_before(int n) {
+  const int out = (n + 1) / 2;
+  const int total = (out - 1) * 2 + 5 - n;
+  return total > 0 ? total / 2 : 0;
+}
+
+// out [Do,Ho,Wo,C] = strided correlation of x [D,H,W,C] with k (zero padding).  2-D: D = Do = 1, k [5][5].
+__global__ void __launch_bounds__(256) lap_down_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                       float* __restrict__ out, int D, int H, int W, int C, int nd) {
+  const int Do = nd == 3 ? (D + 1) / 2 : 1, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)Do * Ho * Wo * C;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const int c = (int)(gid % C);
+  int64_t v = gid / C;
+  const int xo = (int)(v % Wo); v /= Wo;
+  const int yo = (int)(v % Ho);
+  const int zo = (int)(v / Ho);
+  const int pz = nd == 3 ? same_pad_before(D) : 0, py = same_pad_before(H), px = same_pad_before(W);
+  const int nz = nd == 3 ? 5 : 1;
+  float s = 0.f;
+  for (int a = 0; a < nz; ++a) {
+    const int z = nd == 3 ? 2 * zo + a - pz : 0;
+    if (z < 0 || z >= D) continue;
+    for (int b = 0; b < 5; ++b) {
+      const int y = 2 * yo + b - py;
+      if (y < 0 || y >= H) continue;
+      for (int e = 0; e < 5; ++e) {
+        const int xx = 2 * xo + e - px;
+        if (xx < 0 || xx >= W) continue;
+        s += k[(a * 5 + b) * 5 + e] * x[(((int64_t)z * H + y) * W + xx) * C + c];   // nd == 2: a == 0
+      }
+    }
+  }
+  out[gid] = s;
+}
+
+// out [D,H,W,C] = scale * conv_transpose(lo [Do,Ho,Wo,C], k) + addend (nullable): the adjoint of lap_down's geometry,
+// gathered per output element (taps of matching parity only: <= 3 per axis)
+__global__ void __launch_bounds__(256) lap_up_kernel(const float* __restrict__ lo, const float* __restrict__ k,
+                                                     const float* __restrict__ addend, float* __restrict__ out, int D,
+                                                     int H, int W, int C, int nd, float scale) {
+  const int Do = nd == 3 ? (D + 1) / 2 : 1, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)D * H * W * C;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const int c = (int)(gid % C);
+  int64_t v = gid / C;
+  const int x = (int)(v % W); v /= W;
+  const int y = (int)(v % H);
+  const int z = (int)(v / H);
+  const int pz = nd == 3 ? same_pad_before(D) : 0, py = same_pad_before(H), px = same_pad_before(W);
+  const int nz = nd == 3 ? 5 : 1;
+  float s = 0.f;
+  for (int a = 0; a < nz; ++a) {
+    int zo = 0;
+    if (nd == 3) {
+      const int tz = z + pz - a;                 // 2 zo = z + pz - a
+      if (tz < 0 || (tz & 1)) continue;
+      zo = tz >> 1;
+      if (zo >= Do) continue;
+    }
+    for (int b = 0; b < 5; ++b) {
+      const int ty = y + py - b;
+      if (ty < 0 || (ty & 1)) continue;
+      const int yo = ty >> 1;
+      if (yo >= Ho) continue;
+      for (int e = 0; e < 5; ++e) {
+        const int tx = x + px - e;
+        if (tx < 0 || (tx & 1)) continue;
+        const int xo = tx >> 1;
+        if (xo >= Wo) continue;
+        s += k[(a * 5 + b) * 5 + e] * lo[(((int64_t)zo * Ho + yo) * Wo + xo) * C + c];
+      }
+    }
+  }
+  s *= scale;
+  if (addend) s += addend[gid];
+  out[gid] = s;
+}
+
+// normalize_std / mean-abs normalisation: partial sums (fixed block order => deterministic) then scale
+__global__ void __launch_bounds__(256) norm_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part,
+                                                           int use_abs) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    s += use_abs ? fabsf(v) : v * v;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) norm_scale_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                         const float* __restrict__ part, int nparts, int use_abs,
+                                                         float eps) {
+  __shared__ float inv;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += (double)part[i];
+    const float m = use_abs ? (float)(t / (double)n) : sqrtf((float)(t / (double)n));
+    inv = 1.f / fmaxf(m, eps);
+  }
+  __syncthreads();
+  const float r = inv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = x[i] * r;
+}
+
+}  // namespace nfs
+
+extern "C" {
+
+int nfs_lap_down(const float* x, const float* k, float* out, int D, int H, int W, int C, int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(x && k && out, "nfs_lap_down: null pointer");
+  NFS_REQUIRE((nd == 2 && D == 1) || nd == 3, "nfs_lap_down: nd must be 2 (D == 1) or 3");
+  if (int e = check_dims2(D, H, W, C)) return e;
+  const int64_t n = (int64_t)(nd == 3 ? (D + 1) / 2 : 1) * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  hipLaunchKernelGGL(lap_down_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, k, out, D, H, W, C,
+                     nd);
+  return check_launch("nfs_lap_down");
+}
+
+int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend, float* out, int D, int H, int W, int C,
+               int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(lo && k && out, "nfs_lap_up: null pointer");
+  NFS_REQUIRE((nd == 2 && D == 1) || nd == 3, "nfs_lap_up: nd must be 2 (D == 1) or 3");
+  if (int e = check_dims2(D, H, W, C)) return e;
+  const int64_t n = (int64_t)D * H * W * C;
+  hipLaunchKernelGGL(lap_up_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W,
+                     C, nd, scale);
+  return check_launch("nfs_lap_up");
+}
+
+int nfs_normalize_mean(const float* x, float* out, int64_t n, int use_abs, float eps, float* workspace, int ws_floats,
+                       nfs_stream_t stream) {
+  NFS_REQUIRE(x && out && workspace, "nfs_normalize_mean: null pointer");
+  NFS_REQUIRE(n > 0 && ws_floats >= 64, "nfs_normalize_mean: n > 0 and a workspace of >= 64 floats are needed");
+  int parts = ws_floats < 1024 ? ws_floats : 1024;
+  const unsigned need = blocks_for(n, 256 * 8);
+  if ((unsigned)parts > need) parts = (int)need;
+  hipLaunchKernelGGL(norm_partial_kernel, dim3(parts), dim3(256), 0, as_stream(stream), x, n, workspace, use_abs);
+  hipLaunchKernelGGL(norm_scale_kernel, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, as_stream(stream), x, out, n, workspace,
+                     parts, use_abs, eps);
+  return check_launch("nfs_normalize_mean");
+}
+
+}  // extern "C"

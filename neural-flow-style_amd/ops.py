@@ -185,6 +185,34 @@ def curl_bwd(g_out):
     return g_s
 
 
+def lap_down(x, k):
+    """x [D,H,W,C] (3-D, k [5,5,5]) or [H,W,C] (2-D, k [5,5]) -> stride-2 'SAME' smoothing (util.py:60-66)"""
+    nd = 3 if x.dim() == 4 else 2
+    D, (H, W, Cn) = (x.shape[0] if nd == 3 else 1), x.shape[-3:]
+    shp = (((D + 1) // 2,) if nd == 3 else ()) + ((H + 1) // 2, (W + 1) // 2, Cn)
+    out = _empty(shp, x)
+    _lib.call("nfs_lap_down", _ptr(x), _ptr(k), _ptr(out), D, H, W, Cn, nd, _stream())
+    return out
+
+
+def lap_up(lo, k, out_shape, scale, addend=None):
+    """scale * conv_transpose(lo, k, out_shape, stride 2) + addend (util.py:62-65, 80-83)"""
+    nd = 3 if lo.dim() == 4 else 2
+    out = _empty(tuple(out_shape), lo)
+    D, (H, W, Cn) = (out_shape[0] if nd == 3 else 1), tuple(out_shape)[-3:]
+    _lib.call("nfs_lap_up", _ptr(lo), _ptr(k), float(scale), _ptr(addend), _ptr(out), D, H, W, Cn, nd, _stream())
+    return out
+
+
+def normalize_mean(x, use_abs=False, eps=1e-10):
+    """x / max(sqrt(mean(x^2)), eps)  (normalize_std, util.py:86-90)  or  x / max(mean|x|, eps)"""
+    out = _empty(x.shape, x)
+    ws = _empty((1024,), x)
+    _lib.call("nfs_normalize_mean", _ptr(x), _ptr(out), x.numel(), int(bool(use_abs)), float(eps), _ptr(ws), 1024,
+              _stream())
+    return out
+
+
 def transport_step(g, u, scale=1.0, w_g=1.0, addend=None, w_addend=0.0, out=None):
     """out = w_g*advect(g, scale*u) + w_addend*addend: one frame crossing of ``_transport`` (styler_base.py:59-89) for the
     C-channel field g [D,H,W,C] with the temporal filter's accumulation fused in"""

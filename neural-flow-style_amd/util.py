@@ -101,3 +101,59 @@ def temporal_weights(n, sigma, truncate=4.0):
                 s = 2 * n - 1 - s
             W[t, s] += wk
     return W
+
+
+# ---- Laplacian-pyramid gradient normalisation (util.py:27-110) -------------------------------------------------------
+
+def lap_kernel(is_3d):
+    """k5x5[1] / k5x5x5[1] of the reference (util.py:27-46), built the way its module does: outer([1,4,6,4,1]) / sum in
+    2-D; floor(outer(k2, k2) * k2_i) / sum with k2 = [1, 16^(1/3), 36^(1/3), 16^(1/3), 1] in 3-D.  Pinned to the
+    reference's own arrays by tests/golden/util_reference.npz."""
+    if not is_3d:
+        k = np.float32([1, 4, 6, 4, 1])
+        k = np.outer(k, k)
+        return (k / k.sum()).astype(np.float32)
+    k2_ = [1, 16 ** (1 / 3), 36 ** (1 / 3), 16 ** (1 / 3), 1]
+    k2 = np.float32(k2_)
+    k2 = np.outer(k2, k2)
+    k_ = np.floor(np.array([k2 * i for i in k2_]))
+    return (k_ / k_.sum()).astype(np.float32)
+
+
+def cosine_decay(global_step, decay_steps, learning_rate, factor):
+    """util.py:49-53"""
+    global_step = min(global_step, decay_steps)
+    cos_decay = np.cos(np.pi * global_step / decay_steps)
+    cos_decay = (cos_decay + 1) * 0.5 * (factor - 1) + 1
+    return learning_rate * cos_decay
+
+
+_LAP_K = {}
+
+
+def lap_normalize(img, scale_n=3, is_3d=False, c=1):
+    """Laplacian-pyramid normalisation of a gradient field on the device (util.lap_normalize, util.py:95-110): img
+    [D,H,W,c] (3-D) or [H,W,c] (2-D) CUDA tensor.  scale_n = 0: img / max(mean|img|, 1e-7).  Otherwise split into scale_n
+    high-pass levels + the low-pass rest (lap_split_n), divide every level by its RMS (normalize_std), merge."""
+    from . import ops
+    import torch
+    img = img.contiguous()
+    if scale_n == 0:
+        return ops.normalize_mean(img, use_abs=True, eps=1e-7)
+    key = (bool(is_3d), img.device)
+    if key not in _LAP_K:
+        _LAP_K[key] = torch.as_tensor(lap_kernel(is_3d)).to(img.device).contiguous()
+    k = _LAP_K[key]
+    s = 5.0 if is_3d else 4.0
+    levels = []
+    cur = img
+    for _ in range(scale_n):                                   # lap_split_n (util.py:68-75)
+        lo = ops.lap_down(cur, k)
+        levels.append(ops.lap_up(lo, k, cur.shape, -s, addend=cur))   # hi = img - conv_transpose(lo, k * s)
+        cur = lo
+    levels.append(cur)
+    levels = [ops.normalize_mean(l_, use_abs=False, eps=1e-10) for l_ in levels[::-1]]
+    out = levels[0]
+    for hi in levels[1:]:                                       # lap_merge (util.py:77-84)
+        out = ops.lap_up(out, k, hi.shape, s, addend=hi)
+    return out

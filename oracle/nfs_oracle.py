@@ -239,6 +239,50 @@ def curl(s, is_2d=True):
     return torch.stack([dwdy - dvdz, dudz - dwdx, dvdx - dudy], dim=-1)
 
 
+def _tf_same_pads(n, window=5, stride=2):
+    out = -(-n // stride)
+    total = max((out - 1) * stride + window - n, 0)
+    return total // 2, total - total // 2
+
+
+def lap_normalize(img, k, scale_n=3):
+    """util.lap_normalize (util.py:95-110) restated with torch's convolutions: img [D,H,W,C] or [H,W,C], k the
+    reference's k5x5x5[1] / k5x5[1] kernel ([5,5,5] / [5,5]).  TF 'SAME' geometry is written out as explicit
+    asymmetric zero padding; conv_transpose = the exact adjoint of that padded strided correlation."""
+    nd = img.dim() - 1
+    if scale_n == 0:
+        return img / torch.clamp(img.abs().mean(), min=1e-7)
+    C = img.shape[-1]
+    kk = torch.as_tensor(k, dtype=img.dtype)
+    s = 5.0 if nd == 3 else 4.0
+    conv = F.conv3d if nd == 3 else F.conv2d
+    w = kk.reshape((1, 1) + tuple(kk.shape)).repeat(C, 1, *([1] * nd))      # depthwise: the same k per channel
+
+    def down(x):                                                            # x [*dims, C]
+        xc = x.permute(nd, *range(nd)).unsqueeze(0)
+        pads = []
+        for n in reversed(x.shape[:nd]):
+            pads += list(_tf_same_pads(n))
+        return conv(F.pad(xc, pads), w, stride=2, groups=C)[0].permute(*range(1, nd + 1), 0)
+
+    def up(lo, shape):                                                      # adjoint of ``down`` at input shape
+        probe = torch.zeros(shape, dtype=lo.dtype, requires_grad=True)
+        (g,) = torch.autograd.grad(down(probe), probe, lo)
+        return g
+
+    levels, cur = [], img
+    for _ in range(scale_n):
+        lo = down(cur)
+        levels.append(cur - s * up(lo, cur.shape))
+        cur = lo
+    levels.append(cur)
+    levels = [l_ / torch.clamp(torch.sqrt((l_ ** 2).mean()), min=1e-10) for l_ in levels[::-1]]
+    out = levels[0]
+    for hi in levels[1:]:
+        out = s * up(out, hi.shape) + hi
+    return out
+
+
 def transport(g, v, a, b, recursive=True):
     """StylerBase._transport_tf (styler_base.py:76-89): move field g from frame
     a to frame b through the per-frame velocities v[F,D,H,W,3]."""

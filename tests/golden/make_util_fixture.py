@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Golden vectors for the host helpers of the stylisation loop from the REFERENCE ITSELF: its util.py is imported in
 the build container and ``denoise`` (temporal smoothing of the per-frame updates, styler_3p.py:377-381) and
-``crop_ratio`` (style / content image crop, styler_base.py:320-338) are run on seeded inputs.  util.py imports
+``crop_ratio`` (style / content image crop, styler_base.py:320-338) are run on seeded inputs; the Laplacian-pyramid
+kernels ``k5x5`` / ``k5x5x5`` (util.py:27-46) and ``cosine_decay`` values are dumped as the module computes them.  util.py imports
 imageio, skimage, tensorflow, matplotlib and open3d at module level; modules of those names that are absent here are
 registered empty only to let the import statements pass -- neither function touches them (``resize`` does, through
 skimage, and therefore is not part of this fixture).   Run:  python tests/golden/make_util_fixture.py
@@ -57,6 +58,10 @@ for i, img in enumerate(imgs):
     out["crop_in_%d" % i] = img
     for j, ra in enumerate(ratios):
         out["crop_out_%d_%d" % (i, j)] = R.crop_ratio(img, ra)
+# Laplacian-pyramid smoothing kernels (util.py:27-46), as the module builds them at import time
+out["k5x5"] = np.asarray(R.k5x5[1][:, :, 0, 0], np.float64)
+out["k5x5x5"] = np.asarray(R.k5x5x5[1][:, :, :, 0, 0], np.float64)
+out["cosine_decay"] = np.array([R.cosine_decay(s_, 20, 0.1, 2.0) for s_ in (0, 5, 10, 20, 30)], np.float64)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "util_reference.npz")
 np.savez_compressed(path, **out)
 print(path, len(out), "arrays")

@@ -117,3 +117,25 @@ def test_curl_matches_the_reference_lines_and_its_adjoint():
     div = (u[:-2, :-2, 1:-1] - u[:-2, :-2, :-2]) + (v[:-2, 1:-1, :-2] - v[:-2, :-2, :-2]) + \
           (w[1:-1, :-2, :-2] - w[:-2, :-2, :-2])
     assert float(div.abs().max()) < 1e-5
+
+
+def test_laplacian_pyramid_normalisation_matches_the_oracle():
+    """util.lap_normalize on the HIP kernels (strided 'SAME' smoothing, its transpose, RMS normalisation) vs the oracle's
+    restatement with torch convolutions; even / odd sizes exercise both TF padding cases, c = 1 and 3"""
+    from neural_flow_style_amd import util
+    rng = np.random.RandomState(31)
+    for shape, is_3d in (((12, 9, 10, 1), True), ((8, 8, 8, 3), True), ((17, 12, 3), False), ((9, 9, 1), False)):
+        g = rng.randn(*shape).astype(np.float32)
+        k = util.lap_kernel(is_3d)
+        for scale_n in (0, 1, 3) if min(shape[:-1]) >= 8 else (0, 1):
+            want = O.lap_normalize(torch.tensor(g, dtype=torch.float64), k.astype(np.float64), scale_n).numpy()
+            got = util.lap_normalize(torch.tensor(g).cuda(), scale_n=scale_n, is_3d=is_3d, c=shape[-1]).cpu().numpy()
+            assert got.shape == g.shape
+            assert rel(got, want) < 2e-5, (shape, scale_n)
+    # what it is for: every frequency band of the result has unit RMS before the merge, so a gradient dominated by one
+    # scale is flattened -- the normalised field of a smooth + noisy mix has a higher noise-to-smooth ratio than the input
+    zz, yy, xx = np.meshgrid(*[np.linspace(0, 1, 32)] * 3, indexing="ij")
+    smooth = (100 * np.sin(2 * np.pi * zz) * np.cos(2 * np.pi * yy))[..., None].astype(np.float32)
+    noise = rng.randn(32, 32, 32, 1).astype(np.float32)
+    out = util.lap_normalize(torch.tensor(smooth + noise).cuda(), scale_n=3, is_3d=True).cpu().numpy()
+    assert np.isfinite(out).all() and 0.5 < out.std() < 5
