@@ -34,7 +34,8 @@ def test_argument_errors_do_not_need_a_gpu():
     with pytest.raises(RuntimeError, match="null pointer"):
         _lib.call("nfs_render_fwd", None, None, None, 1, 1, 1, 1, 0.1, 0, None)
     assert _lib.lib().nfs_conv3x3_packed_floats(3, 64, 0) == 9 * 3 * 64              # conv1_1: direct only
-    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36) * 64 * 128    # + Winograd F(4x4,3x3)
+    # + Winograd F(4x4,3x3) filters (36 floats per (ci, co)) + their three bf16 limb planes (6 bytes x 36 = 54 floats)
+    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36 + 54) * 64 * 128
 
 
 def test_no_cpu_fallback():
