@@ -107,6 +107,20 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
 int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc,
                   int B, int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream);
 
+/* ---- A7 mask variant (styler_base.py:165-173, style_mask = True) -------------------------------------------------
+ * nfs_resize_bicubic_tf1: tf.compat.v1.image.resize(BICUBIC) (legacy kernel: align_corners False, no half-pixel
+ *   centres, Keys A = -0.75 through the 1024-entry table), x [B,H,W,C] -> out [B,oh,ow,C]; forward only (the mask
+ *   d_gray is a constant of the colour stylizer, styler_2p.py:91-97).
+ * nfs_style_mask_apply: Fm = F * mask (mask [B,HW] broadcast over C), scale[b] = 1 / (2 * sum(mask[b]) * C) -- the
+ *   Gram denominator 2 * area * C of the masked branch (feed scale as nfs_gram_fwd's per-image scale).
+ * nfs_style_mask_bwd: dF = dFm * mask * (F > 0). */
+int nfs_resize_bicubic_tf1(const float* x, float* out, int B, int H, int W, int C, int oh, int ow,
+                           nfs_stream_t stream);
+int nfs_style_mask_apply(const float* F, const float* mask, float* Fm, float* scale, int B, int HW, int C,
+                         nfs_stream_t stream);
+int nfs_style_mask_bwd(const float* dFm, const float* mask, const float* F, float* dF, int B, int HW, int C,
+                       nfs_stream_t stream);
+
 /* ---- A2 (2-D twin): batch_warp2d / _interpolate2d (transform.py:206-236, 280-341) ---------------------------
  * imgs [B,X,Y,C], coords [B,2,X,Y] normalised [-1,1], out [B,X,Y,C]; border-replicating bilinear gather (the
  * reference's only known-answer vector, transform.py:1859-1885, pins this stencil).  bwd: g_imgs_acc (nullable) +=

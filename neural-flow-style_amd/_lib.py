@@ -78,6 +78,9 @@ SIGNATURES = {
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_resize_bicubic_tf1": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_style_mask_apply": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "nfs_style_mask_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nfs_tv_loss": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "nfs_p2g_fwd": [_P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],
     "nfs_p2g_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],

@@ -96,6 +96,81 @@ __global__ void __launch_bounds__(256) hist_loss_kernel(const float* __restrict_
   if (t == 0) atomicAdd(loss_acc + b, weight * part);
 }
 
+// ---- style mask (styler_base.py:165-173): features weighted by the bicubic-resized density mask --------------------
+// TF-1 legacy ResizeBicubic (align_corners = False, no half-pixel centres): src = dst * in/out, taps floor-1..floor+2
+// clamped to the image, Keys weights (A = -0.75) from the 1024-entry table looked up at round(frac * 1024).
+__device__ __forceinline__ void bicubic_taps(int o, int n_in, int n_out, int* idx, float* w) {
+  const float a = -0.75f;
+  const float src = (float)o * ((float)n_in / (float)n_out);
+  const float fl = floorf(src);
+  const int loc = (int)fl;
+  const float t = rintf((src - fl) * 1024.f) / 1024.f;          // table quantisation of the fraction
+  const float t1 = t + 1.f, u = 1.f - t, u1 = u + 1.f;
+  w[0] = ((a * t1 - 5.f * a) * t1 + 8.f * a) * t1 - 4.f * a;
+  w[1] = ((a + 2.f) * t - (a + 3.f)) * t * t + 1.f;
+  w[2] = ((a + 2.f) * u - (a + 3.f)) * u * u + 1.f;
+  w[3] = ((a * u1 - 5.f * a) * u1 + 8.f * a) * u1 - 4.f * a;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = loc - 1 + k;
+    idx[k] = i < 0 ? 0 : (i > n_in - 1 ? n_in - 1 : i);
+  }
+}
+
+__global__ void __launch_bounds__(256) resize_bicubic_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                             int H, int W, int C, int oh, int ow) {
+  const int64_t n = (int64_t)B * oh * ow * C;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const int c = (int)(gid % C);
+  int64_t v = gid / C;
+  const int xo = (int)(v % ow); v /= ow;
+  const int yo = (int)(v % oh);
+  const int b = (int)(v / oh);
+  int iy[4], ix[4];
+  float wy[4], wx[4];
+  bicubic_taps(yo, H, oh, iy, wy);
+  bicubic_taps(xo, W, ow, ix, wx);
+  const float* im = x + (int64_t)b * H * W * C + c;
+  // rows first, then columns (the order of the two passes of the reference restatement)
+  float colv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r += wy[k] * im[((int64_t)iy[k] * W + ix[q]) * C];
+    colv[q] = r;
+  }
+  out[gid] = ((wx[0] * colv[0] + wx[1] * colv[1]) + wx[2] * colv[2]) + wx[3] * colv[3];
+}
+
+// Fm = F * m (mask broadcast over channels) and scale[b] = 1 / (2 * sum_pixels(m) * C)   (styler_base.py:167-169)
+__global__ void __launch_bounds__(256) style_mask_apply_kernel(const float* __restrict__ F, const float* __restrict__ m,
+                                                               float* __restrict__ Fm, float* __restrict__ scale, int HW,
+                                                               int C) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const int64_t base = (int64_t)b * HW * C;
+  const int64_t n = (int64_t)HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Fm[base + i] = F[base + i] * m[(int64_t)b * HW + i / C];
+  if (blockIdx.x == 0) {                                  // one block per image also sums the mask (fixed order)
+    float s = 0.f;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) s += m[(int64_t)b * HW + p];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) scale[b] = 1.f / (2.f * s * (float)C);
+  }
+}
+
+// dF = dFm * m * (F > 0): gradient wrt the pre-activation of the masked feature
+__global__ void __launch_bounds__(256) style_mask_bwd_kernel(const float* __restrict__ dFm, const float* __restrict__ m,
+                                                             const float* __restrict__ F, float* __restrict__ dF, int64_t n,
+                                                             int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dF[i] = F[i] > 0.f ? dFm[i] * m[i / C] : 0.f;
+}
+
 }  // namespace nfs
 
 using namespace nfs;
@@ -110,6 +185,36 @@ int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float*
   hipLaunchKernelGGL(hist_loss_kernel, dim3((unsigned)(B * C)), dim3(256), 0, as_stream(stream), feat, templ, loss_acc,
                      g_acc, B, Bt, HW, HWt, C, weight, relu_mask);
   return check_launch("nfs_hist_loss");
+}
+
+int nfs_resize_bicubic_tf1(const float* x, float* out, int B, int H, int W, int C, int oh, int ow, nfs_stream_t stream) {
+  NFS_REQUIRE(x && out, "nfs_resize_bicubic_tf1: null pointer");
+  NFS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0, "nfs_resize_bicubic_tf1: non-positive dimension");
+  const int64_t n = (int64_t)B * oh * ow * C;
+  hipLaunchKernelGGL(resize_bicubic_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, out, B, H, W, C,
+                     oh, ow);
+  return check_launch("nfs_resize_bicubic_tf1");
+}
+
+int nfs_style_mask_apply(const float* F, const float* mask, float* Fm, float* scale, int B, int HW, int C,
+                         nfs_stream_t stream) {
+  NFS_REQUIRE(F && mask && Fm && scale, "nfs_style_mask_apply: null pointer");
+  NFS_REQUIRE(B > 0 && HW > 0 && C > 0, "nfs_style_mask_apply: non-positive dimension");
+  unsigned bx = blocks_for((int64_t)HW * C, 256 * 4);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(style_mask_apply_kernel, dim3(bx, (unsigned)B), dim3(256), 0, as_stream(stream), F, mask, Fm, scale,
+                     HW, C);
+  return check_launch("nfs_style_mask_apply");
+}
+
+int nfs_style_mask_bwd(const float* dFm, const float* mask, const float* F, float* dF, int B, int HW, int C,
+                       nfs_stream_t stream) {
+  NFS_REQUIRE(dFm && mask && F && dF, "nfs_style_mask_bwd: null pointer");
+  NFS_REQUIRE(B > 0 && HW > 0 && C > 0, "nfs_style_mask_bwd: non-positive dimension");
+  const int64_t n = (int64_t)B * HW * C;
+  hipLaunchKernelGGL(style_mask_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), dFm, mask, F, dF, n,
+                     C);
+  return check_launch("nfs_style_mask_bwd");
 }
 
 }  // extern "C"

@@ -532,34 +532,6 @@ class GridStylizer(object):
 # 2-D colour path (styler_2p.py:91-102 + styler_base.py:152-185, 211-213)
 # --------------------------------------------------------------------------------------
 
-_TF_BICUBIC_TABLE = 1024
-
-
-def _tf1_bicubic_axis(n_in, n_out, device):
-    """indices / weights of TF's legacy ResizeBicubic (A=-0.75, 1024-entry coefficient table,
-    align_corners=False, half_pixel_centers=False) -- used by style_mask (styler_base.py:166)"""
-    a = -0.75
-    t = np.arange(_TF_BICUBIC_TABLE + 1, dtype=np.float32) / np.float32(_TF_BICUBIC_TABLE)
-    c0 = ((a + 2) * t - (a + 3)) * t * t + 1
-    t1 = t + 1
-    c1 = ((a * t1 - 5 * a) * t1 + 8 * a) * t1 - 4 * a
-    src = np.arange(n_out, dtype=np.float32) * (np.float32(n_in) / np.float32(n_out))
-    loc = np.floor(src).astype(np.int64)
-    off = np.rint((src - loc) * _TF_BICUBIC_TABLE).astype(np.int64)
-    w = np.stack([c1[off], c0[off], c0[_TF_BICUBIC_TABLE - off], c1[_TF_BICUBIC_TABLE - off]], 1)
-    idx = np.clip(np.stack([loc - 1, loc, loc + 1, loc + 2], 1), 0, n_in - 1)
-    return torch.as_tensor(idx, device=device), torch.as_tensor(w.astype(np.float32), device=device)
-
-
-def tf1_resize_bicubic(x, oh, ow):
-    """x [B,H,W,C] device tensor -> [B,oh,ow,C] (differentiable torch ops; tiny tensors)"""
-    B, H, W, C = x.shape
-    iy, wy = _tf1_bicubic_axis(H, oh, x.device)
-    ix, wx = _tf1_bicubic_axis(W, ow, x.device)
-    rows = (x[:, iy] * wy.view(1, oh, 4, 1, 1)).sum(2)
-    return (rows[:, :, ix] * wx.view(1, 1, ow, 4, 1)).sum(3)
-
-
 class ImageStyleLoss(object):
     """Style (+TV) loss of a colour image d [B,H,W,3] in [0,1] (the 2-D colour stylizer):
     d*255 -> VGG -> Gram; with ``style_mask`` the features are multiplied by the bicubic-resized
@@ -623,14 +595,12 @@ class ImageStyleLoss(object):
             F = acts[name]
             _, h, w, c = F.shape
             if self.style_mask:
-                m = tf1_resize_bicubic(d_gray, h, w)                       # [B,h,w,1]
-                Fm = (F * m).contiguous()
-                area = m[..., 0].sum(dim=(1, 2))
-                scale_dev = (1.0 / (2.0 * area * c)).contiguous()
+                m = ops.resize_bicubic_tf1(d_gray.contiguous(), h, w)      # [B,h,w,1], constant (no gradient to it)
+                Fm, scale_dev = ops.style_mask_apply(F, m)                 # F * m, 1 / (2 area C)
                 G = ops.gram_fwd(Fm, 1.0, scale_dev=scale_dev)
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
                 dFm = ops.gram_bwd(Fm, Dm, 1.0, scale_dev=scale_dev, relu_mask=False)
-                sg[name] = (dFm * m * (F > 0)).contiguous()
+                sg[name] = ops.style_mask_bwd(dFm, m, F)
             else:
                 scale = 1.0 / (2.0 * h * w * c)
                 G = ops.gram_fwd(F, scale)

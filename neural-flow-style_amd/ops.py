@@ -488,6 +488,33 @@ def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
     return g_acc
 
 
+def resize_bicubic_tf1(x, oh, ow):
+    """TF-1 legacy bicubic resize of x [B,H,W,C] -> [B,oh,ow,C] (styler_base.py:166), forward only"""
+    B, H, W, Cn = x.shape
+    out = _empty((B, oh, ow, Cn), x)
+    _lib.call("nfs_resize_bicubic_tf1", _ptr(x), _ptr(out), B, H, W, Cn, int(oh), int(ow), _stream())
+    return out
+
+
+def style_mask_apply(F, mask):
+    """F [B,h,w,C], mask [B,h,w,1] -> (F * mask, scale [B] = 1 / (2 * sum(mask) * C))  (styler_base.py:167-169)"""
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    Fm = _empty(F.shape, F)
+    scale = _empty((B,), F)
+    _lib.call("nfs_style_mask_apply", _ptr(F), _ptr(mask), _ptr(Fm), _ptr(scale), B, HW, Cn, _stream())
+    return Fm, scale
+
+
+def style_mask_bwd(dFm, mask, F):
+    """dFm * mask * (F > 0)"""
+    B, Cn = F.shape[0], F.shape[-1]
+    HW = F.numel() // (B * Cn)
+    out = _empty(F.shape, F)
+    _lib.call("nfs_style_mask_bwd", _ptr(dFm), _ptr(mask), _ptr(F), _ptr(out), B, HW, Cn, _stream())
+    return out
+
+
 def hist_loss(F, templ, weight, loss_acc, g_acc=None, relu_mask=False):
     """histogram loss of F [B,h,w,C] against the template features templ [Bt,ht,wt,C] (styler_base.py:187-209,
     util.py:317-399): loss_acc [B] += weight * sum((F - matched)^2); g_acc [B,h,w,C] += 2 weight (F - matched)"""

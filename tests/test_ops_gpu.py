@@ -662,3 +662,23 @@ def test_hist_loss_matches_the_oracle_restatement():
         d = (g.cpu() - go).abs()
         assert float((d > 1e-3 * go.abs().max()).float().mean()) < 5e-3
         assert rel(g.cpu(), go) < 3e-2
+
+
+def test_style_mask_kernels():
+    """legacy bicubic resize of the density mask, masked features with the 2*area*C denominator, masked gradient
+    (styler_base.py:165-173) against the oracle's restatement"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(41)
+    x = rng.rand(2, 17, 12, 1).astype(np.float32)
+    for oh, ow in ((8, 6), (17, 12), (25, 30), (4, 3)):
+        want = O.tf1_resize_bicubic(torch.tensor(x), oh, ow)
+        got = ops.resize_bicubic_tf1(torch.tensor(x).cuda(), oh, ow).cpu()
+        assert float((got - want).abs().max()) < 2e-6, (oh, ow)
+    F_ = np.maximum(rng.randn(2, 8, 6, 16), 0).astype(np.float32)
+    m = O.tf1_resize_bicubic(torch.tensor(x), 8, 6)
+    Fm, scale = ops.style_mask_apply(torch.tensor(F_).cuda(), m.cuda().contiguous())
+    assert rel(Fm.cpu(), torch.tensor(F_) * m) < 1e-6
+    assert rel(scale.cpu(), 1.0 / (2.0 * m[..., 0].sum(dim=(1, 2)) * 16)) < 1e-6
+    g = rng.randn(2, 8, 6, 16).astype(np.float32)
+    got = ops.style_mask_bwd(torch.tensor(g).cuda(), m.cuda().contiguous(), torch.tensor(F_).cuda()).cpu()
+    assert rel(got, torch.tensor(g) * m * (torch.tensor(F_) > 0)) < 1e-6
