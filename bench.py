@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the small HIP-vs-oracle gradient check")
+    ap.add_argument("--no-split-limb", action="store_true", help="skip the secondary split-limb GEMM measurement")
     ap.add_argument("--cpu-views", type=int, default=1, help="views in the bounded CPU sample")
     return ap.parse_args()
 
@@ -569,7 +571,7 @@ def main():
         out["sustained"] = dict(sustained(step_fn, barrier, units, device, world), unit=out["unit"])
 
     # ---- the same workload with the Winograd GEMMs in split-limb arithmetic (float32-equivalent, see nfs_gemm_mode) -----
-    if gs is not None and mode == "views":
+    if gs is not None and mode == "views" and not args.no_split_limb:
         from neural_flow_style_amd import ops
         prev = ops.gemm_mode(1)
         try:
@@ -648,10 +650,11 @@ def main():
         out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
 
     if rank == 0 and world == 1:
-        try:
-            out["parity"] = small_parity(device)
-        except Exception as e:  # pragma: no cover
-            out["parity"] = {"error": repr(e)}
+        if not args.no_parity:
+            try:
+                out["parity"] = small_parity(device)
+            except Exception as e:  # pragma: no cover
+                out["parity"] = {"error": repr(e)}
         if not args.no_other_configs:
             out["other_configs"] = other_configs(device, base)
         if not args.no_cpu_baseline:

@@ -15,7 +15,9 @@
 //   winograd_output*_kernel  M                      -> y [B,H,W,N]    + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace nfs {
@@ -872,36 +874,25 @@ static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
-static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
+static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s) {
   static const int nbuf_env = [] { const char* e = getenv("NFS_GEMM_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf = nbuf_env == 1 ? 1 : 2;
-  int bm, bn;
-  pick_gemm_tile(a.T, a.N, Z, cus, &bm, &bn);
   a.mt = (int)((a.T + bm - 1) / bm);
   a.nt = a.N / bn;
   a.Z = Z;
 #ifdef NFS_ABLATE
+  // timing-only ablations, -DNFS_ABLATE builds only (wrong results by construction): 1 no MFMA / operand reads, 2 no
+  // stores of C, 4 no global loads after the first chunk, 8 no LDS staging, 16 no barrier in the K loop
   static const int dbg = getenv("NFS_GEMM_DBG") ? atoi(getenv("NFS_GEMM_DBG")) : 0;
   a.dbg = dbg;
 #endif
   if (g_gemm_mode == 1 && a.Ub && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.K % 64 == 0) {
-    static const int snb = [] { const char* e = getenv("NFS_SPLIT_NBUF"); return e ? atoi(e) : 1; }();
-    if (snb == 2) {
-      if (bm == 128 && bn == 128) launch_gemm_split<128, 128, 2>(a, s);
-      else if (bm == 128) launch_gemm_split<128, 64, 2>(a, s);
-      else if (bn == 128) launch_gemm_split<64, 128, 2>(a, s);
-      else launch_gemm_split<64, 64, 2>(a, s);
-    } else {
-      if (bm == 128 && bn == 128) launch_gemm_split<128, 128, 1>(a, s);
-      else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
-      else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
-      else launch_gemm_split<64, 64, 1>(a, s);
-    }
+    if (bm == 128 && bn == 128) launch_gemm_split<128, 128, 1>(a, s);
+    else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
+    else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
+    else launch_gemm_split<64, 64, 1>(a, s);
     return;
   }
-  // timing-only ablations, -DNFS_ABLATE builds only (wrong results by construction): 1 no MFMA / operand reads, 2 no stores of C, 4 no global
-  // loads after the first chunk, 8 no LDS staging, 16 no barrier in the K loop
-
   // K = 64 (two chunks): nothing to double-buffer; a single LDS buffer doubles the co-resident blocks of this
   // bandwidth-bound shape (conv1_2: 0.103 -> 0.093 ms)
   if (nbuf == 2 && (a.K > 64 || nbuf_env == 2)) {
@@ -915,6 +906,61 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
     else if (bn == 128) launch_gemm_variant<64, 128, 1>(a, s);
     else launch_gemm_variant<64, 64, 1>(a, s);
   }
+}
+
+// Tile shape per problem: the planner's model (pick_gemm_tile) misses by up to 15 % on single layers (it knows nothing
+// about L2 behaviour), so the first launch of every (T, K, N, Z, arithmetic) shape times the four candidates on the
+// device (two runs each, HIP events, the launch's own operands -- every candidate computes the identical result, the
+// k order does not depend on the tile shape) and the fastest is remembered for the process.  Not while a stream
+// capture is in progress, not while the GEMM timer brackets launches, and not with NFS_GEMM_BM / BN / NFS_GEMM_TUNE=0.
+struct GemmKey {
+  int64_t T; int K, N, Z, mode;
+  bool operator<(const GemmKey& o) const {
+    return std::tie(T, K, N, Z, mode) < std::tie(o.T, o.K, o.N, o.Z, o.mode);
+  }
+};
+static std::map<GemmKey, std::pair<int, int>> g_tile_cache;
+static std::mutex g_tile_mu;
+
+static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
+  static const bool tune = [] {
+    const char* e = getenv("NFS_GEMM_TUNE");
+    return !(e && atoi(e) == 0) && !getenv("NFS_GEMM_BM") && !getenv("NFS_GEMM_BN");
+  }();
+  int bm, bn;
+  pick_gemm_tile(a.T, a.N, Z, cus, &bm, &bn);
+  if (tune) {
+    const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
+    std::unique_lock<std::mutex> lk(g_tile_mu);
+    auto it = g_tile_cache.find(key);
+    if (it != g_tile_cache.end()) {
+      bm = it->second.first; bn = it->second.second;
+    } else {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+      hipEvent_t e0, e1;
+      if (!capturing && !g_timer_on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float best = 1e30f;
+        const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
+        for (int c = 0; c < 4; ++c) {
+          if (a.N % cand[c][1]) continue;
+          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);          // warm (L2, instruction cache)
+          (void)hipEventRecord(e0, s);
+          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);
+          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);
+          (void)hipEventRecord(e1, s);
+          float ms = 1e30f;
+          if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+          if (ms < best) { best = ms; bm = cand[c][0]; bn = cand[c][1]; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        g_tile_cache[key] = std::make_pair(bm, bn);
+        return;                                                       // the result is already in place
+      }
+    }
+  }
+  launch_gemm_tile(a, Z, bm, bn, s);
 }
 
 // dF[b] = alpha_b * F[b] @ D[b] (D symmetric, so row n of D serves as column n), optional (F > 0) mask

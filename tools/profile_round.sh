@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-profile"
+BENCH="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-parity --no-sustained --no-other-configs --no-split-limb"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o b -- $BENCH > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -o b -- $BENCH > /dev/null 2> $out/${tag}_pmc_fetch.err
@@ -16,13 +16,15 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc
 cd $root
 f=$(find $out/${tag}_stats -name 'b_kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_bench_kernel_stats.csv
+# in-step averages (set-up launches excluded): what roofline.avg_launch_us has to agree with
+python tools/instep_stats.py $(find $out/${tag}_stats -name 'b_kernel_trace.csv' | head -1) 12 $out/${tag}_instep.json > $out/${tag}_instep.txt
 python tools/pmc_traffic.py $(find $out/${tag}_pmc_fetch -name 'b_counter_collection.csv' | head -1) \
                             $(find $out/${tag}_pmc_write -name 'b_counter_collection.csv' | head -1) \
                             $out/${tag}_traffic.json > $out/${tag}_traffic.txt
 # the raw counter CSVs are large; keep only the summaries
 rm -rf $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_stats
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-tail -c 600 $out/${tag}_bench_under_rocprof.json
+tail -c 600 $out/${tag}_bench_under_rocprof.json; cat $out/${tag}_instep.txt
 python - <<EOF
 import csv
 rows=list(csv.DictReader(open("$out/${tag}_bench_kernel_stats.csv")))
