@@ -69,18 +69,24 @@ def _is_gloo(group=None):
     return dist.get_backend(group) == "gloo"
 
 
-def exchange_frames(have, need, owner, like, group=None):
+def exchange_frames(have, need, owner, like, group=None, need_by_rank=None):
     """Point-to-point exchange of per-frame tensors (the temporal filter's halo): ``have`` {frame: tensor} are this
-    rank's frames, ``need`` the frames this rank wants, ``owner`` {frame: rank} (identical on all ranks, as is
-    ``need_of(rank)`` below).  Every rank calls with the same ``owner`` and its own ``need``; what the others need is
-    derived from the all-gathered need lists (a few integers).  Returns {frame: tensor} for every frame of ``need``.
-    gloo has no GPU point-to-point: tensors are staged through the host there (CPU tests / one-GPU functional
-    checks); under nccl (RCCL) the device buffers go over xGMI directly."""
+    rank's frames, ``need`` the frames this rank wants, ``owner`` {frame: rank} (identical on all ranks).
+    ``need_by_rank`` (list over ranks of frame collections, identical on all ranks) says what every rank wants; it is
+    a pure function of the frame plan and the filter matrix, so callers compute it locally -- when it is not given
+    the need lists are all-gathered (a few integers, but a host round trip per call).  Returns {frame: tensor} for
+    every frame of ``need``.  gloo has no GPU point-to-point: tensors are staged through the host there (CPU tests /
+    one-GPU functional checks); under nccl (RCCL) the device buffers go over xGMI directly, all transfers of a call
+    in one group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return {t: have[t] for t in need}
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    needs = [None] * world
-    dist.all_gather_object(needs, sorted(int(t) for t in need), group=group)
+    if need_by_rank is None:
+        needs = [None] * world
+        dist.all_gather_object(needs, sorted(int(t) for t in need), group=group)
+    else:
+        needs = [sorted(int(t) for t in n_) for n_ in need_by_rank]
+        assert needs[rank] == sorted(int(t) for t in need), "need_by_rank[rank] must equal this rank's need"
     stage = _is_gloo(group) and like.is_cuda
     out, ops_, keep = {}, [], []
     for t in sorted(int(t) for t in need):

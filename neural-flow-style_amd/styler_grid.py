@@ -143,11 +143,16 @@ class Styler(StylerBase):
         st.mine = st.plan[rank]
         st.Wt = temporal_weights(len(st.keys), self.window_sigma) if (self.window_sigma > 0 and F_ > 1) else None
         # which frames' updates this rank's filter reaches (non-zero weights only), and the velocities in between
-        st.need = set(st.mine)
-        if st.Wt is not None:
-            for t in st.mine:
-                j = st.keys.index(t)
-                st.need |= set(st.keys[jj] for jj in np.nonzero(st.Wt[j])[0])
+        def need_of(r):
+            nd = set(st.plan[r])
+            if st.Wt is not None:
+                for t in st.plan[r]:
+                    j = st.keys.index(t)
+                    nd |= set(st.keys[jj] for jj in np.nonzero(st.Wt[j])[0])
+            return nd
+
+        st.need_by_rank = [need_of(r) for r in range(world)]       # a pure function of plan and filter: no exchange
+        st.need = st.need_by_rank[rank]
         want_d = set(range(F_)) if frames_on_device is None else set(frames_on_device) | set(st.mine)
         want_u = set(range(F_)) if frames_on_device is None else \
             set(range(max(min(st.need) - 1, 0), min(max(st.need) + 1, F_))) if st.need else set()
@@ -210,7 +215,8 @@ class Styler(StylerBase):
         if st.world > 1:
             parallel.all_reduce_sum_([losses], group=self.pg)
         if st.Wt is not None:
-            got = parallel.exchange_frames(upd, st.need, st.owner, st.work, group=self.pg)
+            got = parallel.exchange_frames(upd, st.need, st.owner, st.work, group=self.pg,
+                                           need_by_rank=st.need_by_rank)
             for t in st.mine:
                 st.g_opt[t] = st.g_opt[t] + self.aligned_update(t, got, st.u, st.Wt, st.keys)
         else:
@@ -223,8 +229,8 @@ class Styler(StylerBase):
         """frame interpolation (392-397) + final inference of every frame, on every rank"""
         st = self._st
         D, H, W_, _ = st.shape
-        allv = parallel.exchange_frames(st.g_opt, set(st.keys), st.owner, st.work, group=self.pg) \
-            if st.world > 1 else st.g_opt
+        allv = parallel.exchange_frames(st.g_opt, set(st.keys), st.owner, st.work, group=self.pg,
+                                        need_by_rank=[set(st.keys)] * st.world) if st.world > 1 else st.g_opt
         full = {t: allv[t] for t in st.keys}
         if self.interp > 1:
             w = np.linspace(0, 1, self.interp + 1)
