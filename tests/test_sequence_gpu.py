@@ -186,3 +186,28 @@ def test_frames_sharded_over_two_ranks_reproduce_the_single_rank_run(tmp_path):
     np.testing.assert_allclose(b["l"], a["l"], rtol=1e-5)
     assert rel(b["opt"], a["opt"]) < 1e-5
     assert rel(b["d"], a["d"]) < 1e-5
+
+
+def test_grid_driver_demo_run(tmp_path, monkeypatch):
+    """test_smokegun_grid.main on synthetic frames (demo mode): the configs[3] workflow end to end -- frames in, stylised
+    density npz (key x, H flipped back) + rendered png per frame out, loss falling"""
+    import test_smokegun_grid as drv
+    from neural_flow_style_amd.config import get_config
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    cfg, _ = get_config(["--resolution", "16", "24", "16", "--num_frames", "3", "--iter", "3", "--lr", "0.01",
+                         "--window_sigma", "1", "--log_dir", str(tmp_path), "--data_dir", "/nonexistent",
+                         "--sample_type", "uniform"])
+    res = drv.main(cfg)
+    out = tmp_path / "smokegun" / "test"
+    for t in range(3):
+        z = np.load(str(out / ("%03d.npz" % (70 + t))))
+        assert z["x"].shape == (16, 24, 16, 1)
+        assert np.array_equal(z["x"], res["d"][t][:, ::-1])
+        assert (out / ("%03d.png" % (70 + t))).exists()
+    l = np.asarray(res["l_frames"])
+    assert l.shape == (3, 3) and np.isfinite(l).all() and (l[-1] < l[0]).all()
+    # unit conversion of the driver: one cell per frame along W is 2/(W-1) in advect units; y flips sign with H
+    v = np.zeros((4, 5, 6, 3), np.float32); v[..., 0] = 1.0; v[..., 1] = 2.0
+    u = drv.to_advect_units(v)
+    assert np.allclose(u[..., 2], 2.0 / 5) and np.allclose(u[..., 1], -4.0 / 4) and np.allclose(u[..., 0], 0)
