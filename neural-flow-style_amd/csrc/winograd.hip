@@ -370,6 +370,7 @@ struct WgGemmArgs {
   const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
   const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
+  unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
 };
 
@@ -443,6 +444,13 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+#ifdef NFS_ABLATE
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tk = a.prof ? clock64() : 0, t_begin = tk;
+#define NFS_TICK(i_) if (a.prof) { const unsigned long long n_ = clock64(); pt[i_] += n_ - tk; tk = n_; }
+#else
+#define NFS_TICK(i_)
+#endif
   for (int c = 0; c < nchunks; ++c) {
     float* Ac = As + (NBUF == 2 ? (c & 1) : 0) * BM * WG_LS;
     float* Bc = Bs + (NBUF == 2 ? (c & 1) : 0) * BN * WG_LS;
@@ -463,8 +471,11 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
         *reinterpret_cast<float4*>(bd + 96 * WG_LS) = b3;
       }
     }
+    NFS_TICK(0)                                          // wait for the chunk's loads + LDS staging writes
     if (!NFS_DBG(a, 16)) __syncthreads();    // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    NFS_TICK(1)                                          // barrier
     if (c + 1 < nchunks && !NFS_DBG(a, 4)) NFS_WG_LOAD(c + 1)
+    NFS_TICK(2)                                          // issue of the next chunk's loads
     if (!NFS_DBG(a, 1))
 #pragma unroll
     for (int s = 0; s < WG_KC / 8; ++s) {
@@ -487,6 +498,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
           for (int mt = 0; mt < MT; ++mt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][jj], bf[nt][jj], acc[mt][nt], 0, 0, 0);
     }
+    NFS_TICK(3)                                          // fragment reads + MFMA issue
   }
 #undef NFS_WG_LOAD
 
@@ -494,6 +506,7 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   constexpr int OS = BN + 4;
   float* otile = smem;
   __syncthreads();
+  NFS_TICK(4)                                            // drain of the last MFMAs + barrier
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -522,6 +535,16 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
     }
     if (!NFS_DBG(a, 2) || v.x == 12345.f) *reinterpret_cast<float4*>(Mc + idx) = v;
   }
+#ifdef NFS_ABLATE
+  if (a.prof && lane == 0) {
+    NFS_TICK(5)                                          // epilogue: LDS transpose + stores issued
+    unsigned long long* o = a.prof + ((size_t)blockIdx.x * 4 + wid) * 8;
+    for (int q = 0; q < 6; ++q) o[q] = pt[q];
+    o[6] = t_begin;
+    o[7] = tk;
+  }
+#endif
+#undef NFS_TICK
 }
 
 // ---- the batched GEMM in float32-equivalent arithmetic on the bf16 matrix pipe ("split-limb" form) --------------------
@@ -874,7 +897,10 @@ static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
+static unsigned long long* g_gemm_prof = nullptr;        // NFS_ABLATE builds only (nfs_gemm_prof)
+
 static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s) {
+  a.prof = g_gemm_prof;
   static const int nbuf_env = [] { const char* e = getenv("NFS_GEMM_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf = nbuf_env == 1 ? 1 : 2;
   a.mt = (int)((a.T + bm - 1) / bm);
@@ -1045,6 +1071,11 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
 }  // namespace nfs
 
 extern "C" {
+#ifdef NFS_ABLATE
+// measurement builds only: per-wave phase cycle sums of winograd_gemm_kernel, 8 x uint64 per (block, wave):
+// [loads+staging wait, barrier, load issue, fragments+MFMA, drain, epilogue, t_begin, t_end]
+int nfs_gemm_prof(void* buf) { nfs::g_gemm_prof = reinterpret_cast<unsigned long long*>(buf); return 0; }
+#endif
 int nfs_gemm_mode(int mode) {
   const int prev = nfs::g_gemm_mode;
   if (mode == 0 || mode == 1) nfs::g_gemm_mode = mode;
