@@ -16,8 +16,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc
 cd $root
 f=$(find $out/${tag}_stats -name 'b_kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_bench_kernel_stats.csv
-# in-step averages (set-up launches excluded): what roofline.avg_launch_us has to agree with
-python tools/instep_stats.py $(find $out/${tag}_stats -name 'b_kernel_trace.csv' | head -1) 12 $out/${tag}_instep.json > $out/${tag}_instep.txt
+# in-step averages over the 10 TIMED steps (set-up launches, the warm-up steps and the tile tuner's trial launches in
+# them excluded): what roofline.avg_launch_us has to agree with
+python tools/instep_stats.py $(find $out/${tag}_stats -name 'b_kernel_trace.csv' | head -1) 10 $out/${tag}_instep.json > $out/${tag}_instep.txt
 python tools/pmc_traffic.py $(find $out/${tag}_pmc_fetch -name 'b_counter_collection.csv' | head -1) \
                             $(find $out/${tag}_pmc_write -name 'b_counter_collection.csv' | head -1) \
                             $out/${tag}_traffic.json > $out/${tag}_traffic.txt
