@@ -14,6 +14,7 @@
 //   winograd_gemm_kernel     V, U [(m+2)^2][K/32][N][32] -> M [(m+2)^2][T][N]  f32 MFMA, fragment scheme of vgg.hip
 //   winograd_output*_kernel  M                      -> y [B,H,W,N]    + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
 #include "common.h"
+#include "winograd_math.h"
 
 #include <map>
 #include <mutex>
@@ -21,6 +22,15 @@
 #include <vector>
 
 namespace nfs {
+
+// winograd_fused.hip
+bool winograd_fusable(int K, int N);
+bool winograd_fused_takes(int H, int W);
+int64_t winograd_fused_packed_floats(int K, int N);
+int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s);
+int winograd_fused_conv(const float* x, const float* Uf, const float* aux0, const float* aux1, float* y, int B, int H,
+                        int W, int K, int N, int mode, int relu, hipStream_t s, float* ypool, const float* xmask,
+                        uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -150,22 +160,6 @@ __global__ void __launch_bounds__(256) winograd_pack4_kernel(const float* __rest
   }
 }
 
-// B^T (6x6) applied to a column / row of float2 channel pairs
-__device__ __forceinline__ float2 wg_lin(float a, float2 x, float b, float2 y) { return make_float2(a * x.x + b * y.x, a * x.y + b * y.y); }
-__device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
-  // [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0] [0,-2,-1,2,1,0] [0,2,-1,-2,1,0] [0,4,0,-5,0,1]
-  const float2 p = wg_lin(-4.f, d[2], 1.f, d[4]);     // d4 - 4 d2
-  const float2 q = wg_lin(-4.f, d[1], 1.f, d[3]);     // d3 - 4 d1
-  const float2 e = wg_lin(-1.f, d[2], 1.f, d[4]);     // d4 - d2
-  const float2 f = wg_lin(-2.f, d[1], 2.f, d[3]);     // 2 (d3 - d1)
-  o[0] = make_float2(4.f * d[0].x - 5.f * d[2].x + d[4].x, 4.f * d[0].y - 5.f * d[2].y + d[4].y);
-  o[1] = make_float2(p.x + q.x, p.y + q.y);
-  o[2] = make_float2(p.x - q.x, p.y - q.y);
-  o[3] = make_float2(e.x + f.x, e.y + f.y);
-  o[4] = make_float2(e.x - f.x, e.y - f.y);
-  o[5] = make_float2(4.f * d[1].x - 5.f * d[3].x + d[5].x, 4.f * d[1].y - 5.f * d[3].y + d[5].y);
-}
-
 // input transform: one thread = one 6x6 patch x 2 channels (a wave covers 128 contiguous channels per pixel)
 // POOLED: the operand is not stored -- it is the gradient coming through a 2x2 VALID average pool below a ReLU,
 // d(y, x) = 0.25 * gpool[y/2, x/2] * (xmask[y, x] > 0) (0 outside the pooled area), formed on the fly
@@ -252,16 +246,6 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 6; ++q) *reinterpret_cast<float2*>(vo + (int64_t)(r * 6 + q) * comp_stride) = o[q];
   }
-}
-
-// A^T (4x6) = [1,1,1,1,1,0] [0,1,-1,2,-2,0] [0,1,1,4,4,0] [0,1,-1,8,-8,1]
-__device__ __forceinline__ void wg4_at(const float2* m, float2* o) {
-  const float2 s12 = make_float2(m[1].x + m[2].x, m[1].y + m[2].y), d12 = make_float2(m[1].x - m[2].x, m[1].y - m[2].y);
-  const float2 s34 = make_float2(m[3].x + m[4].x, m[3].y + m[4].y), d34 = make_float2(m[3].x - m[4].x, m[3].y - m[4].y);
-  o[0] = make_float2(m[0].x + s12.x + s34.x, m[0].y + s12.y + s34.y);
-  o[1] = make_float2(d12.x + 2.f * d34.x, d12.y + 2.f * d34.y);
-  o[2] = make_float2(s12.x + 4.f * s34.x, s12.y + 4.f * s34.y);
-  o[3] = make_float2(d12.x + 8.f * d34.x + m[5].x, d12.y + 8.f * d34.y + m[5].y);
 }
 
 // output transform + layer epilogue: one thread = one 4x4 output tile x 2 channels
@@ -1011,7 +995,10 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
 
 // 36 floats per (ci, co): room for either tile size
 // plus, for the F(4x4) filters, their three bf16 limb planes (6 bytes per element = 54 floats per (ci, co))
-int64_t winograd_packed_floats(int Ci, int Co) { return (int64_t)(36 + 54) * Ci * Co; }
+// and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
+int64_t winograd_packed_floats(int Ci, int Co) {
+  return (int64_t)(36 + 54) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
+}
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
   const int64_t n = (int64_t)Ci * Co;
@@ -1019,6 +1006,9 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
     hipLaunchKernelGGL(winograd_pack4_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
     hipLaunchKernelGGL(winograd_split_planes_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up,
                        reinterpret_cast<unsigned short*>(up + 36 * n), 36 * n);
+    const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+    if (winograd_fusable(Kc, Nc))
+      if (int e = winograd_pack_fused(up, up + 90 * n, Kc, Nc, s)) return e;
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1033,6 +1023,10 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
                   const float* xmask, uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad) {
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
+  // narrow layers: one kernel, no V / M round trip
+  if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(H, W) && (!pooled_grad || mode == 1))
+    return winograd_fused_conv(x, U + (int64_t)90 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
+                               in_bits, out_bits, pooled_grad);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
