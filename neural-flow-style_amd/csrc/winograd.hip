@@ -25,7 +25,7 @@ namespace nfs {
 
 // winograd_fused.hip
 bool winograd_fusable(int K, int N);
-bool winograd_fused_takes(int H, int W);
+bool winograd_fused_takes(int B, int H, int W, int K, int N);
 int64_t winograd_fused_packed_floats(int K, int N);
 int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s);
 int winograd_fused_conv(const float* x, const float* Uf, const float* aux0, const float* aux1, float* y, int B, int H,
@@ -1024,7 +1024,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
                   const float* xmask, uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad) {
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   // narrow layers: one kernel, no V / M round trip
-  if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(H, W) && (!pooled_grad || mode == 1))
+  if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N) && (!pooled_grad || mode == 1))
     return winograd_fused_conv(x, U + (int64_t)90 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
                                in_bits, out_bits, pooled_grad);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;

@@ -43,6 +43,7 @@ struct WfArgs {
   int B, H, W, TH, TW;
   int64_t T;
   int relu, runs;
+  uint32_t x_bytes, m_bytes;  // sizes of x and of the POOLED mask operand (buffer-load range checks)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_fused_prof)
   int dbg = 0;                          // NFS_FUSED_DBG timing ablations
 };
@@ -72,45 +73,30 @@ __device__ __forceinline__ WfTile wf_tile(uint32_t tile, uint32_t TH, uint32_t T
   return t;
 }
 
-// one staged value: 4 channels (ch .. ch+3) of patch pixel p = 6 r + s of a tile; loads are unconditional (clamped
-// coordinates) and the out-of-image zero is a select, or the compiler drains vmcnt at the join
-template <int K, bool POOLED>
-__device__ __forceinline__ float4 wf_fetch(const WfArgs& a, const WfTile& t, int r, int s, int ch) {
-  const int yy = 4 * t.ty - 1 + r, xx = 4 * t.tx - 1 + s;
-  if (!POOLED) {
-    const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-    const int yc = min(max(yy, 0), a.H - 1), xc = min(max(xx, 0), a.W - 1);
-    const float4 v = *reinterpret_cast<const float4*>(a.x + (((int64_t)t.b * a.H + yc) * a.W + xc) * K + ch);
-    const float m = ok ? 1.f : 0.f;     // (a multiply, not a select: hipcc turns `ok ? load : 0` into a branch around the load)
-    return make_float4(m * v.x, m * v.y, m * v.z, m * v.w);
-  } else {
-    const int PH = a.H >> 1, PW = a.W >> 1;
-    const bool ok = yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW;
-    const int yc = min(max(yy, 0), 2 * PH - 1), xc = min(max(xx, 0), 2 * PW - 1);
-    const float4 g = *reinterpret_cast<const float4*>(a.x + (((int64_t)t.b * PH + (yc >> 1)) * PW + (xc >> 1)) * K + ch);
-    const float q = ok ? 0.25f : 0.f;   // (folded into the scale: no select on a loaded value, see above)
-    if (a.pool_bits) {
-      const uint2 wd = *reinterpret_cast<const uint2*>(
-          a.pool_bits + (((int64_t)t.b * a.TH + (yc >> 2)) * a.TW + (xc >> 2)) * (K >> 1) + (ch >> 1));
-      const int sh = ((yc & 3) * 4 + (xc & 3)) * 2;
-      const uint32_t m0 = wd.x >> sh, m1 = wd.y >> sh;
-      return make_float4((m0 & 1u) ? q * g.x : 0.f, (m0 & 2u) ? q * g.y : 0.f, (m1 & 1u) ? q * g.z : 0.f,
-                         (m1 & 2u) ? q * g.w : 0.f);
-    }
-    const float4 m = *reinterpret_cast<const float4*>(a.xmask + (((int64_t)t.b * a.H + yc) * a.W + xc) * K + ch);
-    return make_float4(m.x > 0.f ? q * g.x : 0.f, m.y > 0.f ? q * g.y : 0.f, m.z > 0.f ? q * g.z : 0.f,
-                       m.w > 0.f ? q * g.w : 0.f);
-  }
+// Staged patches come through buffer loads: one 32-bit byte offset per (lane, pixel), fixed for the whole kernel, plus a
+// scalar offset for the k-slice -- no 64-bit address arithmetic in the loop -- and an offset beyond num_records for the
+// pixels outside the image, which the hardware answers with zeros (no select, no branch around the load).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t WF_OOB = 0x80000000u;       // the launcher keeps every buffer below 2 GB
+__device__ __forceinline__ float4 wf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint2 wf_ld2u(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
-template <int K, int N, int MODE, bool POOLED>
+// POOLED: 0 plain operand; 1 pooled gradient masked from the ReLU bit cache; 2 ... from the float output (a template
+// parameter: a run-time choice is a branch around loads inside the MFMA stream)
+template <int K, int N, int MODE, int POOLED>
 __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   constexpr int NIT = K / 16;         // k-slices of 16 input channels
   constexpr int NWT = N / 16;         // column tiles of the layer (a block takes four: blockIdx.y = 64-channel group)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Pb = smem;                  // [36 pixels][16 tiles][16 channels]  staged patches of one slice
   float* const Vb = smem + WF_BUF;         // [36 components][16 tiles][16 channels, float2 slots swizzled]  B^T d B
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wg = 4 * blockIdx.y + w;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wg = 4 * blockIdx.y + w;      // wave-uniform: scalar registers
   // XCD-aware order (see winograd_input4_kernel): neighbouring runs share patch rows and the filter stream
   const int per_xcd = gridDim.x / 8;
   const int run = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -149,18 +135,6 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   const int j0 = run % NIT;
   const int64_t ctile = tile0 + tt < a.T ? tile0 + tt : a.T - 1;      // tile of the transform role (in_bits)
 
-  // patch slice -> registers (9 pixels per wave) / registers -> LDS
-  auto fetch = [&](float4* v, int slice) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int p = w + 4 * i;
-      v[i] = wf_fetch<K, POOLED>(a, st, p / 6, p % 6, 16 * slice + 4 * gs);
-    }
-  };
-  auto stash = [&](const float4* v, float* P) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) *reinterpret_cast<float4*>(P + (w + 4 * i) * WF_PXF + lane * 4) = v[i];
-  };
   // B^T d B of the lane's (tile, channel): P -> V
   auto transform = [&](const float* P, float* V, int slice) {
     float tcol[6][6];
@@ -192,65 +166,147 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
     }
   };
 
-  // Per slice: patch -> LDS | barrier | transform P -> V | barrier | 144 MFMAs from V.  One buffer each: the phases of a
-  // block are serial, and it is the OTHER block resident on the CU (two fit: 72 KB of LDS and <= 256 registers each)
-  // whose MFMAs run under this block's loads, transform and epilogue.
-  const float4* ub0 = a.Uf + (int64_t)wg * 64 + lane;
-  constexpr int64_t ZS = (int64_t)NWT * 64;                        // float4 stride between component pairs
-  {
-    float4 v[9];
-    fetch(v, j0);
-    stash(v, Pb);
+  // Per slice: [barrier] transform P -> V [barrier] 144 MFMAs from V, in 12 groups of 6 components x 2 k-steps.  Under
+  // the MFMAs: the B fragments of the group three ahead (a ring of four groups: ~1150 cycles of cover for the L2
+  // latency; three / two ahead in the pooled forms; the ring runs on across slices), the A fragments of the next group, and the next slice's patches in
+  // three batches that go to P as they arrive (P is free once the slice is transformed).  One buffer each for P and V:
+  // two blocks fit a CU (72 KB of LDS, <= 256 registers) and fill each other's barrier and epilogue gaps.
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.Uf), 0, 36u * K * N * 4u, 0x00020000);
+  const uint32_t uo = (uint32_t)(wg * 64 + lane) * 16u;
+  constexpr uint32_t ZS = NWT * 64 * 16;                           // bytes between component pairs
+  // staging offsets of this lane's nine pixels (p = w + 4 i; wave-uniform, so r, s and the mask shift are scalars)
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      POOLED == 1 ? (void*)const_cast<uint32_t*>(a.pool_bits) : POOLED == 2 ? (void*)const_cast<float*>(a.xmask) : (void*)const_cast<float*>(a.x),
+      0, a.m_bytes, 0x00020000);
+  // per lane: the offset of its tile's origin in each operand and one validity bit per pixel; the pixel's displacement
+  // is a scalar (p, r, s are wave-uniform), so a load address costs an add and a select and no registers are held
+  const int PHh = a.H >> 1, PWh = a.W >> 1;
+  const uint32_t xb = !POOLED ? (uint32_t)(((st.b * a.H + 4 * st.ty) * a.W + 4 * st.tx) * K + 4 * gs) * 4u
+                              : (uint32_t)(((st.b * PHh + 2 * st.ty) * PWh + 2 * st.tx) * K + 4 * gs) * 4u;
+  const uint32_t mb =
+      POOLED == 1 ? (uint32_t)(((st.b * a.TH + st.ty) * a.TW + st.tx) * (K >> 1) + 2 * gs) * 4u
+                  : (uint32_t)(((st.b * a.H + 4 * st.ty) * a.W + 4 * st.tx) * K + 4 * gs) * 4u;
+  uint32_t okm = 0u;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int p = w + 4 * i, r = p / 6, sx = p - 6 * r;
+    const int yy = 4 * st.ty - 1 + r, xx = 4 * st.tx - 1 + sx;
+    const bool ok = !POOLED ? (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+                            : (yy >= 0 && xx >= 0 && (yy >> 1) < PHh && (xx >> 1) < PWh);
+    okm |= (ok ? 1u : 0u) << i;
   }
+  // displacement of pixel (r, sx) from the tile origin, in bytes of the operand (floor division for the -1 row / column)
+  auto x_disp = [&](int r, int sx) {
+    return !POOLED ? ((r - 1) * a.W + (sx - 1)) * K * 4 : (((r + 1) >> 1) - 1) * PWh * K * 4 + (((sx + 1) >> 1) - 1) * K * 4;
+  };
+  auto m_disp = [&](int r, int sx) {
+    return POOLED == 1 ? ((((r + 3) >> 2) - 1) * a.TW + (((sx + 3) >> 2) - 1)) * (K >> 1) * 4
+                       : ((r - 1) * a.W + (sx - 1)) * K * 4;
+  };
+  // a batch of three pixels: raw loads now, mask arithmetic (POOLED) and the LDS store when they have arrived
+  struct Raw { float4 g; float4 m; };       // m: POOLED 1 -> .x/.y carry the two mask words; POOLED 2 -> the float output
+  auto fetch3 = [&](Raw* v, int batch, int slice) {
+    // (opaque copies: otherwise hipcc hoists the nine / eighteen per-pixel offsets out of the slice loop and spills)
+    uint32_t xb_ = xb, mb_ = mb, okm_ = okm;
+    asm volatile("" : "+v"(xb_), "+v"(mb_), "+v"(okm_));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ii = 3 * batch + i;
+      const int p = w + 4 * ii, r = p / 6, sx = p - 6 * r;
+      const bool ok = (okm_ >> ii) & 1u;
+      const uint32_t xo = ok ? xb_ + (uint32_t)x_disp(r, sx) : WF_OOB;
+      [[maybe_unused]] const uint32_t mo = ok ? mb_ + (uint32_t)m_disp(r, sx) : WF_OOB;
+      v[i].g = wf_ld4(x_rsrc, xo, (uint32_t)slice * 64u);
+      if (POOLED == 1) {
+        const uint2 wd = wf_ld2u(m_rsrc, mo, (uint32_t)slice * 32u);
+        v[i].m.x = __uint_as_float(wd.x);
+        v[i].m.y = __uint_as_float(wd.y);
+      } else if (POOLED == 2) {
+        v[i].m = wf_ld4(m_rsrc, mo, (uint32_t)slice * 64u);
+      }
+    }
+  };
+  auto stash3 = [&](const Raw* v, int batch) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ii = 3 * batch + i;
+      float4 d = v[i].g;
+      if (POOLED == 1) {
+        // d = 0.25 * gpool[y/2, x/2] * (x_out > 0): mask bits of the pixel's own tile, two channels per word
+        const int p = w + 4 * ii, r = p / 6, sx = p - 6 * r;
+        const int sh = (((r + 3) & 3) * 4 + ((sx + 3) & 3)) * 2;
+        const uint32_t m0 = __float_as_uint(v[i].m.x) >> sh, m1 = __float_as_uint(v[i].m.y) >> sh;
+        d = make_float4((m0 & 1u) ? 0.25f * d.x : 0.f, (m0 & 2u) ? 0.25f * d.y : 0.f, (m1 & 1u) ? 0.25f * d.z : 0.f,
+                        (m1 & 2u) ? 0.25f * d.w : 0.f);
+      } else if (POOLED == 2) {
+        const float4 m = v[i].m;
+        d = make_float4(m.x > 0.f ? 0.25f * d.x : 0.f, m.y > 0.f ? 0.25f * d.y : 0.f, m.z > 0.f ? 0.25f * d.z : 0.f,
+                        m.w > 0.f ? 0.25f * d.w : 0.f);
+      }
+      *reinterpret_cast<float4*>(Pb + (w + 4 * ii) * WF_PXF + lane * 4) = d;
+    }
+  };
+  {
+    Raw v[3][3];
+#pragma unroll
+    for (int bt = 0; bt < 3; ++bt) fetch3(v[bt], bt, j0);
+#pragma unroll
+    for (int bt = 0; bt < 3; ++bt) stash3(v[bt], bt);
+  }
+  constexpr int RING = POOLED ? 3 : 4;   // groups of B fragments in registers (the pooled forms hold two raw operands per staged pixel)
+  float4 bq[RING][3];
+#pragma unroll
+  for (int gi = 0; gi < RING - 1; ++gi)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bq[gi][i] = wf_ld4(u_rsrc, uo, (uint32_t)((2 * j0) * 18 + 3 * gi + i) * ZS);
   __syncthreads();
   transform(Pb, Vb, j0);
   __syncthreads();
   NFS_TICK(0)
 #pragma unroll 1
   for (int j = 0; j < NIT; ++j) {
-    const int jj = (j0 + j) % NIT, j1 = (j0 + j + 1) % NIT;
-    // the next slice's patches travel under this slice's MFMAs (after the last slice: a fetch nobody uses -- no branch
-    // around the loads)
-    float4 v[9];
-    fetch(v, j1);
+    const int jj = (j0 + j) % NIT, j1 = (j0 + j + 1) % NIT;       // this slice, the next (after the last: fetched, unused)
+    float2 A[2][6];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const float4* ub = ub0 + (int64_t)(2 * jj + hh) * 18 * ZS;
-      const int rd = hh == 0 ? v_rd0 : v_rd1;
-      // six components at a time: B fragments (3 x 16 bytes) and A fragments (6 x 8 bytes) of the next group are in
-      // flight under the 12 MFMAs of this one
-      float4 bq[2][3];
-      float2 A[2][6];
+    for (int i = 0; i < 6; ++i) A[0][i] = *reinterpret_cast<const float2*>(Vb + i * WF_PXF + v_rd0);
+    Raw v[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) bq[0][i] = ub[i * ZS];
+    for (int gi = 0; gi < 12; ++gi) {
+      {  // B fragments of group gi + RING - 1
+        const int gn = (gi + RING - 1) % 12, sl = gi + RING - 1 < 12 ? jj : j1;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) A[0][i] = *reinterpret_cast<const float2*>(Vb + i * WF_PXF + rd);
-#pragma unroll
-      for (int zg = 0; zg < 6; ++zg) {
-        const int c = zg & 1, n = c ^ 1;
-        if (zg + 1 < 6) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) bq[n][i] = ub[(3 * (zg + 1) + i) * ZS];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) A[n][i] = *reinterpret_cast<const float2*>(Vb + (6 * (zg + 1) + i) * WF_PXF + rd);
-        }
-        // (the two k-steps of a component are issued 6 MFMAs apart: back-to-back MFMAs on one accumulator wait for
-        // each other)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const float4 b4 = bq[c][i >> 1];
-          acc[6 * zg + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][i].x, (i & 1) ? b4.z : b4.x, acc[6 * zg + i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const float4 b4 = bq[c][i >> 1];
-          acc[6 * zg + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][i].y, (i & 1) ? b4.w : b4.y, acc[6 * zg + i], 0, 0, 0);
-        }
+        for (int i = 0; i < 3; ++i)
+          bq[(gi + RING - 1) % RING][i] = wf_ld4(u_rsrc, uo, (uint32_t)((2 * sl + gn / 6) * 18 + 3 * (gn % 6) + i) * ZS);
       }
+      if (gi + 1 < 12) {  // A fragments of group gi + 1
+        const int gn = gi + 1, rd = gn < 6 ? v_rd0 : v_rd1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          A[gn & 1][i] = *reinterpret_cast<const float2*>(Vb + (6 * (gn % 6) + i) * WF_PXF + rd);
+      }
+      if (gi == 4 || gi == 7 || gi == 10) stash3(v, gi / 3 - 1);       // (issued three groups ago)
+      if (gi == 1 || gi == 4 || gi == 7) fetch3(v, gi / 3, j1);
+      __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs they travel under (hipcc sinks them to their uses)
+      // (the two k-steps of a component are issued 6 MFMAs apart: back-to-back MFMAs on one accumulator wait for
+      // each other)
+      const int zb = 6 * (gi % 6);
+      // (inline asm: accumulate in place -- the builtin lets hipcc rotate the accumulators through two dozen spare
+      // registers this kernel does not have)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float4 b4 = bq[gi % RING][i >> 1];
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[zb + i]) : "v"(A[gi & 1][i].x), "v"((i & 1) ? b4.z : b4.x));
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float4 b4 = bq[gi % RING][i >> 1];
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[zb + i]) : "v"(A[gi & 1][i].y), "v"((i & 1) ? b4.w : b4.y));
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     NFS_TICK(1)
-    stash(v, Pb);             // (P was consumed by the transform before this slice's MFMAs)
-    __syncthreads();          // ... and V by the MFMAs above
+    __syncthreads();          // P complete, V consumed
     NFS_TICK(2)
     if (j + 1 < NIT) transform(Pb, Vb, j1);
     __syncthreads();
@@ -258,7 +314,8 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   }
 
   // ---- output transform + layer epilogue, all in-lane: tiles 4 g + {0..3} of the run (as two pairs), channel n0 ----
-  // (H and W are multiples of 4 on this path: every pixel of a live tile is inside the image)
+  // (H and W are multiples of 4 on this path: every pixel of a live tile is inside the image.  Staging the tile through
+  // LDS to store 256-byte rows instead of these 64-byte pieces was measured: no gain, one more barrier.)
   const int n0 = 16 * wg + t;          // (t = lane & 15 is the C column)
   const int N2 = N >> 1;
   const int rowN = a.W * N;
@@ -370,8 +427,11 @@ bool winograd_fusable(int K, int N) {
   static const bool off = [] { const char* e = getenv("NFS_WG_FUSED"); return e && atoi(e) == 0; }();
   return !off && (K == 64 || K == 128) && (N == 64 || N == 128);
 }
-// ... and image sizes: whole 4x4 tiles only (the epilogue has no per-pixel bounds checks)
-bool winograd_fused_takes(int H, int W) { return H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0; }
+// ... and sizes: whole 4x4 tiles only (the epilogue has no per-pixel bounds checks), activations below 2 GB (32-bit
+// buffer offsets)
+bool winograd_fused_takes(int B, int H, int W, int K, int N) {
+  return H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31);
+}
 
 int64_t winograd_fused_packed_floats(int K, int N) { return winograd_fusable(K, N) ? (int64_t)36 * K * N : 0; }
 
@@ -380,7 +440,7 @@ int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s)
   return check_launch("winograd_pack_fused");
 }
 
-template <int K, int N, int MODE, bool POOLED>
+template <int K, int N, int MODE, int POOLED>
 static void launch_fused(const WfArgs& a, hipStream_t s) {
   const size_t lds = 2 * WF_BUF * sizeof(float);
   static bool attr_done = false;
@@ -395,9 +455,10 @@ static void launch_fused(const WfArgs& a, hipStream_t s) {
 
 template <int K, int N>
 static void launch_fused_kn(const WfArgs& a, int mode, bool pooled, hipStream_t s) {
-  if (mode == 0) launch_fused<K, N, 0, false>(a, s);
-  else if (pooled) launch_fused<K, N, 1, true>(a, s);
-  else launch_fused<K, N, 1, false>(a, s);
+  if (mode == 0) launch_fused<K, N, 0, 0>(a, s);
+  else if (!pooled) launch_fused<K, N, 1, 0>(a, s);
+  else if (a.pool_bits) launch_fused<K, N, 1, 1>(a, s);
+  else launch_fused<K, N, 1, 2>(a, s);
 }
 
 // same contract as winograd_conv (winograd.hip) for the shapes winograd_fusable() / winograd_fused_takes() accept; Uf from
@@ -425,6 +486,8 @@ int winograd_fused_conv(const float* x, const float* Uf, const float* aux0, cons
   a.T = (int64_t)B * a.TH * a.TW;
   a.relu = relu;
   a.runs = (int)((a.T + 15) / 16);
+  a.x_bytes = (uint32_t)((int64_t)B * (pooled_grad ? (H / 2) * (W / 2) : H * W) * K * 4);
+  a.m_bytes = !pooled_grad ? a.x_bytes : out_bits ? (uint32_t)(a.T * (K / 2) * 4) : (uint32_t)((int64_t)B * H * W * K * 4);
   if (K == 64 && N == 64) launch_fused_kn<64, 64>(a, mode, pooled_grad, s);
   else if (K == 64 && N == 128) launch_fused_kn<64, 128>(a, mode, pooled_grad, s);
   else if (K == 128 && N == 64) launch_fused_kn<128, 64>(a, mode, pooled_grad, s);

@@ -1,5 +1,5 @@
 """Per-wave phase cycle sums of winograd_fused_kernel (needs a library built with `make ABLATE=1`: nfs_fused_prof).
-Phases are delimited by s_memtime reads at ISSUE time (indicative split; the robust figure is cycles per half slice
+Phases are delimited by s_memtime reads at ISSUE time (indicative split; the robust figure is cycles per slice
 against 72 MFMAs x 32 = 2304 cycles of matrix-pipe work)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,11 +8,20 @@ import neural_flow_style_amd.ops as ops
 from neural_flow_style_amd import _lib
 L = _lib.lib()
 L.nfs_fused_prof.argtypes = [ctypes.c_void_p]
-for (HW, Ci, Co) in [(200, 64, 64), (100, 64, 128), (100, 128, 128)]:
+for (HW, Ci, Co, kind) in [(200, 64, 64, "fwd"), (100, 64, 128, "fwd"), (100, 128, 64, "fwd"), (100, 128, 128, "fwd"),
+                           (200, 64, 64, "dgrad_pool"), (100, 128, 128, "dgrad_pool")]:
     B = 8
-    x = torch.randn(B, HW, HW, Ci, device="cuda"); w = torch.randn(3, 3, Ci, Co, device="cuda") * 0.05
+    x = torch.relu(torch.randn(B, HW, HW, Ci, device="cuda")); w = torch.randn(3, 3, Ci, Co, device="cuda") * 0.05
     b = torch.zeros(Co, device="cuda"); wf = ops.conv3x3_pack(w, 0); out = torch.empty(B, HW, HW, Co, device="cuda")
-    fn = lambda: ops.conv3x3_fwd(x, wf, b, Co, True, out=out)
+    if kind == "fwd":
+        fn = lambda: ops.conv3x3_fwd(x, wf, b, Co, True, out=out)
+    else:
+        wd = ops.conv3x3_pack(w, 1)
+        bits = ops.conv3x3_relu_bits(B, HW, HW, Ci, Co, True, x.device)
+        ops.conv3x3_fwd_pool(x, wf, b, Co, relu=True, relu_bits=bits, want_y=False)
+        gyp = torch.randn(B, HW // 2, HW // 2, Co, device="cuda"); add = torch.randn(B, HW, HW, Ci, device="cuda")
+        fn = lambda: ops.conv3x3_dgrad_pool(gyp, None, wd, Ci, x_in=x, addend=add, relu_bits=bits, hw=(HW, HW),
+                                            addend_unmasked=True)
     for _ in range(3): fn()
     torch.cuda.synchronize()
     buf = torch.zeros(8 * 4 * 16384, dtype=torch.int64, device="cuda")
@@ -22,8 +31,8 @@ for (HW, Ci, Co) in [(200, 64, 64), (100, 64, 128), (100, 128, 128)]:
     ph = p[:, :5].astype(np.float64)
     tot = (p[:, 7] - p[:, 6]).astype(np.float64)
     span = (p[:, 7].max() - p[:, 6].min())
-    halves = 2 * Ci // 16
-    print("%dx%d %d->%d: %d waves, wave life %.0f ticks avg, kernel span %.0f ticks, %d half slices" % (HW, HW, Ci, Co, len(p), tot.mean(), span, halves))
-    names = ["prologue", "patch read + transform", "B loads + MFMAs", "staging store + barrier", "epilogue"]
+    halves = Ci // 16
+    print(kind, "%dx%d %d->%d: %d waves, wave life %.0f ticks avg, kernel span %.0f ticks, %d slices" % (HW, HW, Ci, Co, len(p), tot.mean(), span, halves))
+    names = ["first slice staged+transformed", "fetch issue + MFMAs", "stash + barrier", "transform + barrier", "epilogue"]
     for n, v in zip(names, ph.mean(0)):
-        print("   %-24s %8.0f  (%4.1f %%)  per half slice %7.0f" % (n, v, 100 * v / tot.mean(), v / halves))
+        print("   %-24s %8.0f  (%4.1f %%)  per slice %7.0f" % (n, v, 100 * v / tot.mean(), v / halves))
