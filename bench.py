@@ -625,7 +625,8 @@ def main():
         tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
         out["roofline"] = {
             "kernel": "nfs::winograd_gemm_kernel (batched f32-MFMA GEMM: the 36 Winograd F(4x4,3x3) products of every "
-                      ">=64-channel conv layer, forward and data gradient, and the Gram gradient): %d launches/step, "
+                      "conv layer from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower "
+                      "layers run in the single-kernel form winograd_fused_kernel): %d launches/step, "
                       "%.2f ms/step = the largest share of the step" % (g_n.value // psteps, g_ms.value / psteps),
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
             "traffic": pmc_traffic("winograd_gemm_kernel"),

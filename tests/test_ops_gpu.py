@@ -245,7 +245,11 @@ def _conv_ref(x, w, b, relu=True):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 3, 64), (2, 13, 11, 64, 64), (3, 25, 25, 64, 128),
                                           (1, 12, 12, 128, 256), (2, 7, 50, 128, 128), (8, 6, 6, 256, 128),
-                                          (1, 25, 25, 512, 512), (1, 12, 12, 512, 512)])   # last two: K-split GEMMs
+                                          (1, 25, 25, 512, 512), (1, 12, 12, 512, 512),    # these two: K-split GEMMs
+                                          # the single-kernel Winograd path (64 / 128 channels, whole 4x4 tiles): runs of
+                                          # 16 tiles that wrap rows and images, a ragged last run, both channel groups
+                                          (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
+                                          (1, 4, 4, 64, 128)])
 def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
     rng = np.random.RandomState(7)
     x = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32).requires_grad_()
@@ -269,7 +273,8 @@ def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
         assert rel(gx_m, gx * (xin > 0) + add) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128),
+                                          (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64)])
 def test_conv3x3_fused_pool(ops, B, H, W, Ci, Co):
     """conv + ReLU + 2x2 VALID average pool in one pass, and the data gradient taken from the POOLED gradient
     (pool adjoint + ReLU mask folded into the Winograd input transform); odd sizes floor like slim.avg_pool2d"""
@@ -518,7 +523,8 @@ def test_rotate_render_march_variants_agree(ops, tmp_path):
         assert err < 2e-6, (tag, err)
 
 
-@pytest.mark.parametrize("shape", [(2, 18, 21, 64, 128), (1, 8, 8, 128, 64), (3, 13, 30, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 18, 21, 64, 128), (1, 8, 8, 128, 64), (3, 13, 30, 64, 64), (3, 20, 28, 64, 64),
+                                   (2, 12, 16, 128, 128)])
 def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     """a layer's ReLU bit cache (recorded by its forward transforms) must reproduce, bit for bit, the data gradient
     computed with the float masks x_in > 0 / x_out > 0 -- plain and pooled forms, ragged tile edges, odd sizes"""
@@ -559,10 +565,11 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     assert torch.equal(q3, q3_ref)
 
 
-def test_pooled_layer_without_full_resolution_output(ops):
+@pytest.mark.parametrize("shape", [(2, 18, 22, 64, 128), (2, 20, 24, 64, 128)])     # three-kernel / single-kernel path
+def test_pooled_layer_without_full_resolution_output(ops, shape):
     """with the bit cache a pooled layer need not write its full-resolution output: forward (pool only) and data
     gradient (x_out = None) agree bit for bit with the materialised form"""
-    B, H, W, Ci, Co = 2, 18, 22, 64, 128
+    B, H, W, Ci, Co = shape
     torch.manual_seed(43)
     x = torch.relu(torch.randn(B, H, W, Ci, device="cuda"))
     w = torch.randn(3, 3, Ci, Co) * 0.05
