@@ -354,6 +354,7 @@ struct WgGemmArgs {
   const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
   const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
+  const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
 };
@@ -529,6 +530,152 @@ __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
   }
 #endif
 #undef NFS_TICK
+}
+
+// ---- the same GEMM with B straight from L2 into registers ("register-B" form) ---------------------------------------
+// The filters never change, so they are also kept in the exact order the MFMA wants its B operand: for component z,
+// 32-column tile nn and 8-deep k group kk one kilobyte [64 lanes][4] with element (lane, jj) = U_z[8 kk + 4 (lane>>5) + jj]
+// [32 nn + (lane & 31)] -- one buffer_load_dwordx4 per lane feeds four k-steps.  Only A goes through LDS (half the
+// staging writes, fragment reads and barrier-protected data of winograd_gemm_kernel).  Each B register is reloaded
+// with the next chunk's group as soon as its MFMAs are issued: a prefetch distance of one whole chunk (64 MFMAs) with
+// 8 float4 of registers.  A is staged with buffer loads too (rows beyond T come back as zeros: no branch around a load);
+// the MFMAs are inline asm so that they accumulate in place and stay where they are put.
+__device__ __forceinline__ float4 wg_ld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) winograd_gemm_rb_kernel(WgGemmArgs a) {
+  constexpr int MT = BM / 64, NT = BN / 64;           // 32x32 MFMA tiles per wave (waves 2 x 2)
+  constexpr int AJ = BM / 32;                         // float4 per thread and chunk for the A tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][BM][36]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
+  const int per_xcd = gridDim.x / WG_XCDS;
+  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;   // XCD-aware order, see above
+  if (logical >= a.mt * a.nt * a.Z) return;
+  const int comp = logical / (a.mt * a.nt);
+  const int rem = logical - comp * (a.mt * a.nt);
+  const int64_t m0 = (int64_t)(rem % a.mt) * BM;
+  const int n0 = (rem / a.mt) * BN;
+  const int nchunks = a.K / WG_KC;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Uq + (int64_t)comp * a.K * a.N), 0, (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
+
+  // A staging: thread t moves float4 #(t&7) of rows (t>>3) + 32 j
+  const int q4 = 4 * (t & 7), r0 = t >> 3;
+  uint32_t ao[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int64_t m = m0 + r0 + 32 * j;
+    ao[j] = m < a.T ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
+  }
+  // B fragments: column tile nn = (n0 + wn * BN/2) / 32 + nt, groups of 8 k
+  const uint32_t bo = (uint32_t)lane * 16u;
+  const uint32_t kgs = (uint32_t)(a.K / 8) * 1024u;   // bytes per column tile
+  const uint32_t bt0 = (uint32_t)((n0 + wn * (BN / 2)) / 32) * kgs;
+  float4 av[AJ], bq[NT][4];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], 0);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + g * 1024u);
+
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * (BM / 2) + mt * 32 + i) * WG_LS + 4 * h;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    float* Ac = As + (c & 1) * BM * WG_LS;
+    {
+      float* ad = Ac + r0 * WG_LS + q4;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<float4*>(ad + 32 * j * WG_LS) = av[j];
+    }
+    __syncthreads();                                   // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    const int cn = c + 1 < nchunks ? c + 1 : c;        // (the last iteration re-fetches its own chunk: no branch)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float af[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 x = *reinterpret_cast<const float4*>(Ac + abase[mt] + 8 * s);
+        af[mt][0] = x.x; af[mt][1] = x.y; af[mt][2] = x.z; af[mt][3] = x.w;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = jj == 0 ? bq[nt][s].x : jj == 1 ? bq[nt][s].y : jj == 2 ? bq[nt][s].z : bq[nt][s].w;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(af[mt][jj]), "v"(b));
+        }
+      // this group's registers take the next chunk's group s (one whole chunk of MFMAs ahead of its use)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bq[nt][s] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(4 * cn + s) * 1024u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // epilogue: transpose the tile through LDS, leave as float4 rows -- one half (the rows of waves wm = 0, then wm = 1)
+  // at a time, so that the tile buffer is no larger than the operand buffers and more blocks fit a CU
+  constexpr int OS = BN + 4, HR = BM / 2;
+  float* otile = smem;
+  float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  constexpr int Q = BN / 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) otile[row * OS + wn * (BN / 2) + nt * 32 + i] = acc[mt][nt][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < (HR * Q) / 256; ++e) {
+      const int f = t + 256 * e;
+      const int row = f / Q, q = f - row * Q;
+      const int64_t m = m0 + half * HR + row;
+      if (m >= a.T) continue;
+      *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    }
+  }
+}
+
+// U [Z][K/32][N][32] -> Uq [Z][N/32][K/8][64][4]
+__global__ void __launch_bounds__(256) winograd_pack_frag_kernel(const float* __restrict__ up, float* __restrict__ uq,
+                                                                 int K, int N, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int n = (int)(gid % N), k = (int)((gid / N) % K), z = (int)(gid / ((int64_t)N * K));
+  const float u = up[(((int64_t)z * (K / 32) + k / 32) * N + n) * 32 + (k & 31)];
+  // MFMA step jj of group kk pairs k = 8 kk + jj (lanes 0-31) with k = 8 kk + 4 + jj (lanes 32-63), as the A fragments do
+  const int kk = k >> 3, hh = (k >> 2) & 1, jj = k & 3;
+  uq[((((int64_t)z * (N / 32) + n / 32) * (K / 8) + kk) * 64 + hh * 32 + (n & 31)) * 4 + jj] = u;
 }
 
 // ---- the batched GEMM in float32-equivalent arithmetic on the bf16 matrix pipe ("split-limb" form) --------------------
@@ -881,9 +1028,38 @@ static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
+template <int BM, int BN>
+static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
+  const size_t oper = 2 * BM * WG_LS, tile = (BM / 2) * (BN + 4);
+  const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb_kernel<BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
+  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+  if (timed) (void)hipEventRecord(rec.e0, s);
+  hipLaunchKernelGGL((winograd_gemm_rb_kernel<BM, BN>), dim3(grid), dim3(256), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
+}
+
+// the register-B kernel takes the plain Winograd GEMMs (packed filters, no mask / scale) with 32-bit operand offsets
+static bool gemm_rb_applies(const WgGemmArgs& a) {
+  static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
+  return !off && a.Uq && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.T * a.K * 4 < ((int64_t)1 << 31) &&
+         (int64_t)a.K * a.N * 4 < ((int64_t)1 << 31);
+}
+
 static unsigned long long* g_gemm_prof = nullptr;        // NFS_ABLATE builds only (nfs_gemm_prof)
 
-static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s) {
+static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s, int variant = 0) {
   a.prof = g_gemm_prof;
   static const int nbuf_env = [] { const char* e = getenv("NFS_GEMM_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf = nbuf_env == 1 ? 1 : 2;
@@ -901,6 +1077,13 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s)
     else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
     else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
     else launch_gemm_split<64, 64, 1>(a, s);
+    return;
+  }
+  if (variant == 1 && gemm_rb_applies(a)) {
+    if (bm == 128 && bn == 128) launch_gemm_rb<128, 128>(a, s);
+    else if (bm == 128) launch_gemm_rb<128, 64>(a, s);
+    else if (bn == 128) launch_gemm_rb<64, 128>(a, s);
+    else launch_gemm_rb<64, 64>(a, s);
     return;
   }
   // K = 64 (two chunks): nothing to double-buffer; a single LDS buffer doubles the co-resident blocks of this
@@ -929,7 +1112,7 @@ struct GemmKey {
     return std::tie(T, K, N, Z, mode) < std::tie(o.T, o.K, o.N, o.Z, o.mode);
   }
 };
-static std::map<GemmKey, std::pair<int, int>> g_tile_cache;
+static std::map<GemmKey, std::tuple<int, int, int>> g_tile_cache;   // (BM, BN, kernel variant: 0 LDS-B, 1 register-B)
 static std::mutex g_tile_mu;
 
 static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
@@ -937,14 +1120,16 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
     const char* e = getenv("NFS_GEMM_TUNE");
     return !(e && atoi(e) == 0) && !getenv("NFS_GEMM_BM") && !getenv("NFS_GEMM_BN");
   }();
-  int bm, bn;
+  // NFS_GEMM_RB=2 (with NFS_GEMM_BM / BN or NFS_GEMM_TUNE=0): always the register-B kernel where it applies (tests)
+  static const int force_rb = [] { const char* e = getenv("NFS_GEMM_RB"); return (e && atoi(e) == 2) ? 1 : 0; }();
+  int bm, bn, variant = force_rb;
   pick_gemm_tile(a.T, a.N, Z, cus, &bm, &bn);
   if (tune) {
     const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
     std::unique_lock<std::mutex> lk(g_tile_mu);
     auto it = g_tile_cache.find(key);
     if (it != g_tile_cache.end()) {
-      bm = it->second.first; bn = it->second.second;
+      bm = std::get<0>(it->second); bn = std::get<1>(it->second); variant = std::get<2>(it->second);
     } else {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       const bool capturing = hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
@@ -952,25 +1137,27 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
       if (!capturing && !g_timer_on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         float best = 1e30f;
         const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
-        for (int c = 0; c < 4; ++c) {
-          if (a.N % cand[c][1]) continue;
-          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);          // warm (L2, instruction cache)
-          (void)hipEventRecord(e0, s);
-          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);
-          launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s);
-          (void)hipEventRecord(e1, s);
-          float ms = 1e30f;
-          if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
-          if (ms < best) { best = ms; bm = cand[c][0]; bn = cand[c][1]; }
-        }
+        const int nvar = (g_gemm_mode == 0 && gemm_rb_applies(a)) ? 2 : 1;
+        for (int var = 0; var < nvar; ++var)
+          for (int c = 0; c < 4; ++c) {
+            if (a.N % cand[c][1]) continue;
+            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);     // warm (L2, instruction cache)
+            (void)hipEventRecord(e0, s);
+            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);
+            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);
+            (void)hipEventRecord(e1, s);
+            float ms = 1e30f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+            if (ms < best) { best = ms; bm = cand[c][0]; bn = cand[c][1]; variant = var; }
+          }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        g_tile_cache[key] = std::make_pair(bm, bn);
+        g_tile_cache[key] = std::make_tuple(bm, bn, variant);
         return;                                                       // the result is already in place
       }
     }
   }
-  launch_gemm_tile(a, Z, bm, bn, s);
+  launch_gemm_tile(a, Z, bm, bn, s, variant);
 }
 
 // dF[b] = alpha_b * F[b] @ D[b] (D symmetric, so row n of D serves as column n), optional (F > 0) mask
@@ -996,8 +1183,9 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
 // 36 floats per (ci, co): room for either tile size
 // plus, for the F(4x4) filters, their three bf16 limb planes (6 bytes per element = 54 floats per (ci, co))
 // and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
+// and the filters once more in MFMA fragment order (register-B GEMM kernel)
 int64_t winograd_packed_floats(int Ci, int Co) {
-  return (int64_t)(36 + 54) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
+  return (int64_t)(36 + 54 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
 }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
@@ -1007,8 +1195,10 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
     hipLaunchKernelGGL(winograd_split_planes_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up,
                        reinterpret_cast<unsigned short*>(up + 36 * n), 36 * n);
     const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+    hipLaunchKernelGGL(winograd_pack_frag_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 90 * n, Kc, Nc,
+                       36 * n);
     if (winograd_fusable(Kc, Nc))
-      if (int e = winograd_pack_fused(up, up + 90 * n, Kc, Nc, s)) return e;
+      if (int e = winograd_pack_fused(up, up + 126 * n, Kc, Nc, s)) return e;
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1025,7 +1215,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   // narrow layers: one kernel, no V / M round trip
   if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N) && (!pooled_grad || mode == 1))
-    return winograd_fused_conv(x, U + (int64_t)90 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
+    return winograd_fused_conv(x, U + (int64_t)126 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
                                in_bits, out_bits, pooled_grad);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
@@ -1042,7 +1232,10 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
     hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,
                        TW);
   WgGemmArgs a{V, U, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
-  if (m == 4) a.Ub = reinterpret_cast<const unsigned short*>(U + (int64_t)36 * K * N);
+  if (m == 4) {
+    a.Ub = reinterpret_cast<const unsigned short*>(U + (int64_t)36 * K * N);
+    a.Uq = U + (int64_t)90 * K * N;
+  }
   launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {
     const unsigned ob = blocks_for(T * (N / 2), 256);

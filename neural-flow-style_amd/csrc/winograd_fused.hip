@@ -130,9 +130,9 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
 #define NFS_TICK(i_)
 #endif
 
-  // the k-slices are walked from a block-dependent start: all CUs streaming the same filter lines at the same moment
-  // queue on the same L2 channels
-  const int j0 = run % NIT;
+  // (walking the k-slices from a block-dependent start, so that the CUs do not all stream the same filter lines at the
+  // same moment, was measured: no gain -- and the k order of a tile's sums would then depend on the batch it sits in)
+  constexpr int j0 = 0;
   const int64_t ctile = tile0 + tt < a.T ? tile0 + tt : a.T - 1;      // tile of the transform role (in_bits)
 
   // B^T d B of the lane's (tile, channel): P -> V
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   NFS_TICK(0)
 #pragma unroll 1
   for (int j = 0; j < NIT; ++j) {
-    const int jj = (j0 + j) % NIT, j1 = (j0 + j + 1) % NIT;       // this slice, the next (after the last: fetched, unused)
+    const int jj = j, j1 = (j + 1) % NIT;                          // this slice, the next (after the last: fetched, unused)
     float2 A[2][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) A[0][i] = *reinterpret_cast<const float2*>(Vb + i * WF_PXF + v_rd0);
@@ -486,6 +486,7 @@ int winograd_fused_conv(const float* x, const float* Uf, const float* aux0, cons
   a.T = (int64_t)B * a.TH * a.TW;
   a.relu = relu;
   a.runs = (int)((a.T + 15) / 16);
+
   a.x_bytes = (uint32_t)((int64_t)B * (pooled_grad ? (H / 2) * (W / 2) : H * W) * K * 4);
   a.m_bytes = !pooled_grad ? a.x_bytes : out_bits ? (uint32_t)(a.T * (K / 2) * 4) : (uint32_t)((int64_t)B * H * W * K * 4);
   if (K == 64 && N == 64) launch_fused_kn<64, 64>(a, mode, pooled_grad, s);
