@@ -624,12 +624,13 @@ def main():
         n_launch = sum(r["launches_per_step"] for r in conv)
         tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": "nfs::winograd_gemm_kernel (batched f32-MFMA GEMM: the 36 Winograd F(4x4,3x3) products of every "
+            "kernel": "nfs::winograd_gemm_rb_kernel / winograd_gemm_kernel (batched f32-MFMA GEMM, filters from registers "
+                      "or through LDS as the per-shape tuner measured: the 36 Winograd F(4x4,3x3) products of every "
                       "conv layer from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower "
                       "layers run in the single-kernel form winograd_fused_kernel): %d launches/step, "
                       "%.2f ms/step = the largest share of the step" % (g_n.value // psteps, g_ms.value / psteps),
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-            "traffic": pmc_traffic("winograd_gemm_kernel"),
+            "traffic": pmc_traffic("winograd_gemm_"),
             "flops_per_launch": g_fl.value / max(g_n.value, 1), "avg_launch_us": 1e3 * g_ms.value / max(g_n.value, 1),
             "event_pair_overhead_us": ov_us,
             "frac_net": g_fl.value / (max(g_ms.value - 1e-3 * ov_us * g_n.value, 0.25 * g_ms.value) * 1e-3) / 1e12

@@ -1,28 +1,31 @@
-"""Per-layer timing of the Gram kernels (fwd two-pass, bwd GEMM) at the benchmark shapes."""
+"""Per-layer time of the Gram chain (gram_fwd = tn kernel + slab reduce, style loss, gram_bwd) at the headline shapes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import neural_flow_style_amd.ops as ops
 
-LAYERS = [(200 * 200, 64), (100 * 100, 128), (50 * 50, 256), (25 * 25, 512), (12 * 12, 512)]
-for B in [int(a) for a in sys.argv[1:]] or (8, 1):
-    tf = tb = 0.0
-    fl_all = 0.0
-    for HW, C in LAYERS:
-        F = torch.rand(B, HW, C, device="cuda")
-        D = torch.randn(B, C, C, device="cuda"); D = D + D.transpose(1, 2)
-        dF = torch.empty_like(F)
-        res = []
-        for fn in (lambda: ops.gram_fwd(F, 1.0 / (2 * HW * C)), lambda: ops.gram_bwd(F, D, 1.0, out=dF)):
-            fn(); torch.cuda.synchronize()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                fn()
-            e1.record(); torch.cuda.synchronize()
-            res.append(e0.elapsed_time(e1) / 10)
-        fl = 2.0 * B * HW * C * C
-        fl_all += fl; tf += res[0]; tb += res[1]
-        print("B=%d HW=%6d C=%3d  fwd %7.3f ms %6.1f TF/s   bwd %7.3f ms %6.1f TF/s" %
-              (B, HW, C, res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9))
-    print("B=%d total fwd %.3f ms %.1f TF/s, bwd %.3f ms %.1f TF/s" % (B, tf, fl_all / tf / 1e9, tb, fl_all / tb / 1e9))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+def timed(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+tot = [0, 0, 0]
+for HW, C in [(200, 64), (100, 128), (50, 256), (25, 512), (12, 512)]:
+    F = torch.relu(torch.randn(B, HW, HW, C, device="cuda"))
+    Gs = torch.randn(1, C, C, device="cuda")
+    loss = torch.zeros(B, device="cuda")
+    G = ops.gram_fwd(F, 1.0 / (HW * HW))
+    D = ops.style_loss_fwd(G, Gs, 1.0, loss)
+    out = torch.empty_like(F)
+    t_f = timed(lambda: ops.gram_fwd(F, 1.0 / (HW * HW), G=G))
+    t_l = timed(lambda: ops.style_loss_fwd(G, Gs, 1.0, loss, Dmat=D))
+    t_b = timed(lambda: ops.gram_bwd(F, D, 1.0, out=out))
+    fl = 2.0 * B * HW * HW * C * C
+    by = 4.0 * B * HW * HW * C
+    print("%3dx%-3d C=%3d  gram_fwd %6.1f us (%5.1f TF/s, F read %5.2f TB/s)  style_loss %5.1f us  gram_bwd %6.1f us (%5.1f TF/s, %5.2f TB/s)" % (
+        HW, HW, C, t_f, fl / t_f / 1e6, by / t_f / 1e6, t_l, t_b, fl / t_b / 1e6, 2 * by / t_b / 1e6))
+    tot[0] += t_f; tot[1] += t_l; tot[2] += t_b
+print("totals: gram_fwd %.1f  style_loss %.1f  gram_bwd %.1f us" % tuple(tot))
