@@ -28,9 +28,14 @@ for HW, Ci, Co in LAYERS:
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
     L.nfs_gemm_timer_read(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
     L.nfs_gemm_timer(0)
-    g = ms.value / n.value
     T = B * ((HW + 3) // 4) ** 2
+    if n.value == 0:                      # narrow layer: the single-kernel path, no batched GEMM launch
+        print("B=%d %3dx%-3d %3d->%-3d T=%5d  conv %.3f ms  (winograd_fused_kernel)" % (B, HW, HW, Ci, Co, T, whole))
+        whole_tot = whole_tot + whole if "whole_tot" in dir() else whole
+        continue
+    g = ms.value / n.value
+    whole_tot = whole_tot + whole if "whole_tot" in dir() else whole
     tot += g
     print("B=%d %3dx%-3d %3d->%-3d T=%5d  conv %.3f ms  gemm %.4f ms %6.1f TF/s executed  (transforms %.3f)" %
           (B, HW, HW, Ci, Co, T, whole, g, fl.value / n.value / g / 1e9, whole - g))
-print("gemm total %.3f ms" % tot)
+print("gemm total %.3f ms, conv calls total %.3f ms" % (tot, whole_tot))
