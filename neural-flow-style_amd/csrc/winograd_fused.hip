@@ -429,8 +429,15 @@ bool winograd_fusable(int K, int N) {
 }
 // ... and sizes: whole 4x4 tiles only (the epilogue has no per-pixel bounds checks), activations below 2 GB (32-bit
 // buffer offsets)
+// ... and enough of them: a block walks its K / 16 slices one after the other (~4 us each), so with K = 128 and fewer
+// than ~128 blocks (runs of 16 tiles x 64-channel groups) the three-kernel form, which spreads the same work over 36
+// components, finishes sooner (tools/small_conv_bench.py).  A static rule, not a measurement: the two forms differ in
+// rounding, and which one runs must not depend on timing noise.
 bool winograd_fused_takes(int B, int H, int W, int K, int N) {
-  return H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31);
+  if (!(H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31)))
+    return false;
+  const int64_t blocks = (((int64_t)B * (H / 4) * (W / 4) + 15) / 16) * (N / 64);
+  return K == 64 || blocks >= 128;
 }
 
 int64_t winograd_fused_packed_floats(int K, int N) { return winograd_fusable(K, N) ? (int64_t)36 * K * N : 0; }
