@@ -17,6 +17,8 @@
 //   k order inside a chunk is permuted identically for A and B, which a sum permits.
 // Weights are frozen, so they are packed once on the device into [chunk][tap][N][32].
 #include "common.h"
+
+#include <mutex>
 #include <stdlib.h>
 
 namespace nfs {
@@ -623,12 +625,10 @@ static int launch_conv(const ConvArgs& base, float* ws, int64_t ws_floats, hipSt
     constexpr int BN = 128;
     const size_t oper = PATCH_MAX * LDS_STRIDE + 2 * BN * LDS_STRIDE, tile = BM * (BN + 4);
     const size_t lds = (oper > tile ? oper : tile) * sizeof(float) + BM * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
+    std::call_once(attr_once, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<BN, MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), grid, dim3(256), lds, s, a);
   } else {
     constexpr int BN = 64;

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "winograd_math.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -947,7 +948,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 // ---- host side -----------------------------------------------------------------------------------------------
 // ---- optional per-launch event timing of the GEMM kernel (nfs_gemm_timer) ---------------------------------
 struct GemmTimerRec { hipEvent_t e0, e1; double flops; };
-static bool g_timer_on = false;
+static std::atomic<bool> g_timer_on{false};
 static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
 
@@ -955,12 +956,10 @@ template <int BM, int BN, int NBUF>
 static void launch_gemm_variant(const WgGemmArgs& a, hipStream_t s) {
   const size_t oper = NBUF * (BM + BN) * WG_LS, tile = BM * (BN + 4);
   const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BM, BN, NBUF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
+  if (lds > 65536) std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_kernel<BM, BN, NBUF>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
@@ -1004,18 +1003,16 @@ static void pick_gemm_tile(int64_t T, int N, int Z, int cus, int* bm_out, int* b
 
 // 0: float32-input MFMA (v_mfma_f32_32x32x2_f32); 1: split-limb form on the bf16 MFMA (float32-equivalent, see
 // winograd_gemm_split_kernel).  Process-wide setting (nfs_gemm_mode); NFS_GEMM_MODE presets it.
-static int g_gemm_mode = [] { const char* e = getenv("NFS_GEMM_MODE"); return e ? atoi(e) : 0; }();
+static std::atomic<int> g_gemm_mode{[] { const char* e = getenv("NFS_GEMM_MODE"); return e ? atoi(e) : 0; }()};
 
 template <int BM, int BN, int NBUF>
 static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
   const size_t oper = (size_t)NBUF * 3 * WB_RB * (BM + BN), tile = (size_t)BM * (BN + 4) * sizeof(float);
   const size_t lds = oper > tile ? oper : tile;
-  static bool attr_done = false;
-  if (!attr_done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_split_kernel<BM, BN, NBUF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
+  if (lds > 65536) std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_split_kernel<BM, BN, NBUF>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
@@ -1032,12 +1029,10 @@ template <int BM, int BN>
 static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
   const size_t oper = 2 * BM * WG_LS, tile = (BM / 2) * (BN + 4);
   const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb_kernel<BM, BN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
+  if (lds > 65536) std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb_kernel<BM, BN>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
@@ -1264,8 +1259,8 @@ extern "C" {
 int nfs_gemm_prof(void* buf) { nfs::g_gemm_prof = reinterpret_cast<unsigned long long*>(buf); return 0; }
 #endif
 int nfs_gemm_mode(int mode) {
-  const int prev = nfs::g_gemm_mode;
-  if (mode == 0 || mode == 1) nfs::g_gemm_mode = mode;
+  const int prev = nfs::g_gemm_mode.load();
+  if (mode == 0 || mode == 1) nfs::g_gemm_mode.store(mode);
   return prev;
 }
 

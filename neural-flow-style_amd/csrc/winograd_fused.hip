@@ -20,6 +20,8 @@
 // HBM traffic: x once (plus halo re-reads that hit L2), y once.  Same V, same transforms as winograd.hip; the k order
 // of the sums differs, so results agree to float32 rounding, not bit for bit.
 #include "common.h"
+
+#include <mutex>
 #include "winograd_math.h"
 
 namespace nfs {
@@ -450,12 +452,10 @@ int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s)
 template <int K, int N, int MODE, int POOLED>
 static void launch_fused(const WfArgs& a, hipStream_t s) {
   const size_t lds = 2 * WF_BUF * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_fused_kernel<K, N, MODE, POOLED>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
+  std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_fused_kernel<K, N, MODE, POOLED>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int grid = (a.runs + 7) / 8 * 8;
   hipLaunchKernelGGL((winograd_fused_kernel<K, N, MODE, POOLED>), dim3(grid, N / 64), dim3(256), lds, s, a);
 }
