@@ -16,6 +16,7 @@
 #include "common.h"
 #include "winograd_math.h"
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -356,6 +357,7 @@ struct WgGemmArgs {
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
   const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
   const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
+  const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 kernel)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
 };
@@ -665,6 +667,134 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb_kernel(WgGemmArgs a) {
       *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
     }
   }
+}
+
+// ---- register-B form on 16-row MFMA tiles ("rb16") --------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the same 64 flop / cycle / SIMD as the 32x32x2 form, and lets the row tile be a multiple
+// of 16: 392 Winograd tiles (conv4_x, 8 views) are 5 x 80 rows instead of 7 x 64 = 448, 72 (conv5_1) are 80 instead of
+// 128.  The four waves of a block sit side by side along N (NW16 column tiles of 16 each) and all read the block's BM =
+// 16 MT16 rows of A from LDS; B as in winograd_gemm_rb_kernel, packed for this instruction: element (lane, s) of the
+// kilobyte for (z, 16-column tile nn, 16-deep k group kk) is U_z[16 kk + 4 (lane>>4) + s][16 nn + (lane & 15)], i.e. MFMA
+// step s multiplies k = s, 4 + s, 8 + s, 12 + s of the group -- the lane's A operand for the four steps is then one
+// contiguous float4 of its LDS row.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT16, int NW16>
+__global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
+  constexpr int BM = 16 * MT16, BN = 64 * NW16;
+  constexpr int BMP = (BM + 31) / 32 * 32;            // staged rows (a multiple of the 32 rows one pass of the block moves)
+  constexpr int AJ = BMP / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][BMP][36]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int per_xcd = gridDim.x / WG_XCDS;
+  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;   // XCD-aware order, see above
+  if (logical >= a.mt * a.nt * a.Z) return;
+  const int comp = logical / (a.mt * a.nt);
+  const int rem = logical - comp * (a.mt * a.nt);
+  const int64_t m0 = (int64_t)(rem % a.mt) * BM;
+  const int n0 = (rem / a.mt) * BN;
+  const int nchunks = a.K / WG_KC;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Uq16 + (int64_t)comp * a.K * a.N), 0, (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
+
+  // A staging: thread t moves float4 #(t&7) of rows (t>>3) + 32 j; rows beyond the tile or beyond T read as zeros
+  const int q4 = 4 * (t & 7), r0 = t >> 3;
+  uint32_t ao[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int r = r0 + 32 * j;
+    const int64_t m = m0 + r;
+    ao[j] = (r < BM && m < a.T) ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
+  }
+  const uint32_t bo = (uint32_t)lane * 16u;
+  const uint32_t kgs = (uint32_t)(a.K / 16) * 1024u;  // bytes per 16-column tile
+  const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
+  float4 av[AJ], bq[NW16][2];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], 0);
+#pragma unroll
+  for (int nt = 0; nt < NW16; ++nt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + g * 1024u);
+
+  const int afrag = (lane & 15) * WG_LS + 4 * (lane >> 4);     // + 16 mt rows, + 16 g floats
+
+  f32x4 acc[MT16][NW16];
+#pragma unroll
+  for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NW16; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int c = 0; c < nchunks; ++c) {
+    float* Ac = As + (c & 1) * BMP * WG_LS;
+    {
+      float* ad = Ac + r0 * WG_LS + q4;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<float4*>(ad + 32 * j * WG_LS) = av[j];
+    }
+    __syncthreads();                                   // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
+    const int cn = c + 1 < nchunks ? c + 1 : c;        // (the last iteration re-fetches its own chunk: no branch)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float4 af[MT16];
+#pragma unroll
+      for (int mt = 0; mt < MT16; ++mt) af[mt] = *reinterpret_cast<const float4*>(Ac + afrag + 16 * mt * WG_LS + 16 * g);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int nt = 0; nt < NW16; ++nt) {
+          const float b = ss == 0 ? bq[nt][g].x : ss == 1 ? bq[nt][g].y : ss == 2 ? bq[nt][g].z : bq[nt][g].w;
+#pragma unroll
+          for (int mt = 0; mt < MT16; ++mt) {
+            const float av_ = ss == 0 ? af[mt].x : ss == 1 ? af[mt].y : ss == 2 ? af[mt].z : af[mt].w;
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(av_), "v"(b));
+          }
+        }
+#pragma unroll
+      for (int nt = 0; nt < NW16; ++nt) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // epilogue: the tile through LDS (C layout: lane = column l & 15, rows 4 (l >> 4) + r), out as float4 rows
+  constexpr int OS = BN + 4;
+  float* otile = smem;
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NW16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        otile[(16 * mt + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
+  __syncthreads();
+  float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  constexpr int Q = BN / 4;
+  for (int f = t; f < BM * Q; f += 256) {
+    const int row = f / Q, q = f - row * Q;
+    const int64_t m = m0 + row;
+    if (m >= a.T) continue;
+    *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+  }
+}
+
+// U [Z][K/32][N][32] -> Uq16 [Z][N/16][K/16][64][4]
+__global__ void __launch_bounds__(256) winograd_pack_frag16_kernel(const float* __restrict__ up, float* __restrict__ uq,
+                                                                   int K, int N, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int n = (int)(gid % N), k = (int)((gid / N) % K), z = (int)(gid / ((int64_t)N * K));
+  const float u = up[(((int64_t)z * (K / 32) + k / 32) * N + n) * 32 + (k & 31)];
+  const int kk = k >> 4, kq = (k >> 2) & 3, ss = k & 3;
+  uq[((((int64_t)z * (N / 16) + n / 16) * (K / 16) + kk) * 64 + kq * 16 + (n & 15)) * 4 + ss] = u;
 }
 
 // U [Z][K/32][N][32] -> Uq [Z][N/32][K/8][64][4]
@@ -1045,6 +1175,27 @@ static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
+template <int MT16, int NW16>
+static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
+  constexpr int BM = 16 * MT16, BN = 64 * NW16, BMP = (BM + 31) / 32 * 32;
+  const size_t oper = 2 * BMP * WG_LS, tile = BM * (BN + 4);
+  const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+  static std::once_flag attr_once;
+  if (lds > 65536) std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16_kernel<MT16, NW16>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+  const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
+  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+  if (timed) (void)hipEventRecord(rec.e0, s);
+  hipLaunchKernelGGL((winograd_gemm_rb16_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
+}
+
 // the register-B kernel takes the plain Winograd GEMMs (packed filters, no mask / scale) with 32-bit operand offsets
 static bool gemm_rb_applies(const WgGemmArgs& a) {
   static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
@@ -1072,6 +1223,14 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
     else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
     else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
     else launch_gemm_split<64, 64, 1>(a, s);
+    return;
+  }
+  if (variant == 2 && gemm_rb_applies(a) && a.Uq16 && (bm == 80 || bm == 48) && a.N % bn == 0) {
+    a.mt = (int)((a.T + bm - 1) / bm);
+    if (bm == 80 && bn == 128) launch_gemm_rb16<5, 2>(a, s);
+    else if (bm == 80) launch_gemm_rb16<5, 1>(a, s);
+    else if (bn == 128) launch_gemm_rb16<3, 2>(a, s);
+    else launch_gemm_rb16<3, 1>(a, s);
     return;
   }
   if (variant == 1 && gemm_rb_applies(a)) {
@@ -1116,11 +1275,26 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
     return !(e && atoi(e) == 0) && !getenv("NFS_GEMM_BM") && !getenv("NFS_GEMM_BN");
   }();
   // NFS_GEMM_RB=2 (with NFS_GEMM_BM / BN or NFS_GEMM_TUNE=0): always the register-B kernel where it applies (tests)
-  static const int force_rb = [] { const char* e = getenv("NFS_GEMM_RB"); return (e && atoi(e) == 2) ? 1 : 0; }();
+  // NFS_GEMM_RB=3 NFS_GEMM_BM=80|48 NFS_GEMM_BN=128|64: always the 16-row form
+  static const int force_rb = [] { const char* e = getenv("NFS_GEMM_RB"); const int v = e ? atoi(e) : 0; return v == 2 ? 1 : v == 3 ? 2 : 0; }();
   int bm, bn, variant = force_rb;
   pick_gemm_tile(a.T, a.N, Z, cus, &bm, &bn);
+  // Which MFMA the GEMM runs on is decided by the shape alone (never by a measurement: the two instructions sum k in
+  // different groupings, so their results differ in the last bit): the 16-row form where it executes at least 7 % fewer
+  // rows than the best 32-row tiling.  Within a family every candidate computes the identical result, and the tuner
+  // measures.
+  const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = std::min((a.T + 79) / 80 * 80, (a.T + 47) / 48 * 48);
+  const bool rows16 = g_gemm_mode == 0 && a.Uq16 && gemm_rb_applies(a) && force_rb != 1 && !getenv("NFS_GEMM_BM") &&
+                      pad16 * 100 <= pad32 * 93;
+  if (rows16 && !tune) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }
+  if (force_rb == 2) {
+    static const int fbm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 80; }();
+    static const int fbn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 128; }();
+    if ((fbm == 80 || fbm == 48) && a.N % fbn == 0) { bm = fbm; bn = fbn; } else variant = 0;
+  }
   if (tune) {
     const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
+    if (rows16) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
     std::unique_lock<std::mutex> lk(g_tile_mu);
     auto it = g_tile_cache.find(key);
     if (it != g_tile_cache.end()) {
@@ -1131,20 +1305,27 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
       hipEvent_t e0, e1;
       if (!capturing && !g_timer_on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         float best = 1e30f;
-        const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
-        const int nvar = (g_gemm_mode == 0 && gemm_rb_applies(a)) ? 2 : 1;
-        for (int var = 0; var < nvar; ++var)
-          for (int c = 0; c < 4; ++c) {
-            if (a.N % cand[c][1]) continue;
-            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);     // warm (L2, instruction cache)
-            (void)hipEventRecord(e0, s);
-            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);
-            launch_gemm_tile(a, Z, cand[c][0], cand[c][1], s, var);
-            (void)hipEventRecord(e1, s);
-            float ms = 1e30f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
-            if (ms < best) { best = ms; bm = cand[c][0]; bn = cand[c][1]; variant = var; }
-          }
+        auto trial = [&](int cbm, int cbn, int var) {
+          launch_gemm_tile(a, Z, cbm, cbn, s, var);                     // warm (L2, instruction cache)
+          (void)hipEventRecord(e0, s);
+          launch_gemm_tile(a, Z, cbm, cbn, s, var);
+          launch_gemm_tile(a, Z, cbm, cbn, s, var);
+          (void)hipEventRecord(e1, s);
+          float ms = 1e30f;
+          if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+          if (ms < best) { best = ms; bm = cbm; bn = cbn; variant = var; }
+        };
+        if (rows16) {                                                   // 16-row tiles: 80 / 48 rows x 128 / 64 columns
+          const int cand16[4][2] = {{80, 128}, {80, 64}, {48, 128}, {48, 64}};
+          for (int c = 0; c < 4; ++c)
+            if (a.N % cand16[c][1] == 0) trial(cand16[c][0], cand16[c][1], 2);
+        } else {
+          const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
+          const int nvar = (g_gemm_mode == 0 && gemm_rb_applies(a)) ? 2 : 1;
+          for (int var = 0; var < nvar; ++var)
+            for (int c = 0; c < 4; ++c)
+              if (a.N % cand[c][1] == 0) trial(cand[c][0], cand[c][1], var);
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         g_tile_cache[key] = std::make_tuple(bm, bn, variant);
@@ -1178,9 +1359,9 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
 // 36 floats per (ci, co): room for either tile size
 // plus, for the F(4x4) filters, their three bf16 limb planes (6 bytes per element = 54 floats per (ci, co))
 // and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
-// and the filters once more in MFMA fragment order (register-B GEMM kernel)
+// and the filters twice more in MFMA fragment order (register-B GEMM kernels, 32x32x2 and 16x16x4 forms)
 int64_t winograd_packed_floats(int Ci, int Co) {
-  return (int64_t)(36 + 54 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
+  return (int64_t)(36 + 54 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
 }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
@@ -1192,8 +1373,10 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
     const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
     hipLaunchKernelGGL(winograd_pack_frag_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 90 * n, Kc, Nc,
                        36 * n);
+    hipLaunchKernelGGL(winograd_pack_frag16_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 126 * n, Kc,
+                       Nc, 36 * n);
     if (winograd_fusable(Kc, Nc))
-      if (int e = winograd_pack_fused(up, up + 126 * n, Kc, Nc, s)) return e;
+      if (int e = winograd_pack_fused(up, up + 162 * n, Kc, Nc, s)) return e;
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1210,7 +1393,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   // narrow layers: one kernel, no V / M round trip
   if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N) && (!pooled_grad || mode == 1))
-    return winograd_fused_conv(x, U + (int64_t)126 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
+    return winograd_fused_conv(x, U + (int64_t)162 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
                                in_bits, out_bits, pooled_grad);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
@@ -1230,6 +1413,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   if (m == 4) {
     a.Ub = reinterpret_cast<const unsigned short*>(U + (int64_t)36 * K * N);
     a.Uq = U + (int64_t)90 * K * N;
+    a.Uq16 = U + (int64_t)126 * K * N;
   }
   launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {
