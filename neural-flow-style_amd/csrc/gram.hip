@@ -10,8 +10,9 @@
 //   k-major operand layout of v_mfma_f32_32x32x2_f32, no transposition anywhere.  The partial tile goes to the
 //   workspace; gram_reduce_kernel sums the slabs in a fixed order, applies the scale and writes the tile and
 //   its mirror image (deterministic).  Without a workspace the scaled tile (and its mirror) is added with float atomics.
-// gram_bwd: dF_b = 2 s_b F_b D_b is a plain batched GEMM (M = pixels, N = K = C): it runs on the LDS-staged
-//   batched f32-MFMA GEMM of winograd.hip (D is symmetric: its rows are read as columns), ReLU mask fused.
+// gram_bwd: dF_b = 2 s_b F_b D_b is a plain batched GEMM (M = pixels, N = K = C): it runs on the batched f32-MFMA GEMMs
+//   of winograd.hip -- the register-B 16-row form, D read in place (symmetric: row n serves as column n, a lane's four
+//   k are consecutive floats), ReLU mask and scale in the epilogue.
 #include "common.h"
 
 namespace nfs {

@@ -358,6 +358,7 @@ struct WgGemmArgs {
   const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
   const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
   const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 kernel)
+  int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
 };
@@ -710,8 +711,12 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
     const int64_t m = m0 + r;
     ao[j] = (r < BM && m < a.T) ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
   }
-  const uint32_t bo = (uint32_t)lane * 16u;
-  const uint32_t kgs = (uint32_t)(a.K / 16) * 1024u;  // bytes per 16-column tile
+  // B fragment of (16-column tile nn, 16-deep k group kk): packed filters -> one kilobyte, lane-linear.  A symmetric
+  // matrix needs no packing at all: B[k][n] = D[n][k], so the lane's four k (16 kk + 4 (lane>>4) + s) are four
+  // consecutive floats of ROW 16 nn + (lane & 15) of the plain matrix.
+  const uint32_t bo = a.symb ? (uint32_t)((lane & 15) * a.N + 4 * (lane >> 4)) * 4u : (uint32_t)lane * 16u;
+  const uint32_t kgs = a.symb ? (uint32_t)(16 * a.N) * 4u : (uint32_t)(a.K / 16) * 1024u;   // bytes per 16-column tile
+  const uint32_t gst = a.symb ? 64u : 1024u;                                               // ... per 16-deep k group
   const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
   float4 av[AJ], bq[NW16][2];
 #pragma unroll
@@ -719,7 +724,7 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NW16; ++nt)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + g * 1024u);
+    for (int g = 0; g < 2; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + g * gst);
 
   const int afrag = (lane & 15) * WG_LS + 4 * (lane >> 4);     // + 16 mt rows, + 16 g floats
 
@@ -759,7 +764,7 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
           }
         }
 #pragma unroll
-      for (int nt = 0; nt < NW16; ++nt) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);
+      for (int nt = 0; nt < NW16; ++nt) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * gst);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -777,12 +782,21 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
         otile[(16 * mt + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
   __syncthreads();
   float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
   constexpr int Q = BN / 4;
   for (int f = t; f < BM * Q; f += 256) {
     const int row = f / Q, q = f - row * Q;
     const int64_t m = m0 + row;
     if (m >= a.T) continue;
-    *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    const int64_t idx = m * a.N + n0 + 4 * q;
+    if (a.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)comp * a.T * a.N + idx);
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+      v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(Mc + idx) = v;
   }
 }
 
@@ -1197,6 +1211,11 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
 }
 
 // the register-B kernel takes the plain Winograd GEMMs (packed filters, no mask / scale) with 32-bit operand offsets
+// ... the 16-row form also scales and masks (the Gram gradient runs on it, its symmetric D read in place)
+static bool gemm_rb16_applies(const WgGemmArgs& a) {
+  static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
+  return !off && a.Uq16 && a.T * a.K * 4 < ((int64_t)1 << 31) && (int64_t)a.K * a.N * 4 < ((int64_t)1 << 31);
+}
 static bool gemm_rb_applies(const WgGemmArgs& a) {
   static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
   return !off && a.Uq && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.T * a.K * 4 < ((int64_t)1 << 31) &&
@@ -1225,7 +1244,7 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
     else launch_gemm_split<64, 64, 1>(a, s);
     return;
   }
-  if (variant == 2 && gemm_rb_applies(a) && a.Uq16 && (bm == 80 || bm == 48) && a.N % bn == 0) {
+  if (variant == 2 && gemm_rb16_applies(a) && (bm == 80 || bm == 48) && a.N % bn == 0) {
     a.mt = (int)((a.T + bm - 1) / bm);
     if (bm == 80 && bn == 128) launch_gemm_rb16<5, 2>(a, s);
     else if (bm == 80) launch_gemm_rb16<5, 1>(a, s);
@@ -1285,13 +1304,13 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   // measures.
   static const int rows16_pct = [] { const char* e = getenv("NFS_GEMM_ROWS16_PCT"); return e ? atoi(e) : 100; }();
   const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = std::min((a.T + 79) / 80 * 80, (a.T + 47) / 48 * 48);
-  const bool rows16 = g_gemm_mode == 0 && a.Uq16 && gemm_rb_applies(a) && force_rb != 1 && !getenv("NFS_GEMM_BM") &&
+  const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !getenv("NFS_GEMM_BM") &&
                       pad16 * 100 <= pad32 * rows16_pct;
   if (rows16 && !tune) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }
   if (force_rb == 2) {
     static const int fbm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 80; }();
     static const int fbn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 128; }();
-    if ((fbm == 80 || fbm == 48) && a.N % fbn == 0) { bm = fbm; bn = fbn; } else variant = 0;
+    if ((fbm == 80 || fbm == 48) && a.N % fbn == 0 && gemm_rb16_applies(a)) { bm = fbm; bn = fbn; } else variant = 0;
   }
   if (tune) {
     const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
@@ -1341,6 +1360,8 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
 int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
                   int relu_mask, int cus, hipStream_t s) {
   WgGemmArgs a{F, Dm, dF, (int64_t)HW, C, C, (int64_t)C * C, 32, C, alpha, alpha_dev, relu_mask ? F : nullptr};
+  a.Uq16 = Dm;               // rb16 reads the symmetric D in place (row n as column n)
+  a.symb = 1;
   launch_batched_gemm(a, B, cus, s);
   return check_launch("gram_bwd_gemm");
 }
