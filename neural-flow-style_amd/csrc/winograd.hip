@@ -1304,7 +1304,8 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   // measures.
   static const int rows16_pct = [] { const char* e = getenv("NFS_GEMM_ROWS16_PCT"); return e ? atoi(e) : 100; }();
   const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = std::min((a.T + 79) / 80 * 80, (a.T + 47) / 48 * 48);
-  const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !getenv("NFS_GEMM_BM") &&
+  static const bool bm_forced = getenv("NFS_GEMM_BM") != nullptr;
+  const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
                       pad16 * 100 <= pad32 * rows16_pct;
   if (rows16 && !tune) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }
   if (force_rb == 2) {
