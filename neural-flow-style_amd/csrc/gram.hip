@@ -166,6 +166,24 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   }
   const float sc = a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
   float* Gb = a.G + (int64_t)b * a.C * a.C;
+  if (a.nslab == 1) {
+    // one slab per tile pair (many pairs, few pixels: the deep layers): this block holds the complete sums -- the scaled
+    // tile and its mirror image are written directly, no partials and no second pass
+    for (int f = t; f < TS * R4; f += 256) {
+      const int row = f / R4, q = f - row * R4;
+      float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      *reinterpret_cast<float4*>(Gb + (int64_t)(t1 * TS + row) * a.C + t2 * TS + 4 * q) = v;
+    }
+    if (!diag)
+      for (int f = t; f < TS * R4; f += 256) {
+        const int col = f / R4, q = f - col * R4;            // mirrored row t2*TS + col, columns t1*TS + 4q ..
+        const float4 v = make_float4(otile[(4 * q) * OS + col] * sc, otile[(4 * q + 1) * OS + col] * sc,
+                                     otile[(4 * q + 2) * OS + col] * sc, otile[(4 * q + 3) * OS + col] * sc);
+        *reinterpret_cast<float4*>(Gb + (int64_t)(t2 * TS + col) * a.C + t1 * TS + 4 * q) = v;
+      }
+    return;
+  }
   for (int f = t; f < TS * TS; f += 256) {
     const int row = f / TS, col = f - row * TS;
     const float v = otile[row * OS + col] * sc;
@@ -307,6 +325,8 @@ static void gram_plan(GramArgs& a, int cus) {
   while (cps > 4 && pairs * ((total_chunks + cps - 1) / cps) < 2 * (int64_t)cus) cps >>= 1;
   if (cps > total_chunks) cps = total_chunks;
   if ((total_chunks + cps - 1) / cps > 256) cps = (total_chunks + 255) / 256;   // bound the reduce fan-in
+  // many tile pairs, few pixels (relu4_1, relu5_1 at 8 views): one slab -- the tile kernel then writes G itself
+  if (pairs >= cus && total_chunks <= 32) cps = total_chunks;
   if (env_cps > 0) cps = env_cps < total_chunks ? env_cps : total_chunks;
   a.cps = cps;
   a.nslab = (total_chunks + cps - 1) / cps;
@@ -329,7 +349,7 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
   a.F = F; a.G = G; a.scale_dev = scale_dev; a.scale = scale; a.B = B; a.HW = HW; a.C = C;
   gram_plan(a, gram_cus());
   const int64_t units = (int64_t)B * (a.ntile * (a.ntile + 1) / 2) * a.nslab;
-  a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C)) ? workspace : nullptr;
+  a.ws = (workspace && workspace_floats >= nfs_gram_workspace_floats(B, HW, C) && a.nslab > 1) ? workspace : nullptr;
   const size_t lds = 4 * GR_KC * 64 * sizeof(float);            // 32 KB (>= the 64 x 68 epilogue tile)
   hipLaunchKernelGGL(gram_tn_kernel<64>, dim3((unsigned)((units + 7) / 8 * 8)), dim3(256), lds, as_stream(stream), a);
   if (a.ws) {
