@@ -370,9 +370,11 @@ __global__ void __launch_bounds__(256) transport_step_generic_kernel(const float
 // belong to neighbouring tiles; only the owned cells are written back).  No global atomics; the integer
 // sums make the result independent of the traversal order.
 #ifndef NFS_RT_TZ
+// (tile shapes swept on 8 views of 200^3, tools/rot_bench.py: 14x14x30 0.375 ms, 12x12x40 0.349, 14x12x40 0.345, 12x12x48 0.47;
+// long tiles along x = long lattice rows for most views = fewer idle lanes in the row tails)
 #define NFS_RT_TZ 14
-#define NFS_RT_TY 14
-#define NFS_RT_TX 30
+#define NFS_RT_TY 12
+#define NFS_RT_TX 40
 #define NFS_RT_GROUP 8
 #endif
 constexpr int RT_TZ = NFS_RT_TZ, RT_TY = NFS_RT_TY, RT_TX = NFS_RT_TX;
