@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
             const float wz1 = gs * wz, wz0 = gs - wz1;
             const float w01 = wz0 * wy, w00 = wz0 - w01, w11 = wz1 * wy, w10 = wz1 - w11;
             const float ax_w1 = wx, ax_w0 = 1.f - wx;
-            unsigned long long* cell = acc + (lz * RT_LY + ly) * RT_LX + lx;
+            unsigned long long* cell = acc + (__mul24(__mul24(lz, RT_LY) + ly, RT_LX) + lx);   // (24-bit multiplies: full rate)
 // float -> 64-bit two's-complement fixed point in 4 instructions: high word = floor (v_cvt_flr_i32_f32),
 // low word = fract * 2^32 (v_fract_f32 is < 1 by construction; v_cvt_u32_f32 saturates)
 #define NFS_RT_ADD(off_, w_)                                                                       \
