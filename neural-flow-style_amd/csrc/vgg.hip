@@ -26,6 +26,8 @@ namespace nfs {
 // winograd.hip
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N);
 int64_t winograd_packed_floats(int Ci, int Co);
+int winograd_path(int B, int H, int W, int K, int N);
+int64_t winograd5_bits_words(int B, int H, int W, int C);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, float* ypool,
@@ -685,6 +687,7 @@ int64_t nfs_conv3x3_relu_bits_words(int B, int H, int W, int Ci, int Co, int poo
   ConvArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Ci, Co, 0, 0, 0, 1, 1, 0};
   float dummy = 0.f;
   if (off || !takes_fused_pool(a, &dummy, INT64_MAX)) return 0;
+  if (!pooled && winograd_path(B, H, W, Ci, Co) == 2) return winograd5_bits_words(B, H, W, Ci);   // F(5x5): its own layout
   const int64_t T = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
   return T * (Ci / 2) + (pooled ? T * (Co / 2) : 0);
 }

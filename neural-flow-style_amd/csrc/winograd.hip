@@ -15,6 +15,7 @@
 //   winograd_output*_kernel  M                      -> y [B,H,W,N]    + bias/ReLU (fwd) or ReLU mask/addend (dgrad)
 #include "common.h"
 #include "winograd_math.h"
+#include "winograd_gemm.h"
 
 #include <algorithm>
 #include <atomic>
@@ -33,6 +34,16 @@ int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s)
 int winograd_fused_conv(const float* x, const float* Uf, const float* aux0, const float* aux1, float* y, int B, int H,
                         int W, int K, int N, int mode, int relu, hipStream_t s, float* ypool, const float* xmask,
                         uint32_t* in_bits, uint32_t* out_bits, bool pooled_grad);
+
+// winograd5.hip
+bool winograd5_channels(int K, int N);
+bool winograd5_takes(int H, int W, int K, int N);
+int64_t winograd5_packed_floats(int Ci, int Co);
+int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N);
+int winograd5_pack(const float* w_hwio, float* up5, int Ci, int Co, int kind, hipStream_t s);
+int64_t winograd5_bits_words(int B, int H, int W, int C);
+int winograd5_conv(const float* x, const float* U5, const float* aux0, const float* aux1, float* y, float* ws, int B,
+                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -341,27 +352,6 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
 // reads, 4 consecutive k per lane feeding 4 MFMA steps -- the scheme of conv3x3_mfma_kernel).
 constexpr int WG_KC = 32, WG_LS = 36, WG_XCDS = 8;
 
-// Batched C_z = alpha_z * A_z B_z (optionally masked): the Winograd GEMMs (z = transform component) and the
-// Gram gradient dF_b = 2 s_b F_b D_b (z = image) share this kernel.
-struct WgGemmArgs {
-  const float* V;    // A: [Z][T][K] row-major
-  const float* U;    // B: element (k, n) of batch z at z*b_batch + (k/32)*b_chunk + n*b_row + k%32
-  float* M;          // C: [Z][T][N] row-major
-  int64_t T;
-  int K, N;
-  int64_t b_batch, b_chunk;
-  int b_row;
-  float alpha;               // C scale (1 for Winograd)
-  const float* alpha_dev;    // optional per-batch scale (device)
-  const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
-  int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
-  const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
-  const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
-  const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 kernel)
-  int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
-  unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
-  int dbg = 0;               // NFS_GEMM_DBG timing ablations
-};
 
 template <int BM, int BN, int NBUF>
 __global__ void __launch_bounds__(256, 2) winograd_gemm_kernel(WgGemmArgs a) {
@@ -769,34 +759,40 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
     }
   }
 
-  // epilogue: the tile through LDS (C layout: lane = column l & 15, rows 4 (l >> 4) + r), out as float4 rows
-  constexpr int OS = BN + 4;
+  // epilogue: the tile through LDS (C layout: lane = column l & 15, rows 4 (l >> 4) + r), out as float4 rows; at most
+  // five row tiles (80 rows) per pass, so that a tall tile does not need a tall buffer
+  constexpr int OS = BN + 4, EP = MT16 < 5 ? MT16 : 5, NPASS = (MT16 + EP - 1) / EP;
   float* otile = smem;
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < MT16; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NW16; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        otile[(16 * mt + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
-  __syncthreads();
   float* Mc = a.M + (int64_t)comp * a.T * a.N;
   const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
   constexpr int Q = BN / 4;
-  for (int f = t; f < BM * Q; f += 256) {
-    const int row = f / Q, q = f - row * Q;
-    const int64_t m = m0 + row;
-    if (m >= a.T) continue;
-    float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
-    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-    const int64_t idx = m * a.N + n0 + 4 * q;
-    if (a.mask) {
-      const float4 mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)comp * a.T * a.N + idx);
-      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-      v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT16; ++mt)
+      if (mt / EP == pass)
+#pragma unroll
+        for (int nt = 0; nt < NW16; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            otile[(16 * (mt % EP) + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
+    __syncthreads();
+    const int rows = 16 * ((pass + 1) * EP <= MT16 ? EP : MT16 - pass * EP);
+    for (int f = t; f < rows * Q; f += 256) {
+      const int row = f / Q, q = f - row * Q;
+      const int64_t m = m0 + 16 * EP * pass + row;
+      if (m >= a.T) continue;
+      float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+      v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+      const int64_t idx = m * a.N + n0 + 4 * q;
+      if (a.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(a.mask + (int64_t)comp * a.T * a.N + idx);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(Mc + idx) = v;
     }
-    *reinterpret_cast<float4*>(Mc + idx) = v;
   }
 }
 
@@ -1192,7 +1188,7 @@ static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
 template <int MT16, int NW16>
 static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16, BMP = (BM + 31) / 32 * 32;
-  const size_t oper = 2 * BMP * WG_LS, tile = BM * (BN + 4);
+  const size_t oper = 2 * BMP * WG_LS, tile = 16 * (MT16 < 5 ? MT16 : 5) * (BN + 4);
   const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
   static std::once_flag attr_once;
   if (lds > 65536) std::call_once(attr_once, [&] {
@@ -1211,6 +1207,18 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
 }
 
 // the register-B kernel takes the plain Winograd GEMMs (packed filters, no mask / scale) with 32-bit operand offsets
+// row tiles of the 16-row form: 80 (5 MFMA tiles), 48, 112, 208 (e.g. the 200 rows of an F(5x5) layer at 8 views)
+static const int kRb16Rows[4] = {80, 48, 112, 208};
+static bool rb16_rows_ok(int bm) { return bm == 80 || bm == 48 || bm == 112 || bm == 208; }
+static int64_t rb16_best_rows(int64_t T, int* bm_out) {
+  int64_t best = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t p = (T + kRb16Rows[i] - 1) / kRb16Rows[i] * kRb16Rows[i];
+    if (best < 0 || p < best) { best = p; if (bm_out) *bm_out = kRb16Rows[i]; }
+  }
+  return best;
+}
+
 // ... the 16-row form also scales and masks (the Gram gradient runs on it, its symmetric D read in place)
 static bool gemm_rb16_applies(const WgGemmArgs& a) {
   static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
@@ -1220,6 +1228,10 @@ static bool gemm_rb_applies(const WgGemmArgs& a) {
   static const bool off = [] { const char* e = getenv("NFS_GEMM_RB"); return e && atoi(e) == 0; }();
   return !off && a.Uq && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.T * a.K * 4 < ((int64_t)1 << 31) &&
          (int64_t)a.K * a.N * 4 < ((int64_t)1 << 31);
+}
+
+void winograd_pack_frag16(const float* up, float* uq, int K, int N, int64_t total, hipStream_t s) {
+  hipLaunchKernelGGL(winograd_pack_frag16_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, up, uq, K, N, total);
 }
 
 static unsigned long long* g_gemm_prof = nullptr;        // NFS_ABLATE builds only (nfs_gemm_prof)
@@ -1244,12 +1256,12 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
     else launch_gemm_split<64, 64, 1>(a, s);
     return;
   }
-  if (variant == 2 && gemm_rb16_applies(a) && (bm == 80 || bm == 48) && a.N % bn == 0) {
+  if (variant == 2 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0) {
     a.mt = (int)((a.T + bm - 1) / bm);
-    if (bm == 80 && bn == 128) launch_gemm_rb16<5, 2>(a, s);
-    else if (bm == 80) launch_gemm_rb16<5, 1>(a, s);
-    else if (bn == 128) launch_gemm_rb16<3, 2>(a, s);
-    else launch_gemm_rb16<3, 1>(a, s);
+    if (bm == 80) { if (bn == 128) launch_gemm_rb16<5, 2>(a, s); else launch_gemm_rb16<5, 1>(a, s); }
+    else if (bm == 48) { if (bn == 128) launch_gemm_rb16<3, 2>(a, s); else launch_gemm_rb16<3, 1>(a, s); }
+    else if (bm == 112) { if (bn == 128) launch_gemm_rb16<7, 2>(a, s); else launch_gemm_rb16<7, 1>(a, s); }
+    else { if (bn == 128) launch_gemm_rb16<13, 2>(a, s); else launch_gemm_rb16<13, 1>(a, s); }
     return;
   }
   if (variant == 1 && gemm_rb_applies(a)) {
@@ -1303,19 +1315,20 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   // than the best 32-row tiling (NFS_GEMM_ROWS16_PCT, default 100: at equal rows it measured 3-5 % faster).  Within a family every candidate computes the identical result, and the tuner
   // measures.
   static const int rows16_pct = [] { const char* e = getenv("NFS_GEMM_ROWS16_PCT"); return e ? atoi(e) : 100; }();
-  const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = std::min((a.T + 79) / 80 * 80, (a.T + 47) / 48 * 48);
+  int bm16 = 80;
+  const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = rb16_best_rows(a.T, &bm16);
   static const bool bm_forced = getenv("NFS_GEMM_BM") != nullptr;
   const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
                       pad16 * 100 <= pad32 * rows16_pct;
-  if (rows16 && !tune) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }
+  if (rows16 && !tune) { variant = 2; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }
   if (force_rb == 2) {
     static const int fbm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 80; }();
     static const int fbn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 128; }();
-    if ((fbm == 80 || fbm == 48) && a.N % fbn == 0 && gemm_rb16_applies(a)) { bm = fbm; bn = fbn; } else variant = 0;
+    if (rb16_rows_ok(fbm) && a.N % fbn == 0 && gemm_rb16_applies(a)) { bm = fbm; bn = fbn; } else variant = 0;
   }
   if (tune) {
     const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
-    if (rows16) { variant = 2; bm = (a.T + 79) / 80 * 80 <= (a.T + 47) / 48 * 48 ? 80 : 48; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
+    if (rows16) { variant = 2; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
     std::unique_lock<std::mutex> lk(g_tile_mu);
     auto it = g_tile_cache.find(key);
     if (it != g_tile_cache.end()) {
@@ -1337,9 +1350,12 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
           if (ms < best) { best = ms; bm = cbm; bn = cbn; variant = var; }
         };
         if (rows16) {                                                   // 16-row tiles: 80 / 48 rows x 128 / 64 columns
-          const int cand16[4][2] = {{80, 128}, {80, 64}, {48, 128}, {48, 64}};
-          for (int c = 0; c < 4; ++c)
-            if (a.N % cand16[c][1] == 0) trial(cand16[c][0], cand16[c][1], 2);
+          for (int i = 0; i < 4; ++i) {                                  // row tiles that pad no worse than 1.1 x the best
+            const int64_t p = (a.T + kRb16Rows[i] - 1) / kRb16Rows[i] * kRb16Rows[i];
+            if (p * 10 > pad16 * 11) continue;
+            for (int cbn = 128; cbn >= 64; cbn -= 64)
+              if (a.N % cbn == 0) trial(kRb16Rows[i], cbn, 2);
+          }
         } else {
           const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
           const int nvar = (g_gemm_mode == 0 && gemm_rb_applies(a)) ? 2 : 1;
@@ -1357,6 +1373,8 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   launch_gemm_tile(a, Z, bm, bn, s, variant);
 }
 
+void winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s) { launch_batched_gemm(a, Z, cus, s); }
+
 // dF[b] = alpha_b * F[b] @ D[b] (D symmetric, so row n of D serves as column n), optional (F > 0) mask
 int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
                   int relu_mask, int cus, hipStream_t s) {
@@ -1373,10 +1391,19 @@ int winograd_tile() {
   return m;
 }
 
+// Which form a (non-pooled) conv call takes: 1 the single-kernel path (narrow layers), 2 F(5x5) (deep layers whose
+// image F(4x4) would pad heavily), 0 the three-kernel F(4x4) / F(2x2).  A function of the shapes alone.
+int winograd_path(int B, int H, int W, int K, int N) {
+  if (winograd_tile() != 4) return 0;
+  if (winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N)) return 1;
+  return winograd5_takes(H, W, K, N) ? 2 : 0;
+}
+
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
   const int m = winograd_tile();
   const int64_t T = (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
-  return (m + 2) * (m + 2) * T * ((int64_t)K + N);
+  const int64_t f4 = (m + 2) * (m + 2) * T * ((int64_t)K + N), f5 = m == 4 ? winograd5_workspace_floats(B, H, W, K, N) : 0;
+  return f4 > f5 ? f4 : f5;
 }
 
 // 36 floats per (ci, co): room for either tile size
@@ -1384,7 +1411,7 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
 // and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
 // and the filters twice more in MFMA fragment order (register-B GEMM kernels, 32x32x2 and 16x16x4 forms)
 int64_t winograd_packed_floats(int Ci, int Co) {
-  return (int64_t)(36 + 54 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co);
+  return (int64_t)(36 + 54 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co);
 }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
@@ -1400,6 +1427,8 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
                        Nc, 36 * n);
     if (winograd_fusable(Kc, Nc))
       if (int e = winograd_pack_fused(up, up + 162 * n, Kc, Nc, s)) return e;
+    if (winograd5_channels(Kc, Nc))       // the F(5x5) filters and their fragment order, behind everything else
+      if (int e = winograd5_pack(w_hwio, up + 162 * n + winograd_fused_packed_floats(Ci, Co), Ci, Co, kind, s)) return e;
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1418,6 +1447,11 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N) && (!pooled_grad || mode == 1))
     return winograd_fused_conv(x, U + (int64_t)162 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
                                in_bits, out_bits, pooled_grad);
+  // deep layers with heavily padded F(4x4) tilings: F(5x5) (no pooling fused there; its ReLU bit cache has its own
+  // layout, sized by nfs_conv3x3_relu_bits_words for exactly the layers that come here)
+  if (m == 4 && !pooled_grad && !ypool && !out_bits && y && winograd5_takes(H, W, K, N))
+    return winograd5_conv(x, U + (int64_t)162 * K * N + winograd_fused_packed_floats(K, N), aux0, aux1, y, ws, B, H, W, K, N,
+                          mode, relu, cus, s, in_bits);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;

@@ -1,0 +1,269 @@
+// A6, deep layers whose image side is a multiple of 5 or close to one (25 x 25, 50 x 50): Winograd F(5x5, 3x3) in float32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per 5 x 5 output tile from a 7 x 7 input patch: 49 products per 25 outputs
+//
+// (1.96 multiplies per output against F(4x4)'s 2.25), and -- what matters more here -- no tile padding: a 25 x 25 image is
+// 5 x 5 tiles of 5 where F(4x4) needs 7 x 7 tiles of 4 (28 x 28: 20 % of its multiplies fall on padding), 50 x 50 is 10 x 10
+// against 13 x 13.  49 T5 against 36 T4 rows of GEMM work: 0.69 x at 25 x 25, 0.81 x at 50 x 50; V and M shrink alike.
+// Interpolation points 0, +-1, +-2, 1/2, inf (exact rational matrices below, Cook-Toom).  Float32 error against a float64
+// convolution, 512 input channels, post-ReLU activations: 4.8e-6 relative where F(4x4) has 2.3e-6 and the direct form
+// 7e-7 (tests/test_ops_gpu.py states the budget).  Which form a layer takes is a static function of its shape
+// (winograd5_takes), never of a measurement.
+//
+//   winograd5_input_kernel   x [B,H,W,K]               -> V [49][T][K]      T = B * ceil(H/5) * ceil(W/5) tiles
+//   (batched GEMMs: winograd_launch_batched_gemm, Z = 49 -- the 16-row register-B kernel for these row counts)
+//   winograd5_output_kernel  M [49][T][N]              -> y [B,H,W,N]   + bias / ReLU (fwd) or ReLU mask / addend (dgrad)
+//
+// No fused pooling on this path (a 5 x 5 tile does not hold whole 2 x 2 windows): pooled layers stay on F(4x4).  The ReLU
+// bit cache has its own layout here -- two words per (5 x 5 tile, channel pair): bit 2 p + c of the 64 = (x > 0) of pixel p,
+// channel c -- written by the forward input transform (whose thread holds exactly those 50 values), read by the data
+// gradient's output transform (same tiling, one 8-byte load per thread) instead of x_in.
+#include "common.h"
+#include "winograd_gemm.h"
+
+namespace nfs {
+
+// G (7 x 3) = {-1/2,0,0} {-1/3,-1/3,-1/3} {1/9,-1/9,1/9} {1/36,1/18,1/9} {-1/60,1/30,-1/15} {32/45,16/45,8/45} {0,0,1}
+__device__ __forceinline__ void w5_g(const float g0, const float g1, const float g2, float* u) {
+  u[0] = -0.5f * g0;
+  u[1] = (-1.f / 3.f) * (g0 + g1 + g2);
+  u[2] = (1.f / 9.f) * (g0 - g1 + g2);
+  u[3] = (1.f / 36.f) * g0 + (1.f / 18.f) * g1 + (1.f / 9.f) * g2;
+  u[4] = (-1.f / 60.f) * g0 + (1.f / 30.f) * g1 - (1.f / 15.f) * g2;
+  u[5] = (32.f / 45.f) * g0 + (16.f / 45.f) * g1 + (8.f / 45.f) * g2;
+  u[6] = g2;
+}
+
+// U_z[ci][co] = (G g G^T)[z], z = 7 r + q, packed [49][K/32][N][32] (the layout of winograd_pack4_kernel); kind as there
+__global__ void __launch_bounds__(256) winograd5_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Ci,
+                                                             int Co, int kind) {
+  const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)Kc * Nc) return;
+  const int n = (int)(gid % Nc), k = (int)(gid / Nc);
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (kind == 0) g[r][s] = w[((int64_t)(r * 3 + s) * Ci + k) * Co + n];
+      else g[r][s] = w[((int64_t)((2 - r) * 3 + (2 - s)) * Ci + n) * Co + k];
+    }
+  float t[7][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float u[7];
+    w5_g(g[0][s], g[1][s], g[2][s], u);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) t[r][s] = u[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    float u[7];
+    w5_g(t[r][0], t[r][1], t[r][2], u);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) up[(((int64_t)(r * 7 + q) * (Kc / 32) + k / 32) * Nc + n) * 32 + (k & 31)] = u[q];
+  }
+}
+
+// B^T (7 x 7) = {-2,4,5/2,-5,-1/2,1,0} {0,2,-2,-9/2,1/2,1,0} {0,-2,6,-7/2,-3/2,1,0} {0,1,-3/2,-2,3/2,1,0}
+//               {0,-1,5/2,0,-5/2,1,0} {0,4,0,-5,0,1,0} {0,-2,4,5/2,-5,-1/2,1}
+#define NFS_W5_2(expr_x, expr_y) make_float2(expr_x, expr_y)
+__device__ __forceinline__ void w5_bt(const float2* d, float2* o) {
+#define X(i) d[i].x
+#define Y(i) d[i].y
+  o[0] = NFS_W5_2(-2.f * X(0) + 4.f * X(1) + 2.5f * X(2) - 5.f * X(3) - 0.5f * X(4) + X(5),
+                  -2.f * Y(0) + 4.f * Y(1) + 2.5f * Y(2) - 5.f * Y(3) - 0.5f * Y(4) + Y(5));
+  o[1] = NFS_W5_2(2.f * X(1) - 2.f * X(2) - 4.5f * X(3) + 0.5f * X(4) + X(5),
+                  2.f * Y(1) - 2.f * Y(2) - 4.5f * Y(3) + 0.5f * Y(4) + Y(5));
+  o[2] = NFS_W5_2(-2.f * X(1) + 6.f * X(2) - 3.5f * X(3) - 1.5f * X(4) + X(5),
+                  -2.f * Y(1) + 6.f * Y(2) - 3.5f * Y(3) - 1.5f * Y(4) + Y(5));
+  o[3] = NFS_W5_2(X(1) - 1.5f * X(2) - 2.f * X(3) + 1.5f * X(4) + X(5),
+                  Y(1) - 1.5f * Y(2) - 2.f * Y(3) + 1.5f * Y(4) + Y(5));
+  o[4] = NFS_W5_2(-X(1) + 2.5f * X(2) - 2.5f * X(4) + X(5), -Y(1) + 2.5f * Y(2) - 2.5f * Y(4) + Y(5));
+  o[5] = NFS_W5_2(4.f * X(1) - 5.f * X(3) + X(5), 4.f * Y(1) - 5.f * Y(3) + Y(5));
+  o[6] = NFS_W5_2(-2.f * X(1) + 4.f * X(2) + 2.5f * X(3) - 5.f * X(4) - 0.5f * X(5) + X(6),
+                  -2.f * Y(1) + 4.f * Y(2) + 2.5f * Y(3) - 5.f * Y(4) - 0.5f * Y(5) + Y(6));
+#undef X
+#undef Y
+}
+#undef NFS_W5_2
+
+// A^T (5 x 7) = {1,1,1,1,1,1,0} {0,1,-1,2,-2,1/2,0} {0,1,1,4,4,1/4,0} {0,1,-1,8,-8,1/8,0} {0,1,1,16,16,1/16,1}
+__device__ __forceinline__ void w5_at(const float2* m, float2* o) {
+  const float2 s12 = make_float2(m[1].x + m[2].x, m[1].y + m[2].y), d12 = make_float2(m[1].x - m[2].x, m[1].y - m[2].y);
+  const float2 s34 = make_float2(m[3].x + m[4].x, m[3].y + m[4].y), d34 = make_float2(m[3].x - m[4].x, m[3].y - m[4].y);
+  o[0] = make_float2(m[0].x + s12.x + s34.x + m[5].x, m[0].y + s12.y + s34.y + m[5].y);
+  o[1] = make_float2(d12.x + 2.f * d34.x + 0.5f * m[5].x, d12.y + 2.f * d34.y + 0.5f * m[5].y);
+  o[2] = make_float2(s12.x + 4.f * s34.x + 0.25f * m[5].x, s12.y + 4.f * s34.y + 0.25f * m[5].y);
+  o[3] = make_float2(d12.x + 8.f * d34.x + 0.125f * m[5].x, d12.y + 8.f * d34.y + 0.125f * m[5].y);
+  o[4] = make_float2(s12.x + 16.f * s34.x + 0.0625f * m[5].x + m[6].x, s12.y + 16.f * s34.y + 0.0625f * m[5].y + m[6].y);
+}
+
+// input transform: one thread = one 7 x 7 patch x 2 channels (a wave covers 128 contiguous channels per pixel); a
+// contiguous range of tiles per XCD, as in winograd_input4_kernel
+__global__ void __launch_bounds__(256) winograd5_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
+                                                              int H, int W, int K, int TH, int TW,
+                                                              uint32_t* __restrict__ bits) {
+  const int K2 = K >> 1;
+  const int64_t T = (int64_t)B * TH * TW;
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int64_t gid = (int64_t)lb * blockDim.x + threadIdx.x;
+  if (gid >= T * K2) return;
+  const int c2 = (int)(gid % K2);
+  const int64_t tile = gid / K2;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int y0 = 5 * ty - 1, x0 = 5 * tx - 1;
+  float2 t[7][7];   // t[s][r]: column s after the vertical pass
+  unsigned long long mask = 0ull;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    float2 d[7];
+    const int xx = x0 + s;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int yy = y0 + r;
+      d[r] = make_float2(0.f, 0.f);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+      if (r >= 1 && r <= 5 && s >= 1 && s <= 5) {      // the tile's own 5 x 5 pixels (zeros outside the image: bit 0)
+        const int pbit = 2 * ((r - 1) * 5 + (s - 1));
+        mask |= (unsigned long long)((d[r].x > 0.f ? 1u : 0u) | (d[r].y > 0.f ? 2u : 0u)) << pbit;
+      }
+    }
+    w5_bt(d, t[s]);
+  }
+  if (bits) *reinterpret_cast<uint2*>(bits + 2 * gid) = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+  const int64_t comp_stride = T * K;
+  float* vo = V + tile * K + 2 * c2;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const float2 row[7] = {t[0][r], t[1][r], t[2][r], t[3][r], t[4][r], t[5][r], t[6][r]};
+    float2 o[7];
+    w5_bt(row, o);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) *reinterpret_cast<float2*>(vo + (int64_t)(r * 7 + q) * comp_stride) = o[q];
+  }
+}
+
+// output transform + layer epilogue: one thread = one 5 x 5 output tile x 2 channels
+template <int MODE>  // 0: y = relu?(Y + bias); 1: y = (Y [+ addend if relu]) * (x_in > 0) [+ addend if !relu]
+__global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
+                                                               const float* __restrict__ aux1, float* __restrict__ y,
+                                                               int B, int H, int W, int N, int TH, int TW, int relu,
+                                                               const uint32_t* __restrict__ bits) {
+  const int N2 = N >> 1;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= T * N2) return;
+  const int c2 = (int)(gid % N2);
+  const int64_t tile = gid / N2;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int64_t comp_stride = T * N;
+  const float* mi = M + tile * N + 2 * c2;
+  float2 t[7][5];   // t[s][a]: column s after the vertical pass
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    float2 m[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 7 + s) * comp_stride);
+    w5_at(m, t[s]);
+  }
+  float2 bias = make_float2(0.f, 0.f);
+  if (MODE == 0 && aux0) bias = *reinterpret_cast<const float2*>(aux0 + 2 * c2);
+  unsigned long long mask = 0ull;
+  if (MODE == 1 && bits) {
+    const uint2 mw = *reinterpret_cast<const uint2*>(bits + 2 * gid);
+    mask = ((unsigned long long)mw.y << 32) | mw.x;
+  }
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const int yy = 5 * ty + a;
+    if (yy >= H) continue;
+    const float2 row[7] = {t[0][a], t[1][a], t[2][a], t[3][a], t[4][a], t[5][a], t[6][a]};
+    float2 o[5];
+    w5_at(row, o);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int xx = 5 * tx + c;
+      if (xx >= W) continue;
+      float2 v = o[c];
+      const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + 2 * c2;
+      if (MODE == 0) {
+        v.x += bias.x; v.y += bias.y;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+      } else {
+        float2 ad = make_float2(0.f, 0.f);
+        if (aux1) ad = *reinterpret_cast<const float2*>(aux1 + idx);
+        if (relu) { v.x += ad.x; v.y += ad.y; }      // addend not yet through the mask: add first
+        if (bits) {
+          const unsigned long long mv = mask >> (2 * (a * 5 + c));
+          v.x = (mv & 1ull) ? v.x : 0.f; v.y = (mv & 2ull) ? v.y : 0.f;
+        } else if (aux0) {
+          const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
+          v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
+        }
+        if (!relu) { v.x += ad.x; v.y += ad.y; }
+      }
+      *reinterpret_cast<float2*>(y + idx) = v;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+// F(5x5) where it executes at most 0.9 x the GEMM rows of F(4x4) (49 tiles5 vs 36 tiles4) and both channel counts are
+// >= 128 (the narrower layers have their own single-kernel path, and their images are large: the padding saved is small)
+bool winograd5_channels(int K, int N) {
+  static const bool off = [] { const char* e = getenv("NFS_WG5"); return e && atoi(e) == 0; }();
+  return !off && K >= 128 && N >= 128 && K % 64 == 0 && N % 64 == 0;
+}
+bool winograd5_takes(int H, int W, int K, int N) {
+  if (!winograd5_channels(K, N) || H < 5 || W < 5) return false;
+  const int64_t r5 = (int64_t)49 * ((H + 4) / 5) * ((W + 4) / 5), r4 = (int64_t)36 * ((H + 3) / 4) * ((W + 3) / 4);
+  return r5 * 10 <= r4 * 9;
+}
+
+int64_t winograd5_packed_floats(int Ci, int Co) { return winograd5_channels(Ci, Co) ? (int64_t)98 * Ci * Co : 0; }
+
+int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N) {
+  if (!winograd5_takes(H, W, K, N)) return 0;
+  return (int64_t)49 * B * ((H + 4) / 5) * ((W + 4) / 5) * ((int64_t)K + N);
+}
+
+// up5: [49][K/32][N][32] followed by the 16x16x4 fragment order of the same
+int winograd5_pack(const float* w_hwio, float* up5, int Ci, int Co, int kind, hipStream_t s) {
+  const int64_t n = (int64_t)Ci * Co;
+  const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
+  hipLaunchKernelGGL(winograd5_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up5, Ci, Co, kind);
+  winograd_pack_frag16(up5, up5 + 49 * n, Kc, Nc, 49 * n, s);
+  return check_launch("winograd5_pack");
+}
+
+// x [B,H,W,K] -> y [B,H,W,N]; U5 from winograd5_pack; ws >= winograd5_workspace_floats.  mode / relu / aux as winograd_conv.
+int64_t winograd5_bits_words(int B, int H, int W, int C) { return (int64_t)B * ((H + 4) / 5) * ((W + 4) / 5) * C; }
+
+int winograd5_conv(const float* x, const float* U5, const float* aux0, const float* aux1, float* y, float* ws, int B,
+                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits) {
+  const int TH = (H + 4) / 5, TW = (W + 4) / 5;
+  const int64_t T = (int64_t)B * TH * TW;
+  float* V = ws;
+  float* M = ws + 49 * T * K;
+  const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
+  // forward: record the mask of x (the layer's own data gradient reads it); data gradient: read the mask of x_in
+  hipLaunchKernelGGL(winograd5_input_kernel, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
+                     mode == 0 ? in_bits : nullptr);
+  WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
+  a.Uq16 = U5 + (int64_t)49 * K * N;
+  winograd_launch_batched_gemm(a, 49, cus, s);
+  const unsigned ob = blocks_for(T * (N / 2), 256);
+  if (mode == 0)
+    hipLaunchKernelGGL(winograd5_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                       (const uint32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(winograd5_output_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                       aux0 ? in_bits : nullptr);
+  return check_launch("winograd5_conv");
+}
+
+}  // namespace nfs

@@ -274,6 +274,28 @@ def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
         assert rel(gx_m, gx * (xin > 0) + add) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 25, 25, 512, 512), (1, 50, 50, 256, 256), (1, 23, 48, 128, 256)])
+def test_winograd_f5_error_budget(ops, B, H, W, Ci, Co):
+    """the deep layers with heavily padded F(4x4) tilings run F(5x5,3x3) (interpolation points 0, +-1, +-2, 1/2, inf) in
+    float32.  Stated budget against a float64 convolution, at activations of O(10^2..10^3) as the real vgg_19 produces
+    them: 2e-5 relative L2 for the forward pass and for the data gradient (measured ~5e-6; F(4x4) ~2.5e-6, the direct
+    form ~7e-7)"""
+    rng = np.random.RandomState(23)
+    x = torch.tensor(np.maximum(rng.randn(B, H, W, Ci), 0) * 300.0, dtype=torch.float32)
+    w = (rng.randn(3, 3, Ci, Co) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    b = (rng.randn(Co) * 1.0).astype(np.float32)
+    x64 = x.double().requires_grad_()
+    w64 = torch.tensor(w).double().permute(3, 2, 0, 1)
+    pre = torch.nn.functional.conv2d(x64.permute(0, 3, 1, 2), w64, torch.tensor(b).double(), padding=1).permute(0, 2, 3, 1)
+    wf = ops.conv3x3_pack(dev(torch.tensor(w)), 0)
+    out = ops.conv3x3_fwd(dev(x), wf, dev(torch.tensor(b)), Co, relu=True)
+    assert rel(out, torch.relu(pre).detach()) < 2e-5
+    gy = torch.tensor(rng.randn(B, H, W, Co), dtype=torch.float32)
+    (gx,) = torch.autograd.grad(pre, x64, gy.double())
+    wd = ops.conv3x3_pack(dev(torch.tensor(w)), 1)
+    assert rel(ops.conv3x3_dgrad(dev(gy), wd, Ci), gx) < 2e-5
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128),
                                           (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
                                           (4, 64, 64, 128, 128)])
@@ -538,7 +560,8 @@ def test_rotate_render_march_variants_agree(ops, tmp_path):
 
 
 @pytest.mark.parametrize("shape", [(2, 18, 21, 64, 128), (1, 8, 8, 128, 64), (3, 13, 30, 64, 64), (3, 20, 28, 64, 64),
-                                   (2, 12, 16, 128, 128), (4, 64, 64, 128, 128)])
+                                   (2, 12, 16, 128, 128), (4, 64, 64, 128, 128),
+                                   (2, 25, 25, 128, 256), (1, 50, 45, 256, 128)])    # F(5x5) layers: their own cache layout
 def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     """a layer's ReLU bit cache (recorded by its forward transforms) must reproduce, bit for bit, the data gradient
     computed with the float masks x_in > 0 / x_out > 0 -- plain and pooled forms, ragged tile edges, odd sizes"""
