@@ -584,7 +584,9 @@ def main():
                         "as three bf16 limbs, the six leading limb products on v_mfma_f32_32x32x16_bf16, float32 "
                         "accumulation; inputs/outputs/accumulators float32, per-product error <= 2^-26 (parity tests: "
                         "same error against float64 as the float32-input MFMA).  The headline `value` uses the "
-                        "float32-input MFMA."}
+                        "float32-input MFMA -- which, since the narrow layers run in one kernel and the deep ones on "
+                        "F(5x5) tiles and register-B kernels (neither has a split-limb form), is no longer the slower of "
+                        "the two."}
         finally:
             ops.gemm_mode(prev)
 
