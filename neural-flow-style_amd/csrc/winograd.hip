@@ -1350,9 +1350,9 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
           if (ms < best) { best = ms; bm = cbm; bn = cbn; variant = var; }
         };
         if (rows16) {                                                   // 16-row tiles: 80 / 48 rows x 128 / 64 columns
-          for (int i = 0; i < 4; ++i) {                                  // row tiles that pad no worse than 1.1 x the best
+          for (int i = 0; i < 4; ++i) {                                  // row tiles that pad no worse than 1.2 x the best
             const int64_t p = (a.T + kRb16Rows[i] - 1) / kRb16Rows[i] * kRb16Rows[i];
-            if (p * 10 > pad16 * 11) continue;
+            if (p * 10 > pad16 * 12) continue;
             for (int cbn = 128; cbn >= 64; cbn -= 64)
               if (a.N % cbn == 0) trial(kRb16Rows[i], cbn, 2);
           }

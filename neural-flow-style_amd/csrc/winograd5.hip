@@ -68,145 +68,127 @@ __global__ void __launch_bounds__(256) winograd5_pack_kernel(const float* __rest
 
 // B^T (7 x 7) = {-2,4,5/2,-5,-1/2,1,0} {0,2,-2,-9/2,1/2,1,0} {0,-2,6,-7/2,-3/2,1,0} {0,1,-3/2,-2,3/2,1,0}
 //               {0,-1,5/2,0,-5/2,1,0} {0,4,0,-5,0,1,0} {0,-2,4,5/2,-5,-1/2,1}
-#define NFS_W5_2(expr_x, expr_y) make_float2(expr_x, expr_y)
-__device__ __forceinline__ void w5_bt(const float2* d, float2* o) {
-#define X(i) d[i].x
-#define Y(i) d[i].y
-  o[0] = NFS_W5_2(-2.f * X(0) + 4.f * X(1) + 2.5f * X(2) - 5.f * X(3) - 0.5f * X(4) + X(5),
-                  -2.f * Y(0) + 4.f * Y(1) + 2.5f * Y(2) - 5.f * Y(3) - 0.5f * Y(4) + Y(5));
-  o[1] = NFS_W5_2(2.f * X(1) - 2.f * X(2) - 4.5f * X(3) + 0.5f * X(4) + X(5),
-                  2.f * Y(1) - 2.f * Y(2) - 4.5f * Y(3) + 0.5f * Y(4) + Y(5));
-  o[2] = NFS_W5_2(-2.f * X(1) + 6.f * X(2) - 3.5f * X(3) - 1.5f * X(4) + X(5),
-                  -2.f * Y(1) + 6.f * Y(2) - 3.5f * Y(3) - 1.5f * Y(4) + Y(5));
-  o[3] = NFS_W5_2(X(1) - 1.5f * X(2) - 2.f * X(3) + 1.5f * X(4) + X(5),
-                  Y(1) - 1.5f * Y(2) - 2.f * Y(3) + 1.5f * Y(4) + Y(5));
-  o[4] = NFS_W5_2(-X(1) + 2.5f * X(2) - 2.5f * X(4) + X(5), -Y(1) + 2.5f * Y(2) - 2.5f * Y(4) + Y(5));
-  o[5] = NFS_W5_2(4.f * X(1) - 5.f * X(3) + X(5), 4.f * Y(1) - 5.f * Y(3) + Y(5));
-  o[6] = NFS_W5_2(-2.f * X(1) + 4.f * X(2) + 2.5f * X(3) - 5.f * X(4) - 0.5f * X(5) + X(6),
-                  -2.f * Y(1) + 4.f * Y(2) + 2.5f * Y(3) - 5.f * Y(4) - 0.5f * Y(5) + Y(6));
-#undef X
-#undef Y
-}
-#undef NFS_W5_2
-
 // A^T (5 x 7) = {1,1,1,1,1,1,0} {0,1,-1,2,-2,1/2,0} {0,1,1,4,4,1/4,0} {0,1,-1,8,-8,1/8,0} {0,1,1,16,16,1/16,1}
-__device__ __forceinline__ void w5_at(const float2* m, float2* o) {
-  const float2 s12 = make_float2(m[1].x + m[2].x, m[1].y + m[2].y), d12 = make_float2(m[1].x - m[2].x, m[1].y - m[2].y);
-  const float2 s34 = make_float2(m[3].x + m[4].x, m[3].y + m[4].y), d34 = make_float2(m[3].x - m[4].x, m[3].y - m[4].y);
-  o[0] = make_float2(m[0].x + s12.x + s34.x + m[5].x, m[0].y + s12.y + s34.y + m[5].y);
-  o[1] = make_float2(d12.x + 2.f * d34.x + 0.5f * m[5].x, d12.y + 2.f * d34.y + 0.5f * m[5].y);
-  o[2] = make_float2(s12.x + 4.f * s34.x + 0.25f * m[5].x, s12.y + 4.f * s34.y + 0.25f * m[5].y);
-  o[3] = make_float2(d12.x + 8.f * d34.x + 0.125f * m[5].x, d12.y + 8.f * d34.y + 0.125f * m[5].y);
-  o[4] = make_float2(s12.x + 16.f * s34.x + 0.0625f * m[5].x + m[6].x, s12.y + 16.f * s34.y + 0.0625f * m[5].y + m[6].y);
+// (written for one float; a thread owns ONE channel of a tile: the deep layers have few tiles -- 200 at 25 x 25 and 8 views --
+// and two channels per thread, as in the F(4x4) transforms, leave the chip with less than one wave per SIMD)
+__device__ __forceinline__ void w5_bt(const float* d, float* o) {
+  o[0] = -2.f * d[0] + 4.f * d[1] + 2.5f * d[2] - 5.f * d[3] - 0.5f * d[4] + d[5];
+  o[1] = 2.f * d[1] - 2.f * d[2] - 4.5f * d[3] + 0.5f * d[4] + d[5];
+  o[2] = -2.f * d[1] + 6.f * d[2] - 3.5f * d[3] - 1.5f * d[4] + d[5];
+  o[3] = d[1] - 1.5f * d[2] - 2.f * d[3] + 1.5f * d[4] + d[5];
+  o[4] = -d[1] + 2.5f * d[2] - 2.5f * d[4] + d[5];
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+  o[6] = -2.f * d[1] + 4.f * d[2] + 2.5f * d[3] - 5.f * d[4] - 0.5f * d[5] + d[6];
+}
+__device__ __forceinline__ void w5_at(const float* m, float* o) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = m[0] + s12 + s34 + m[5];
+  o[1] = d12 + 2.f * d34 + 0.5f * m[5];
+  o[2] = s12 + 4.f * s34 + 0.25f * m[5];
+  o[3] = d12 + 8.f * d34 + 0.125f * m[5];
+  o[4] = s12 + 16.f * s34 + 0.0625f * m[5] + m[6];
 }
 
-// input transform: one thread = one 7 x 7 patch x 2 channels (a wave covers 128 contiguous channels per pixel); a
-// contiguous range of tiles per XCD, as in winograd_input4_kernel
+// input transform: one thread = one 7 x 7 patch x 1 channel (a wave covers 64 contiguous channels per pixel); a contiguous
+// range of tiles per XCD, as in winograd_input4_kernel.  bits (nullable): two words per (tile, channel PAIR) -- the mask of
+// the tile's own 5 x 5 pixels, bit 2 p + (channel & 1); the two lanes of a pair combine theirs with one __shfl_xor.
 __global__ void __launch_bounds__(256) winograd5_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
                                                               int H, int W, int K, int TH, int TW,
                                                               uint32_t* __restrict__ bits) {
-  const int K2 = K >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   const unsigned per_xcd = gridDim.x / 8;
   const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const int64_t gid = (int64_t)lb * blockDim.x + threadIdx.x;
-  if (gid >= T * K2) return;
-  const int c2 = (int)(gid % K2);
-  const int64_t tile = gid / K2;
+  if (gid >= T * K) return;
+  const int c = (int)(gid % K);
+  const int64_t tile = gid / K;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int y0 = 5 * ty - 1, x0 = 5 * tx - 1;
-  float2 t[7][7];   // t[s][r]: column s after the vertical pass
+  float t[7][7];   // t[s][r]: column s after the vertical pass
   unsigned long long mask = 0ull;
 #pragma unroll
   for (int s = 0; s < 7; ++s) {
-    float2 d[7];
+    float d[7];
     const int xx = x0 + s;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
       const int yy = y0 + r;
-      d[r] = make_float2(0.f, 0.f);
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
-      if (r >= 1 && r <= 5 && s >= 1 && s <= 5) {      // the tile's own 5 x 5 pixels (zeros outside the image: bit 0)
-        const int pbit = 2 * ((r - 1) * 5 + (s - 1));
-        mask |= (unsigned long long)((d[r].x > 0.f ? 1u : 0u) | (d[r].y > 0.f ? 2u : 0u)) << pbit;
-      }
+      d[r] = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) d[r] = x[(((int64_t)b * H + yy) * W + xx) * K + c];
+      if (r >= 1 && r <= 5 && s >= 1 && s <= 5)        // the tile's own pixels (zeros outside the image: bit 0)
+        mask |= (unsigned long long)(d[r] > 0.f ? 1u : 0u) << (2 * ((r - 1) * 5 + (s - 1)));
     }
     w5_bt(d, t[s]);
   }
-  if (bits) *reinterpret_cast<uint2*>(bits + 2 * gid) = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+  if (bits) {
+    const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+    const uint32_t plo = __shfl_xor(lo, 1, 64), phi = __shfl_xor(hi, 1, 64);       // the odd channel of the pair
+    if (!(c & 1)) *reinterpret_cast<uint2*>(bits + gid) = make_uint2(lo | (plo << 1), hi | (phi << 1));   // 2 * (gid / 2)
+  }
   const int64_t comp_stride = T * K;
-  float* vo = V + tile * K + 2 * c2;
+  float* vo = V + tile * K + c;
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    const float2 row[7] = {t[0][r], t[1][r], t[2][r], t[3][r], t[4][r], t[5][r], t[6][r]};
-    float2 o[7];
+    const float row[7] = {t[0][r], t[1][r], t[2][r], t[3][r], t[4][r], t[5][r], t[6][r]};
+    float o[7];
     w5_bt(row, o);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) *reinterpret_cast<float2*>(vo + (int64_t)(r * 7 + q) * comp_stride) = o[q];
+    for (int q = 0; q < 7; ++q) vo[(int64_t)(r * 7 + q) * comp_stride] = o[q];
   }
 }
 
-// output transform + layer epilogue: one thread = one 5 x 5 output tile x 2 channels
+// output transform + layer epilogue: one thread = one 5 x 5 output tile x 1 channel
 template <int MODE>  // 0: y = relu?(Y + bias); 1: y = (Y [+ addend if relu]) * (x_in > 0) [+ addend if !relu]
 __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
                                                                int B, int H, int W, int N, int TH, int TW, int relu,
                                                                const uint32_t* __restrict__ bits) {
-  const int N2 = N >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= T * N2) return;
-  const int c2 = (int)(gid % N2);
-  const int64_t tile = gid / N2;
+  if (gid >= T * N) return;
+  const int c = (int)(gid % N);
+  const int64_t tile = gid / N;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int64_t comp_stride = T * N;
-  const float* mi = M + tile * N + 2 * c2;
-  float2 t[7][5];   // t[s][a]: column s after the vertical pass
+  const float* mi = M + tile * N + c;
+  float t[7][5];   // t[s][a]: column s after the vertical pass
 #pragma unroll
   for (int s = 0; s < 7; ++s) {
-    float2 m[7];
+    float m[7];
 #pragma unroll
-    for (int r = 0; r < 7; ++r) m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 7 + s) * comp_stride);
+    for (int r = 0; r < 7; ++r) m[r] = mi[(int64_t)(r * 7 + s) * comp_stride];
     w5_at(m, t[s]);
   }
-  float2 bias = make_float2(0.f, 0.f);
-  if (MODE == 0 && aux0) bias = *reinterpret_cast<const float2*>(aux0 + 2 * c2);
+  const float bias = (MODE == 0 && aux0) ? aux0[c] : 0.f;
   unsigned long long mask = 0ull;
   if (MODE == 1 && bits) {
-    const uint2 mw = *reinterpret_cast<const uint2*>(bits + 2 * gid);
-    mask = ((unsigned long long)mw.y << 32) | mw.x;
+    const uint2 mw = *reinterpret_cast<const uint2*>(bits + (gid & ~(int64_t)1));
+    mask = (((unsigned long long)mw.y << 32) | mw.x) >> (c & 1);
   }
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
     const int yy = 5 * ty + a;
     if (yy >= H) continue;
-    const float2 row[7] = {t[0][a], t[1][a], t[2][a], t[3][a], t[4][a], t[5][a], t[6][a]};
-    float2 o[5];
+    const float row[7] = {t[0][a], t[1][a], t[2][a], t[3][a], t[4][a], t[5][a], t[6][a]};
+    float o[5];
     w5_at(row, o);
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int xx = 5 * tx + c;
+    for (int cc = 0; cc < 5; ++cc) {
+      const int xx = 5 * tx + cc;
       if (xx >= W) continue;
-      float2 v = o[c];
-      const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + 2 * c2;
+      float v = o[cc];
+      const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + c;
       if (MODE == 0) {
-        v.x += bias.x; v.y += bias.y;
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        v += bias;
+        if (relu) v = fmaxf(v, 0.f);
       } else {
-        float2 ad = make_float2(0.f, 0.f);
-        if (aux1) ad = *reinterpret_cast<const float2*>(aux1 + idx);
-        if (relu) { v.x += ad.x; v.y += ad.y; }      // addend not yet through the mask: add first
-        if (bits) {
-          const unsigned long long mv = mask >> (2 * (a * 5 + c));
-          v.x = (mv & 1ull) ? v.x : 0.f; v.y = (mv & 2ull) ? v.y : 0.f;
-        } else if (aux0) {
-          const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
-          v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
-        }
-        if (!relu) { v.x += ad.x; v.y += ad.y; }
+        const float ad = aux1 ? aux1[idx] : 0.f;
+        if (relu) v += ad;                       // addend not yet through the mask: add first
+        if (bits) v = ((mask >> (2 * (a * 5 + cc))) & 1ull) ? v : 0.f;
+        else if (aux0) v = aux0[idx] > 0.f ? v : 0.f;
+        if (!relu) v += ad;
       }
-      *reinterpret_cast<float2*>(y + idx) = v;
+      y[idx] = v;
     }
   }
 }
@@ -249,14 +231,14 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
   float* M = ws + 49 * T * K;
-  const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
+  const dim3 ig((blocks_for(T * K, 256) + 7) / 8 * 8);
   // forward: record the mask of x (the layer's own data gradient reads it); data gradient: read the mask of x_in
   hipLaunchKernelGGL(winograd5_input_kernel, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
                      mode == 0 ? in_bits : nullptr);
   WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   a.Uq16 = U5 + (int64_t)49 * K * N;
   winograd_launch_batched_gemm(a, 49, cus, s);
-  const unsigned ob = blocks_for(T * (N / 2), 256);
+  const unsigned ob = blocks_for(T * N, 256);
   if (mode == 0)
     hipLaunchKernelGGL(winograd5_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                        (const uint32_t*)nullptr);
