@@ -8,6 +8,8 @@
 
 namespace nfs {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 enum CoordKind { COORD_EXPLICIT = 0, COORD_ROTATE = 1, COORD_ADVECT = 2 };
 
 struct WarpArgs {
@@ -370,12 +372,14 @@ __global__ void __launch_bounds__(256) transport_step_generic_kernel(const float
 // belong to neighbouring tiles; only the owned cells are written back).  No global atomics; the integer
 // sums make the result independent of the traversal order.
 #ifndef NFS_RT_TZ
-// (tile shapes swept on 8 views of 200^3, tools/rot_bench.py: 14x14x30 0.375 ms, 12x12x40 0.349, 14x12x40 0.345, 12x12x48 0.47;
-// long tiles along x = long lattice rows for most views = fewer idle lanes in the row tails)
+// (tile shape x lanes per lattice row swept on 8 views of 200^3, tools/rot_tile_sweep.sh: 14x12x40 x 8 0.331 ms, x 4 0.305,
+// x 2 0.357, x 16 0.42; 14x14x34 x 4 0.296; 16x12x34 x 4 0.307; 10x10x40 x 4 0.324; 12x12x48 x 4 0.41 (240-wide for 200);
+// the lattice rows of one (tile, view) are ~20 samples long on average and many are much shorter, so narrow groups
+// idle less in the row tails)
 #define NFS_RT_TZ 14
-#define NFS_RT_TY 12
-#define NFS_RT_TX 40
-#define NFS_RT_GROUP 8
+#define NFS_RT_TY 14
+#define NFS_RT_TX 34
+#define NFS_RT_GROUP 4
 #endif
 constexpr int RT_TZ = NFS_RT_TZ, RT_TY = NFS_RT_TY, RT_TX = NFS_RT_TX;
 constexpr int RT_LZ = RT_TZ + 2, RT_LY = RT_TY + 2, RT_LX = RT_TX + 2;
@@ -525,6 +529,7 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   constexpr int NGRP = RT_THREADS / RT_GROUP;
   const unsigned nz = (unsigned)(z1 - z0 + 1), ny = (unsigned)(y1 - y0 + 1), nx = (unsigned)(x1 - x0 + 1);
   const float3 dm1 = make_float3((float)(D - 1), (float)(H - 1), (float)(W - 1));
+  const float oz1 = (float)(1 - z0), oy1 = (float)(1 - y0), ox1 = (float)(1 - x0);
   for (int v = 0; v < V; ++v) {
     const ViewRows& vr = vrows[v];
     const int rows = vr.rows;
@@ -560,41 +565,54 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
         const float gn = oxn <= xb ? grow[oxn] : 0.f;
         if (g != 0.f) {
           // lean stencil (same form as the ray march): the sample's voxel coordinate is affine in ox; border
-          // replication = clamp the coordinate, base cell min(floor, n-2), weights (1-w, w) with w in [0,1]
-          // (at the far border w = 1 puts the whole weight on voxel n-1, below 0 w = 0 puts it on voxel 0)
+          // replication = clamp the coordinate; base cell floor(c), weights (1-w, w).  A sample clamped onto the far
+          // border has base cell n-1 and w = 0: the whole weight on voxel n-1 and an exact zero into the halo cell
+          // beyond it (adding zero changes nothing in the fixed-point sum).
           const float fx = (float)ox;
           const float cz = __builtin_amdgcn_fmed3f(fmaf(sz, fx, pv[0]), 0.f, dm1.x);
           const float cy = __builtin_amdgcn_fmed3f(fmaf(sy, fx, pv[1]), 0.f, dm1.y);
           const float cx = __builtin_amdgcn_fmed3f(fmaf(sx, fx, pv[2]), 0.f, dm1.z);
-          const float bz = fminf(floorf(cz), dm1.x - 1.f), by_ = fminf(floorf(cy), dm1.y - 1.f),
-                      bx_ = fminf(floorf(cx), dm1.z - 1.f);
+          const float bz = floorf(cz), by_ = floorf(cy), bx_ = floorf(cx);
           const float wz = cz - bz, wy = cy - by_, wx = cx - bx_;
-          const int lz = (int)bz - z0 + 1, ly = (int)by_ - y0 + 1, lx = (int)bx_ - x0 + 1;   // halo'd local base cell
+          // halo'd local base cell (small integers: exact in float)
+          const int lz = (int)(bz + oz1), ly = (int)(by_ + oy1), lx = (int)(bx_ + ox1);
           if ((unsigned)lz <= nz && (unsigned)ly <= ny && (unsigned)lx <= nx) {
             const float gs = g * fscale * fscale2;
             const float wz1 = gs * wz, wz0 = gs - wz1;
-            const float w01 = wz0 * wy, w00 = wz0 - w01, w11 = wz1 * wy, w10 = wz1 - w11;
-            const float ax_w1 = wx, ax_w0 = 1.f - wx;
-            unsigned long long* cell = acc + (__mul24(__mul24(lz, RT_LY) + ly, RT_LX) + lx);   // (24-bit multiplies: full rate)
-// float -> 64-bit two's-complement fixed point in 4 instructions: high word = floor (v_cvt_flr_i32_f32),
-// low word = fract * 2^32 (v_fract_f32 is < 1 by construction; v_cvt_u32_f32 saturates)
-#define NFS_RT_ADD(off_, w_)                                                                       \
+            // packed f32 (v_pk_*_f32, two results per instruction): (w01, w11) = (wz0, wz1) * wy; (w00, w10) = rest
+            const f32x2 wzp = {wz0, wz1};
+            const f32x2 wy1 = wzp * wy, wy0 = wzp - wy1;
+            const f32x2 ax = {1.f - wx, wx};
+            f32x2 c00, c01, c10, c11;      // (x, x+1) corner pairs of the rows (z,y), (z,y+1), (z+1,y), (z+1,y+1)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(c00) : "v"(wy0), "v"(ax));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(c01) : "v"(wy1), "v"(ax));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(c10) : "v"(wy0), "v"(ax));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(c11) : "v"(wy1), "v"(ax));
+            // LDS byte address of the base cell: two full-rate 24-bit multiply-adds (the compiler's own choice for
+            // this expression is a quarter-rate v_mad_u64_u32)
+            unsigned zy, cell_b;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(zy) : "v"(lz), "n"(RT_LY), "v"(ly));
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell_b) : "v"(zy), "s"(RT_LX * 8), "v"(lx * 8));
+            unsigned long long* cell = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(acc) + cell_b);
+// float -> 64-bit two's-complement fixed point: high word = floor (v_cvt_flr_i32_f32), low word = fract * 2^32
+// (v_fract_f32 is < 1 by construction; the scaling is one packed multiply per corner pair; v_cvt_u32_f32 saturates)
+#define NFS_RT_ADD2(off_, c_)                                                                      \
   {                                                                                                \
-    const float c_ = (w_);                                                                         \
-    unsigned lo_, hi_;                                                                             \
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi_) : "v"(c_));                                         \
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo_) : "v"(__builtin_amdgcn_fractf(c_) * 4294967296.f));     \
-    atomicAdd(cell + (off_), ((unsigned long long)hi_ << 32) | lo_);                               \
+    unsigned lo0_, hi0_, lo1_, hi1_;                                                               \
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi0_) : "v"((c_).x));                                    \
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi1_) : "v"((c_).y));                                    \
+    f32x2 fr_ = {__builtin_amdgcn_fractf((c_).x), __builtin_amdgcn_fractf((c_).y)};                \
+    fr_ = fr_ * 4294967296.f;                                                                      \
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo0_) : "v"(fr_.x));                                         \
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo1_) : "v"(fr_.y));                                         \
+    atomicAdd(cell + (off_), ((unsigned long long)hi0_ << 32) | lo0_);                             \
+    atomicAdd(cell + (off_) + 1, ((unsigned long long)hi1_ << 32) | lo1_);                         \
   }
-            NFS_RT_ADD(0, w00 * ax_w0)
-            NFS_RT_ADD(1, w00 * ax_w1)
-            NFS_RT_ADD(RT_LX, w01 * ax_w0)
-            NFS_RT_ADD(RT_LX + 1, w01 * ax_w1)
-            NFS_RT_ADD(RT_LY * RT_LX, w10 * ax_w0)
-            NFS_RT_ADD(RT_LY * RT_LX + 1, w10 * ax_w1)
-            NFS_RT_ADD(RT_LY * RT_LX + RT_LX, w11 * ax_w0)
-            NFS_RT_ADD(RT_LY * RT_LX + RT_LX + 1, w11 * ax_w1)
-#undef NFS_RT_ADD
+            NFS_RT_ADD2(0, c00)
+            NFS_RT_ADD2(RT_LX, c01)
+            NFS_RT_ADD2(RT_LY * RT_LX, c10)
+            NFS_RT_ADD2(RT_LY * RT_LX + RT_LX, c11)
+#undef NFS_RT_ADD2
           }
         }
         g = gn;
