@@ -670,22 +670,16 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb_kernel(WgGemmArgs a) {
 // contiguous float4 of its LDS row.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One block's work on MT16 live row tiles starting at row m0 (a block of a taller grid tile whose last rows lie beyond T
+// runs the instance for the row tiles that exist: no MFMA, LDS read or staging load is spent on rows of padding).
 template <int MT16, int NW16>
-__global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
+__device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, float* smem, int comp, int64_t m0, int n0) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16;
   constexpr int BMP = (BM + 31) / 32 * 32;            // staged rows (a multiple of the 32 rows one pass of the block moves)
   constexpr int AJ = BMP / 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                   // [2][BMP][36]
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int per_xcd = gridDim.x / WG_XCDS;
-  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;   // XCD-aware order, see above
-  if (logical >= a.mt * a.nt * a.Z) return;
-  const int comp = logical / (a.mt * a.nt);
-  const int rem = logical - comp * (a.mt * a.nt);
-  const int64_t m0 = (int64_t)(rem % a.mt) * BM;
-  const int n0 = (rem / a.mt) * BN;
   const int nchunks = a.K / WG_KC;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
@@ -793,6 +787,31 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
       }
       *reinterpret_cast<float4*>(Mc + idx) = v;
     }
+  }
+}
+
+// The grid tiles the rows in blocks of 16 MT16; the last block of a component runs the instance for the row tiles it
+// really has (up to five: the taller tiles keep their zero-padded rows, their share of padding is small)
+template <int MT16, int NW16>
+__global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int per_xcd = gridDim.x / WG_XCDS;
+  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;   // XCD-aware order, see above
+  if (logical >= a.mt * a.nt * a.Z) return;
+  const int comp = logical / (a.mt * a.nt);
+  const int rem = logical - comp * (a.mt * a.nt);
+  const int64_t m0 = (int64_t)(rem % a.mt) * (16 * MT16);
+  const int n0 = (rem / a.mt) * (64 * NW16);
+  if constexpr (MT16 <= 5) {
+    const int64_t left = (a.T - m0 + 15) / 16;
+    const int live = left < MT16 ? (int)left : MT16;
+    if (live == MT16) winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0);
+    else if (live == 1) winograd_gemm_rb16_block<1, NW16>(a, smem, comp, m0, n0);
+    else if (MT16 > 2 && live == 2) winograd_gemm_rb16_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem, comp, m0, n0);
+    else if (MT16 > 3 && live == 3) winograd_gemm_rb16_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem, comp, m0, n0);
+    else if (MT16 > 4 && live == 4) winograd_gemm_rb16_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem, comp, m0, n0);
+  } else {
+    winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0);
   }
 }
 
@@ -1210,10 +1229,13 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
 // row tiles of the 16-row form: 80 (5 MFMA tiles), 48, 112, 208 (e.g. the 200 rows of an F(5x5) layer at 8 views)
 static const int kRb16Rows[4] = {80, 48, 112, 208};
 static bool rb16_rows_ok(int bm) { return bm == 80 || bm == 48 || bm == 112 || bm == 208; }
+// rows the 16-row form executes with row tile bm: the 80- and 48-row blocks run only the 16-row tiles that exist (their
+// last block is ragged), the taller ones keep whole zero-padded blocks
+static int64_t rb16_rows_executed(int64_t T, int bm) { return bm <= 80 ? (T + 15) / 16 * 16 : (T + bm - 1) / bm * bm; }
 static int64_t rb16_best_rows(int64_t T, int* bm_out) {
   int64_t best = -1;
   for (int i = 0; i < 4; ++i) {
-    const int64_t p = (T + kRb16Rows[i] - 1) / kRb16Rows[i] * kRb16Rows[i];
+    const int64_t p = rb16_rows_executed(T, kRb16Rows[i]);
     if (best < 0 || p < best) { best = p; if (bm_out) *bm_out = kRb16Rows[i]; }
   }
   return best;
@@ -1351,7 +1373,7 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
         };
         if (rows16) {                                                   // 16-row tiles: 80 / 48 rows x 128 / 64 columns
           for (int i = 0; i < 4; ++i) {                                  // row tiles that pad no worse than 1.2 x the best
-            const int64_t p = (a.T + kRb16Rows[i] - 1) / kRb16Rows[i] * kRb16Rows[i];
+            const int64_t p = rb16_rows_executed(a.T, kRb16Rows[i]);
             if (p * 10 > pad16 * 12) continue;
             for (int cbn = 128; cbn >= 64; cbn -= 64)
               if (a.N % cbn == 0) trial(kRb16Rows[i], cbn, 2);

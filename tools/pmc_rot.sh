@@ -2,7 +2,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 cd /tmp
 i=0
-for s in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
+for s in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_SALU"; do
   rm -rf /tmp/pr$i
   timeout 150 rocprofv3 --pmc $s --kernel-trace --output-format csv -d /tmp/pr$i -o c -- python $root/tools/rot_bench.py > /dev/null 2>&1 || echo "pass $i failed: $s"
   i=$((i+1))
