@@ -1,0 +1,60 @@
+"""RCCL smoke check on the GPU box: a one-rank `nccl` process group (the box has one GPU; the N-rank runs are the
+driver's) -- the collectives the sharded path issues (all-reduce of the field gradient + loss, broadcast, barrier) run
+through RCCL on the buffers and streams the engine produces, and leave a one-rank sum unchanged."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from neural_flow_style_amd import engine, vgg, parallel
+from neural_flow_style_amd import synthetic as S, transform as T
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+G, V = 32, 2
+rng = np.random.RandomState(5)
+d0 = S.blob_density(G, rng); vel = S.curl_velocity(G, rng, max_cells=1.0); simg = S.style_image(G, G, rng)
+net = vgg.VGG(vgg.synthetic_weights(123, upto="conv3_1"), dev)
+def run(pg):
+    loss = engine.RenderStyleLoss(net, ["conv1_1", "conv2_1", "conv3_1"], [1.0] * 3, 1.0, transmit=0.01)
+    loss.set_style_image(simg)
+    gs = engine.GridStylizer(loss, torch.tensor(d0, device=dev), k=3, target="v", lr=1e-3, process_group=pg)
+    gs.var.copy_(torch.tensor(vel))
+    rot = T.rot_to_device(S.uniform_views(V), dev)
+    for _ in range(3):
+        total = gs.step(rot)
+    return float(total), gs.var.clone()
+l0, v0 = run(None)
+l1, v1 = run(dist.group.WORLD)
+assert l0 == l1 and torch.equal(v0, v1), (l0, l1)
+# the collectives themselves, on a gradient-sized device buffer written by a side stream
+g = torch.randn(G, G, G, 1, device=dev); ref = g.clone(); l = torch.tensor([3.5], device=dev)
+flat = torch.cat([g.reshape(-1), l])
+dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+dist.broadcast(g, src=0)
+t = torch.tensor([float(l1)], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(flat[:-1].view_as(ref), ref) and float(flat[-1]) == 3.5 and torch.equal(g, ref) and float(t) == l1
+assert parallel.replicas_identical(v1)
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_one_rank_rccl_group_runs_the_collectives_of_the_sharded_path(tmp_path):
+    script = tmp_path / "rccl_rank.py"
+    script.write_text(_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
