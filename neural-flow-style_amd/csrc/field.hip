@@ -22,22 +22,24 @@ namespace nfs {
 // instruction issue at 0.8-1.0 TB/s whatever the chunk length.  Planes are double-buffered in LDS and the
 // next plane's global loads are issued before the current plane is consumed: one barrier per plane.
 constexpr int SM_TY = 8, SM_TXMAX = 64, SM_THREADS = 512, SM_ZCHUNK = 25;
+#ifndef NFS_SM_PF
+#define NFS_SM_PF 2
+#endif
+constexpr int SM_PF = NFS_SM_PF;                  // planes of register look-ahead (even: the LDS buffer parity follows the ring slot)
 
-template <bool BWD>
-__device__ __forceinline__ float smooth_fetch(const float* __restrict__ in, const float* __restrict__ act, int z,
-                                              int yy, int xx, int D, int H, int W) {
-  if (z < 0 || z >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.f;
-  const int64_t idx = ((int64_t)z * H + yy) * W + xx;
-  float v = in[idx];
-  if (BWD) v = signbit(act[idx]) ? 0.f : v;          // g_out * (pre >= 0)
-  return v;
-}
+// Loads and stores go through buffer descriptors based at the block's first plane (32-bit offsets relative to it, so
+// volumes beyond 4 GB work): an element outside the volume or outside the thread's staging slots gets an offset beyond
+// num_records -- the hardware returns zero for the load (= SAME padding) and drops the store.  No branch surrounds a
+// load or a store, so the compiler counts them (s_waitcnt vmcnt(n), not 0) and SM_PF planes really stay in flight.
+constexpr uint32_t SM_OOB = 0x80000000u;
 
 template <bool BWD>
 __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ act, float* __restrict__ out,
                                                               int D, int H, int W, float k, int txe, int ntx, int nty, int nz) {
+  constexpr int TB = (SM_TY + 2) * (SM_TXMAX + 2);
   __shared__ float tile[2][SM_TY + 2][SM_TXMAX + 2];
+  __shared__ float dump[TB + 1];                  // where the threads without a staging slot put their zeros
   const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
   // consecutive workgroups go round-robin to the 8 XCDs: give each XCD a contiguous range of tiles, so that x / y
   // neighbours (which share halo lines, and 128-byte lines at 50-column tile edges) meet in one L2
@@ -51,51 +53,87 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
   // 1-D weights [1,k,1]/(k+2); k <= 0 skips the conv (identity)
   const float inv = k > 0.f ? 1.f / (k + 2.f) : 1.f;
   const float wa = k > 0.f ? inv : 0.f, wb = k > 0.f ? k * inv : 1.f;
+  // the planes this block touches: zb .. ze - 1 (its chunk plus one plane either side, inside the volume)
+  const int zb = max(z0 - 1, 0), ze = min(z1 + 1, D);
+  const uint32_t plane_b = (uint32_t)H * (uint32_t)W * 4u, recs = (uint32_t)(ze - zb) * plane_b;
+  const int64_t base = (int64_t)zb * H * W;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + base), 0, recs, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t act_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? act + base : in + base), 0, recs, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out + base, 0, recs, 0x00020000);
   // staging slots of this thread: elements t and t + 512 of the (SM_TY+2) x (txe+2) halo'd tile
   const int cols = txe + 2, ne = (SM_TY + 2) * cols;
   const int e0 = t, e1 = t + SM_THREADS;
   const int r0 = e0 / cols, c0 = e0 - r0 * cols, r1 = e1 / cols, c1 = e1 - r1 * cols;
-  const bool has0 = e0 < ne, has1 = e1 < ne;
-  float v0 = 0.f, v1 = 0.f;
-#define NFS_SM_GLOAD(p_)                                                                        \
-  {                                                                                             \
-    v0 = has0 ? smooth_fetch<BWD>(in, act, (p_), y0 - 1 + r0, x0 - 1 + c0, D, H, W) : 0.f;      \
-    v1 = has1 ? smooth_fetch<BWD>(in, act, (p_), y0 - 1 + r1, x0 - 1 + c1, D, H, W) : 0.f;      \
+  const int yy0 = y0 - 1 + r0, xx0 = x0 - 1 + c0, yy1 = y0 - 1 + r1, xx1 = x0 - 1 + c1;
+  const uint32_t o0 = (e0 < ne && yy0 >= 0 && yy0 < H && xx0 >= 0 && xx0 < W) ? (uint32_t)(yy0 * W + xx0) * 4u : SM_OOB;
+  const uint32_t o1 = (e1 < ne && yy1 >= 0 && yy1 < H && xx1 >= 0 && xx1 < W) ? (uint32_t)(yy1 * W + xx1) * 4u : SM_OOB;
+  float* const s0 = e0 < ne ? &tile[0][r0][c0] : dump;          // (+ TB for the second buffer: dump[TB])
+  float* const s1 = e1 < ne ? &tile[0][r1][c1] : dump;
+  const uint32_t oo = owner ? (uint32_t)(y * W + x) * 4u : SM_OOB;
+  float v0, v1;
+  // plane p_ of the volume -> (v0, v1); a plane outside the block's range reads as zeros
+#define NFS_SM_GLOAD(p_)                                                                               \
+  {                                                                                                    \
+    const int pz_ = (p_);                                                                              \
+    const bool in_ = pz_ >= zb && pz_ < ze;                                                            \
+    const uint32_t so_ = in_ ? (uint32_t)(pz_ - zb) * plane_b : 0u;                                    \
+    const uint32_t a0_ = in_ ? o0 : SM_OOB, a1_ = in_ ? o1 : SM_OOB;                                   \
+    v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, a0_, so_, 0));        \
+    v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, a1_, so_, 0));        \
+    if (BWD) {                                     /* g_out * (pre >= 0): the sign bit of the forward output */ \
+      const uint32_t m0_ = __builtin_amdgcn_raw_buffer_load_b32(act_rsrc, a0_, so_, 0);                \
+      const uint32_t m1_ = __builtin_amdgcn_raw_buffer_load_b32(act_rsrc, a1_, so_, 0);                \
+      v0 = (m0_ >> 31) ? 0.f : v0;                                                                     \
+      v1 = (m1_ >> 31) ? 0.f : v1;                                                                     \
+    }                                                                                                  \
   }
-#define NFS_SM_STORE(b_)                                                                        \
-  {                                                                                             \
-    if (has0) tile[b_][r0][c0] = v0;                                                            \
-    if (has1) tile[b_][r1][c1] = v1;                                                            \
-  }
+  // plane z0 - 1 goes to LDS directly; planes z0 .. z0 + SM_PF - 1 wait in a register ring (measured at 200^3,
+  // tools/variant_sweep.sh: forward 24.8 us with branches around the loads, 21.2 branch-free with SM_PF = 2, 23.2 with
+  // 4 or 6 -- the stores of the same loop share the counter with the loads and the compiler keeps the waits near
+  // vmcnt(2) whatever the ring depth; what is left is the per-plane barrier of eight waves)
   NFS_SM_GLOAD(z0 - 1)
-  NFS_SM_STORE(0)
-  NFS_SM_GLOAD(z0)
+  s0[0] = v0;
+  s1[0] = v1;
+  float rv0[SM_PF], rv1[SM_PF];
+#pragma unroll
+  for (int u = 0; u < SM_PF; ++u) {
+    NFS_SM_GLOAD(z0 + u)
+    rv0[u] = v0;
+    rv1[u] = v1;
+  }
   __syncthreads();
   float pm = 0.f, pc = 0.f;
-  // iteration p consumes plane p (buffer (p - z0 + 1) & 1), stages plane p + 1 and fetches plane p + 2
-  for (int p = z0 - 1; p <= z1; ++p) {
-    const int b = (p - z0 + 1) & 1;
-    const float* t0 = &tile[b][ty][tx];
-    const float ra = wa * t0[0] + wb * t0[1] + wa * t0[2];
-    const float rb = wa * t0[SM_TXMAX + 2] + wb * t0[SM_TXMAX + 3] + wa * t0[SM_TXMAX + 4];
-    const float rc = wa * t0[2 * (SM_TXMAX + 2)] + wb * t0[2 * (SM_TXMAX + 2) + 1] + wa * t0[2 * (SM_TXMAX + 2) + 2];
-    const float pn = wa * ra + wb * rb + wa * rc;
-    if (p < z1) {
-      NFS_SM_STORE(b ^ 1)                      // plane p + 1 (its buffer was last read in iteration p - 1)
-      if (p + 2 <= z1) NFS_SM_GLOAD(p + 2)
-    }
-    if (p >= z0 + 1 && owner) {
-      float r = wa * pm + wb * pc + wa * pn;   // output plane p - 1
+  // iteration p consumes plane p (buffer (p - z0 + 1) & 1), stages plane p + 1 from the ring and fetches plane
+  // p + 1 + SM_PF into the freed ring slot
+  for (int pb = z0 - 1; pb <= z1; pb += SM_PF) {
+#pragma unroll
+    for (int u = 0; u < SM_PF; ++u) {
+      const int p = pb + u;
+      if (p > z1) break;
+      const int b = u & 1;
+      const float* t0 = &tile[b][ty][tx];
+      const float ra = wa * t0[0] + wb * t0[1] + wa * t0[2];
+      const float rb = wa * t0[SM_TXMAX + 2] + wb * t0[SM_TXMAX + 3] + wa * t0[SM_TXMAX + 4];
+      const float rc = wa * t0[2 * (SM_TXMAX + 2)] + wb * t0[2 * (SM_TXMAX + 2) + 1] + wa * t0[2 * (SM_TXMAX + 2) + 2];
+      const float pn = wa * ra + wb * rb + wa * rc;
+      s0[(b ^ 1) * TB] = rv0[u];                 // plane p + 1 (its buffer was last read in iteration p - 1)
+      s1[(b ^ 1) * TB] = rv1[u];
+      NFS_SM_GLOAD(p + 1 + SM_PF)
+      rv0[u] = v0;
+      rv1[u] = v1;
+      float r = wa * pm + wb * pc + wa * pn;     // output plane p - 1
       // forward: max(pre,0) with the sign bit carrying (pre < 0) for the TF Maximum gradient
       if (!BWD) r = (r >= 0.f) ? fabsf(r) : (r < 0.f ? -0.0f : r);
-      out[((int64_t)(p - 1) * H + y) * W + x] = r;
+      const bool wr = p >= z0 + 1;               // (p - 1 is a plane of this chunk: inside [zb, ze))
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), out_rsrc, wr ? oo : SM_OOB,
+                                            wr ? (uint32_t)(p - 1 - zb) * plane_b : 0u, 0);
+      pm = pc;
+      pc = pn;
+      __syncthreads();
     }
-    pm = pc;
-    pc = pn;
-    __syncthreads();
   }
 #undef NFS_SM_GLOAD
-#undef NFS_SM_STORE
 }
 
 // ---- A10 -----------------------------------------------------------------------------

@@ -35,7 +35,8 @@ def run(pg):
     return float(total), gs.var.clone()
 l0, v0 = run(None)
 l1, v1 = run(dist.group.WORLD)
-assert l0 == l1 and torch.equal(v0, v1), (l0, l1)
+# (the loss VALUE is a float-atomic sum of block partials: last-bit order effects; the update is order-free)
+assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.equal(v0, v1), (l0, l1)
 # the collectives themselves, on a gradient-sized device buffer written by a side stream
 g = torch.randn(G, G, G, 1, device=dev); ref = g.clone(); l = torch.tensor([3.5], device=dev)
 flat = torch.cat([g.reshape(-1), l])
@@ -57,4 +58,5 @@ def test_one_rank_rccl_group_runs_the_collectives_of_the_sharded_path(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    sys.stderr.write(r.stderr[-6000:] if r.returncode else "")
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1500:]
