@@ -626,10 +626,11 @@ def main():
         n_launch = sum(r["launches_per_step"] for r in conv)
         tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": "nfs::winograd_gemm_rb_kernel / winograd_gemm_kernel (batched f32-MFMA GEMM, filters from registers "
-                      "or through LDS as the per-shape tuner measured: the 36 Winograd F(4x4,3x3) products of every "
-                      "conv layer from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower "
-                      "layers run in the single-kernel form winograd_fused_kernel): %d launches/step, "
+            "kernel": "nfs::winograd_gemm_rb16_kernel (batched f32-MFMA GEMM on v_mfma_f32_16x16x4_f32, filters from L2 "
+                      "straight into registers; the 32-row / LDS-B forms winograd_gemm_rb_kernel / winograd_gemm_kernel take "
+                      "the shapes the static rule gives them): the 49 Winograd F(5x5,3x3) or 36 F(4x4,3x3) products of "
+                      "every conv layer from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower "
+                      "layers run in the single-kernel form winograd_fused_kernel: %d launches/step, "
                       "%.2f ms/step = the largest share of the step" % (g_n.value // psteps, g_ms.value / psteps),
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
             "traffic": pmc_traffic("winograd_gemm_"),
