@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   for (int z = 0; z < 36; ++z) acc[z] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef NFS_ABLATE
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tk = a.prof ? clock64() : 0, t_begin = tk;
+  unsigned long long tk = a.prof ? clock64() : 0;
+  const unsigned long long t_begin = a.prof ? wall_clock64() : 0;   // (100 MHz, one counter for the whole chip)
 #define NFS_TICK(i_) if (a.prof) { const unsigned long long n_ = clock64(); pt[i_] += n_ - tk; tk = n_; }
 #else
 #define NFS_TICK(i_)
@@ -413,9 +414,10 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   NFS_TICK(4)
   if (a.prof && lane == 0) {
     unsigned long long* o = a.prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
-    for (int i = 0; i < 6; ++i) o[i] = pt[i];
+    for (int i = 0; i < 5; ++i) o[i] = pt[i];
+    o[5] = pt[0] + pt[1] + pt[2] + pt[3] + pt[4];   // wave life in shader cycles
     o[6] = t_begin;
-    o[7] = tk;
+    o[7] = wall_clock64();
   }
 #endif
 #undef NFS_TICK

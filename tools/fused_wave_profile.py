@@ -29,10 +29,17 @@ for (HW, Ci, Co, kind) in [(200, 64, 64, "fwd"), (100, 64, 128, "fwd"), (100, 12
     p = buf.cpu().numpy().reshape(-1, 8)
     p = p[p[:, 7] > 0]
     ph = p[:, :5].astype(np.float64)
-    tot = (p[:, 7] - p[:, 6]).astype(np.float64)
-    span = (p[:, 7].max() - p[:, 6].min())
+    tot = p[:, 5].astype(np.float64)
+    t0 = p[:, 6].min()
+    start = (p[:, 6] - t0) / 100.0; end = (p[:, 7] - t0) / 100.0      # us (s_memrealtime: 100 MHz)
+    span = end.max()
     halves = Ci // 16
-    print(kind, "%dx%d %d->%d: %d waves, wave life %.0f ticks avg, kernel span %.0f ticks, %d slices" % (HW, HW, Ci, Co, len(p), tot.mean(), span, halves))
+    print(kind, "%dx%d %d->%d: %d waves, wave life %.0f cycles avg, kernel span %.1f us, %d slices" % (HW, HW, Ci, Co, len(p), tot.mean(), span, halves))
+    late = start > 0.25 * span
+    print("   timeline: %d waves start in the first quarter (life %.1f us avg, last ends %.1f us); %d start later "
+          "(at %.1f..%.1f us, life %.1f us avg)" % ((~late).sum(), (end - start)[~late].mean(), end[~late].max(), late.sum(),
+          start[late].min() if late.any() else 0, start[late].max() if late.any() else 0, (end - start)[late].mean() if late.any() else 0))
+    print("   waves running over time (10 bins):", [int(((start <= x) & (end > x)).sum()) for x in np.linspace(0, span, 11)[:-1] + span / 20])
     names = ["first slice staged+transformed", "fetch issue + MFMAs", "stash + barrier", "transform + barrier", "epilogue"]
     for n, v in zip(names, ph.mean(0)):
         print("   %-24s %8.0f  (%4.1f %%)  per slice %7.0f" % (n, v, 100 * v / tot.mean(), v / halves))
