@@ -348,8 +348,9 @@ def test_avgpool2(ops):
     assert rel(gx_m, gx * (x > 0) + add) < TOL
 
 
-@pytest.mark.parametrize("B,HW,C", [(2, 300, 64), (1, 1000, 128), (3, 37, 256), (1, 144, 512),
-                                    (8, 144, 512)])     # last: >= 256 tile pairs and a short image -> one slab, no reduce pass
+@pytest.mark.parametrize("B,HW,C", [(2, 300, 64), (3, 5003, 64), (1, 1000, 128), (3, 37, 256), (1, 144, 512),
+                                    (8, 144, 512)])     # last: >= 256 tile pairs and a short image -> one slab, no reduce pass;
+                                                        # C = 64: the streaming Gram gradient (ragged last row tile, several runs)
 def test_gram_style_loss(ops, B, HW, C):
     torch.manual_seed(9)
     F = torch.relu(torch.randn(B, HW, C)).requires_grad_()
