@@ -279,6 +279,19 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
   const int64_t comp_stride = T * N;
   const float* mi = M + tile * N + 2 * c2;
   float2 pool[2][2] = {{make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}};
+  // data gradient: the 16 addend pairs are requested BEFORE the 36 components (clamped addresses, no branch around a
+  // load; without an addend the loads read M, which is at least as large, and are ignored): one round trip, not two
+  float2 adq[4][4];
+  if (MODE == 1) {
+    const float* ap = aux1 ? aux1 : M;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int yc = min(4 * ty + a, H - 1), xc = min(4 * tx + c, W - 1);
+        adq[a][c] = *reinterpret_cast<const float2*>(ap + (((int64_t)b * H + yc) * W + xc) * N + 2 * c2);
+      }
+  }
   float2 t[6][4];   // t[s][a]: column s after the vertical pass
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
@@ -310,10 +323,8 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
       } else {
         // relu != 0 in this mode: the addend has NOT been through the ReLU mask yet (same mask: both are gradients
         // wrt the output of the layer below), so it is added first and masked with the rest
-        if (relu && aux1) {
-          const float2 ad = *reinterpret_cast<const float2*>(aux1 + idx);
-          v.x += ad.x; v.y += ad.y;
-        }
+        const float2 ad = aux1 ? adq[a][c] : make_float2(0.f, 0.f);
+        if (relu) { v.x += ad.x; v.y += ad.y; }
         if (bits) {
           const uint32_t wv = word >> ((a * 4 + c) * 2);
           v.x = (wv & 1u) ? v.x : 0.f; v.y = (wv & 2u) ? v.y : 0.f;
@@ -321,10 +332,7 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
           const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
           v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
         }
-        if (!relu && aux1) {
-          const float2 ad = *reinterpret_cast<const float2*>(aux1 + idx);
-          v.x += ad.x; v.y += ad.y;
-        }
+        if (!relu) { v.x += ad.x; v.y += ad.y; }
       }
       if (MODE != 0 || y) *reinterpret_cast<float2*>(y + idx) = v;   // MODE 0: y is optional when only the pool is wanted
       if (MODE == 0) { pool[a >> 1][c >> 1].x += v.x; pool[a >> 1][c >> 1].y += v.y; }

@@ -151,6 +151,19 @@ __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __re
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int64_t comp_stride = T * N;
   const float* mi = M + tile * N + c;
+  // data gradient: the 25 addend values are requested BEFORE the 49 components (clamped addresses, no branch around a
+  // load), so that the two round trips to memory overlap -- the small deep layers are latency-bound here
+  float ad[5][5];
+  if (MODE == 1) {
+    const float* ap = aux1 ? aux1 : M;      // (no addend: the loads still go out -- M is at least as large -- and are ignored)
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        const int yc = min(5 * ty + a, H - 1), xc = min(5 * tx + cc, W - 1);
+        ad[a][cc] = ap[(((int64_t)b * H + yc) * W + xc) * N + c];
+      }
+  }
   float t[7][5];   // t[s][a]: column s after the vertical pass
 #pragma unroll
   for (int s = 0; s < 7; ++s) {
@@ -182,11 +195,11 @@ __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __re
         v += bias;
         if (relu) v = fmaxf(v, 0.f);
       } else {
-        const float ad = aux1 ? aux1[idx] : 0.f;
-        if (relu) v += ad;                       // addend not yet through the mask: add first
+        const float adv = aux1 ? ad[a][cc] : 0.f;
+        if (relu) v += adv;                      // addend not yet through the mask: add first
         if (bits) v = ((mask >> (2 * (a * 5 + cc))) & 1ull) ? v : 0.f;
         else if (aux0) v = aux0[idx] > 0.f ? v : 0.f;
-        if (!relu) v += ad;
+        if (!relu) v += adv;
       }
       y[idx] = v;
     }
