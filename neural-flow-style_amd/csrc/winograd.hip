@@ -177,15 +177,19 @@ __global__ void __launch_bounds__(256) winograd_pack4_kernel(const float* __rest
 // POOLED: the operand is not stored -- it is the gradient coming through a 2x2 VALID average pool below a ReLU,
 // d(y, x) = 0.25 * gpool[y/2, x/2] * (xmask[y, x] > 0) (0 outside the pooled area), formed on the fly
 // (the separate avgpool adjoint kernel and its full-resolution round trip through HBM disappear).
-template <bool POOLED>
+// POOLED: 0 plain operand; 1 pooled gradient masked from the ReLU bit cache; 2 ... from the float output xmask.
+// Every load is unconditional (clamped address, the value dropped by a select afterwards): a bounds test around a load
+// is a branch, hipcc drains vmcnt at every join, and the 36 loads of a patch went out as seven dependent round trips
+// (conv5_1 / conv4_4 at 8 views are a few hundred thousand threads: latency is all there is).
+template <int POOLED>
 __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                               int B, int H, int W, int K, int TH, int TW,
                                                               const float* __restrict__ xmask,
                                                               uint32_t* __restrict__ bits) {
   // ReLU bit cache (word = one 4x4 tile x one channel pair, bit ((row*4 + col)*2 + channel) = value > 0):
-  //   !POOLED: `bits` (nullable) is WRITTEN with the mask of the tile's own 4x4 input pixels -- the forward pass of a
-  //            layer records (x > 0) for its data gradient, which then never reads x again;
-  //   POOLED:  `bits` (nullable) is READ instead of xmask (recorded by the forward output transform of this layer).
+  //   POOLED 0: `bits` (nullable) is WRITTEN with the mask of the tile's own 4x4 input pixels -- the forward pass of a
+  //             layer records (x > 0) for its data gradient, which then never reads x again;
+  //   POOLED 1: `bits` is READ instead of xmask (recorded by the forward output transform of this layer).
   const int K2 = K >> 1;
   const int64_t T = (int64_t)B * TH * TW;
   // 6x6 input patches of neighbouring tiles overlap by two pixels: give each XCD a contiguous range of tiles
@@ -199,54 +203,69 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
   const int64_t tile = gid / K2;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-  float2 t[6][6];   // t[s][r]: column s after the vertical pass
-  uint32_t word = 0u;
-  uint32_t nb[3][3];      // POOLED with bits: the words of the 3 x 3 tiles the 6 x 6 patch reaches into
-  if (POOLED && bits) {
+  const int PH = H >> 1, PW = W >> 1;
+  float2 d[6][6];         // d[s][r]: patch column s, row r
+  [[maybe_unused]] float2 mk[6][6];
+  [[maybe_unused]] uint32_t nb[3][3];      // POOLED 1: the words of the 3 x 3 tiles the 6 x 6 patch reaches into
+  if (POOLED == 1) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const int ny = ty + dy - 1, nx = tx + dx - 1;
-        nb[dy][dx] = (ny >= 0 && ny < TH && nx >= 0 && nx < TW)
-                         ? bits[(((int64_t)b * TH + ny) * TW + nx) * K2 + c2] : 0u;
+        const int ny = min(max(ty + dy - 1, 0), TH - 1), nx = min(max(tx + dx - 1, 0), TW - 1);
+        nb[dy][dx] = bits[(((int64_t)b * TH + ny) * TW + nx) * K2 + c2];
       }
   }
 #pragma unroll
+  for (int s = 0; s < 6; ++s)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = y0 + r, xx = x0 + s;
+      if (!POOLED) {
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        d[s][r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yc) * W + xc) * K + 2 * c2);
+      } else {
+        const int yc = min(max(yy, 0) >> 1, PH - 1), xc = min(max(xx, 0) >> 1, PW - 1);
+        d[s][r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * PH + yc) * PW + xc) * K + 2 * c2);
+        if (POOLED == 2) {
+          const int ym = min(max(yy, 0), H - 1), xm = min(max(xx, 0), W - 1);
+          mk[s][r] = *reinterpret_cast<const float2*>(xmask + (((int64_t)b * H + ym) * W + xm) * K + 2 * c2);
+        }
+      }
+    }
+  float2 t[6][6];   // t[s][r]: column s after the vertical pass
+  uint32_t word = 0u;
+#pragma unroll
   for (int s = 0; s < 6; ++s) {
-    float2 d[6];
     const int xx = x0 + s;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int yy = y0 + r;
-      d[r] = make_float2(0.f, 0.f);
+      float2 v = d[s][r];
       if (!POOLED) {
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-          d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        v = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
         if (r >= 1 && r <= 4 && s >= 1 && s <= 4)
-          word |= ((d[r].x > 0.f ? 1u : 0u) | (d[r].y > 0.f ? 2u : 0u)) << (((r - 1) * 4 + (s - 1)) * 2);
+          word |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u)) << (((r - 1) * 4 + (s - 1)) * 2);
       } else {
-        const int PH = H >> 1, PW = W >> 1;
-        if (yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW) {
-          const float2 g = *reinterpret_cast<const float2*>(x + (((int64_t)b * PH + (yy >> 1)) * PW + (xx >> 1)) * K + 2 * c2);
-          bool mx, my;
-          if (bits) {
-            // patch row r: tile offset / row inside that tile (row 0 = last row of the tile above, 5 = first below)
-            const int dy = r == 0 ? 0 : (r == 5 ? 2 : 1), ir = r == 0 ? 3 : (r == 5 ? 0 : r - 1);
-            const int dx = s == 0 ? 0 : (s == 5 ? 2 : 1), is = s == 0 ? 3 : (s == 5 ? 0 : s - 1);
-            const uint32_t wv = nb[dy][dx] >> ((ir * 4 + is) * 2);
-            mx = wv & 1u;
-            my = wv & 2u;
-          } else {
-            const float2 m = *reinterpret_cast<const float2*>(xmask + (((int64_t)b * H + yy) * W + xx) * K + 2 * c2);
-            mx = m.x > 0.f;
-            my = m.y > 0.f;
-          }
-          d[r] = make_float2(mx ? 0.25f * g.x : 0.f, my ? 0.25f * g.y : 0.f);
+        const bool ok = yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW;
+        bool mx, my;
+        if (POOLED == 1) {
+          // patch row r: tile offset / row inside that tile (row 0 = last row of the tile above, 5 = first below)
+          const int dy = r == 0 ? 0 : (r == 5 ? 2 : 1), ir = r == 0 ? 3 : (r == 5 ? 0 : r - 1);
+          const int dx = s == 0 ? 0 : (s == 5 ? 2 : 1), is = s == 0 ? 3 : (s == 5 ? 0 : s - 1);
+          const uint32_t wv = nb[dy][dx] >> ((ir * 4 + is) * 2);
+          mx = wv & 1u;
+          my = wv & 2u;
+        } else {
+          mx = mk[s][r].x > 0.f;
+          my = mk[s][r].y > 0.f;
         }
+        v = make_float2((ok && mx) ? 0.25f * v.x : 0.f, (ok && my) ? 0.25f * v.y : 0.f);
       }
+      d[s][r] = v;
     }
-    wg4_bt(d, t[s]);
+    wg4_bt(d[s], t[s]);
   }
   if (!POOLED && bits) bits[gid] = word;
   const int64_t comp_stride = T * K;
@@ -261,7 +280,6 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
   }
 }
 
-// output transform + layer epilogue: one thread = one 4x4 output tile x 2 channels
 template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
 __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
@@ -1487,11 +1505,13 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   float* V = ws;
   float* M = ws + comps * T * K;
   const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
-  if (m == 4 && pooled_grad)   // pooled data gradient: the mask of the layer's own output, from the bit cache if there is one
-    hipLaunchKernelGGL(winograd_input4_kernel<true>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask,
-                       mode == 1 ? out_bits : nullptr);
+  if (m == 4 && pooled_grad && mode == 1 && out_bits)   // pooled data gradient: the mask of the layer's own output from the bit cache ...
+    hipLaunchKernelGGL(winograd_input4_kernel<1>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask, out_bits);
+  else if (m == 4 && pooled_grad)                       // ... or from the float output
+    hipLaunchKernelGGL(winograd_input4_kernel<2>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask,
+                       (uint32_t*)nullptr);
   else if (m == 4)
-    hipLaunchKernelGGL(winograd_input4_kernel<false>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
+    hipLaunchKernelGGL(winograd_input4_kernel<0>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
                        (const float*)nullptr, mode == 0 ? in_bits : nullptr);
   else
     hipLaunchKernelGGL(winograd_input_kernel, dim3(blocks_for(T * (K / 4), 256)), dim3(256), 0, s, x, V, B, H, W, K, TH,

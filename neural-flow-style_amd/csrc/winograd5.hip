@@ -104,6 +104,16 @@ __global__ void __launch_bounds__(256) winograd5_input_kernel(const float* __res
   const int64_t tile = gid / K;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
   const int y0 = 5 * ty - 1, x0 = 5 * tx - 1;
+  // all 49 loads go out before anything waits: clamped addresses, the value outside the image dropped by a select
+  // (a bounds test around a load is a branch, and hipcc drains vmcnt at the join: three dependent round trips before)
+  float dv[7][7];  // dv[s][r]: patch column s, row r
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int yc = min(max(y0 + r, 0), H - 1), xc = min(max(x0 + s, 0), W - 1);
+      dv[s][r] = x[(((int64_t)b * H + yc) * W + xc) * K + c];
+    }
   float t[7][7];   // t[s][r]: column s after the vertical pass
   unsigned long long mask = 0ull;
 #pragma unroll
@@ -113,8 +123,7 @@ __global__ void __launch_bounds__(256) winograd5_input_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
       const int yy = y0 + r;
-      d[r] = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) d[r] = x[(((int64_t)b * H + yy) * W + xx) * K + c];
+      d[r] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dv[s][r] : 0.f;
       if (r >= 1 && r <= 5 && s >= 1 && s <= 5)        // the tile's own pixels (zeros outside the image: bit 0)
         mask |= (unsigned long long)(d[r] > 0.f ? 1u : 0u) << (2 * ((r - 1) * 5 + (s - 1)));
     }
