@@ -488,14 +488,14 @@ class GridStylizer(object):
             if self._graph_warm < 1:
                 self._graph_warm += 1
                 losses, g_ds = self.field_gradient(rot_local)
-                self._loss_slot.copy_(losses.sum().reshape(1))
+                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
                 return self._loss_slot, g_ds
             self._graph_rot = rot_local.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 losses, _ = self.field_gradient(self._graph_rot)
-                self._loss_slot.copy_(losses.sum().reshape(1))
+                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
             self._graph = g
             self._graph_key = key
         elif rot_local.data_ptr() != self._graph_rot.data_ptr():
@@ -511,7 +511,7 @@ class GridStylizer(object):
             total, g_ds = self._field_gradient_graphed(rot_local)
         else:
             losses, g_ds = self.field_gradient(rot_local)
-            self._loss_slot.copy_(losses.sum().reshape(1))
+            torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
             total = self._loss_slot
         if self.pg is not None:
             # The one exchange step (RCCL over xGMI): ONE all-reduce of gradient + loss.  The reduction is placed on
