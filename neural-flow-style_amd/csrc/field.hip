@@ -330,6 +330,7 @@ extern "C" {
 int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float k, nfs_stream_t stream) {
   NFS_REQUIRE(d && out, "nfs_smooth3d_relu_fwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_fwd: non-positive dimension");
+  NFS_REQUIRE((int64_t)H * W * 4 * (SM_ZCHUNK + 2) < ((int64_t)1 << 31), "nfs_smooth3d_relu_fwd: a z-chunk of planes must stay below 2 GB (32-bit buffer offsets)");
   const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;   // balanced column tiles
   const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
   hipLaunchKernelGGL(smooth3d_kernel<false>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
@@ -341,6 +342,7 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d, int 
                           nfs_stream_t stream) {
   NFS_REQUIRE(out && g_out && g_d, "nfs_smooth3d_relu_bwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_bwd: non-positive dimension");
+  NFS_REQUIRE((int64_t)H * W * 4 * (SM_ZCHUNK + 2) < ((int64_t)1 << 31), "nfs_smooth3d_relu_bwd: a z-chunk of planes must stay below 2 GB (32-bit buffer offsets)");
   const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;
   const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
   hipLaunchKernelGGL(smooth3d_kernel<true>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
