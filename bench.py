@@ -314,17 +314,18 @@ def build_sequence(args, device, rank, world, n_frames, base, pg):
     st.pg = pg
     st.rot_mat_ = [np.asarray(m, np.float32) for m in base["mats"]]     # the benchmark's 8-view lattice
     st.load_img([G, G])
-    mine = parallel.plan_frames(n_frames, 1, 1, world)[rank]
     # only the frames this rank touches go to its HBM: its own densities + the velocities its filter window crosses
-    r = int(4.0 * args.window_sigma + 0.5) if n_frames > 1 else 0
-    lo, hi = max(min(mine) - r - 1, 0), min(max(mine) + r + 2, n_frames)
+    # (a rank beyond the number of frames owns nothing and only takes part in the collectives)
+    mine, vel_frames = st.frames_needed(rank, world)
     dd, uu, vi = {}, {}, {}
-    for t in range(lo, hi):
+    for t in sorted(mine | vel_frames):
         d_t, u_t = frame_data(G, t, base)
-        uu[t] = u_t
+        if t in vel_frames:
+            uu[t] = u_t
         if t in mine:
             dd[t] = d_t
             vi[t] = base["vel"]            # non-zero initial stylisation velocity (as the single-frame bench)
+    mine = sorted(mine)
     st.prepare({"d": dd, "v": uu, "v_init": vi}, frames_on_device=mine)
     return st
 

@@ -106,6 +106,13 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
  * of a post-ReLU layer].  `matched` is piecewise constant in feat (no gradient through it, as in the TF graph). */
 int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc,
                   int B, int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream);
+/* The masked branch (styler_base.py:104-125, 196-201; style_mask = True): mask [B,HW] (nullable = nfs_hist_loss) is the
+ * density mask d_gray resized to the layer (nfs_resize_bicubic_tf1); pixels where it is 0 are removed from the source
+ * (tf.boolean_mask: out of the value range, the source histogram and the loss), the template stays whole.
+ * Both entry points: a channel with nothing to match -- max == min over source and template (the reference's
+ * tf.range(min, max, 0) has no defined result there), or every source pixel masked out -- adds loss 0, gradient 0. */
+int nfs_hist_loss_masked(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc,
+                         int B, int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream);
 
 /* ---- A7 mask variant (styler_base.py:165-173, style_mask = True) -------------------------------------------------
  * nfs_resize_bicubic_tf1: tf.compat.v1.image.resize(BICUBIC) (legacy kernel: align_corners False, no half-pixel

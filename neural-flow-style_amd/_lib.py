@@ -78,6 +78,7 @@ SIGNATURES = {
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_hist_loss_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "nfs_resize_bicubic_tf1": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_style_mask_apply": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nfs_style_mask_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -3,6 +3,11 @@
 //   over the joint value range, template CDF inverted by linear interpolation of the bin index, bin-centre values),
 //   loss += sum((feature - matched)^2);  `matched` carries no gradient (py_func / integer casts / tf.range in the
 //   reference graph), so d loss / d feature = 2 (feature - matched).
+// Deliberate divergence from the mounted reference (also DESIGN.md section 5): the caller passes the template
+// features OF THE HIST LAYER and the weight w_hist_layer.  The reference's unmasked branch (styler_base.py:203, 207) reads
+// `style_feature` / `w_style_layer` -- stale loop variables of the style loop above it, i.e. the LAST style layer's
+// placeholder and weight -- so its results coincide with this only for hist_layer == [style_layer[-1]] and
+// w_hist_layer == [w_style_layer[-1]].  The masked branch (196-201) uses the hist placeholder and is followed as written.
 // One block per (image, channel): min/max -> two 255-bin histograms in LDS (integer atomics) -> quantiles (double, as
 // NumPy's cumsum / total) -> the 255-entry lookup table -> one pass applying it.  The activations of a channel are
 // read three times by the same block (L2-resident); everything else lives in LDS.
@@ -16,9 +21,15 @@ __device__ __forceinline__ float block_min(float v, float* red) {
   return -block_max(-v, red);
 }
 
+// ``mask`` [B,HW] (styler_base.py:104-125, 196-201: the bicubic-resized density mask): pixels where it is 0 are removed from
+// the source (tf.boolean_mask) -- they count neither for the value range nor for the source histogram nor for the loss;
+// the template stays whole.  A channel with nothing to match -- flat (max == min over source and template: the
+// reference's tf.range(min, max, 0) has no defined result) or with every source pixel masked out -- contributes loss 0
+// and gradient 0.
 __global__ void __launch_bounds__(256) hist_loss_kernel(const float* __restrict__ feat, const float* __restrict__ templ,
-                                                        float* __restrict__ loss_acc, float* __restrict__ g_acc, int B,
-                                                        int Bt, int HW, int HWt, int C, float weight, int relu_mask) {
+                                                        const float* __restrict__ mask, float* __restrict__ loss_acc,
+                                                        float* __restrict__ g_acc, int B, int Bt, int HW, int HWt, int C,
+                                                        float weight, int relu_mask) {
   __shared__ float red[16];
   __shared__ unsigned hs[256], ht[256];
   __shared__ double sq[256], tq[256];
@@ -27,19 +38,27 @@ __global__ void __launch_bounds__(256) hist_loss_kernel(const float* __restrict_
   const int bt = b < Bt ? b : Bt - 1;
   const float* s = feat + (int64_t)b * HW * C + c;
   const float* tp = templ + (int64_t)bt * HWt * C + c;
+  const float* mk = mask ? mask + (int64_t)b * HW : nullptr;
   const int t = threadIdx.x;
   // 1. joint value range (util.py:326-327)
   float lo = 3.0e38f, hi = -3.0e38f;
-  for (int p = t; p < HW; p += 256) { const float v = s[(int64_t)p * C]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  int live = 0;
+  for (int p = t; p < HW; p += 256) {
+    if (mk && mk[p] == 0.f) continue;
+    const float v = s[(int64_t)p * C]; lo = fminf(lo, v); hi = fmaxf(hi, v); live = 1;
+  }
   for (int p = t; p < HWt; p += 256) { const float v = tp[(int64_t)p * C]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
   const float vmax = block_max(hi, red);
   const float vmin = block_min(lo, red);
+  const float any_live = block_max((float)live, red);
+  if (!(vmax > vmin) || any_live == 0.f) return;           // nothing to match (uniform across the block): loss 0, gradient 0
   const float range = vmax - vmin;
   const float delta = range / (float)HB;
   // 2. tf.histogram_fixed_width: index = floor(nbins * (v - min) / (max - min)) clipped to [0, nbins-1]
   hs[t] = 0u; ht[t] = 0u;
   __syncthreads();
   for (int p = t; p < HW; p += 256) {
+    if (mk && mk[p] == 0.f) continue;
     const float sc = (s[(int64_t)p * C] - vmin) / range;
     int k = (int)floorf((float)HB * sc);
     k = k < 0 ? 0 : (k > HB - 1 ? HB - 1 : k);
@@ -84,6 +103,7 @@ __global__ void __launch_bounds__(256) hist_loss_kernel(const float* __restrict_
   // 5. matched = lut[clip(int((source - min) / delta))];  loss and gradient
   float part = 0.f;
   for (int p = t; p < HW; p += 256) {
+    if (mk && mk[p] == 0.f) continue;
     const int64_t o = (int64_t)p * C;
     const float v = s[o];
     int k = (int)((v - vmin) / delta);
@@ -177,14 +197,19 @@ using namespace nfs;
 
 extern "C" {
 
-int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc, int B, int Bt, int HW, int HWt,
-                  int C, float weight, int relu_mask, nfs_stream_t stream) {
+int nfs_hist_loss_masked(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc, int B,
+                         int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream) {
   NFS_REQUIRE(feat && templ && loss_acc, "nfs_hist_loss: null pointer");
   NFS_REQUIRE(B > 0 && Bt > 0 && HW > 0 && HWt > 0 && C > 0, "nfs_hist_loss: non-positive dimension");
   NFS_REQUIRE((int64_t)B * C < (int64_t)1 << 30, "nfs_hist_loss: too many (image, channel) pairs");
-  hipLaunchKernelGGL(hist_loss_kernel, dim3((unsigned)(B * C)), dim3(256), 0, as_stream(stream), feat, templ, loss_acc,
-                     g_acc, B, Bt, HW, HWt, C, weight, relu_mask);
+  hipLaunchKernelGGL(hist_loss_kernel, dim3((unsigned)(B * C)), dim3(256), 0, as_stream(stream), feat, templ, mask,
+                     loss_acc, g_acc, B, Bt, HW, HWt, C, weight, relu_mask);
   return check_launch("nfs_hist_loss");
+}
+
+int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc, int B, int Bt, int HW, int HWt,
+                  int C, float weight, int relu_mask, nfs_stream_t stream) {
+  return nfs_hist_loss_masked(feat, templ, nullptr, loss_acc, g_acc, B, Bt, HW, HWt, C, weight, relu_mask, stream);
 }
 
 int nfs_resize_bicubic_tf1(const float* x, float* out, int B, int H, int W, int C, int oh, int ow, nfs_stream_t stream) {

@@ -61,6 +61,9 @@ class RenderStyleLoss(object):
         self.w_hist_layers = [float(w) for w in w_hist_layer] if self.w_hist else []
         if len(self.w_hist_layers) == 1 and len(self.hist_layers) > 1:
             self.w_hist_layers = self.w_hist_layers * len(self.hist_layers)
+        if len(self.w_hist_layers) != len(self.hist_layers):
+            raise ValueError("w_hist_layer has %d entries for %d hist layers (one weight, or one per layer)"
+                             % (len(self.w_hist_layers), len(self.hist_layers)))
         for name in self.hist_layers:
             if "input" not in name and name not in order:
                 raise KeyError("hist_layer %r is not a layer of the loss network" % (name,))
@@ -87,9 +90,16 @@ class RenderStyleLoss(object):
                              for n in self.hist_layers}
         return self.hist_targets
 
-    def _hist_job(self, acts, sg, loss):
+    def _hist_job(self, acts, sg, loss, d_gray=None):
         """histogram losses on layers of the loss network: per-view losses into ``loss``, gradients (ReLU-masked) into
-        the layers' entries of ``sg``"""
+        the layers' entries of ``sg``.  ``d_gray`` [B,H,W,1]: the masked branch (styler_base.py:196-201) -- the density
+        mask, bicubic-resized to each layer, removes its zero pixels from the source of the match.
+
+        Deliberate divergence from the mounted reference (documented in DESIGN.md section 5, INTEGRATION.md and the
+        hist.hip header): the template of a layer is the style image's features OF THAT LAYER and the weight is
+        ``w_hist_layer`` -- the reference's lines 203 / 207 read the stale ``style_feature`` / ``w_style_layer`` left
+        over from the style loop (the last style layer's placeholder and weight), which only coincide with this when
+        hist_layer == [style_layer[-1]] and w_hist_layer == [w_style_layer[-1]]."""
         for name, wl in zip(self.hist_layers, self.w_hist_layers):
             if "input" in name:
                 continue
@@ -98,14 +108,16 @@ class RenderStyleLoss(object):
             g = sg.get(name)
             if g is None:
                 g = sg[name] = torch.zeros_like(F)
-            ops.hist_loss(F, self.hist_targets[name], wl * self.w_hist, loss, g, relu_mask=True)
+            m = None if d_gray is None else ops.resize_bicubic_tf1(d_gray.contiguous(), F.shape[1], F.shape[2])
+            ops.hist_loss(F, self.hist_targets[name], wl * self.w_hist, loss, g, relu_mask=True, mask=m)
 
-    def _hist_input(self, dimg, loss, g_x):
+    def _hist_input(self, dimg, loss, g_x, d_gray=None):
         """hist_layer 'input': the term on d_img itself (gradient wrt d_img = gradient wrt the mean-subtracted x)"""
         for name, wl in zip(self.hist_layers, self.w_hist_layers):
             if "input" in name:
                 assert self.hist_targets is not None, "call set_hist_image first"
-                ops.hist_loss(dimg, self.hist_targets[name], wl * self.w_hist, loss, g_x, relu_mask=False)
+                m = None if d_gray is None else ops.resize_bicubic_tf1(d_gray.contiguous(), dimg.shape[1], dimg.shape[2])
+                ops.hist_loss(dimg, self.hist_targets[name], wl * self.w_hist, loss, g_x, relu_mask=False, mask=m)
 
     def set_content_image(self, content_img):
         """content_img: float32 [h,w,3] in 0..255 at the loss-net input size, or None (styler_base.py:232-247)"""
@@ -228,6 +240,12 @@ class RenderStyleLoss(object):
         self._hist_job(acts, sg, loss)
         return self.net.backward(acts, sg, self.top, unmasked=unmasked)
 
+    def _batch_views(self, V):
+        """views per loss-net batch of the reference graph: v_batch (RenderStyleLoss: a property of the run, not of
+        the shard -- a rank holding fewer views still divides by v_batch); the whole image batch for the 2-D loss
+        (``v_batch is None``: one sess.run sees every image)"""
+        return float(V) if self.v_batch is None else float(max(int(self.v_batch), 1))
+
     def _keep(self):
         """the activations the loss itself reads: the forward pass need not materialise the full-resolution output
         of a pooled layer that is not among them"""
@@ -241,7 +259,7 @@ class RenderStyleLoss(object):
         F = acts[self.content_layer]
         V = F.shape[0]
         # the reference's means run over one loss-net batch (v_batch views); here all V views share the batch
-        w = self.w_content * V / float(min(max(self.v_batch, 1), V))
+        w = self.w_content * V / self._batch_views(V)
         g = sg.get(self.content_layer)
         if g is None:
             g = sg[self.content_layer] = torch.zeros_like(F)
@@ -267,9 +285,11 @@ class RenderStyleLoss(object):
         if self.w_tv > 0:
             # the reference's batch mean runs over one loss-net batch (v_batch views, styler_base.py:211-213); with
             # all V local views in one batch the weight is rescaled so that the term is w_tv * sum_v TV_v / v_batch
-            # whatever the number of views this rank holds (sharded runs then sum to the single-rank value)
+            # whatever the number of views this rank holds -- ALSO when a rank holds fewer views than one loss-net
+            # batch (8 views over 8 ranks with v_batch 2): the divisor is v_batch, never the local V, so that sharded
+            # runs sum to the single-rank value
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
-            ops.tv_loss(dimg, self.w_tv * V / float(min(max(self.v_batch, 1), V)), tv, g_x)
+            ops.tv_loss(dimg, self.w_tv * V / self._batch_views(V), tv, g_x)
             loss = loss + tv / V
         g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
         g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
@@ -464,14 +484,19 @@ class GridStylizer(object):
 
     def _capture_key(self, rot_local):
         """everything a captured graph has baked in by address or by value: a mismatch forces a re-capture
-        (set_style_image / set_content_image allocate new targets; loss weights are kernel arguments)"""
+        (set_style_image / set_content_image / set_hist_image allocate new targets; loss weights are kernel
+        arguments)"""
         L = self.loss
         grams = tuple(int(t.data_ptr()) for t in (L.style_grams or {}).values())
         cf = getattr(L, "content_feature", None)
         hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "liquid", "resize_scale", "rotate", "w_tv",
                                                     "v_batch", "w_content", "content_layer", "content_channel",
                                                     "w_content_amp"))
-        return (grams, tuple(getattr(L, "w_layers", ())), hyper, None if cf is None else int(cf.data_ptr()),
+        # histogram term: template tensors by address, its weights and layer list by value
+        hist = (tuple(sorted((n, int(t.data_ptr())) for n, t in (getattr(L, "hist_targets", None) or {}).items())),
+                getattr(L, "w_hist", 0.0), tuple(getattr(L, "hist_layers", ())), tuple(getattr(L, "w_hist_layers", ())),
+                getattr(L, "style_mask", False))
+        return (grams, tuple(getattr(L, "w_layers", ())), hyper, None if cf is None else int(cf.data_ptr()), hist,
                 int(self.d0.data_ptr()), int(self.var.data_ptr()), tuple(rot_local.shape), self.k, self.target)
 
     def _field_gradient_graphed(self, rot_local):
@@ -555,13 +580,15 @@ class ImageStyleLoss(object):
         self.content_feature = None
         if self.content_layer is not None and dict((s[0], s[1]) for s in net.seq).get(self.content_layer) != "conv":
             raise KeyError("content_layer %r is not a conv layer of the loss network" % (self.content_layer,))
-        self.v_batch = 1 << 30                      # the content means run over the whole image batch (one sess.run)
+        self.v_batch = None                         # the content means run over the whole image batch (one sess.run)
         self.w_hist = float(w_hist)
         self.hist_layers = list(hist_layer) if self.w_hist else []
         self.w_hist_layers = [float(w) for w in w_hist_layer] if self.w_hist else []
         if len(self.w_hist_layers) == 1 and len(self.hist_layers) > 1:
             self.w_hist_layers = self.w_hist_layers * len(self.hist_layers)
-        assert not (self.hist_layers and style_mask), "the masked histogram branch (styler_base.py:196-201) is not built"
+        if len(self.w_hist_layers) != len(self.hist_layers):
+            raise ValueError("w_hist_layer has %d entries for %d hist layers (one weight, or one per layer)"
+                             % (len(self.w_hist_layers), len(self.hist_layers)))
         self.hist_targets = None
         vgg_hist = [n for n in self.hist_layers if "input" not in n]
         self.top = max(self.layers + vgg_hist + ([self.content_layer] if self.content_layer else []), key=order.index)
@@ -574,6 +601,7 @@ class ImageStyleLoss(object):
     _hist_input = RenderStyleLoss._hist_input
     _content_job = RenderStyleLoss._content_job
     _keep = RenderStyleLoss._keep
+    _batch_views = RenderStyleLoss._batch_views
     out_hw = RenderStyleLoss.out_hw
 
     def d_img(self, d):
@@ -607,10 +635,11 @@ class ImageStyleLoss(object):
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
                 sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
         self._content_job(acts, sg, loss)
-        self._hist_job(acts, sg, loss)
+        hmask = d_gray if self.style_mask else None     # masked histogram branch (styler_base.py:196-201)
+        self._hist_job(acts, sg, loss, hmask)
         g_x = self.net.backward(acts, sg, self.top)
         if hist_in:
-            self._hist_input(dimg, loss, g_x)
+            self._hist_input(dimg, loss, g_x, hmask)
         if self.w_tv > 0:
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
             ops.tv_loss(dimg, self.w_tv, tv, g_x)

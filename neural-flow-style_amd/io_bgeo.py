@@ -67,24 +67,35 @@ class ParticleSet(object):
         return self.addParticles(1)
 
     def addParticles(self, count):
+        """Capacity grows geometrically (amortised doubling): the drivers' per-particle loop -- ``addParticle`` + ``set``
+        per particle, test_smokegun_resim.py:295-319 -- is O(N), not O(N^2).  ``_n`` counts the particles, the arrays
+        may be longer; every reader goes through ``array`` (trimmed view)."""
         first = self._n
         self._n += int(count)
         for a in self._attrs:
             cur = self._data[a.name]
-            grown = np.zeros((self._n, a.count), cur.dtype)
-            grown[:first] = cur
-            self._data[a.name] = grown
+            if cur.shape[0] < self._n:
+                grown = np.zeros((max(self._n, 2 * cur.shape[0], 16), a.count), cur.dtype)
+                grown[:first] = cur[:first]
+                self._data[a.name] = grown
         return first
 
     def set(self, attr, index, value):
-        self._data[attr.name][index] = np.asarray(value)
+        if not 0 <= index < self._n:
+            raise IndexError("particle %d of %d" % (index, self._n))
+        v = np.asarray(value)
+        if attr.type == INT and v.dtype.kind == "f" and not np.all(v == np.floor(v)):
+            raise ValueError("attribute %r is INT: refusing to truncate %r" % (attr.name, value))
+        self._data[attr.name][index] = v
 
     def get(self, attr, index):
+        if not 0 <= index < self._n:
+            raise IndexError("particle %d of %d" % (index, self._n))
         return tuple(self._data[attr.name][index].tolist())
 
     # ---- vectorised access (build extension) -------------------------------------------------------------------------
     def array(self, name):
-        return self._data[name]
+        return self._data[name][:self._n]
 
     def set_array(self, name, values):
         a = self.attributeInfo(name)

@@ -515,14 +515,20 @@ def style_mask_bwd(dFm, mask, F):
     return out
 
 
-def hist_loss(F, templ, weight, loss_acc, g_acc=None, relu_mask=False):
+def hist_loss(F, templ, weight, loss_acc, g_acc=None, relu_mask=False, mask=None):
     """histogram loss of F [B,h,w,C] against the template features templ [Bt,ht,wt,C] (styler_base.py:187-209,
-    util.py:317-399): loss_acc [B] += weight * sum((F - matched)^2); g_acc [B,h,w,C] += 2 weight (F - matched)"""
+    util.py:317-399): loss_acc [B] += weight * sum((F - matched)^2); g_acc [B,h,w,C] += 2 weight (F - matched).
+    ``mask`` [B,h,w(,1)]: the masked branch (styler_base.py:104-125, 196-201) -- pixels where it is 0 leave the source."""
     B, Cn = F.shape[0], F.shape[-1]
     HW = F.numel() // (B * Cn)
     Bt = templ.shape[0]
     HWt = templ.numel() // (Bt * Cn)
     assert templ.shape[-1] == Cn
+    if mask is not None:
+        assert mask.numel() == B * HW and mask.is_contiguous(), "mask must be [B,h,w] of the feature's size"
+        _lib.call("nfs_hist_loss_masked", _ptr(F), _ptr(templ), _ptr(mask), _ptr(loss_acc), _ptr(g_acc), B, Bt, HW, HWt,
+                  Cn, float(weight), int(bool(relu_mask)), _stream())
+        return g_acc
     _lib.call("nfs_hist_loss", _ptr(F), _ptr(templ), _ptr(loss_acc), _ptr(g_acc), B, Bt, HW, HWt, Cn, float(weight),
               int(bool(relu_mask)), _stream())
     return g_acc

@@ -127,10 +127,32 @@ class Styler(StylerBase):
         get = (lambda t: x[t]) if not isinstance(x, dict) else (lambda t: x.get(t))
         return {t: self._dev(get(t)) for t in wanted if get(t) is not None}
 
+    def frames_needed(self, rank=None, world=None):
+        """(density frames, simulation-velocity frames) rank ``rank`` of ``world`` touches in a sharded run: its own
+        key frames, and the velocities of every frame crossing its temporal filter makes (the non-zero columns of the
+        ``denoise`` matrix).  A pure function of the configuration: a driver can load exactly these frames and pass
+        ``prepare(params, frames_on_device=densities)``.  A rank beyond the number of optimiser groups gets two empty
+        sets (it still takes part in the collectives)."""
+        if rank is None or world is None:
+            rank, world = self._rank_world()
+        F_ = int(self.num_frames)
+        keys = list(range(0, F_, self.interp))
+        plan = parallel.plan_frames(F_, self.interp, self.frames_per_opt, world)
+        mine = plan[rank]
+        if not mine:
+            return set(), set()
+        need = set(mine)
+        if self.window_sigma > 0 and F_ > 1:
+            Wt = temporal_weights(len(keys), self.window_sigma)
+            for t in mine:
+                need |= set(keys[jj] for jj in np.nonzero(Wt[keys.index(t)])[0])
+            return set(mine), set(range(max(min(need) - 1, 0), min(max(need) + 1, F_)))
+        return set(mine), set()
+
     def prepare(self, params, frames_on_device=None):
         """Put this rank's share of the sequence on the device and set up the loop state.  ``params['d']`` /
         ``params['v']`` / ``params['v_init']``: list over frames or {frame: array}; a sharded run only needs the
-        frames this rank touches (``frames_needed(rank)``)."""
+        frames this rank touches (``frames_needed(rank, world)``; ``frames_on_device`` = its density frames)."""
         assert self.octave_n == 1, "the grid path has one octave (the reference's octaves resize the SPLAT target, " \
                                    "styler_3p.py:241-247; a grid sequence comes at its own resolution)"
         F_ = int(self.num_frames)
@@ -158,8 +180,9 @@ class Styler(StylerBase):
             set(range(max(min(st.need) - 1, 0), min(max(st.need) + 1, F_))) if st.need else set()
         st.d = {t: x.reshape(tuple(self.resolution)) for t, x in self._frames(params["d"], sorted(want_d)).items()}
         st.u = self._frames(params.get("v"), sorted(want_u))
-        if st.Wt is not None and not st.u:
+        if st.Wt is not None and st.mine and not st.u:
             raise ValueError("params['v'] (simulation velocities) is needed to align the updates of a sequence")
+        st.u = st.u or {}
         D, H, W_ = tuple(self.resolution)
         st.C = 3 if self.target == "v" else 1
         st.shape = (D, H, W_, st.C)
@@ -176,7 +199,9 @@ class Styler(StylerBase):
         st.v_init = params.get("v_init")
         st.g_opt = {t: self._initial(t) for t in st.mine}
         st.work = torch.zeros(st.shape, device=self.device)     # the variable (re-assigned per frame, 312)
-        first = st.d[st.mine[0]] if st.mine else next(iter(st.d.values()))
+        # (a rank beyond the number of optimiser groups owns no frame: it only takes part in the collectives)
+        first = st.d[st.mine[0]] if st.mine else (next(iter(st.d.values())) if st.d else
+                                                  torch.zeros(tuple(self.resolution), device=self.device))
         st.gs = engine.GridStylizer(self.loss, first, k=self.k, target=self.target, lr=st.lr)
         st.opt_ = {}
         st.hist = []
@@ -226,7 +251,10 @@ class Styler(StylerBase):
         return losses
 
     def finish(self):
-        """frame interpolation (392-397) + final inference of every frame, on every rank"""
+        """frame interpolation (392-397) + final inference of every frame whose density this rank holds: all of them
+        in an unsharded run (or a sharded one prepared with every frame), the rank's own frames after
+        ``prepare(frames_on_device=...)`` -- ``result['frames']`` lists which entries of ``d`` / ``r`` / ``v`` these
+        are"""
         st = self._st
         D, H, W_, _ = st.shape
         allv = parallel.exchange_frames(st.g_opt, set(st.keys), st.owner, st.work, group=self.pg,
@@ -239,7 +267,8 @@ class Styler(StylerBase):
                     if t + self.interp < st.F:
                         full[t + i] = full[t] * float(1 - w[i]) + full[t + self.interp] * float(w[i])
         d_sty, r_sty, v_sty = [], [], []
-        for t in range(st.F):
+        present = [t for t in range(st.F) if t in st.d]
+        for t in present:
             var = full.get(t)
             if var is None:                                        # trailing frames past the last key frame
                 var = self._initial(t)
@@ -255,7 +284,7 @@ class Styler(StylerBase):
         hist = [[float(x) for x in l_.cpu()] for l_ in st.hist]
         return {"l": [[x for l_ in hist for x in l_]], "l_frames": hist, "d_intm": [],
                 "d": np.array(d_sty), "r": np.array(r_sty), "v": v_sty if self.target == "v" else None,
-                "opt": v_sty, "p": None, "c": None}
+                "opt": v_sty, "p": None, "c": None, "frames": present}
 
     def run(self, params):
         self.prepare(params)

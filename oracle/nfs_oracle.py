@@ -572,12 +572,20 @@ def histogram_match(source, template, hist_bins=255):
     nearest_indices = round(interp1d(t_quantiles, arange(nbins), fill (0, nbins-1))(s_quantiles)) (358-362);
     matched = hist_range[nearest_indices[clip(int((source - min) / delta), 0, nbins-1)]] (370-379).
     Returns the matched array (same shape as source).  No gradient flows through it (py_func / integer casts /
-    tf.range): d loss / d source = 2 (source - matched)."""
+    tf.range): d loss / d source = 2 (source - matched).
+
+    Nothing to match -- an empty source (every pixel masked out) or a flat channel (max == min over source and
+    template) -- is outside the reference's domain: its tf.range(min, max, 0) / 0-count division have no defined result.
+    The build DEFINES that case as "the channel is skipped": matched = source (loss 0, gradient 0)."""
     from scipy.interpolate import interp1d
     src = np.asarray(source, np.float32).reshape(-1)
     tpl = np.asarray(template, np.float32).reshape(-1)
+    if src.size == 0:
+        return src.reshape(np.shape(source))
     vmax = np.float32(max(src.max(), tpl.max()))
     vmin = np.float32(min(src.min(), tpl.min()))
+    if not vmax > vmin:
+        return src.reshape(np.shape(source)).copy()
     delta = np.float32((vmax - vmin) / np.float32(hist_bins))
     hist_range = (vmin + delta * np.arange(hist_bins, dtype=np.float32)).astype(np.float32) + delta / np.float32(2)
 
@@ -589,23 +597,33 @@ def histogram_match(source, template, hist_bins=255):
     s_q = np.cumsum(fixed_width(src)).astype(np.float64); s_q /= s_q[-1]
     t_q = np.cumsum(fixed_width(tpl)).astype(np.float64); t_q /= t_q[-1]
     f = interp1d(t_q, np.arange(hist_bins), bounds_error=False, fill_value=(0, hist_bins - 1))
-    nearest = np.round(np.nan_to_num(f(s_q))).astype(np.int64)   # 0/0 at a flat start of the template CDF -> bin 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        nearest = np.round(np.nan_to_num(f(s_q))).astype(np.int64)   # 0/0 at a flat start of the template CDF -> bin 0
     s_bin = np.clip(((src - vmin) / delta).astype(np.int64), 0, hist_bins - 1)
     return hist_range[nearest[s_bin]].reshape(np.shape(source))
 
 
-def hist_loss(feature, hist_feature):
-    """histogram term of _loss (styler_base.py:187-209, the non-mask branch as intended: the template is the fed
-    ``hist_feature`` of the same layer -- the mounted line 203 reads the stale ``style_feature`` of the style loop):
+def hist_loss(feature, hist_feature, mask=None):
+    """histogram term of _loss (styler_base.py:187-209, as intended: the template is the fed ``hist_feature`` of the
+    same layer -- the mounted line 203 reads the stale ``style_feature`` of the style loop):
     sum over images i < batch and channels j of sum((feature[i,...,j] - matched)^2) with
     matched = histogram_match(feature[i,...,j], hist_feature[i,...,j]) held constant.  feature [B,h,w,C] torch tensor
-    (differentiable), hist_feature [Bt,ht,wt,C]."""
+    (differentiable), hist_feature [Bt,ht,wt,C].
+    ``mask`` [B,h,w,1] (the masked branch, _hist_match 104-125 + 196-201): ``tf.boolean_mask(s_, mask != 0)`` removes
+    the masked-out pixels from the source before the match; the loss sums (matched - masked source)^2."""
     f = feature.detach().cpu().numpy()
     t = np.asarray(hist_feature.detach().cpu().numpy() if torch.is_tensor(hist_feature) else hist_feature)
-    m = np.empty_like(f)
+    mk = None if mask is None else (np.asarray(mask.detach().cpu().numpy() if torch.is_tensor(mask) else mask)
+                                    .reshape(f.shape[:-1]) != 0)
+    m = f.copy()                                   # outside the mask: matched := source (no loss, no gradient)
     for i in range(f.shape[0]):
         for j in range(f.shape[-1]):
-            m[i, ..., j] = histogram_match(f[i, ..., j], t[min(i, t.shape[0] - 1), ..., j])
+            tpl = t[min(i, t.shape[0] - 1), ..., j]
+            if mk is None:
+                m[i, ..., j] = histogram_match(f[i, ..., j], tpl)
+            else:
+                sel = mk[i]
+                m[i, ..., j][sel] = histogram_match(f[i, ..., j][sel], tpl)
     return ((feature - torch.as_tensor(m, dtype=feature.dtype)) ** 2).sum()
 
 
@@ -1073,13 +1091,21 @@ def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
     d, d_gray, _ = colour_field2d(p, r, var, cfg, res)
     d_img = plugin_to_loss_net(d, cfg.get("resize_scale", 1.0), is_color=True)
     use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
-    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] +
+    vgg_hist = [n for n in cfg.get("hist_layer", []) if "input" not in n] if cfg.get("w_hist", 0) else []
+    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] + vgg_hist +
                                                       ([cfg["content_layer"]] if use_content else [])))
     l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"],
                       d_gray=d_gray if cfg.get("style_mask") else None)
     if use_content:
         l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
                                                 cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
+    if cfg.get("w_hist", 0):
+        # histogram term (styler_base.py:187-209); with style_mask the masked branch (196-201): the density mask,
+        # bicubic-resized to the layer, removes its zero pixels from the source of the match
+        for name, wl in zip(cfg["hist_layer"], cfg["w_hist_layer"]):
+            f = d_img if "input" in name else feats[name]
+            m = tf1_resize_bicubic(d_gray, f.shape[1], f.shape[2]) if cfg.get("style_mask") else None
+            l = l + cfg["w_hist"] * wl * hist_loss(f, cfg["hist_feature"][name], mask=m)
     if cfg.get("w_tv", 0):
         l = l + tv_loss(d_img) * cfg["w_tv"]
     return l

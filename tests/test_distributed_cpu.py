@@ -102,6 +102,38 @@ def test_plan_frames_is_a_partition_and_keeps_optimiser_groups_whole():
             assert max(n_groups) - min(n_groups) <= 1
 
 
+def test_frames_needed_covers_the_filter_window_and_tolerates_idle_ranks():
+    """styler_grid.Styler.frames_needed(rank, world): a rank's density frames are its block of the plan, its velocity
+    frames span every crossing its temporal filter makes; a world larger than the number of optimiser groups leaves
+    ranks with two empty sets instead of an error (host logic only: no device is touched)"""
+    from neural_flow_style_amd import parallel
+    from neural_flow_style_amd.styler_grid import Styler
+    from neural_flow_style_amd.util import temporal_weights
+    st = Styler.__new__(Styler)
+    for F, interp, fpo, sigma, world in ((12, 1, 1, 0.9, 3), (12, 1, 4, 2.0, 2), (3, 1, 1, 1.0, 8), (9, 2, 1, 0.0, 2)):
+        st.num_frames, st.interp, st.frames_per_opt, st.window_sigma, st.pg = F, interp, fpo, sigma, None
+        plan = parallel.plan_frames(F, interp, fpo, world)
+        keys = list(range(0, F, interp))
+        seen = []
+        for r in range(world):
+            dens, vels = st.frames_needed(r, world)
+            assert dens == set(plan[r])
+            seen += sorted(dens)
+            if not plan[r]:
+                assert vels == set()
+                continue
+            if sigma > 0:
+                W = temporal_weights(len(keys), sigma)
+                for t in plan[r]:
+                    for jj in np.nonzero(W[keys.index(t)])[0]:
+                        s_ = keys[jj]
+                        # every frame crossed between s_ and t (forwards: s_..t-1, backwards: t..s_-1) has a velocity
+                        assert set(range(min(s_, t), max(s_, t))) <= vels
+            else:
+                assert vels == set()
+        assert seen == keys
+
+
 def test_temporal_weights_is_the_matrix_of_denoise():
     """W @ x == util.denoise(x, (sigma,0,..)) -- the function pinned to the reference's own util.denoise by
     tests/golden/util_reference.npz; rows sum to one; non-zero band <= 4 sigma"""

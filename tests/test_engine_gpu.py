@@ -306,3 +306,79 @@ def test_gradient_parity_with_histogram_loss():
     losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
     assert rel(losses, torch.stack(per_view).detach()) < 2e-3
     assert rel(g_h, g_o[0, ..., 0]) < 2e-2
+
+
+def test_image_style_loss_with_masked_histogram_branch():
+    """the 2-D colour loss with style_mask AND the histogram term: the masked branch of _loss (styler_base.py:196-201;
+    hist layers 'input' and conv2_1) next to the masked style loss, loss and image gradient vs the oracle"""
+    import neural_flow_style_amd.vgg as vgg
+    import neural_flow_style_amd.engine as eng
+    rng = np.random.RandomState(17)
+    H = W = 24
+    layers = ["conv1_1", "conv2_1"]
+    w_np = vgg.synthetic_weights(123, upto="conv2_1")
+    w_or = O.synthetic_vgg19_weights(123, upto="conv2_1")
+    net = vgg.VGG(w_np, "cuda")
+    simg = style_image(H, W, rng)
+    d = rng.rand(1, H, W, 3).astype(np.float32)
+    d_gray = np.clip(rng.rand(1, H, W, 1) * 1.6 - 0.5, 0, 1).astype(np.float32)     # ~30 % exact zeros
+    hl, hw = ["input", "conv2_1"], [1.0, 0.5]
+    loss = eng.ImageStyleLoss(net, layers, [1.0, 1.0], 1.0, w_tv=0.01, style_mask=True, w_hist=0.3, hist_layer=hl,
+                              w_hist_layer=hw)
+    loss.set_style_image(simg)
+    loss.set_hist_image(simg)
+    losses, g_h = loss.loss_and_grad(torch.tensor(d).cuda(), torch.tensor(d_gray).cuda())
+    # oracle: the same graph from the image on
+    d_o = torch.tensor(d, requires_grad=True)
+    dg = torch.tensor(d_gray)
+    d_img = O.plugin_to_loss_net(d_o, 1.0, is_color=True)
+    feats = O.vgg19_features(d_img, w_or, "conv2_1")
+    sfe = O.style_target_features(torch.tensor(simg)[None], w_or, layers, upto="conv2_1")
+    feats_s = O.vgg19_features(torch.tensor(simg)[None], w_or, "conv2_1")
+    total, _ = O.style_loss(feats, sfe, layers, [1.0, 1.0], 1.0, d_gray=dg)
+    for name, wl in zip(hl, hw):
+        f = d_img if name == "input" else feats[name]
+        tpl = torch.tensor(simg)[None] if name == "input" else feats_s[name]
+        m = O.tf1_resize_bicubic(dg, f.shape[1], f.shape[2])
+        total = total + 0.3 * wl * O.hist_loss(f, tpl, mask=m)
+    total = total + 0.01 * O.tv_loss(d_img)
+    (g_o,) = torch.autograd.grad(total, d_o)
+    e_l = abs(float(losses.sum()) - float(total.detach())) / float(total.detach())
+    e_g = rel(g_h, g_o)
+    print("masked histogram branch: loss rel %.2e, gradient rel-L2 %.2e" % (e_l, e_g))
+    assert e_l < 2e-3
+    assert e_g < 2e-2
+
+
+def test_graph_is_recaptured_when_the_histogram_targets_change():
+    """a captured hipGraph bakes in the histogram templates' addresses and the hist weights (kernel arguments):
+    set_hist_image / a changed weight after the capture must force a re-capture, not a replay against freed tensors"""
+    layers = ["conv1_1", "conv2_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 2, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    rng = np.random.RandomState(4)
+    s1, s2 = style_image(24, 24, rng), style_image(24, 24, np.random.RandomState(9))
+    out = []
+    for graph in (False, True):
+        l2 = eng.RenderStyleLoss(loss.net, layers, [1.0, 1.0], 1.0, transmit=0.05, w_hist=0.3, hist_layer=["conv2_1"],
+                                 w_hist_layer=[1.0])
+        l2.set_style_image(s1)
+        keep = l2.set_hist_image(s1)                         # (held: the old templates must not be what is replayed)
+        gs = eng.GridStylizer(l2, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3, graph=graph)
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(3)]
+        g_before = gs._graph
+        l2.set_hist_image(s2)
+        ls += [float(gs.step(rot)) for _ in range(3)]
+        if graph:
+            assert g_before is not None and gs._graph is not None and gs._graph is not g_before
+        g_mid = gs._graph
+        l2.w_hist = 0.6
+        ls += [float(gs.step(rot)) for _ in range(3)]
+        if graph:
+            assert gs._graph is not g_mid
+        out.append((ls, gs.var.clone()))
+        del keep
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-5)
+    assert rel(out[0][1], out[1][1]) < 1e-5
+    assert abs(out[0][0][3] - out[0][0][2]) > 1e-6 * abs(out[0][0][2])      # the new template does change the loss

@@ -83,3 +83,36 @@ def test_partio_calls_of_the_reference_drivers(tmp_path):
         got_r.append(rd.get(a_den, j_id))
     assert np.allclose(got_p, p_[p_id]) and np.allclose(got_r, p_den[p_id])
     assert np.allclose(rd.array("Cd"), np.repeat(p_den[:, :1], 3, 1)) and np.allclose(rd.array("radius"), 0.5)
+
+
+def test_per_particle_loop_is_linear_and_ints_are_not_truncated(tmp_path):
+    """the reference drivers' unchanged per-particle loop (addParticle + set per particle,
+    test_smokegun_resim.py:295-319) must not re-allocate every attribute on every call; INT attributes refuse
+    fractional values instead of truncating them"""
+    import time
+    import io_bgeo as partio
+    pt = partio.create()
+    P = pt.addAttribute("position", partio.VECTOR, 3)
+    I = pt.addAttribute("id", partio.INT, 1)
+    Dn = pt.addAttribute("density", partio.FLOAT, 1)
+    n = 60000
+    t0 = time.time()
+    for i in range(n):
+        k = pt.addParticle()
+        pt.set(P, k, (i * 1e-5, 0.5, 0.25))
+        pt.set(I, k, [i])
+        pt.set(Dn, k, (1.0 + i,))
+    dt = time.time() - t0
+    assert dt < 8.0, "per-particle loop took %.1f s for %d particles" % (dt, n)     # quadratic growth: minutes
+    assert pt.numParticles() == n and pt.array("id").shape == (n, 1)
+    assert pt.get(I, n - 1) == (n - 1,)
+    with pytest.raises(ValueError):
+        pt.set(I, 0, [0.5])
+    with pytest.raises(IndexError):
+        pt.set(I, n, [1])
+    path = str(tmp_path / "loop.bgeo")
+    partio.write(path, pt)
+    back = partio.read(path)
+    assert back.numParticles() == n
+    np.testing.assert_array_equal(back.array("id")[:, 0], np.arange(n))
+    np.testing.assert_allclose(back.array("density")[:, 0], 1.0 + np.arange(n, dtype=np.float32))

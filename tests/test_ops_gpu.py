@@ -709,6 +709,44 @@ def test_hist_loss_matches_the_oracle_restatement():
         assert rel(g.cpu(), go) < 3e-2
 
 
+def test_hist_loss_masked_branch_flat_channels_and_empty_masks():
+    """the masked branch (styler_base.py:104-125, 196-201: tf.boolean_mask of the source by mask != 0) against the
+    oracle, and the cases the reference leaves undefined -- a flat channel (max == min over source and template) and a
+    source with every pixel masked out -- which this build defines as "skipped": loss 0, gradient 0, no NaN"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(33)
+    B, h, w, C = 2, 14, 10, 4
+    f = rng.gamma(2.0, 15.0, (B, h, w, C)).astype(np.float32)
+    f[rng.rand(*f.shape) < 0.3] = 0.0
+    t = (rng.rand(1, 9, 12, C) * 180).astype(np.float32)
+    m = (rng.rand(B, h, w, 1) * (rng.rand(B, h, w, 1) < 0.6)).astype(np.float32)     # 40 % exact zeros
+    f[..., 2] = 7.5; t[..., 2] = 7.5                       # flat channel
+    m[1] = 0.0                                             # image 1: nothing left to match
+    ft = torch.tensor(f, requires_grad=True)
+    lo = O.hist_loss(ft, torch.tensor(t), mask=torch.tensor(m))
+    (go,) = torch.autograd.grad(lo * 0.7, ft)
+    go = go * (ft.detach() > 0)
+    loss = torch.zeros(B, device="cuda")
+    g = torch.zeros(B, h, w, C, device="cuda")
+    ops.hist_loss(torch.tensor(f).cuda(), torch.tensor(t).cuda(), 0.7, loss, g, relu_mask=True,
+                  mask=torch.tensor(m).cuda().contiguous())
+    assert torch.isfinite(loss).all() and torch.isfinite(g).all()
+    assert float(loss[1]) == 0.0 and float(g[1].abs().max()) == 0.0          # empty mask
+    assert float(g[..., 2].abs().max()) == 0.0                                # flat channel
+    assert float(g[0][torch.tensor(m[0, ..., 0]) == 0].abs().max()) == 0.0    # masked-out pixels carry no gradient
+    assert abs(float(loss.sum()) - 0.7 * float(lo)) < 2e-3 * 0.7 * float(lo)
+    d = (g.cpu() - go).abs()
+    assert float((d > 1e-3 * go.abs().max()).float().mean()) < 5e-3
+    assert rel(g.cpu(), go) < 3e-2
+    # unmasked entry point, flat channel: same definition
+    loss2 = torch.zeros(B, device="cuda")
+    g2 = torch.zeros(B, h, w, C, device="cuda")
+    ops.hist_loss(torch.tensor(f).cuda(), torch.tensor(t).cuda(), 1.0, loss2, g2, relu_mask=False)
+    assert torch.isfinite(loss2).all() and float(g2[..., 2].abs().max()) == 0.0
+    lo2 = O.hist_loss(torch.tensor(f), torch.tensor(t))
+    assert abs(float(loss2.sum()) - float(lo2)) < 2e-3 * float(lo2)
+
+
 def test_style_mask_kernels():
     """legacy bicubic resize of the density mask, masked features with the 2*area*C denominator, masked gradient
     (styler_base.py:165-173) against the oracle's restatement"""

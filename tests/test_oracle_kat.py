@@ -189,3 +189,40 @@ def test_content_loss_known_answers():
     assert abs(float(O.content_loss(f, 0, f / 2 + 0.5, 2.0)) - 1.0) < 1e-6
     # the last channel has no upper slice
     assert abs(float(O.content_loss(f, 3)) - (-3.0 + 13.0 / 6.0)) < 1e-6
+
+
+def test_histogram_match_known_answers_and_the_skipped_cases():
+    """util.histogram_match_tf (util.py:317-399) by hand on a case small enough to follow, plus the two cases the
+    reference leaves undefined and this build defines as "channel skipped" (matched = source: loss 0, gradient 0)"""
+    # source uniform on [0, 254] in steps of 1, template = the same values doubled in count: identical CDFs on the joint
+    # range [0, 254] -> every source value maps to the centre of its own bin (delta = 254/255)
+    src = np.arange(255, dtype=np.float32)
+    tpl = np.repeat(src, 2)
+    m = O.histogram_match(src, tpl)
+    delta = np.float32(254.0 / 255.0)
+    k = np.clip((src / delta).astype(np.int64), 0, 254)
+    # identical CDFs: nearest_indices is the identity up to the round() of the interpolated bin index
+    assert np.abs(m - ((delta * k).astype(np.float32) + delta / 2)).max() <= 1.01 * delta
+    # a template living in the upper half of the range pulls every source value there
+    src = np.linspace(0, 1, 101, dtype=np.float32)
+    tpl = np.linspace(3, 4, 50, dtype=np.float32)
+    m = O.histogram_match(src, tpl)
+    assert m.min() >= 3 - 4 / 255 and m.max() <= 4 + 4 / 255 and np.all(np.diff(m) >= 0)
+    # flat channel and empty source: skipped
+    f = np.full((4, 3), 2.5, np.float32)
+    assert np.array_equal(O.histogram_match(f, np.full((5,), 2.5, np.float32)), f)
+    assert O.histogram_match(np.zeros((0,), np.float32), tpl).size == 0
+    # masked loss: only the pixels under a non-zero mask enter the match and the sum
+    rng = np.random.RandomState(0)
+    feat = torch.tensor(rng.rand(1, 6, 5, 2).astype(np.float32) * 10, requires_grad=True)
+    templ = torch.tensor(rng.rand(1, 4, 4, 2).astype(np.float32) * 10)
+    mask = (rng.rand(1, 6, 5, 1) < 0.5).astype(np.float32)
+    l = O.hist_loss(feat, templ, mask=torch.tensor(mask))
+    (g,) = torch.autograd.grad(l, feat)
+    assert float(g[0][torch.tensor(mask[0, ..., 0]) == 0].abs().max()) == 0.0
+    sel = mask[0, ..., 0] != 0
+    want = sum(float(((feat.detach().numpy()[0, ..., j][sel]
+                       - O.histogram_match(feat.detach().numpy()[0, ..., j][sel], templ.numpy()[0, ..., j])) ** 2).sum())
+               for j in range(2))
+    assert abs(float(l.detach()) - want) < 1e-4 * want
+    assert float(O.hist_loss(feat, templ, mask=torch.zeros(1, 6, 5, 1))) == 0.0

@@ -354,3 +354,28 @@ def test_particle_sum_mode_tv_weight_matches_the_oracle_per_view_sum():
     losses = loss.loss_and_grad(d, T.rot_to_device(mats, "cuda"), g)
     assert abs(float(losses.sum()) - float(tot)) < 1e-4 * abs(float(tot))
     assert rel(g.cpu(), go[0, ..., 0]) < 1e-4
+
+
+def test_tv_and_content_divisors_do_not_depend_on_the_local_view_count():
+    """views sharded so that a rank holds FEWER views than one loss-net batch (2 views, v_batch 2, one view per rank):
+    the TV and content terms divide by v_batch, not by the local view count -- the shards' losses and gradients sum to
+    the unsharded ones (liquid render: no max-normalisation coupling the views of a batch)"""
+    from neural_flow_style_amd import engine, vgg
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd import transform as T
+    G, V = 16, 2
+    rng = np.random.RandomState(5)
+    d = torch.tensor(S.blob_density(G, rng)).cuda()
+    simg = S.style_image(G, G, rng)
+    layers = ["conv1_1", "conv2_1"]
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv2_1"), "cuda")
+    rot = T.rot_to_device(S.uniform_views(V), "cuda")
+    loss = engine.RenderStyleLoss(net, layers, [1.0, 1.0], 1.0, transmit=0.2, render_liquid=True, w_tv=0.05, v_batch=2,
+                                  w_content=50.0, content_layer="conv2_1", content_channel=3)
+    loss.set_style_image(simg)
+    g_all = torch.zeros_like(d)
+    l_all = loss.loss_and_grad(d, rot, g_all)
+    g_sh = torch.zeros_like(d)
+    l_sh = [loss.loss_and_grad(d, rot[v:v + 1].contiguous(), g_sh) for v in range(V)]     # "rank v" holds view v only
+    assert abs(float(sum(x.sum() for x in l_sh)) - float(l_all.sum())) < 1e-5 * abs(float(l_all.sum()))
+    assert rel(g_sh, g_all) < 1e-5
