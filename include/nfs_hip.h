@@ -313,6 +313,32 @@ int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* 
 int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, int C,
                  const float* scale_dev, float scale, int relu_mask, nfs_stream_t stream);
 
+/* ---- A7, all style layers of a step at once (the loop of styler_base.py:152-185 as three launches) ---------------
+ * One descriptor per style layer; every layer has the same batch B (the local views).
+ *   nfs_gram_style_group_fwd: per layer G = F^T F * scale (written only when G != NULL), Dmat = 2 weight (G - Gs[b % Bs]),
+ *     and the layer's share of the style loss as PARTIAL SUMS: loss_parts is [P][B] floats, P =
+ *     nfs_gram_style_group_parts(...); every entry is written (plain stores, no atomics, fixed order: deterministic) and
+ *     the style loss of image b is sum_p loss_parts[p][b].  Launches: the tile pairs of every layer (big units first) +
+ *     one slab reduction; workspace >= nfs_gram_style_group_workspace_floats(...) floats.
+ *   nfs_gram_group_bwd: per layer dF = 2 scale F @ Dmat, masked by (F > 0) where relu_mask != 0 -- the five GEMMs of
+ *     nfs_gram_bwd as ONE launch of the batched f32-MFMA GEMM (tile list over all layers, deep K first). */
+typedef struct {
+  const float* F;     /* [B,HW,C] post-ReLU activation of the layer */
+  const float* Gs;    /* [Bs,C,C] style Gram (scaled like G) */
+  float* G;           /* [B,C,C] out, nullable */
+  float* Dmat;        /* [B,C,C] out (fwd) / in (bwd) */
+  float* dF;          /* [B,HW,C] out of nfs_gram_group_bwd (unused by fwd) */
+  int B, Bs, HW, C;
+  float scale;        /* 1 / (2 HW C), styler_base.py:157,176 */
+  float weight;       /* w_style_layer * w_style */
+  int relu_mask;      /* bwd: fold the ReLU gradient of the style layer */
+} nfs_gram_layer_t;
+int64_t nfs_gram_style_group_workspace_floats(const nfs_gram_layer_t* layers, int n);
+int nfs_gram_style_group_parts(const nfs_gram_layer_t* layers, int n);
+int nfs_gram_style_group_fwd(const nfs_gram_layer_t* layers, int n, float* loss_parts, float* workspace,
+                             int64_t workspace_floats, nfs_stream_t stream);
+int nfs_gram_group_bwd(const nfs_gram_layer_t* layers, int n, nfs_stream_t stream);
+
 /* ---- content loss on a layer of the loss network (styler_base.py:135-150) ---------------
  * F [B,HW,C] is a post-ReLU activation.  loss_acc[b] += image b's share of weight * L, g_acc [B,HW,C] +=
  * dL/d(pre-activation) = weight * dL/dF * (F > 0), with L (means over the whole batch, as reduce_mean):

@@ -24,6 +24,13 @@ class SplatCfg(C.Structure):
                 ("nsize", C.c_int), ("clip", C.c_int), ("mode", C.c_int)]
 
 
+class GramLayer(C.Structure):
+    """nfs_gram_layer_t (include/nfs_hip.h): one style layer of the grouped Gram / style-loss entry points"""
+    _fields_ = [("F", C.c_void_p), ("Gs", C.c_void_p), ("G", C.c_void_p), ("Dmat", C.c_void_p), ("dF", C.c_void_p),
+                ("B", C.c_int), ("Bs", C.c_int), ("HW", C.c_int), ("C", C.c_int),
+                ("scale", C.c_float), ("weight", C.c_float), ("relu_mask", C.c_int)]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes (all return int unless listed in _RESTYPE)
@@ -78,6 +85,10 @@ SIGNATURES = {
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_gram_style_group_workspace_floats": [_P, _I],
+    "nfs_gram_style_group_parts": [_P, _I],
+    "nfs_gram_style_group_fwd": [_P, _I, _P, _P, _L, _P],
+    "nfs_gram_group_bwd": [_P, _I, _P],
     "nfs_hist_loss_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "nfs_resize_bicubic_tf1": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_style_mask_apply": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -94,7 +105,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
-            "nfs_conv3x3_relu_bits_words": C.c_int64}
+            "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64}
 
 _lib = None
 

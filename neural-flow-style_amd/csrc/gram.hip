@@ -30,16 +30,31 @@ struct GramArgs {
   int cps;      // 32-pixel chunks per slab
   int nslab;    // slabs per image
   int ntile;    // C / ts
+  // grouped form (nfs_gram_style_group_fwd): the style loss is folded into whichever kernel completes a tile
+  const float* Gs = nullptr;   // style Gram [Bs][C][C]
+  float* Dmat = nullptr;       // 2 w (G - Gs) [B][C][C]
+  float* part = nullptr;       // loss partials [slot][B] (one slot per finishing block of an image; plain stores)
+  float weight = 0.f;
+  int Bs = 1;
+  int slot0 = 0;               // first slot of this layer
+};
+
+// all style layers of a step in one launch (the tile pairs of every layer, big units first) + one slab-reduce launch
+constexpr int GR_MAXL = 8;
+struct GramGroupArgs {
+  GramArgs L[GR_MAXL];
+  int ustart[GR_MAXL + 1];     // first block of layer l (multiples of 8: the XCD deal restarts per layer)
+  int n;
 };
 
 constexpr int GR_KC = 32;
 
+// One block's work: ``block`` of ``nblocks`` (a multiple of 8) dealt to this layer.
 template <int TS>
-__global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
+__device__ __forceinline__ void gram_tn_block(const GramArgs& a, float* smem, int block, int nblocks) {
   constexpr int MT = TS / 64;                 // 32x32 MFMA tiles per wave and dimension (waves 2 x 2)
   constexpr int J = TS / 32;                  // float4 per thread, chunk and strip
   constexpr int R4 = TS / 4;                  // float4 per staged row
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                           // [2][32][TS]
   float* Bs = smem + 2 * GR_KC * TS;          // [2][32][TS]
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -49,8 +64,8 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   // unit order (image, slab, tile pair) with the pair fastest, and a contiguous range of units per XCD (workgroups
   // are dealt round-robin to the 8 XCDs): the npair blocks that read the same 512-pixel slab of F then run together
   // behind one L2, and each 64-channel strip comes from HBM once instead of once per pair it takes part in
-  const int64_t per_xcd = gridDim.x / 8;
-  int64_t unit = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int64_t per_xcd = nblocks / 8;
+  int64_t unit = (int64_t)(block % 8) * per_xcd + block / 8;
   const int64_t per_img = (int64_t)a.nslab * npair;
   if (unit >= per_img * a.B) return;
   const int b = (int)(unit / per_img);
@@ -166,6 +181,42 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   }
   const float sc = a.scale * (a.scale_dev ? a.scale_dev[b] : 1.f);
   float* Gb = a.G + (int64_t)b * a.C * a.C;
+  if (a.nslab == 1 && a.Dmat) {
+    // grouped form, one slab per tile pair: this block holds the complete sums of its tile, so it also forms the style
+    // loss of the tile (styler_base.py:181: sum (G - Gs)^2; an off-diagonal tile stands for its mirror image too) and
+    // D = 2 w (G - Gs) (tile and mirror; Gs is exactly symmetric -- its mirrored tiles are copies); G itself is written
+    // only when asked for
+    const float* Gsb = a.Gs + (int64_t)(b % a.Bs) * a.C * a.C;
+    float* Db = a.Dmat + (int64_t)b * a.C * a.C;
+    float* Go = a.G ? a.G + (int64_t)b * a.C * a.C : nullptr;
+    const float w2 = 2.f * a.weight;
+    float lp = 0.f;
+    for (int f = t; f < TS * R4; f += 256) {
+      const int row = f / R4, q = f - row * R4;
+      const int64_t o = (int64_t)(t1 * TS + row) * a.C + t2 * TS + 4 * q;
+      float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      if (Go) *reinterpret_cast<float4*>(Go + o) = v;
+      const float4 g = *reinterpret_cast<const float4*>(Gsb + o);
+      const float4 d = make_float4(v.x - g.x, v.y - g.y, v.z - g.z, v.w - g.w);
+      lp += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      *reinterpret_cast<float4*>(Db + o) = make_float4(w2 * d.x, w2 * d.y, w2 * d.z, w2 * d.w);
+    }
+    if (!diag)
+      for (int f = t; f < TS * R4; f += 256) {
+        const int col = f / R4, q = f - col * R4;            // mirrored row t2*TS + col, columns t1*TS + 4q ..
+        const float4 v = make_float4(otile[(4 * q) * OS + col] * sc, otile[(4 * q + 1) * OS + col] * sc,
+                                     otile[(4 * q + 2) * OS + col] * sc, otile[(4 * q + 3) * OS + col] * sc);
+        const int64_t o = (int64_t)(t2 * TS + col) * a.C + t1 * TS + 4 * q;
+        if (Go) *reinterpret_cast<float4*>(Go + o) = v;
+        const float4 g = *reinterpret_cast<const float4*>(Gsb + o);
+        *reinterpret_cast<float4*>(Db + o) = make_float4(w2 * (v.x - g.x), w2 * (v.y - g.y), w2 * (v.z - g.z),
+                                                         w2 * (v.w - g.w));
+      }
+    lp = block_sum(lp, smem + TS * OS);        // (scratch behind the tile: 64 x 68 floats of the 32 KB)
+    if (t == 0) a.part[(int64_t)(a.slot0 + pair) * a.B + b] = a.weight * (diag ? lp : 2.f * lp);
+    return;
+  }
   if (a.nslab == 1) {
     // one slab per tile pair (many pairs, few pixels: the deep layers): this block holds the complete sums -- the scaled
     // tile and its mirror image are written directly, no partials and no second pass
@@ -193,11 +244,25 @@ __global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
   }
 }
 
+template <int TS>
+__global__ void __launch_bounds__(256, 2) gram_tn_kernel(GramArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gram_tn_block<TS>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// every style layer's tile pairs in one launch: block -> (layer, its block within the layer)
+__global__ void __launch_bounds__(256, 2) gram_tn_group_kernel(GramGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int l = 0;
+  while (l + 1 < g.n && (int)blockIdx.x >= g.ustart[l + 1]) ++l;
+  gram_tn_block<64>(g.L[l], smem, (int)blockIdx.x - g.ustart[l], g.ustart[l + 1] - g.ustart[l]);
+}
+
 // Second pass: a block owns GRD_ROWS rows of one (image, tile pair).  Its 4 waves sum interleaved slabs (wave g
 // takes slabs g, g+4, ...), the partial sums are combined in a fixed order (deterministic), scaled, written
 // into G as float4 rows and -- for an off-diagonal pair -- mirrored into the transposed tile.
 constexpr int GRD_ROWS = 4;
-__global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
+__device__ __forceinline__ void gram_reduce_block(const GramArgs& a, int unit) {
   constexpr int TS = 64;
   __shared__ float4 part[4][64];
   __shared__ float tile[GRD_ROWS][TS + 1];
@@ -205,7 +270,6 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
   const int row = lane >> 4, q = lane & 15;
   constexpr int groups = TS / GRD_ROWS;
   const int npair = a.ntile * (a.ntile + 1) / 2;
-  int unit = blockIdx.x;
   const int rg = unit % groups;
   unit /= groups;
   const int pair = unit % npair, b = unit / npair;
@@ -226,15 +290,43 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) {
   const float4 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
   s.x = ((s.x + p1.x) + (p2.x + p3.x)) * sc; s.y = ((s.y + p1.y) + (p2.y + p3.y)) * sc;
   s.z = ((s.z + p1.z) + (p2.z + p3.z)) * sc; s.w = ((s.w + p1.w) + (p2.w + p3.w)) * sc;
-  float* Gb = a.G + (int64_t)b * a.C * a.C;
-  *reinterpret_cast<float4*>(Gb + (int64_t)(t1 * TS + rg * GRD_ROWS + row) * a.C + t2 * TS + 4 * q) = s;
+  float* Gb = a.G ? a.G + (int64_t)b * a.C * a.C : nullptr;
+  const int64_t o = (int64_t)(t1 * TS + rg * GRD_ROWS + row) * a.C + t2 * TS + 4 * q;
+  if (Gb) *reinterpret_cast<float4*>(Gb + o) = s;
+  // grouped form: the style loss of these four rows (an off-diagonal tile stands for its mirror image too) and
+  // D = 2 w (G - Gs); one loss partial per block, a plain store into the block's own slot (deterministic, no atomics)
+  const float* Gsb = a.Dmat ? a.Gs + (int64_t)(b % a.Bs) * a.C * a.C : nullptr;
+  float* Db = a.Dmat ? a.Dmat + (int64_t)b * a.C * a.C : nullptr;
+  const float w2 = 2.f * a.weight;
+  if (Db) {
+    const float4 gs = *reinterpret_cast<const float4*>(Gsb + o);
+    const float4 d = make_float4(s.x - gs.x, s.y - gs.y, s.z - gs.z, s.w - gs.w);
+    *reinterpret_cast<float4*>(Db + o) = make_float4(w2 * d.x, w2 * d.y, w2 * d.z, w2 * d.w);
+    const float lp = wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
+    if (lane == 0) a.part[(int64_t)(a.slot0 + pair * groups + rg) * a.B + b] = a.weight * (t1 == t2 ? lp : 2.f * lp);
+  }
   if (t1 == t2) return;
   tile[row][4 * q] = s.x; tile[row][4 * q + 1] = s.y; tile[row][4 * q + 2] = s.z; tile[row][4 * q + 3] = s.w;
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done (single wave from here)
   __builtin_amdgcn_wave_barrier();
   // mirrored: G[t2*TS + c][t1*TS + rg*GRD_ROWS + 0..3] = tile[0..3][c], one float4 per lane (c = lane)
   const float4 v = make_float4(tile[0][lane], tile[1][lane], tile[2][lane], tile[3][lane]);
-  *reinterpret_cast<float4*>(Gb + (int64_t)(t2 * TS + lane) * a.C + t1 * TS + rg * GRD_ROWS) = v;
+  const int64_t om = (int64_t)(t2 * TS + lane) * a.C + t1 * TS + rg * GRD_ROWS;
+  if (Gb) *reinterpret_cast<float4*>(Gb + om) = v;
+  if (Db) {
+    const float4 gs = *reinterpret_cast<const float4*>(Gsb + om);
+    *reinterpret_cast<float4*>(Db + om) = make_float4(w2 * (v.x - gs.x), w2 * (v.y - gs.y), w2 * (v.z - gs.z),
+                                                      w2 * (v.w - gs.w));
+  }
+}
+
+__global__ void __launch_bounds__(256) gram_reduce_kernel(GramArgs a) { gram_reduce_block(a, (int)blockIdx.x); }
+
+// the slab reductions of every layer that has slabs, one launch (ustart: first block of layer l, any alignment)
+__global__ void __launch_bounds__(256) gram_reduce_group_kernel(GramGroupArgs g) {
+  int l = 0;
+  while (l + 1 < g.n && (int)blockIdx.x >= g.ustart[l + 1]) ++l;
+  gram_reduce_block(g.L[l], (int)blockIdx.x - g.ustart[l]);
 }
 
 // loss += weight * sum (G - Gs)^2 ; Dmat = 2*weight*(G - Gs)
@@ -298,6 +390,8 @@ __global__ void __launch_bounds__(256) content_loss_kernel(const float* __restri
 // winograd.hip: batched f32-MFMA GEMM (LDS-staged, double-buffered) shared with the Winograd convolution
 int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
                   int relu_mask, int cus, hipStream_t s);
+int gram_bwd_gemm_group(const float* const* F, const float* const* Dm, float* const* dF, const int* HW, const int* C,
+                        const float* alpha, const int* relu_mask, int n, int B, hipStream_t s);
 
 }  // namespace nfs
 
@@ -357,6 +451,119 @@ int nfs_gram_fwd(const float* F, float* G, int B, int HW, int C, const float* sc
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(rb), dim3(256), 0, as_stream(stream), a);
   }
   return check_launch("nfs_gram_fwd");
+}
+
+// ---- grouped form: every style layer of a step in two launches (tile pairs + slab reduce), style loss folded in ----
+struct GramGroupPlan {
+  GramGroupArgs tn, rd;
+  int tn_blocks, rd_blocks, parts;
+  int64_t ws_floats;
+};
+
+static int gram_group_plan(const nfs_gram_layer_t* layers, int n, GramGroupPlan& P) {
+  if (!layers || n < 1 || n > GR_MAXL) return -1;
+  int order[GR_MAXL];
+  GramArgs L[GR_MAXL];
+  for (int l = 0; l < n; ++l) {
+    const nfs_gram_layer_t& y = layers[l];
+    if (!y.F || !y.Gs || !y.Dmat || y.B <= 0 || y.Bs <= 0 || y.HW <= 0 || y.C <= 0 || y.C % 64 || y.B != layers[0].B)
+      return -1;
+    GramArgs& a = L[l];
+    a = GramArgs();
+    a.F = y.F; a.G = y.G; a.scale_dev = nullptr; a.scale = y.scale; a.B = y.B; a.HW = y.HW; a.C = y.C;
+    a.Gs = y.Gs; a.Dmat = y.Dmat; a.weight = y.weight; a.Bs = y.Bs;
+    a.ts = 64;
+    a.ntile = y.C / 64;
+    // units of ~16 chunks (512 pixels) whatever the layer: the launch is filled by all layers together; a short image
+    // (<= 32 chunks) is one slab, its tile kernel completes the tile itself
+    const int total_chunks = (y.HW + GR_KC - 1) / GR_KC;
+    a.cps = total_chunks <= 32 ? total_chunks : 16;
+    a.nslab = (total_chunks + a.cps - 1) / a.cps;
+    order[l] = l;
+  }
+  // big units first (chunks per unit, off-diagonal pairs stage two strips: more pairs first among equals)
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && (L[order[j]].cps > L[order[j - 1]].cps ||
+                              (L[order[j]].cps == L[order[j - 1]].cps && L[order[j]].ntile > L[order[j - 1]].ntile)); --j) {
+      const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
+    }
+  P.tn.n = n;
+  P.rd.n = 0;
+  int ub = 0, rb = 0, slot = 0;
+  int64_t ws = 0;
+  for (int k = 0; k < n; ++k) {
+    GramArgs a = L[order[k]];
+    const int npair = a.ntile * (a.ntile + 1) / 2;
+    a.slot0 = slot;
+    a.ws = nullptr;
+    P.tn.ustart[k] = ub;
+    ub += (int)(((int64_t)a.B * npair * a.nslab + 7) / 8 * 8);
+    if (a.nslab > 1) {
+      a.ws = reinterpret_cast<float*>(ws * sizeof(float));      // offset for now; the base is added at launch
+      ws += (int64_t)a.B * npair * a.nslab * 64 * 64;
+      slot += npair * (64 / GRD_ROWS);
+      P.rd.ustart[P.rd.n] = rb;
+      rb += a.B * npair * (64 / GRD_ROWS);
+      P.rd.L[P.rd.n++] = a;
+    } else {
+      slot += npair;
+    }
+    P.tn.L[k] = a;
+  }
+  P.tn.ustart[n] = ub;
+  P.rd.ustart[P.rd.n] = rb;
+  P.tn_blocks = ub; P.rd_blocks = rb; P.parts = slot; P.ws_floats = ws;
+  return 0;
+}
+
+int64_t nfs_gram_style_group_workspace_floats(const nfs_gram_layer_t* layers, int n) {
+  GramGroupPlan P;
+  return gram_group_plan(layers, n, P) == 0 ? P.ws_floats : -1;
+}
+
+int nfs_gram_style_group_parts(const nfs_gram_layer_t* layers, int n) {
+  GramGroupPlan P;
+  return gram_group_plan(layers, n, P) == 0 ? P.parts : -1;
+}
+
+int nfs_gram_style_group_fwd(const nfs_gram_layer_t* layers, int n, float* loss_parts, float* workspace,
+                             int64_t workspace_floats, nfs_stream_t stream) {
+  GramGroupPlan P;
+  NFS_REQUIRE(gram_group_plan(layers, n, P) == 0,
+              "nfs_gram_style_group_fwd: 1..8 layers with F, Gs, Dmat set, one batch size, C a multiple of 64");
+  NFS_REQUIRE(loss_parts, "nfs_gram_style_group_fwd: null loss_parts");
+  NFS_REQUIRE(P.ws_floats == 0 || (workspace && workspace_floats >= P.ws_floats),
+              "nfs_gram_style_group_fwd: workspace smaller than nfs_gram_style_group_workspace_floats");
+  for (int k = 0; k < n; ++k) {
+    P.tn.L[k].part = loss_parts;
+    if (P.tn.L[k].nslab > 1) P.tn.L[k].ws = workspace + reinterpret_cast<int64_t>(P.tn.L[k].ws) / (int64_t)sizeof(float);
+  }
+  for (int k = 0; k < P.rd.n; ++k) {
+    P.rd.L[k].part = loss_parts;
+    P.rd.L[k].ws = workspace + reinterpret_cast<int64_t>(P.rd.L[k].ws) / (int64_t)sizeof(float);
+  }
+  const size_t lds = 4 * GR_KC * 64 * sizeof(float);
+  hipLaunchKernelGGL(gram_tn_group_kernel, dim3((unsigned)P.tn_blocks), dim3(256), lds, as_stream(stream), P.tn);
+  if (P.rd_blocks > 0)
+    hipLaunchKernelGGL(gram_reduce_group_kernel, dim3((unsigned)P.rd_blocks), dim3(256), 0, as_stream(stream), P.rd);
+  return check_launch("nfs_gram_style_group_fwd");
+}
+
+int nfs_gram_group_bwd(const nfs_gram_layer_t* layers, int n, nfs_stream_t stream) {
+  NFS_REQUIRE(layers && n >= 1 && n <= GR_MAXL, "nfs_gram_group_bwd: 1..8 layers");
+  const float* F[GR_MAXL]; const float* Dm[GR_MAXL]; float* dF[GR_MAXL];
+  int HW[GR_MAXL], C[GR_MAXL], mask[GR_MAXL];
+  float alpha[GR_MAXL];
+  for (int l = 0; l < n; ++l) {
+    const nfs_gram_layer_t& y = layers[l];
+    NFS_REQUIRE(y.F && y.Dmat && y.dF, "nfs_gram_group_bwd: null pointer");
+    NFS_REQUIRE(y.B > 0 && y.B == layers[0].B && y.HW > 0 && y.C > 0 && y.C % 64 == 0,
+                "nfs_gram_group_bwd: one batch size, C a multiple of 64");
+    F[l] = y.F; Dm[l] = y.Dmat; dF[l] = y.dF; HW[l] = y.HW; C[l] = y.C; mask[l] = y.relu_mask; alpha[l] = 2.f * y.scale;
+  }
+  NFS_REQUIRE(gram_bwd_gemm_group(F, Dm, dF, HW, C, alpha, mask, n, layers[0].B, as_stream(stream)) == 0,
+              "nfs_gram_group_bwd: shape outside the 16-row GEMM's 32-bit operand offsets");
+  return 0;
 }
 
 int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* Dmat, int B, int Bs, int C,

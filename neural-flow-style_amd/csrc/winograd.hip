@@ -819,10 +819,9 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
 // The grid tiles the rows in blocks of 16 MT16; the last block of a component runs the instance for the row tiles it
 // really has (up to five: the taller tiles keep their zero-padded rows, their share of padding is small)
 template <int MT16, int NW16>
-__global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int per_xcd = gridDim.x / WG_XCDS;
-  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;   // XCD-aware order, see above
+__device__ __forceinline__ void winograd_gemm_rb16_tile(const WgGemmArgs& a, float* smem, int block, int nblocks) {
+  const int per_xcd = nblocks / WG_XCDS;
+  const int logical = (block % WG_XCDS) * per_xcd + block / WG_XCDS;   // XCD-aware order, see above
   if (logical >= a.mt * a.nt * a.Z) return;
   const int comp = logical / (a.mt * a.nt);
   const int rem = logical - comp * (a.mt * a.nt);
@@ -839,6 +838,28 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
   } else {
     winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0);
   }
+}
+
+template <int MT16, int NW16>
+__global__ void __launch_bounds__(256) winograd_gemm_rb16_kernel(WgGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  winograd_gemm_rb16_tile<MT16, NW16>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several batched GEMMs in one launch (the Gram gradients of all style layers): block -> (problem, its block within the
+// problem); ustart are multiples of 8, so the XCD deal restarts with every problem.
+constexpr int WG_MAXG = 8;
+struct WgGroupArgs {
+  WgGemmArgs g[WG_MAXG];
+  int ustart[WG_MAXG + 1];
+  int n;
+};
+template <int MT16, int NW16>
+__global__ void __launch_bounds__(256) winograd_gemm_rb16_group_kernel(WgGroupArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int p = 0;
+  while (p + 1 < G.n && (int)blockIdx.x >= G.ustart[p + 1]) ++p;
+  winograd_gemm_rb16_tile<MT16, NW16>(G.g[p], smem, (int)blockIdx.x - G.ustart[p], G.ustart[p + 1] - G.ustart[p]);
 }
 
 // U [Z][K/32][N][32] -> Uq16 [Z][N/16][K/16][64][4]
@@ -1431,6 +1452,51 @@ int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int
   a.symb = 1;
   launch_batched_gemm(a, B, cus, s);
   return check_launch("gram_bwd_gemm");
+}
+
+// The Gram gradients of n layers as ONE launch of the 16-row register-B GEMM (80 x 64 tiles: the common denominator of
+// C = 64 ... 512), problems ordered deep K first (long tiles first, the two-chunk tiles of the 64-channel layer fill the
+// tail).  Same per-tile arithmetic as gram_bwd_gemm on the rb16 kernel: bit-identical results.
+int gram_bwd_gemm_group(const float* const* F, const float* const* Dm, float* const* dF, const int* HW, const int* C,
+                        const float* alpha, const int* relu_mask, int n, int B, hipStream_t s) {
+  if (n < 1 || n > WG_MAXG) return -1;
+  int order[WG_MAXG];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && C[order[j]] > C[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  WgGroupArgs G;
+  G.n = n;
+  int ub = 0;
+  double flops = 0;
+  for (int k = 0; k < n; ++k) {
+    const int l = order[k];
+    WgGemmArgs a{F[l], Dm[l], dF[l], (int64_t)HW[l], C[l], C[l], (int64_t)C[l] * C[l], 32, C[l], alpha[l], nullptr,
+                 relu_mask[l] ? F[l] : nullptr};
+    a.Uq16 = Dm[l];
+    a.symb = 1;
+    if (!gemm_rb16_applies(a) || C[l] % 64) return -1;
+    a.mt = (int)((a.T + 79) / 80);
+    a.nt = a.N / 64;
+    a.Z = B;
+    G.g[k] = a;
+    G.ustart[k] = ub;
+    ub += (a.mt * a.nt * a.Z + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+    flops += 2.0 * B * (double)a.T * a.K * a.N;
+  }
+  G.ustart[n] = ub;
+  constexpr int BMP = 96;
+  const size_t oper = 2 * BMP * WG_LS, tile = 16 * 5 * (64 + 4);
+  const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
+  GemmTimerRec rec{nullptr, nullptr, flops};
+  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+  if (timed) (void)hipEventRecord(rec.e0, s);
+  hipLaunchKernelGGL((winograd_gemm_rb16_group_kernel<5, 1>), dim3(ub), dim3(256), lds, s, G);
+  if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
+  return check_launch("gram_bwd_gemm_group");
 }
 
 // ---- Winograd host side (called from vgg.hip) ------------------------------------------------------------

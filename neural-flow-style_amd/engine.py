@@ -38,6 +38,8 @@ class RenderStyleLoss(object):
         # With the direct conv kernels two groups overlapped each other's launch tails (7.32 -> 7.01 ms/step);
         # with the Winograd path one batch of all views on one stream is fastest (8 views of 200^2: 1 stream
         # 4.73 ms/step, 2 streams 4.79, 4 streams 6.38), so that is the default.
+        # all style layers' Gram work as three launches after the forward pass (default) / per layer (side stream)
+        self.gram_grouped = os.environ.get("NFS_GRAM_GROUP", "1") != "0"
         self.gram_side_stream = os.environ.get("NFS_GRAM_STREAM", "1") != "0"
         self._side = None
         self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "1"))
@@ -186,32 +188,56 @@ class RenderStyleLoss(object):
         scale = 1.0 / (2.0 * h * w * c)
         G = ops.gram_fwd(F, scale)
         Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
-        defer = (unmasked is not None and name != self.top and name != self.content_layer
-                 and os.environ.get("NFS_NO_DEFER_MASK") is None and self.net.masks_addend_of(name, F.shape))
+        defer = unmasked is not None and self._defers_mask(name, F)
         if defer:
             unmasked.add(name)
         return ops.gram_bwd(F, Dm, scale, relu_mask=not defer)
 
-    def _vgg_loss_grad(self, x, loss):
-        """x [B,h,w,3] (mean-subtracted) -> dL/dx; adds the per-image style losses into ``loss`` [B].
+    def _defers_mask(self, name, F):
+        """True when dF of style layer ``name`` is handed over WITHOUT its ReLU mask: the data gradient that adds it
+        applies that very mask to the sum anyway ("Deferred ReLU mask")"""
+        return (name != self.top and name != self.content_layer and os.environ.get("NFS_NO_DEFER_MASK") is None
+                and self.net.masks_addend_of(name, F.shape))
 
-        The Gram work of a style layer (Gram matrix -> loss -> dF) depends only on that layer's activations, so it
-        is enqueued on a side stream as soon as the layer exists and overlaps the following convolutions (short
-        MFMA kernels that fill the launch tails of the conv GEMMs); the backward chain waits for it once."""
+    def _vgg_loss_grad(self, x):
+        """x [B,h,w,3] (mean-subtracted) -> (dL/dx, per-image losses [B] of the style / content / histogram terms).
+
+        Default: the Gram work of ALL style layers runs after the forward pass as three launches (tile pairs of every
+        layer, slab reduction with the style loss folded in, the five Gram gradients as one batched GEMM launch:
+        ``ops.gram_style_group``); the loss leaves the kernels as per-block partial sums (no atomics) and is summed
+        here.  ``NFS_GRAM_GROUP=0`` restores the per-layer chain (Gram -> loss -> dF per layer), which can run on a
+        side stream as soon as a layer exists (``gram_side_stream``)."""
         sg = {}
         unmasked = set()                            # style layers whose dF is handed over without its ReLU mask
+        if self.gram_grouped:
+            acts = self.net.forward(x, self.top, keep=self._keep())
+            Fs = [acts[n] for n in self.layers]
+            masks = []
+            for n, F in zip(self.layers, Fs):
+                d = self._defers_mask(n, F)
+                if d:
+                    unmasked.add(n)
+                masks.append(not d)
+            parts, dFs, _ = ops.gram_style_group(Fs, [self.style_grams[n] for n in self.layers],
+                                                 [w * self.w_style for w in self.w_layers], masks)
+            sg.update(zip(self.layers, dFs))
+            loss = parts.sum(0)
+            self._content_job(acts, sg, loss)
+            self._hist_job(acts, sg, loss)
+            return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
+        loss = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
         if not self.gram_side_stream:
             acts = self.net.forward(x, self.top, keep=self._keep())
             for name in self.layers:
                 sg[name] = self._gram_job(name, acts[name], loss, unmasked)
             self._content_job(acts, sg, loss)
             self._hist_job(acts, sg, loss)
-            return self.net.backward(acts, sg, self.top, unmasked=unmasked)
+            return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
         main = torch.cuda.current_stream(x.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=x.device)
         side = self._side
-        side.wait_stream(main)                      # ``loss`` / style targets were produced on the main stream
+        side.wait_stream(main)                      # style targets were produced on the main stream
 
         top_inline = os.environ.get("NFS_GRAM_TOP_INLINE", "1") != "0"
 
@@ -238,7 +264,7 @@ class RenderStyleLoss(object):
         main.wait_stream(side)
         self._content_job(acts, sg, loss)
         self._hist_job(acts, sg, loss)
-        return self.net.backward(acts, sg, self.top, unmasked=unmasked)
+        return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
 
     def _batch_views(self, V):
         """views per loss-net batch of the reference graph: v_batch (RenderStyleLoss: a property of the run, not of
@@ -278,8 +304,7 @@ class RenderStyleLoss(object):
         H2, W2 = self.out_hw(H, W)
         hist_in = any("input" in n for n in self.hist_layers)
         dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
-        loss = torch.zeros(V, dtype=torch.float32, device=d.device)
-        g_x = self._vgg_loss_grad(x, loss)
+        g_x, loss = self._vgg_loss_grad(x)
         if hist_in:
             self._hist_input(dimg, loss, g_x)
         if self.w_tv > 0:

@@ -475,6 +475,45 @@ def style_loss_fwd(G, Gs, weight, loss_acc, Dmat=None):
     return Dmat
 
 
+def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False):
+    """Gram matrix, style loss and Gram gradient of SEVERAL style layers in three launches (the loop of
+    styler_base.py:152-185): ``Fs`` list of [B,h,w,C] activations, ``Gss`` their style Grams [Bs,C,C] (scaled by
+    1/(2 h w C) like G), ``weights`` w_layer * w_style, ``relu_masks`` whether dF carries the layer's ReLU mask.
+    Returns (loss_parts [P,B] -- the style loss of image b is loss_parts[:, b].sum(), every entry written, no atomics --,
+    list of dF, list of G or None)."""
+    import ctypes
+    n = len(Fs)
+    if n > 8:                                          # the descriptor table of one launch holds 8 layers
+        a = gram_style_group(Fs[:8], Gss[:8], weights[:8], relu_masks[:8], want_G)
+        b = gram_style_group(Fs[8:], Gss[8:], weights[8:], relu_masks[8:], want_G)
+        return torch.cat([a[0], b[0]]), a[1] + b[1], (a[2] + b[2] if want_G else None)
+    arr = (_lib.GramLayer * n)()
+    keep = []
+    B = Fs[0].shape[0]
+    for l, (F, Gs, w, rm) in enumerate(zip(Fs, Gss, weights, relu_masks)):
+        Cn = F.shape[-1]
+        HW = F.numel() // (B * Cn)
+        Dm = _empty((B, Cn, Cn), F)
+        dF = _empty(F.shape, F)
+        G = _empty((B, Cn, Cn), F) if want_G else None
+        keep.append((Dm, dF, G))
+        y = arr[l]
+        y.F, y.Gs, y.G, y.Dmat, y.dF = _ptr(F), _ptr(Gs), _ptr(G), _ptr(Dm), _ptr(dF)
+        y.B, y.Bs, y.HW, y.C = B, Gs.shape[0], HW, Cn
+        y.scale, y.weight, y.relu_mask = 1.0 / (2.0 * HW * Cn), float(w), int(bool(rm))
+    L = _lib.lib()
+    ap = ctypes.cast(arr, ctypes.c_void_p)
+    P = L.nfs_gram_style_group_parts(ap, n)
+    nws = L.nfs_gram_style_group_workspace_floats(ap, n)
+    if P < 0 or nws < 0:
+        raise ValueError("gram_style_group: 1..8 layers of one batch size with C a multiple of 64")
+    ws = conv_workspace(Fs[0].device, max(nws, 1))      # shared scratch (calls on one stream are ordered)
+    parts = _empty((P, B), Fs[0])
+    _lib.call("nfs_gram_style_group_fwd", ap, n, _ptr(parts), _ptr(ws), ws.numel(), _stream())
+    _lib.call("nfs_gram_group_bwd", ap, n, _stream())
+    return parts, [k[1] for k in keep], ([k[2] for k in keep] if want_G else None)
+
+
 def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
     """content loss of the post-ReLU activation F [B,h,w,C] (styler_base.py:135-150): with ``target`` [Bt,h,w,C]
     mean((F - amp*target)^2), else channel maximisation (channel != 0) or -mean(F); loss_acc [B] and

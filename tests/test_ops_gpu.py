@@ -709,6 +709,42 @@ def test_hist_loss_matches_the_oracle_restatement():
         assert rel(g.cpu(), go) < 3e-2
 
 
+def test_gram_style_group_equals_the_per_layer_chain():
+    """nfs_gram_style_group_fwd + nfs_gram_group_bwd (all style layers in three launches, the style loss as per-block
+    partial sums) against the per-layer entry points nfs_gram_fwd -> nfs_style_loss_fwd -> nfs_gram_bwd: slab layers,
+    one-slab layers, diagonal-only (C = 64) and off-diagonal tile pairs, ragged last chunks, masked and unmasked dF"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(5)
+    B = 3
+    shapes = [(40, 40, 64), (37, 35, 128), (35, 36, 256), (6, 5, 512), (3, 3, 512), (24, 25, 64)]
+    Fs, Gss, ws, masks = [], [], [], []
+    for i, (h, w, C) in enumerate(shapes):
+        F = np.maximum(rng.randn(B, h, w, C), 0).astype(np.float32)
+        Fs.append(torch.tensor(F).cuda())
+        S = np.maximum(rng.randn(1, h, w, C), 0).astype(np.float32)
+        Gss.append(ops.gram_fwd(torch.tensor(S).cuda(), 1.0 / (2.0 * h * w * C)))
+        ws.append(0.5 + 0.25 * i)
+        masks.append(i % 2 == 0)
+    parts, dFs, Gs_out = ops.gram_style_group(Fs, Gss, ws, masks, want_G=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(parts).all()
+    loss_ref = torch.zeros(B, device="cuda")
+    for F, Gs, w, m, dF, G in zip(Fs, Gss, ws, masks, dFs, Gs_out):
+        _, h, w_, C = F.shape
+        sc = 1.0 / (2.0 * h * w_ * C)
+        G_ref = ops.gram_fwd(F, sc)
+        assert rel(G.cpu(), G_ref.cpu()) < 1e-6
+        assert float((G - G.transpose(1, 2)).abs().max()) == 0.0          # mirrored tiles are copies
+        Dm = ops.style_loss_fwd(G_ref, Gs, w, loss_ref)
+        dF_ref = ops.gram_bwd(F, Dm, sc, relu_mask=m)
+        assert rel(dF.cpu(), dF_ref.cpu()) < 2e-5, (h, w_, C)
+    got = parts.sum(0)
+    assert rel(got.cpu(), loss_ref.cpu()) < 1e-5
+    # deterministic: no atomics anywhere in the grouped chain
+    parts2, dFs2, _ = ops.gram_style_group(Fs, Gss, ws, masks)
+    assert torch.equal(parts, parts2) and all(torch.equal(a, b) for a, b in zip(dFs, dFs2))
+
+
 def test_hist_loss_masked_branch_flat_channels_and_empty_masks():
     """the masked branch (styler_base.py:104-125, 196-201: tf.boolean_mask of the source by mask != 0) against the
     oracle, and the cases the reference leaves undefined -- a flat channel (max == min over source and template) and a

@@ -378,4 +378,4 @@ def test_tv_and_content_divisors_do_not_depend_on_the_local_view_count():
     g_sh = torch.zeros_like(d)
     l_sh = [loss.loss_and_grad(d, rot[v:v + 1].contiguous(), g_sh) for v in range(V)]     # "rank v" holds view v only
     assert abs(float(sum(x.sum() for x in l_sh)) - float(l_all.sum())) < 1e-5 * abs(float(l_all.sum()))
-    assert rel(g_sh, g_all) < 1e-5
+    assert rel(g_sh.cpu(), g_all.cpu()) < 1e-5

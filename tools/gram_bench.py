@@ -29,3 +29,21 @@ for HW, C in [(200, 64), (100, 128), (50, 256), (25, 512), (12, 512)]:
         HW, HW, C, t_f, fl / t_f / 1e6, by / t_f / 1e6, t_l, t_b, fl / t_b / 1e6, 2 * by / t_b / 1e6))
     tot[0] += t_f; tot[1] += t_l; tot[2] += t_b
 print("totals: gram_fwd %.1f  style_loss %.1f  gram_bwd %.1f us" % tuple(tot))
+
+# the grouped form: all five layers in three launches (tile pairs, slab reduce + style loss, one batched Gram-gradient GEMM)
+import ctypes
+from neural_flow_style_amd import _lib
+Fs, Gss = [], []
+for HW, C in [(200, 64), (100, 128), (50, 256), (25, 512), (12, 512)]:
+    Fs.append(torch.relu(torch.randn(B, HW, HW, C, device="cuda")))
+    Gss.append(torch.randn(1, C, C, device="cuda"))
+t_all = timed(lambda: ops.gram_style_group(Fs, Gss, [1.0] * 5, [True] * 5))
+L = _lib.lib()
+import neural_flow_style_amd.ops as O2
+_lib.PROFILE = {}
+for _ in range(20): ops.gram_style_group(Fs, Gss, [1.0] * 5, [True] * 5)
+torch.cuda.synchronize()
+for k, v in _lib.PROFILE.items():
+    print("  %-28s %7.1f us (event pair included)" % (k, sum(a.elapsed_time(b) for a, b, _ in v) / len(v) * 1e3))
+_lib.PROFILE = None
+print("grouped: fwd + loss + bwd of the five layers %.1f us per call (was %.1f)" % (t_all, sum(tot)))
