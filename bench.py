@@ -107,19 +107,32 @@ def build_problem(G, V, device, rank, world):
 
 # ---- algorithmic work per call ---------------------------------------
 def work_of(name, a):
-    """-> (kind, amount): kind 'B' bytes or 'F' flops, from the C-ABI call arguments"""
+    """-> (kind, amount): kind 'B' bytes or 'F' flops, from the C-ABI call arguments.  Convolutions count the MFMA flops
+    their kernels EXECUTE (Winograd F(4x4) / F(5x5) products incl. tile padding, nfs_conv3x3_executed_flops), so that a
+    fraction of the MFMA peak stays a fraction; the direct-conv flops of the same calls are reported beside them as
+    `algorithmic`."""
+    from neural_flow_style_amd import _lib
+    ex = _lib.lib().nfs_conv3x3_executed_flops
     if name == "nfs_conv3x3_fwd":
         B, H, W, Ci, Co = a[4:9]
-        return "F", 2.0 * B * H * W * 9 * Ci * Co
+        return "F", ex(B, H, W, Ci, Co, 0)
     if name == "nfs_conv3x3_dgrad":
         B, H, W, Ci, Co = a[5:10]
-        return "F", 2.0 * B * H * W * 9 * Ci * Co
+        return "F", ex(B, H, W, Co, Ci, 0)
     if name == "nfs_conv3x3_fwd_pool":
         B, H, W, Ci, Co = a[5:10]
-        return "F", 2.0 * B * H * W * 9 * Ci * Co
+        return "F", ex(B, H, W, Ci, Co, 1)
     if name == "nfs_conv3x3_dgrad_pool":
         B, H, W, Ci, Co = a[6:11]
-        return "F", 2.0 * B * H * W * 9 * Ci * Co
+        return "F", ex(B, H, W, Co, Ci, 1)
+    if name in ("nfs_gram_style_group_fwd", "nfs_gram_group_bwd"):
+        import ctypes
+        n = a[1]
+        L_ = ctypes.cast(a[0], ctypes.POINTER(_lib.GramLayer * n)).contents
+        # forward: the symmetric tile pairs t1 <= t2 of 64-channel tiles are executed; gradient: the full product
+        if name == "nfs_gram_group_bwd":
+            return "F", sum(2.0 * y.B * y.HW * y.C * y.C for y in L_)
+        return "F", sum(2.0 * y.B * y.HW * 64 * 64 * ((y.C // 64) * (y.C // 64 + 1) // 2) for y in L_)
     if name == "nfs_gram_fwd":
         B, HW, C = a[2:5]
         return "F", 2.0 * B * HW * C * C
@@ -164,6 +177,15 @@ def work_of(name, a):
     return None, 0.0
 
 
+def conv_direct_flops(name, a):
+    """direct-convolution flops 2*B*H*W*9*Ci*Co of a conv C-ABI call (what the layer computes), else 0"""
+    off = {"nfs_conv3x3_fwd": 4, "nfs_conv3x3_dgrad": 5, "nfs_conv3x3_fwd_pool": 5, "nfs_conv3x3_dgrad_pool": 6}.get(name)
+    if off is None:
+        return 0.0
+    B, H, W, Ci, Co = a[off:off + 5]
+    return 2.0 * B * H * W * 9 * Ci * Co
+
+
 def pmc_traffic(kernel_substr):
     """Mean HBM bytes per launch (read + write) of a kernel (all template instances whose name contains
     ``kernel_substr``) from the committed rocprofv3 PMC passes (profiles/r*_traffic.json, produced by
@@ -205,23 +227,26 @@ def event_pair_overhead_us(device):
     return us[len(us) // 2]
 
 
-def kernel_table(profile, steps, overhead_us=0.0):
+def kernel_table(profile, steps):
+    """per C-ABI family: time from HIP event pairs around every call (single-stream pass; the pair's own dispatch
+    latency, `event_pair_overhead_us`, is INSIDE these figures: they are the conservative side)"""
     rows = []
     for name, recs in sorted(profile.items()):
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-        ms_net = max(ms - 1e-3 * overhead_us * len(recs), 0.25 * ms)
         kind, _ = work_of(name, recs[0][2])
         amount = sum(work_of(name, r[2])[1] for r in recs)
         row = {"kernel": name, "launches_per_step": len(recs) / steps, "ms_per_step": ms / steps,
-               "avg_launch_us": 1e3 * ms / len(recs), "ms_per_step_net": ms_net / steps}
+               "avg_launch_us": 1e3 * ms / len(recs)}
         if kind == "B":
             ach = amount / (ms * 1e-3) / 1e9
-            row.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                       frac_net=amount / (ms_net * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            row.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
         elif kind == "F":
             ach = amount / (ms * 1e-3) / 1e12
-            row.update(bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF,
-                       frac_net=amount / (ms_net * 1e-3) / 1e12 / MFMA_F32_PEAK_TF)
+            row.update(bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF)
+            direct = sum(conv_direct_flops(name, r[2]) for r in recs)
+            if direct:
+                row.update(flops="executed (Winograd products incl. tile padding)",
+                           algorithmic_tflops=direct / (ms * 1e-3) / 1e12, executed_over_algorithmic=amount / direct)
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
@@ -439,6 +464,96 @@ def other_configs(device, base):
     except Exception as e:  # pragma: no cover
         out.append({"config": "configs[4]", "error": repr(e)})
 
+    # configs[4] end to end: one iteration of the particle stylizer at the chocolate scale -- 5e5 particles -> 200^3,
+    # 'p' field (the variable is a displacement per particle), liquid render (transmit 0.2), rotate False, k 3, VGG-19
+    # conv1_1..conv4_1, TF-Adam (test_chocolate.py:148-252 with the VGG network) -- and where its time goes
+    try:
+        from neural_flow_style_amd.config import get_config
+        from neural_flow_style_amd.styler_3p import Styler
+        N, G = 500000, 200
+        rng = np.random.RandomState(0)
+        cfg, _ = get_config([])
+        for k_, v_ in dict(network="vgg_19.ckpt", data_dir="/nonexistent", synthetic_weights=True, resolution=[G, G, G],
+                           domain=[12.8] * 3, radius=0.025, support=4, nsize=1, rest_density=1000, k=3, clip=False,
+                           target_field="p", num_frames=1, batch_size=1, frames_per_opt=120, window_sigma=9, interp=1,
+                           lr=0.002, iter=1, octave_n=1, style_layer=STYLE_LAYERS[:4], w_style_layer=[1.0] * 4,
+                           w_style=1.0, w_content=0, transmit=0.2, render_liquid=True, rotate=False, resize_scale=1.0,
+                           num_kernels=1, kernel_scale=2, style_target=S.style_image(G, G, rng)).items():
+            setattr(cfg, k_, v_)
+        cfg.rng = np.random.RandomState(123)
+        stp = Styler(cfg)
+        stp.load_img([G, G])
+        stp.loss.set_style_image(stp._style_feature(stp.style_img, [G, G]))
+        pp = torch.tensor(S.blob_particles(N, rng), device=device)
+        cell = (pp * G).floor().clamp(0, G - 1).long()
+        pp = pp[torch.argsort((cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2])].contiguous()   # as Styler.run orders them
+        var = torch.zeros(N, 3, device=device)
+        adam = engine.TFAdamState()
+
+        def p_iter():
+            losses, g = stp._value_and_grad(pp, None, var, [G, G, G], stp._identity)
+            adam.step(var, g.contiguous(), cfg.lr)
+            return losses
+        ms_it = ev_time(p_iter, 10)
+        # stage split (each stage alone, same operands)
+        v_ = var.detach().clone().requires_grad_(True)
+        ms_f = ev_time(lambda: stp._field(pp, None, v_, [G, G, G]), 10)
+        _, d_out, _ = stp._field(pp, None, v_, [G, G, G])
+        d3 = d_out.detach().reshape(G, G, G).contiguous()
+        g_d = torch.zeros_like(d3)
+        ms_l = ev_time(lambda: stp.loss.loss_and_grad(d3, stp._identity, g_d), 10)
+        gd5 = g_d.reshape(d_out.shape)
+
+        def back():
+            _, d_o, _ = stp._field(pp, None, v_, [G, G, G])
+            v_.grad = None
+            d_o.backward(gd5)
+        ms_fb = ev_time(back, 10)
+        out.append({"config": "configs[4] chocolate-scale particle stylizer END TO END: 5e5 particles -> 200^3, 'p' field, "
+                              "liquid render (transmit 0.2), one view (rotate False), VGG-19 conv1_1..conv4_1, TF-Adam "
+                              "on the displacements: one iteration",
+                    "value": 1e3 / ms_it, "unit": "iters/s", "ms_per_step": ms_it,
+                    "stages_ms": {"field forward (splat p2g + smooth/clamp, through autograd)": ms_f,
+                                  "render + VGG + Gram losses + adjoint down to the grid": ms_l,
+                                  "field forward + backward (smooth adjoint + splat gather adjoint)": ms_fb},
+                    "note": "stages timed alone on the same operands (their sum exceeds the iteration by the forward "
+                            "pass counted twice)"})
+        del stp
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "configs[4] end to end", "error": repr(e)})
+
+    # configs[2] at fewer local views: the per-rank step of the view-sharded (strong-scaling) run at 4 / 2 / 1 views per
+    # rank, measured on this one GPU -- what a rank of an 8-view job on 2 / 4 / 8 GPUs executes per iteration before the
+    # all-reduce (DESIGN.md section 7 derives the strong-scaling bound from these)
+    try:
+        G2 = int(base["d0"].shape[0])
+        net2 = vgg.VGG(vgg.synthetic_weights(123, upto="conv5_1"), device)
+        rows = {}
+        for nv in (8, 4, 2, 1):
+            loss2 = engine.RenderStyleLoss(net2, STYLE_LAYERS, [1.0] * 5, 1.0, transmit=0.01)
+            loss2.set_style_image(base["simg"])
+            gs2 = engine.GridStylizer(loss2, torch.tensor(base["d0"], device=device), k=3, target="v", lr=1e-3)
+            gs2.var.copy_(torch.tensor(base["vel"]))
+            rot2 = T.rot_to_device(base["mats"][:nv], device)
+            for _ in range(4):
+                gs2.step(rot2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                gs2.step(rot2)
+            torch.cuda.synchronize()
+            rows[str(nv)] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / 30, "hipgraph": bool(gs2.use_graph)}
+            del gs2, loss2
+        t8 = rows["8"]["ms_per_step"]
+        out.append({"config": "configs[2] per-rank step at 8 / 4 / 2 / 1 local views (one GPU; the compute side of view-"
+                              "sharded strong scaling on 1 / 2 / 4 / 8 GPUs, collective not included)",
+                    "local_views": rows,
+                    "compute_bound_speedup": {"2_gpus": t8 / rows["4"]["ms_per_step"],
+                                              "4_gpus": t8 / rows["2"]["ms_per_step"],
+                                              "8_gpus": t8 / rows["1"]["ms_per_step"]}})
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "configs[2] per-rank step", "error": repr(e)})
+
     # configs[3]: the sequence loop on 4 frames of 200^3 (one GPU): frame-iterations/s incl. temporal alignment, and
     # the transport step kernel against its HBM roofline
     try:
@@ -597,8 +712,8 @@ def main():
         psteps = max(2, min(args.steps, 5))
         gs.use_graph = False          # the per-call timers hook the C-ABI calls: a graph replay would bypass them
         L = _lib.lib()
-        # pass 1 -- the HEADLINE configuration (Gram work on its side stream): HIP event pair around every launch of
-        # the GEMM kernel, recorded inside the library on the stream the kernel is launched on
+        # pass 1 -- the HEADLINE configuration: HIP event pair around every launch of the GEMM kernel, recorded inside
+        # the library on the stream the kernel is launched on
         L.nfs_gemm_timer(1)
         for _ in range(psteps):
             gs.step(rot_local)
@@ -619,40 +734,58 @@ def main():
         prof, _lib.PROFILE = _lib.PROFILE, None
         gs.loss.gram_side_stream = side
         ov_us = event_pair_overhead_us(device)
-        rows = kernel_table(prof, psteps, ov_us)
+        rows = kernel_table(prof, psteps)
         conv = [r for r in rows if r["kernel"] in ("nfs_conv3x3_fwd", "nfs_conv3x3_dgrad", "nfs_conv3x3_fwd_pool",
                                                    "nfs_conv3x3_dgrad_pool")]
         ms = sum(r["ms_per_step"] for r in conv)
-        fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)  # TF/s * ms
+        fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)              # executed TF/s * ms
+        fa = sum(r.get("algorithmic_tflops", 0.0) * r["ms_per_step"] for r in conv)   # direct-conv TF/s * ms
         n_launch = sum(r["launches_per_step"] for r in conv)
         tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": "nfs::winograd_gemm_rb16_kernel (batched f32-MFMA GEMM on v_mfma_f32_16x16x4_f32, filters from L2 "
-                      "straight into registers; the 32-row / LDS-B forms winograd_gemm_rb_kernel / winograd_gemm_kernel take "
-                      "the shapes the static rule gives them): the 49 Winograd F(5x5,3x3) or 36 F(4x4,3x3) products of "
-                      "every conv layer from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower "
-                      "layers run in the single-kernel form winograd_fused_kernel: %d launches/step, "
-                      "%.2f ms/step = the largest share of the step" % (g_n.value // psteps, g_ms.value / psteps),
+            "kernel": "nfs::winograd_gemm_rb16_kernel (+ its grouped form winograd_gemm_rb16_group_kernel: the five Gram "
+                      "gradients in one launch): batched f32-MFMA GEMM on v_mfma_f32_16x16x4_f32, filters from L2 "
+                      "straight into registers -- the 49 Winograd F(5x5,3x3) or 36 F(4x4,3x3) products of every conv layer "
+                      "from conv3_1 on, forward and data gradient, and the Gram gradient; the narrower layers run in the "
+                      "single-kernel form winograd_fused_kernel: %d launches/step, %.2f ms/step = the largest share of "
+                      "the step" % (g_n.value // psteps, g_ms.value / psteps),
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
             "traffic": pmc_traffic("winograd_gemm_"),
             "flops_per_launch": g_fl.value / max(g_n.value, 1), "avg_launch_us": 1e3 * g_ms.value / max(g_n.value, 1),
             "event_pair_overhead_us": ov_us,
-            "frac_net": g_fl.value / (max(g_ms.value - 1e-3 * ov_us * g_n.value, 0.25 * g_ms.value) * 1e-3) / 1e12
-                        / MFMA_F32_PEAK_TF,
             "ms_per_step": g_ms.value / psteps,
-            "configuration": "headline (Gram work on its side stream: %s), %d local views" % (side, rot_local.shape[0]),
+            "configuration": "headline, %d local views, one stream" % rot_local.shape[0],
             "note": "achieved = executed MFMA flops (2*Z*T*K*N per launch) / summed launch durations, HIP events on "
-                    "the launch stream (nfs_gemm_timer) in the headline configuration; with the Gram side stream on, a "
-                    "pair also spans whatever the side stream runs concurrently (conservative).  frac_net subtracts "
-                    "event_pair_overhead_us per launch (the dispatch latency an event pair adds on a busy stream, "
-                    "measured around a 1-element fill kernel) and is what rocprofv3's kernel-only durations "
-                    "correspond to",
-            # the whole conv family seen from the operator boundary: what the layer computes (direct-conv flops)
-            # over the time of the ABI call (input transform + GEMM + output transform, or the direct kernel)
-            "conv_family": {"launches_per_step": n_launch, "ms_per_step": ms, "algorithmic_tflops": fl / ms,
-                            "algorithmic_over_mfma_peak": fl / ms / MFMA_F32_PEAK_TF,
-                            "note": "ALGORITHMIC direct-conv flops (2*B*H*W*9*Ci*Co) / ABI-call time; Winograd "
-                                    "executes 4x fewer multiplies, so this may exceed the MFMA peak"}}
+                    "the launch stream around every launch (nfs_gemm_timer) in the headline configuration.  An event "
+                    "pair adds dispatch latency that rocprofv3's kernel-only durations do not contain "
+                    "(event_pair_overhead_us, measured around a 1-element fill kernel, for information: it is NOT "
+                    "subtracted anywhere); profiles/ holds the rocprofv3 in-step average of the same launches",
+            # the whole conv family seen from the operator boundary (input transform + GEMM + output transform, the
+            # single-kernel form, or the direct kernel): EXECUTED MFMA flops over the ABI-call time
+            "conv_family": {"launches_per_step": n_launch, "ms_per_step": ms, "executed_tflops": fl / ms,
+                            "frac": fl / ms / MFMA_F32_PEAK_TF, "algorithmic_tflops": fa / ms,
+                            "note": "frac = executed MFMA flops (Winograd products incl. tile padding, "
+                                    "nfs_conv3x3_executed_flops) / ABI-call time / f32 MFMA peak; algorithmic_tflops = "
+                                    "the direct-conv flops 2*B*H*W*9*Ci*Co of the same calls over the same time, for "
+                                    "reference (Winograd executes 2.25-4.6x fewer multiplies: not a roofline figure)"}}
+        # render + advect family against the HBM roofline (north_star's >= 40 % target): measured kernels, two byte
+        # accountings -- the kernels as built (the rotated volume is KEPT for the adjoint: written once, read once more)
+        # and SURVEY 8(d)'s fully fused counts (rotate+render fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + 4VG^2)
+        fam = [r for r in rows if r["kernel"] in ("nfs_rotate_render_fwd", "nfs_render_bwd", "nfs_rotate_bwd",
+                                                  "nfs_advect_fwd", "nfs_advect_bwd_adam", "nfs_advect_bwd")]
+        if fam:
+            fms = sum(r["ms_per_step"] for r in fam)
+            built = sum(r["achieved"] * r["ms_per_step"] for r in fam)        # GB/s * ms = MB
+            Vl, G3 = int(rot_local.shape[0]), float(G) ** 3
+            fused = (4.0 * Vl * G3 + 4.0 * Vl * G * G) + (8.0 * Vl * G3 + 4.0 * Vl * G * G)
+            fused += sum(r["achieved"] * r["ms_per_step"] * 1e6 for r in fam if "advect" in r["kernel"])
+            out["render_advect_family"] = {
+                "kernels": [r["kernel"] for r in fam], "ms_per_step": fms,
+                "as_built": {"bytes_per_step": built * 1e6, "frac_hbm": built / fms / HBM_PEAK_GBS,
+                             "note": "rotated volume kept: fwd 8VG^3, render adjoint 8VG^3, rotate adjoint 4VG^3 + 8G^3"},
+                "survey_fused": {"bytes_per_step": fused, "frac_hbm": fused / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "SURVEY 8(d) fully fused rotate+render (fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + "
+                                         "4VG^2) + the advect kernels as built, over the same measured time"}}
         out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
 
     if rank == 0 and world == 1:

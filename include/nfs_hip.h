@@ -257,6 +257,10 @@ int64_t nfs_conv3x3_workspace_floats(int B, int H, int W, int Ci, int Co);
  * T = B*ceil(H/4)*ceil(W/4).  The query returns 0 for a layer that does not keep the cache (pass NULL then;
  * x_in / x_out are still required arguments and are what a NULL cache falls back to). */
 int64_t nfs_conv3x3_relu_bits_words(int B, int H, int W, int Ci, int Co, int pooled);
+/* MFMA flops the conv call for K input / N output channels of its kernel EXECUTES (forward: K = Ci, N = Co; data
+ * gradient: K = Co, N = Ci; pooled != 0: the fused-pool forms): 2*36*T4*K*N for F(4x4,3x3), 2*49*T5*K*N for F(5x5,3x3),
+ * the direct 2*B*H*W*9*K*N otherwise.  The path is a function of the shapes alone, so this is too (measurement aid). */
+double nfs_conv3x3_executed_flops(int B, int H, int W, int K, int N, int pooled);
 /* y = relu?(conv(x) + bias); x [B,H,W,Ci], y [B,H,W,Co]; bias nullable; relu_bits nullable (written) */
 int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, float* y,
                     int B, int H, int W, int Ci, int Co, int relu,

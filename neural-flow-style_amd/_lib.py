@@ -85,6 +85,7 @@ SIGNATURES = {
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_conv3x3_executed_flops": [_I, _I, _I, _I, _I, _I],
     "nfs_gram_style_group_workspace_floats": [_P, _I],
     "nfs_gram_style_group_parts": [_P, _I],
     "nfs_gram_style_group_fwd": [_P, _I, _P, _P, _L, _P],
@@ -105,7 +106,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
-            "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64}
+            "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64,
+            "nfs_conv3x3_executed_flops": C.c_double}
 
 _lib = None
 

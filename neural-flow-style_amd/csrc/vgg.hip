@@ -27,6 +27,7 @@ namespace nfs {
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N);
 int64_t winograd_packed_floats(int Ci, int Co);
 int winograd_path(int B, int H, int W, int K, int N);
+int winograd_tile();
 int64_t winograd5_bits_words(int B, int H, int W, int C);
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s);
 int winograd_conv(const float* x, const float* U, const float* aux0, const float* aux1, float* y, float* ws, int B,
@@ -690,6 +691,24 @@ int64_t nfs_conv3x3_relu_bits_words(int B, int H, int W, int Ci, int Co, int poo
   if (!pooled && winograd_path(B, H, W, Ci, Co) == 2) return winograd5_bits_words(B, H, W, Ci);   // F(5x5): its own layout
   const int64_t T = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4);
   return T * (Ci / 2) + (pooled ? T * (Co / 2) : 0);
+}
+
+// MFMA flops a conv call EXECUTES for K input and N output channels of the kernel it runs (forward: K = Ci, N = Co; data
+// gradient: K = Co, N = Ci) -- the path is a function of the shapes alone (winograd_path), so this is too:
+//   F(4x4,3x3), three kernels or one: 2 * 36 * T4 * K * N, T4 = B ceil(H/4) ceil(W/4)   (direct / 2.25, + tile padding)
+//   F(5x5,3x3):                       2 * 49 * T5 * K * N, T5 = B ceil(H/5) ceil(W/5)   (direct / 4.59)
+//   direct implicit GEMM (conv1_1, NFS_NO_WINOGRAD): 2 * B H W * 9 * K * N
+// `pooled`: the fused-pool forms, which never take F(5x5).  What bench.py divides by the measured time, so that a
+// fraction of the MFMA peak is a fraction of the peak.
+double nfs_conv3x3_executed_flops(int B, int H, int W, int K, int N, int pooled) {
+  if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0.0;
+  static const bool no_wg = getenv("NFS_NO_WINOGRAD") != nullptr;
+  const double direct = 2.0 * B * H * W * 9.0 * K * N;
+  if (no_wg || !winograd_eligible(K, N) || H < 2 || W < 2) return direct;
+  const int m = winograd_tile();
+  if (m == 4 && !pooled && winograd_path(B, H, W, K, N) == 2)
+    return 2.0 * 49.0 * B * ((H + 4) / 5) * ((W + 4) / 5) * (double)K * N;
+  return 2.0 * (m + 2) * (m + 2) * B * ((H + m - 1) / m) * ((W + m - 1) / m) * (double)K * N;
 }
 
 static inline uint32_t* out_bits_of(uint32_t* relu_bits, int B, int H, int W, int Ci) {

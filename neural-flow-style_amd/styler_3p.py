@@ -29,7 +29,7 @@ import torch
 from . import engine, ops, parallel
 from . import transform as T
 from .styler_base import StylerBase
-from .util import denoise
+from .util import temporal_weights
 
 
 class _SmoothRelu(torch.autograd.Function):
@@ -64,7 +64,12 @@ class Styler(StylerBase):
             assert self.n_views % self.v_batch == 0
         self.loss = self._make_loss(rotate=self.rotate)
         self._identity = T.rot_to_device([np.identity(3)], self.device)
-        self.pg = None   # set by the driver for multi-GPU views=sum runs
+        # multi-GPU (set by the driver): ``pg`` = the process group; ``shard_by`` = 'views' (views=sum: the views of every
+        # frame over the ranks, ONE all-reduce of the variable's gradient + loss per frame step) or 'frames' (SURVEY 8(e)
+        # "Frames (config 4/5)": contiguous blocks of key frames per rank, full view batches per rank, and the only
+        # exchange is the halo of per-frame updates the temporal filter reaches, point-to-point)
+        self.pg = None
+        self.shard_by = getattr(self, "shard_by", None) or "views"
 
     # ---- forward graph: variable -> d_out [1,D,H,W,1] (autograd) ---------------------------------
     def _field(self, p, r, var, res):
@@ -100,8 +105,9 @@ class Styler(StylerBase):
         d_out = _SmoothRelu.apply(d_, float(self.k)) if self.k > 0 else _SmoothRelu.apply(d_, 0.0)
         return p_[0], d_out, extra
 
-    def _value_and_grad(self, p, r, var, res, rot):
-        """loss (per view, device) and d loss / d var for one frame"""
+    def _value_and_grad(self, p, r, var, res, rot, view_shard=True):
+        """loss (per view, device) and d loss / d var for one frame.  ``view_shard``: the views are sharded over the
+        ranks of ``self.pg`` (then only rank 0 adds the view-independent terms)"""
         v = var.detach().clone().requires_grad_(True)
         _, d_out, extra = self._field(p, r, v, res)
         d3 = d_out.detach().reshape(d_out.shape[1:4]).contiguous()
@@ -110,7 +116,7 @@ class Styler(StylerBase):
         # view-independent terms (pressure / density preservation) belong to the iteration, not to a view: with the
         # views sharded over ranks (views=sum) only rank 0 adds them, so that the all-reduced loss and gradient
         # contain them ONCE (every rank would otherwise contribute a copy: world x the single-rank weight)
-        if extra is not None and self._rank_world()[0] != 0:
+        if extra is not None and view_shard and self._rank_world()[0] != 0:
             extra = None
         if extra is not None:
             losses = losses + extra.detach() / losses.numel()
@@ -179,6 +185,43 @@ class Styler(StylerBase):
         g_opt = [torch.zeros(p[i].shape[0], nvar, device=self.device) for i in range(self.num_frames)]
         mode = getattr(self, "views_mode", "sequential")
 
+        # key frames (304-309) and who stylises them.  Frame sharding follows SURVEY 8(e): contiguous blocks of optimiser
+        # groups per rank (one Adam state never straddles ranks), every rank keeps full view batches for its frames.
+        keys = list(range(0, self.num_frames, self.batch_size * self.interp))
+        rank, world = self._rank_world()
+        by_frames = self.pg is not None and world > 1 and self.shard_by == "frames"
+        if by_frames:
+            plan = parallel.plan_frames(self.num_frames, self.batch_size * self.interp, self.frames_per_opt, world)
+            owner = {t: rk for rk, ts in enumerate(plan) for t in ts}
+        else:
+            owner = {t: rank for t in keys}
+        mine = [t for t in keys if owner[t] == rank]
+        # the temporal Gaussian over the per-frame updates (382-383: scipy gaussian_filter along the frame axis, reflect,
+        # truncate 4 sigma) as its matrix (util.temporal_weights == util.denoise, pinned to the reference's own function
+        # by tests/golden/util_reference.npz): evaluated on the device, and -- frames sharded -- only the frames inside a
+        # rank's filter window travel (point-to-point halo, parallel.exchange_frames)
+        Wt = temporal_weights(len(keys), self.window_sigma) if (self.window_sigma > 0 and len(keys) > 1) else None
+        if Wt is not None:
+            assert len(set(int(x.shape[0]) for x in p)) == 1, "temporal smoothing needs the same particles in every frame"
+        need_by_rank = []
+        for rk in range(world):
+            nd = set(t for t in keys if owner[t] == rk) if by_frames else set(keys)
+            if Wt is not None:
+                for t in list(nd):
+                    nd |= set(keys[jj] for jj in np.nonzero(Wt[keys.index(t)])[0])
+            need_by_rank.append(nd)
+        like = torch.zeros(p[0].shape[0], nvar, device=self.device)
+
+        def sync_all(g):
+            """every rank receives every key frame's variable (octave ends, final inference: a few MB per frame)"""
+            if not by_frames:
+                return g
+            got = parallel.exchange_frames({t: g[t] for t in mine}, set(keys), owner, like, group=self.pg,
+                                           need_by_rank=[set(keys)] * world)
+            for t in keys:
+                g[t] = got[t]
+            return g
+
         loss_history, d_intm, opt_ = [], [], {}
         for octave in range(self.octave_n):
             loss_history_o, d_intm_o = [], []
@@ -192,8 +235,14 @@ class Styler(StylerBase):
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
 
             for step in range(self.iter):
-                g_tmp = [None] * self.num_frames
-                for t in range(0, self.num_frames, self.batch_size * self.interp):
+                g_tmp = {}
+                l_step = torch.zeros(len(keys), device=self.device)
+                for j, t in enumerate(keys):
+                    if owner[t] != rank:
+                        # every rank draws the same view sequence whoever owns the frame (344-349)
+                        if self.rotate:
+                            self._resample_views()
+                        continue
                     var = g_opt[t].clone()                       # variable re-assigned from g_opt (312)
                     opt_id = t // self.frames_per_opt
                     if opt_id not in opt_:
@@ -203,28 +252,31 @@ class Styler(StylerBase):
                     if self.rotate and mode == "sequential":
                         acc, l_ = None, []
                         for i in range(0, self.n_views, self.v_batch):
-                            losses, g = self._value_and_grad(p[t], r[t], var, res, self._rot(i, i + self.v_batch))
+                            losses, g = self._value_and_grad(p[t], r[t], var, res, self._rot(i, i + self.v_batch),
+                                                             view_shard=False)     # (the sequential mode never shards views)
                             adam.step(var, g.contiguous(), lr)
                             l_.append(losses.sum())
                             cur = torch.nan_to_num(var)
                             acc = cur.clone() if acc is None else acc + cur
-                        loss_history_o.append(float(torch.stack(l_).mean()))
+                        l_step[j] = torch.stack(l_).mean()
                         self._resample_views()
                         new = acc / (self.n_views / self.v_batch)
                     else:
                         if self.rotate:
                             nvw = len(self.rot_mat_)
-                            rank, world = self._rank_world()
-                            rot = self._rot(0, nvw)[rank::world].contiguous()
+                            rot = self._rot(0, nvw)
+                            if self.pg is not None and not by_frames:
+                                rot = rot[rank::world].contiguous()
                         else:
                             rot = self._identity
-                        losses, g = self._value_and_grad(p[t], r[t], var, res, rot)
+                        losses, g = self._value_and_grad(p[t], r[t], var, res, rot,
+                                                         view_shard=self.pg is not None and not by_frames)
                         total = losses.sum()
-                        if self.pg is not None:
+                        if self.pg is not None and not by_frames:
                             g = g.contiguous()
                             parallel.all_reduce_sum_([g, total], group=self.pg)
                         adam.step(var, g.contiguous(), lr)
-                        loss_history_o.append(float(total))
+                        l_step[j] = total
                         if self.rotate:
                             self._resample_views()
                         new = torch.nan_to_num(var)
@@ -234,22 +286,38 @@ class Styler(StylerBase):
                         upd = upd * r[t][..., 0:1]                  # masking by original density (361-363)
                     g_tmp[t] = upd
 
-                    if step == self.iter - 1 and octave < self.octave_n - 1:
+                    if step == self.iter - 1 and octave < self.octave_n - 1 and not by_frames:
                         with torch.no_grad():
                             _, d_out, _ = self._field(p[t], r[t], var, res)
                             dimg = self.loss_d_img(d_out)
                         d_intm_o.append(dimg.cpu().numpy().astype(np.uint8))
 
-                idx = list(range(0, self.num_frames, self.interp))
-                if self.window_sigma > 0 and self.num_frames > 1:
-                    stack = np.stack([g_tmp[i].cpu().numpy() for i in idx])
-                    stack = denoise(stack, sigma=(self.window_sigma, 0, 0))
-                    for j, i in enumerate(idx):
-                        g_tmp[i] = self._dev(stack[j])
-                for i in idx:
-                    g_opt[i] = g_opt[i] + g_tmp[i]
+                if by_frames:
+                    parallel.all_reduce_sum_([l_step], group=self.pg)
+                loss_history_o.extend(float(x) for x in l_step.cpu())
+                if Wt is not None:
+                    got = parallel.exchange_frames(g_tmp, need_by_rank[rank], owner, like, group=self.pg,
+                                                   need_by_rank=need_by_rank) if by_frames else g_tmp
+                    for t in mine:
+                        jrow = Wt[keys.index(t)]
+                        f = None
+                        for jj in np.nonzero(jrow)[0]:
+                            term = got[keys[jj]] * float(jrow[jj])
+                            f = term if f is None else f.add_(term)
+                        g_opt[t] = g_opt[t] + f
+                else:
+                    for t in mine:
+                        g_opt[t] = g_opt[t] + g_tmp[t]
 
             loss_history.append(loss_history_o)
+            if by_frames:
+                g_opt = sync_all(g_opt)
+                if octave < self.octave_n - 1:                   # (every rank renders every key frame: same d_intm everywhere)
+                    for t in keys:
+                        with torch.no_grad():
+                            _, d_out, _ = self._field(p[t], r[t], g_opt[t], res)
+                            dimg = self.loss_d_img(d_out)
+                        d_intm_o.append(dimg.cpu().numpy().astype(np.uint8))
             if octave < self.octave_n - 1:
                 d_intm.append(np.concatenate(d_intm_o, axis=0))
 
