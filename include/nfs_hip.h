@@ -98,6 +98,17 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
                         int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
                         nfs_stream_t stream);
 
+/* Slab forms for the view-sharded (strong-scaling) run, where the replicated field work -- advect, smooth, their
+ * adjoints, ApplyAdam -- is sharded over D-slabs between a reduce-scatter of the density-field gradient and an
+ * all-gather of the smoothed density (engine.GridStylizer): d is the WHOLE [D,H,W] density (back-traced
+ * points leave the slab), vel / out / g_out / m / v hold the nz planes [z0, z0 + nz) only.  Same arithmetic per voxel
+ * as nfs_advect_fwd (C = 1) / nfs_advect_bwd_adam; nz*H*W % 4 == 0. */
+int nfs_advect_fwd_slab(const float* d, const float* vel, float* out, int D, int H, int W, int z0, int nz,
+                        nfs_stream_t stream);
+int nfs_advect_bwd_adam_slab(const float* d, float* vel, const float* g_out, float* m, float* v,
+                             int D, int H, int W, int z0, int nz, float lr_t, float beta1, float beta2, float eps,
+                             nfs_stream_t stream);
+
 /* ---- histogram loss (styler_base.py:187-209 + util.histogram_match_tf, util.py:317-399) -------------
  * feat [B,HW,C] (a layer of the loss network, or d_img for hist_layer 'input'), templ [Bt,HWt,C] (the same layer of
  * the style image; image b uses template min(b, Bt-1)).  Per (image, channel): 255-bin histogram matching of feat to

@@ -152,10 +152,12 @@ struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; };
 // the 96 MB gradient never goes to HBM)
 struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
 
+// Slab form (zoff, Dfull): vel / g_out / out / the moments hold only the D planes [zoff, zoff + D) of a volume of Dfull
+// planes, d is the WHOLE density (the back-traced points leave the slab); zoff = 0, Dfull = D is the whole volume.
 template <int MODE>
 __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* vel,
                                                       const float* __restrict__ g_out, float* out,
-                                                      int D, int H, int W, AdamFused ad) {
+                                                      int D, int H, int W, AdamFused ad, int zoff, int Dfull) {
   constexpr bool BWD = MODE != 0;
   const int n = D * H * W;
   // a wave owns 256 consecutive voxels and lane l takes l, l+64, l+128, l+192: every streamed access (the
@@ -189,13 +191,14 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       uu[j] = u3[ic];
     }
   }
-  const float hz = 0.5f * (float)(D - 1), hy = 0.5f * (float)(H - 1), hx = 0.5f * (float)(W - 1);
-  const float nz1 = (float)(D - 1), ny1 = (float)(H - 1), nx1 = (float)(W - 1);
+  const float hz = 0.5f * (float)(Dfull - 1), hy = 0.5f * (float)(H - 1), hx = 0.5f * (float)(W - 1);
+  const float nz1 = (float)(Dfull - 1), ny1 = (float)(H - 1), nx1 = (float)(W - 1);
   const unsigned uW = (unsigned)W, uHW = (unsigned)(H * W);
   const int f0 = min(first, n - 1);
   int w = f0 % W;
   const int t2 = f0 / W;
-  int h = t2 % H, z = t2 / H;
+  int h = t2 % H, z = t2 / H + zoff;
+  const int zlast = zoff + D - 1;
   F2u p[4][4];
   float wz[4], wy[4], wx[4], mz[4], my[4], mx[4];
 #pragma unroll
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
     p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
     // next voxel of this lane: 64 further on (clamped at the end of the volume; those results are not stored)
     w += 64;
-    while (w >= W) { w -= W; if (++h == H) { h = 0; if (z < D - 1) ++z; } }
+    while (w >= W) { w -= W; if (++h == H) { h = 0; if (z < zlast) ++z; } }
   }
   if (!BWD) {
 #pragma unroll
@@ -721,7 +724,7 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {
     hipLaunchKernelGGL(advect1_kernel<0>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
-                       (const float*)nullptr, out, D, H, W, AdamFused{});
+                       (const float*)nullptr, out, D, H, W, AdamFused{}, 0, D);
     return check_launch("nfs_advect_fwd(x4)");
   }
   hipLaunchKernelGGL(warp_fwd_kernel<COORD_ADVECT>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a, out);
@@ -738,7 +741,7 @@ int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* 
   const int64_t n = (int64_t)D * H * W;
   if (C == 1 && !g_d_acc && W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30)) {   // velocity gradient only: no atomics
     hipLaunchKernelGGL(advect1_kernel<1>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
-                       g_out, g_vel, D, H, W, AdamFused{});
+                       g_out, g_vel, D, H, W, AdamFused{}, 0, D);
     return check_launch("nfs_advect_bwd(x4)");
   }
   hipLaunchKernelGGL(warp_bwd_kernel<COORD_ADVECT>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a,
@@ -755,8 +758,37 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
   NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
               "nfs_advect_bwd_adam: needs D, H, W >= 2 and D*H*W %% 4 == 0 (use nfs_advect_bwd + nfs_adam_tf_step)");
   hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
-                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps});
+                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps}, 0, D);
   return check_launch("nfs_advect_bwd_adam");
+}
+
+// Slab forms (view-sharded runs shard the replicated field work over D-slabs, engine.GridStylizer): d is the whole
+// [D,H,W] density, vel / out / g_out / m / v hold the nz planes [z0, z0 + nz) only.  Same arithmetic per voxel as the
+// whole-volume entry points (the same kernel with a plane offset).
+int nfs_advect_fwd_slab(const float* d, const float* vel, float* out, int D, int H, int W, int z0, int nz,
+                        nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && out, "nfs_advect_fwd_slab: null pointer");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  NFS_REQUIRE(z0 >= 0 && nz >= 1 && z0 + nz <= D, "nfs_advect_fwd_slab: slab outside the volume");
+  const int64_t n = (int64_t)nz * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && (int64_t)D * H * W < ((int64_t)1 << 30),
+              "nfs_advect_fwd_slab: needs D, H, W >= 2 and nz*H*W %% 4 == 0");
+  hipLaunchKernelGGL(advect1_kernel<0>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
+                     (const float*)nullptr, out, nz, H, W, AdamFused{}, z0, D);
+  return check_launch("nfs_advect_fwd_slab");
+}
+
+int nfs_advect_bwd_adam_slab(const float* d, float* vel, const float* g_out, float* m, float* v, int D, int H, int W,
+                             int z0, int nz, float lr_t, float beta1, float beta2, float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v, "nfs_advect_bwd_adam_slab: null pointer");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  NFS_REQUIRE(z0 >= 0 && nz >= 1 && z0 + nz <= D, "nfs_advect_bwd_adam_slab: slab outside the volume");
+  const int64_t n = (int64_t)nz * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && (int64_t)D * H * W < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam_slab: needs D, H, W >= 2 and nz*H*W %% 4 == 0");
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out,
+                     vel, nz, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps}, z0, D);
+  return check_launch("nfs_advect_bwd_adam_slab");
 }
 
 // one step of StylerBase._transport (styler_base.py:59-89) with the temporal filter's weighted accumulation fused in

@@ -370,6 +370,10 @@ class RenderStyleLoss(object):
         return loss
 
 
+class argparse_ns(object):
+    """plain attribute bag"""
+
+
 class TFAdamState(object):
     """tf.compat.v1.train.AdamOptimizer state (m, v, beta powers) living on the device; one
     instance per ``opt_id`` (styler_3p.py:315-323), persisting across frames/views/octaves."""
@@ -403,13 +407,30 @@ class TFAdamState(object):
                             float(self.eps))
 
 
+    def step_through_advect_slab(self, vel_slab, d0, g_adv_slab, z0, lr):
+        """``step_through_advect`` on the planes [z0, z0 + nz) only: the moments exist for these planes alone (the Adam
+        state of a D-slab-sharded run is sharded with the variable)"""
+        if self.m is None or self.m.shape != vel_slab.shape:
+            self.m = torch.zeros_like(vel_slab)
+            self.v = torch.zeros_like(vel_slab)
+        self.b1p = np.float32(self.b1p * self.b1)
+        self.b2p = np.float32(self.b2p * self.b2)
+        lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
+        ops.advect_bwd_adam_slab(d0, vel_slab, g_adv_slab, self.m, self.v, z0, float(lr_t), float(self.b1),
+                                 float(self.b2), float(self.eps))
+
+
 class GridStylizer(object):
     """TNST-style grid path assembled from the reference's operators:
         d^ = advect(d0, vel)  ->  smooth+max  ->  RenderStyleLoss
     with the velocity field ``vel`` [D,H,W,3] (target 'v') or the density itself (target 'd')
     as the Adam variable.  Views shard over ranks (``views=sum``): each rank evaluates its slice
-    of the rotation matrices, the field gradient is all-reduced (sum) and every rank applies the
-    identical Adam step.  ``bind`` swaps the frame (density, variable, Adam state) under the same
+    of the rotation matrices; the exchange is ONE all-reduce's worth of link traffic per iteration,
+    split around the field work so that this work is sharded too (``slab`` mode, the default for the
+    velocity variable): reduce-scatter of the density-field gradient over D-slabs -> slab-local smooth
+    adjoint, advect adjoint + ApplyAdam, advect, smooth -> all-gather of the smoothed density (see
+    ``_slab_setup``).  Otherwise the gradient is all-reduced and every rank applies the identical step.
+    ``bind`` swaps the frame (density, variable, Adam state) under the same
     stylizer: the frame loop of a sequence (styler_grid.py) re-uses one instance."""
 
     def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None, graph=None):
@@ -443,9 +464,118 @@ class GridStylizer(object):
         # field gradient and the summed loss share one buffer: the multi-rank exchange is ONE all-reduce
         # (the loss rides in the slot behind the gradient)
         n = D * H * W
-        self._gbuf = torch.zeros(n + 4, dtype=torch.float32, device=d0.device)
-        self.g_ds = self._gbuf[:n].view(D, H, W)
-        self._loss_slot = self._gbuf[n:n + 1]
+        self.slab = None
+        if self.pg is not None and os.environ.get("NFS_SLAB_SHARD", "1") != "0":
+            self._slab_setup()
+        if self.slab is None:
+            self._gbuf = torch.zeros(n + 4, dtype=torch.float32, device=d0.device)
+            self.g_ds = self._gbuf[:n].view(D, H, W)
+            self._loss_slot = self._gbuf[n:n + 1]
+
+    # ---- D-slab sharding of the replicated field work (view-sharded runs) ---------------------------------------------------
+    def _slab_setup(self):
+        """Strong scaling of the 8-view problem is capped by what every rank repeats: advect, smooth, their adjoints and
+        ApplyAdam on the whole field (~0.2 ms of a 1.1 ms one-view step).  All of it is LOCAL in z up to a one-plane
+        stencil, so the all-reduce of the density gradient is taken apart into its two halves with that work in between:
+
+            reduce-scatter(g_ds)      rank k receives the summed gradient of ITS slab of planes, with a two-plane halo
+                                      (the chunks of the send buffer overlap: no separate halo exchange)
+            smooth adjoint            on slab +- 2 planes -> valid on slab +- 1
+            advect adjoint + Adam     on slab +- 1: the variable, its moments and the update exist per slab (+ one plane
+                                      each side, computed identically by both neighbours -- deterministic kernels)
+            advect, smooth            next iteration's field on slab +- 1 -> valid smoothed density on the slab
+            all-gather(d_s)           every rank holds the whole smoothed density for its views' rotate + render
+
+        Same bytes over the links as the all-reduce it replaces (+ 4 halo planes per chunk); d0 stays replicated and
+        constant (the back-traced points leave the slab).  The loss rides in an extra plane of every chunk.  Off when
+        the variable is the density itself, when a slab would be thinner than two planes, or with NFS_SLAB_SHARD=0."""
+        rank, world = parallel.rank_world(self.pg)
+        D, H, W = self.d0.shape
+        force = os.environ.get("NFS_SLAB_SHARD") == "2"           # also on a one-rank group (RCCL smoke test on one GPU)
+        if (world <= 1 and not force) or self.target != "v" or not self.fuse_adam or D // world < 2 or (H * W) % 4 \
+                or min(D, H, W) < 2:
+            return
+        dev = self.d0.device
+        cs, plan = parallel.slab_plan(D, world)
+        z0, z1 = plan[rank]
+        sl = argparse_ns()
+        sl.rank, sl.world, sl.cs, sl.z0, sl.z1 = rank, world, cs, z0, z1
+        sl.lo, sl.hi = max(z0 - 1, 0), min(z1 + 1, D)                     # planes whose variable this rank maintains
+        # padded gradient volume: planes [2, D + 2) = g_ds, two zero planes either side, one more for the loss
+        self._gpad = torch.zeros(D + 5, H, W, dtype=torch.float32, device=dev)
+        self.g_ds = self._gpad[2:D + 2]
+        self._loss_slot = self._gpad[D + 4].view(-1)[:1]
+        idx = []
+        for k in range(world):
+            for j in range(cs + 4):
+                z = k * cs - 2 + j
+                idx.append(z + 2 if -2 <= z < D + 2 else 0)               # (plane 0 is a zero plane)
+            idx.append(D + 4)
+        sl.idx = torch.tensor(idx, dtype=torch.int64, device=dev)
+        sl.pack = torch.empty(world, cs + 5, H, W, dtype=torch.float32, device=dev)
+        sl.recv = torch.empty(cs + 5, H, W, dtype=torch.float32, device=dev)
+        # padded smoothed density: planes [2, 2 + world * cs) are gathered, d_s = planes [2, 2 + D)
+        sl.ds_full = torch.zeros(world * cs + 4, H, W, dtype=torch.float32, device=dev)
+        sl.stage = torch.zeros(cs, H, W, dtype=torch.float32, device=dev)
+        self.slab = sl
+
+    def gather_variable(self):
+        """slab mode: every rank keeps only its planes of the variable current -- all-gather them into ``self.var``
+        (results, checkpoints); a no-op otherwise"""
+        sl = self.slab
+        if sl is None:
+            return self.var
+        D, H, W = self.d0.shape
+        mine = torch.zeros(sl.cs, H, W, 3, dtype=torch.float32, device=self.var.device)
+        if sl.z1 > sl.z0:
+            mine[:sl.z1 - sl.z0] = self.var[sl.z0:sl.z1]
+        full = torch.empty(sl.world, sl.cs, H, W, 3, dtype=torch.float32, device=self.var.device)
+        parallel.all_gather_into(full, mine, group=self.pg)
+        self.var.copy_(full.view(sl.world * sl.cs, H, W, 3)[:D])
+        return self.var
+
+    def _forward_field_slab(self):
+        sl = self.slab
+        assert self._pending is None, "bind() is not available with the D-slab sharding (one frame per stylizer)"
+        D, H, W = self.d0.shape
+        if sl.z1 > sl.z0:
+            self.d_adv = ops.advect_fwd_slab(self.d0, self.var[sl.lo:sl.hi], sl.lo)
+            d_s_ext = ops.smooth3d_relu_fwd(self.d_adv, self.k)        # exact on the slab (cut planes are one further out)
+            own = d_s_ext[sl.z0 - sl.lo: sl.z0 - sl.lo + (sl.z1 - sl.z0)]
+            if sl.z1 - sl.z0 == sl.cs:
+                src = own
+            else:
+                sl.stage[:sl.z1 - sl.z0].copy_(own)
+                src = sl.stage
+        else:
+            src = sl.stage                                             # an idle rank contributes zero planes
+        parallel.all_gather_into(sl.ds_full[2:2 + sl.world * sl.cs].view(sl.world, sl.cs, H, W), src, group=self.pg)
+        self.d_s = sl.ds_full[2:2 + D]
+        return self.d_s
+
+    def _step_slab(self, rot_local):
+        """one iteration with the field work sharded over D-slabs (see ``_slab_setup``)"""
+        sl = self.slab
+        D, H, W = self.d0.shape
+        if self.use_graph:
+            self._forward_field_slab()                                  # (holds a collective: outside the graph)
+            self._loss_gradient_graphed(rot_local)
+        else:
+            losses, _ = self.field_gradient(rot_local)
+            torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)
+        torch.index_select(self._gpad, 0, sl.idx, out=sl.pack.view(-1, H, W))
+        parallel.reduce_scatter_sum(sl.recv, sl.pack, group=self.pg)
+        total = sl.recv[sl.cs + 4].view(-1)[0].clone()
+        if sl.z1 > sl.z0:
+            # chunk planes = global [z0 - 2, z0 + cs + 2); the same planes of the padded smoothed density
+            g_adv = ops.smooth3d_relu_bwd(sl.ds_full[sl.z0:sl.z0 + sl.cs + 4], sl.recv[:sl.cs + 4], self.k)
+            off = sl.lo - (sl.z0 - 2)
+            self.adam.step_through_advect_slab(self.var[sl.lo:sl.hi], self.d0, g_adv[off:off + (sl.hi - sl.lo)], sl.lo,
+                                               self.lr)
+        else:
+            self.adam.b1p = np.float32(self.adam.b1p * self.adam.b1)      # (an idle rank keeps the step count)
+            self.adam.b2p = np.float32(self.adam.b2p * self.adam.b2)
+        return total
 
     def bind(self, d0, var=None, adam=None):
         """Re-point the stylizer at another frame of the same shape (takes effect at the next step / gradient).
@@ -474,6 +604,8 @@ class GridStylizer(object):
                 self.var = var
 
     def forward_field(self):
+        if self.slab is not None:
+            return self._forward_field_slab()
         self._apply_binding()
         if self.target == "v":
             self.d_adv = ops.advect_fwd(self.d0.unsqueeze(-1), self.var).squeeze(-1)
@@ -484,7 +616,9 @@ class GridStylizer(object):
 
     def field_gradient(self, rot_local):
         """forward + adjoint down to the smoothed density: (loss_per_view, dL/d d_s of the LOCAL views)"""
-        d_s = self.forward_field()
+        return self._loss_gradient(self.forward_field(), rot_local)
+
+    def _loss_gradient(self, d_s, rot_local):
         V = rot_local.shape[0]
         fresh = hasattr(self.loss, "writes_gradient") and self.loss.writes_gradient(V)
         if not fresh:
@@ -524,27 +658,32 @@ class GridStylizer(object):
         return (grams, tuple(getattr(L, "w_layers", ())), hyper, None if cf is None else int(cf.data_ptr()), hist,
                 int(self.d0.data_ptr()), int(self.var.data_ptr()), tuple(rot_local.shape), self.k, self.target)
 
-    def _field_gradient_graphed(self, rot_local):
+    def _loss_gradient_graphed(self, rot_local):
+        """the graph without the field ops (slab mode: their all-gather stays outside the capture)"""
+        return self._field_gradient_graphed(rot_local, with_field=False)
+
+    def _field_gradient_graphed(self, rot_local, with_field=True):
         """field_gradient as one hipGraph: the first call runs eagerly (lazy state: packed Winograd filters, side
         streams, workspaces), the second is captured, later ones replay.  The capture is keyed on what it bakes in
         (style / content targets, loss hyper-parameters, the addresses of d0 and the variable, the number of views):
         when any of that changes the graph is dropped and captured again.  The view matrices are copied into a
         static buffer."""
-        key = self._capture_key(rot_local)
+        body = self.field_gradient if with_field else (lambda r: self._loss_gradient(self.d_s, r))
+        key = self._capture_key(rot_local) + (with_field,)
         if self._graph is not None and key != self._graph_key:
             self._graph = None
             self._graph_warm = 0
         if self._graph is None:
             if self._graph_warm < 1:
                 self._graph_warm += 1
-                losses, g_ds = self.field_gradient(rot_local)
+                losses, g_ds = body(rot_local)
                 torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
                 return self._loss_slot, g_ds
             self._graph_rot = rot_local.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                losses, _ = self.field_gradient(self._graph_rot)
+                losses, _ = body(self._graph_rot)
                 torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
             self._graph = g
             self._graph_key = key
@@ -556,6 +695,8 @@ class GridStylizer(object):
     def step(self, rot_local):
         if self.use_graph is None:                  # host-bound regime only: small volumes, few views
             self.use_graph = self.d0.numel() * max(int(rot_local.shape[0]), 1) <= (2 << 20)
+        if self.slab is not None:
+            return self._step_slab(rot_local)
         self._apply_binding()
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)

@@ -114,6 +114,25 @@ def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8)
               float(beta1), float(beta2), float(eps), _stream())
 
 
+def advect_fwd_slab(d, vel_slab, z0, out=None):
+    """planes [z0, z0 + nz) of advect(d, vel): d the WHOLE density [D,H,W], vel_slab [nz,H,W,3] -> [nz,H,W]"""
+    D, H, W = d.shape
+    nz = vel_slab.shape[0]
+    if out is None:
+        out = _empty((nz, H, W), d)
+    _lib.call("nfs_advect_fwd_slab", _ptr(d), _ptr(vel_slab), _ptr(out), D, H, W, int(z0), nz, _stream())
+    return out
+
+
+def advect_bwd_adam_slab(d, vel_slab, g_slab, m_slab, v_slab, z0, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """advect_bwd_adam on the planes [z0, z0 + nz) only (vel_slab, m_slab, v_slab [nz,H,W,3] in place, g_slab [nz,H,W]);
+    d is the whole density [D,H,W]"""
+    D, H, W = d.shape
+    nz = vel_slab.shape[0]
+    _lib.call("nfs_advect_bwd_adam_slab", _ptr(d), _ptr(vel_slab), _ptr(g_slab), _ptr(m_slab), _ptr(v_slab), D, H, W,
+              int(z0), nz, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+
+
 def warp2d_fwd(imgs, coords):
     """imgs [B,X,Y,C], coords [B,2,X,Y] -> [B,X,Y,C]  (transform.py:206-236, 280-341)"""
     B, X, Y, Cn = imgs.shape

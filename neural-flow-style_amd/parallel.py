@@ -34,6 +34,29 @@ def all_reduce_sum_(tensors, group=None):
     return tensors
 
 
+def reduce_scatter_sum(out, inp, group=None):
+    """out [chunk...] = sum over ranks of inp[rank] (inp [world, chunk...], contiguous): the first half of an all-reduce,
+    every rank keeps only its own chunk"""
+    assert out.is_contiguous() and inp.is_contiguous() and inp.numel() == out.numel() * dist.get_world_size(group)
+    # (flat views: gloo wants input.shape[0] == world * output.shape[0])
+    dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def all_gather_into(out, inp, group=None):
+    """out [world, chunk...] <- every rank's inp [chunk...]: the second half of an all-reduce"""
+    assert out.is_contiguous() and inp.is_contiguous() and out.numel() == inp.numel() * dist.get_world_size(group)
+    dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
+    return out
+
+
+def slab_plan(D, world):
+    """D planes in ``world`` contiguous slabs of ``cs = ceil(D / world)`` planes (the last ranks may be short or empty):
+    -> (cs, [(z0, z1)] per rank)"""
+    cs = -(-int(D) // int(world))
+    return cs, [(min(r * cs, D), min((r + 1) * cs, D)) for r in range(world)]
+
+
 def replicas_identical(t, group=None, atol=0.0):
     """debug check: max |t - t_rank0| over ranks is <= atol"""
     if not (dist.is_available() and dist.is_initialized()):

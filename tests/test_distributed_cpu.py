@@ -196,3 +196,64 @@ def test_halo_exchange_of_frame_updates_world3():
             np.testing.assert_allclose(v, want[t], atol=1e-6)
             seen.add(t)
     assert seen == set(range(F))
+
+
+def _slab_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_flow_style_amd import parallel
+    D, H, W = 11, 3, 4
+    cs, plan = parallel.slab_plan(D, world)
+    z0, z1 = plan[rank]
+    # every rank's local "gradient" (a function of rank and voxel), packed as engine.GridStylizer packs it: chunk k =
+    # planes [k cs - 2, k cs + cs + 2) of the zero-padded volume + one plane whose first element is the local loss
+    g = torch.arange(D * H * W, dtype=torch.float32).view(D, H, W) * (rank + 1)
+    gpad = torch.zeros(D + 5, H, W)
+    gpad[2:D + 2] = g
+    gpad[D + 4].view(-1)[0] = 10.0 + rank
+    idx = []
+    for k in range(world):
+        idx += [(k * cs - 2 + j + 2 if -2 <= k * cs - 2 + j < D + 2 else 0) for j in range(cs + 4)] + [D + 4]
+    pack = gpad.index_select(0, torch.tensor(idx)).view(world, cs + 5, H, W).contiguous()
+    recv = torch.empty(cs + 5, H, W)
+    parallel.reduce_scatter_sum(recv, pack)
+    # all-gather of a per-slab result (here: the received interior, i.e. the summed gradient of the slab)
+    mine = torch.zeros(cs, H, W)
+    mine[:z1 - z0] = recv[2:2 + (z1 - z0)]
+    full = torch.empty(world, cs, H, W)
+    parallel.all_gather_into(full, mine)
+    q.put((rank, recv.numpy(), full.view(world * cs, H, W)[:D].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_reduce_scatter_with_overlapping_chunks_and_all_gather_world3():
+    """the exchange of the D-slab sharded step (engine.GridStylizer._step_slab) on a ragged split (11 planes over 3
+    ranks: 4 + 4 + 3): every rank receives the SUM over ranks of its slab with a two-plane halo (zero beyond the volume)
+    and the summed loss; the all-gather of the slabs rebuilds the whole volume"""
+    from neural_flow_style_amd import parallel
+    world, D, H, W = 3, 11, 3, 4
+    cs, plan = parallel.slab_plan(D, world)
+    assert cs == 4 and plan == [(0, 4), (4, 8), (8, 11)]
+    assert parallel.slab_plan(200, 8) == (25, [(25 * r, 25 * r + 25) for r in range(8)])
+    assert parallel.slab_plan(5, 8)[1][5:] == [(5, 5)] * 3                      # idle ranks: empty slabs
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    total = np.arange(D * H * W, dtype=np.float32).reshape(D, H, W) * 6.0        # ranks 1 + 2 + 3
+    padded = np.zeros((D + 4, H, W), np.float32)
+    padded[2:D + 2] = total
+    for rank, recv, full in got:
+        z0 = plan[rank][0]
+        want = np.zeros((cs + 4, H, W), np.float32)
+        hi = min(z0 + cs + 4, D + 4)
+        want[:hi - z0] = padded[z0:hi]
+        np.testing.assert_array_equal(recv[:cs + 4], want)
+        assert recv[cs + 4].reshape(-1)[0] == 33.0                               # 10 + 11 + 12
+        np.testing.assert_array_equal(full, total)

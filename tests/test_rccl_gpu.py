@@ -35,6 +35,23 @@ def run(pg):
     return float(total), gs.var.clone()
 l0, v0 = run(None)
 l1, v1 = run(dist.group.WORLD)
+# the D-slab sharded form of the same step (reduce_scatter_tensor of the packed gradient chunks, slab-local adjoints +
+# Adam, all_gather_into_tensor of the smoothed density) through RCCL on a one-rank group: same trajectory
+os.environ["NFS_SLAB_SHARD"] = "2"
+def run_slab():
+    loss = engine.RenderStyleLoss(net, ["conv1_1", "conv2_1", "conv3_1"], [1.0] * 3, 1.0, transmit=0.01)
+    loss.set_style_image(simg)
+    gs = engine.GridStylizer(loss, torch.tensor(d0, device=dev), k=3, target="v", lr=1e-3, process_group=dist.group.WORLD)
+    assert gs.slab is not None
+    gs.var.copy_(torch.tensor(vel))
+    rot = T.rot_to_device(S.uniform_views(V), dev)
+    for _ in range(3):
+        total = gs.step(rot)
+    return float(total), gs.gather_variable().clone()
+l2, v2 = run_slab()
+del os.environ["NFS_SLAB_SHARD"]
+assert abs(l0 - l2) <= 1e-6 * abs(l0), (l0, l2)
+assert float((v2 - v0).abs().max()) <= 1e-6 * float(v0.abs().max()), float((v2 - v0).abs().max())
 # (the loss VALUE is a float-atomic sum of block partials: last-bit order effects; the update is order-free)
 assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.equal(v0, v1), (l0, l1)
 # the collectives themselves, on a gradient-sized device buffer written by a side stream
