@@ -545,12 +545,50 @@ def other_configs(device, base):
             rows[str(nv)] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / 30, "hipgraph": bool(gs2.use_graph)}
             del gs2, loss2
         t8 = rows["8"]["ms_per_step"]
+        # the same with the field work sharded over D-slabs (engine.GridStylizer._slab_setup): a rank then runs the loss
+        # chain of its views + the field ops on 1/world of the planes (+ halo) + the packing gather; measured piecewise on
+        # this GPU (rank 1's slab), the two collectives (reduce-scatter + all-gather = one all-reduce's traffic) excluded
+        loss2 = engine.RenderStyleLoss(net2, STYLE_LAYERS, [1.0] * 5, 1.0, transmit=0.01)
+        loss2.set_style_image(base["simg"])
+        gs2 = engine.GridStylizer(loss2, torch.tensor(base["d0"], device=device), k=3, target="v", lr=1e-3)
+        gs2.var.copy_(torch.tensor(base["vel"]))
+        d_s2 = gs2.forward_field()
+        slab_rows = {}
+        for world_ in (2, 4, 8):
+            nv = len(base["mats"]) // world_
+            rot2 = T.rot_to_device(base["mats"][:nv], device)
+            t_loss = ev_time(lambda: gs2._loss_gradient(d_s2, rot2), 20)
+            cs = G2 // world_
+            z0 = cs
+            lo, hi = z0 - 1, z0 + cs + 1
+            vel_s = gs2.var[lo:hi].clone(); m_s = torch.zeros_like(vel_s); v_s = torch.zeros_like(vel_s)
+            gpad = torch.zeros(G2 + 5, G2, G2, device=device)
+            idx = torch.arange(world_ * (cs + 5), device=device) % (G2 + 5)
+            pack = torch.empty(world_ * (cs + 5), G2, G2, device=device)
+            g_chunk = torch.randn(cs + 4, G2, G2, device=device)
+
+            def field_slab():
+                d_adv = ops.advect_fwd_slab(gs2.d0, vel_s, lo)
+                ops.smooth3d_relu_fwd(d_adv, 3.0)
+                torch.index_select(gpad, 0, idx, out=pack)
+                g_adv = ops.smooth3d_relu_bwd(d_s2[z0 - 2:z0 + cs + 2], g_chunk, 3.0)
+                ops.advect_bwd_adam_slab(gs2.d0, vel_s, g_adv[1:1 + (hi - lo)], m_s, v_s, lo, 1e-3)
+            t_field = ev_time(field_slab, 20)
+            slab_rows[str(world_)] = {"local_views": nv, "loss_chain_ms": t_loss, "field_slab_ms": t_field,
+                                      "ms_per_step": t_loss + t_field}
         out.append({"config": "configs[2] per-rank step at 8 / 4 / 2 / 1 local views (one GPU; the compute side of view-"
                               "sharded strong scaling on 1 / 2 / 4 / 8 GPUs, collective not included)",
                     "local_views": rows,
                     "compute_bound_speedup": {"2_gpus": t8 / rows["4"]["ms_per_step"],
                                               "4_gpus": t8 / rows["2"]["ms_per_step"],
-                                              "8_gpus": t8 / rows["1"]["ms_per_step"]}})
+                                              "8_gpus": t8 / rows["1"]["ms_per_step"]},
+                    "slab_sharded_field_work": slab_rows,
+                    "compute_bound_speedup_slab": {"%s_gpus" % w_: t8 / r_["ms_per_step"] for w_, r_ in slab_rows.items()},
+                    "note": "local_views: the whole step of one rank with the field work replicated (NFS_SLAB_SHARD=0); "
+                            "slab_sharded_field_work: loss chain of the rank's views + the field ops on its D-slab, measured "
+                            "piecewise (what a rank executes with the default sharding); the 32 MB reduce-scatter + "
+                            "all-gather over xGMI come on top (SURVEY 8(e): 0.05-0.37 ms)"})
+        del gs2, loss2
     except Exception as e:  # pragma: no cover
         out.append({"config": "configs[2] per-rank step", "error": repr(e)})
 
