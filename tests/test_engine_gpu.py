@@ -285,8 +285,9 @@ def test_gradient_parity_at_real_vgg_dynamic_range():
 
 def test_gradient_parity_with_histogram_loss():
     """style + histogram terms (styler_base.py:187-209; hist layers 'input' and conv2_1) through the whole chain vs the
-    oracle.  The matching is a staircase in the feature values, so single pixels may sit on the other side of a bin
-    edge in float32: the gradient is held to 2e-2, the loss to 2e-3"""
+    oracle.  The matching is a staircase in the feature values, so a pixel within float rounding of a bin edge may take
+    the neighbouring step; measured on MI355X: loss 1.8e-7, gradient 1.3e-6 relative -- held to the metric's own bar
+    (1e-3 on the gradient), the loss to 1e-4"""
     G, V = 24, 2
     layers = ["conv1_1", "conv2_1"]
     d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(G, V, layers)
@@ -310,8 +311,8 @@ def test_gradient_parity_with_histogram_loss():
     losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
     e_l, e_g = rel(losses, torch.stack(per_view).detach()), rel(g_h, g_o[0, ..., 0])
     print("histogram term: loss rel %.2e, gradient rel-L2 %.2e" % (e_l, e_g))
-    assert e_l < 2e-3
-    assert e_g < 2e-2
+    assert e_l < 1e-4
+    assert e_g < 1e-3
 
 
 def test_image_style_loss_with_masked_histogram_branch():
@@ -352,8 +353,8 @@ def test_image_style_loss_with_masked_histogram_branch():
     e_l = abs(float(losses.sum()) - float(total.detach())) / float(total.detach())
     e_g = rel(g_h, g_o)
     print("masked histogram branch: loss rel %.2e, gradient rel-L2 %.2e" % (e_l, e_g))
-    assert e_l < 2e-3
-    assert e_g < 2e-2
+    assert e_l < 2e-4          # (measured 2.6e-5 / 1.3e-4: a few pixels on the other side of a bin edge)
+    assert e_g < 1e-3
 
 
 def test_graph_is_recaptured_when_the_histogram_targets_change():
