@@ -233,6 +233,15 @@ int nfs_maxnorm_fwd(const float* img, float* out, float* gmax, int G, int n,
                     nfs_stream_t stream);
 int nfs_maxnorm_bwd(const float* img, const float* gmax, const float* g_out, float* g_img,
                     int G, int n, float* workspace, nfs_stream_t stream);
+/* The same normalisation fused with the loss-net input (styler_base.py:41-45 + vgg.py:50-53) for the grey render at the loss
+ * net's own size (resize_scale 1): x [.,3] = (img / max) * 255 - mean[c]; adjoint g_img = adjoint_maxnorm(255 * (g_x[.,0] +
+ * g_x[.,1] + g_x[.,2])).  To float32 rounding the arithmetic of nfs_maxnorm_fwd + nfs_loss_net_input_fwd and of
+ * nfs_loss_net_input_bwd + nfs_maxnorm_bwd, without the [V,H,W] intermediates and two launches less per direction.
+ * img [G*n], x / g_x [G*n,3], gmax [G] (written by fwd), workspace >= 64*G floats. */
+int nfs_maxnorm_input_fwd(const float* img, float* x, float* gmax, int G, int n, nfs_stream_t stream);
+int nfs_maxnorm_input_bwd(const float* img, const float* gmax, const float* g_x, float* g_img, int G, int n,
+                          float* workspace, nfs_stream_t stream);
+
 
 /* ---- A5: _plugin_to_loss_net + vgg.preprocess (styler_base.py:33-45, vgg.py:50-53) ---
  * img [B,H,W,Cin] in [0,1] (Cin=1 grey or 3 colour) -> d_img [B,H2,W2,3] in 0..255

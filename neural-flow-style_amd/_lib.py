@@ -69,6 +69,8 @@ SIGNATURES = {
     "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_maxnorm_fwd": [_P, _P, _P, _I, _I, _P],
     "nfs_maxnorm_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],
+    "nfs_maxnorm_input_fwd": [_P, _P, _P, _I, _I, _P],
+    "nfs_maxnorm_input_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],
     "nfs_loss_net_input_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_loss_net_input_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_conv3x3_packed_floats": [_I, _I, _I],

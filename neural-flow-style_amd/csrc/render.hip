@@ -502,6 +502,13 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
 }
 
+// (a kernel, not hipMemsetD32Async: as a memset NODE of a captured hipGraph the -inf fill was seen to run out of order with
+// the atomics behind it -- two ranks sharing a GPU, 64^3 sequence: losses off by +361 M from the first replay on)
+__global__ void maxnorm_init_kernel(float* __restrict__ gmax, int G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G) gmax[i] = -INFINITY;
+}
+
 __global__ void __launch_bounds__(256) maxnorm_max_kernel(const float* __restrict__ img, float* __restrict__ gmax, int n) {
   __shared__ float red[16];
   const float* x = img + (int64_t)blockIdx.y * n;
@@ -563,6 +570,93 @@ __global__ void __launch_bounds__(256) maxnorm_bwd_apply_kernel(const float* __r
     float g = gy[i] / m;
     if (x[i] == m) g -= corr;
     gx[i] = g;
+  }
+}
+
+// ---- max-normalisation fused with the loss-net input (styler_3p.py:158 + styler_base.py:41-45, vgg.py:50-53) ------------
+// The grey render at the loss net's own size (resize_scale 1): x[.,c] = (img / max) * 255 - mean[c] in one pass, and the
+// adjoint g_img = adjoint_maxnorm(255 * (g_x[.,0] + g_x[.,1] + g_x[.,2])) in two (partial sums, apply) -- the same
+// arithmetic (to float32 rounding) as nfs_maxnorm_fwd + nfs_loss_net_input_fwd and nfs_loss_net_input_bwd + nfs_maxnorm_bwd,
+// without the [V,H,W] intermediates and with two launches less per direction.
+__constant__ float kInputMean[3] = {0.485f * 255.f, 0.456f * 255.f, 0.406f * 255.f};
+
+__global__ void __launch_bounds__(256) maxnorm_input_kernel(const float* __restrict__ img, const float* __restrict__ gmax,
+                                                            float* __restrict__ xo, int n) {
+  const float m = gmax[blockIdx.y];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  float* o = xo + (int64_t)blockIdx.y * n * 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = __fmul_rn(x[i] / m, 255.f);        // (rounded like the stored intermediate of the two-step form)
+    o[3 * (int64_t)i] = __fsub_rn(v, kInputMean[0]);
+    o[3 * (int64_t)i + 1] = __fsub_rn(v, kInputMean[1]);
+    o[3 * (int64_t)i + 2] = __fsub_rn(v, kInputMean[2]);
+  }
+}
+
+// small groups (< 16384 pixels): one block per group does the maximum and the pass (no memset, no atomics)
+__global__ void __launch_bounds__(1024) maxnorm_input_small_kernel(const float* __restrict__ img, float* __restrict__ gmax,
+                                                                   float* __restrict__ xo, int n) {
+  __shared__ float red[16];
+  const float* x = img + (int64_t)blockIdx.x * n;
+  float* o = xo + (int64_t)blockIdx.x * n * 3;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, x[i]);
+  m = block_max(m, red);
+  if (threadIdx.x == 0) gmax[blockIdx.x] = m;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = __fmul_rn(x[i] / m, 255.f);        // (rounded like the stored intermediate of the two-step form)
+    o[3 * (int64_t)i] = __fsub_rn(v, kInputMean[0]);
+    o[3 * (int64_t)i + 1] = __fsub_rn(v, kInputMean[1]);
+    o[3 * (int64_t)i + 2] = __fsub_rn(v, kInputMean[2]);
+  }
+}
+
+__device__ __forceinline__ float input_grad_sum(const float* g, int64_t i) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(g[3 * i], 255.f), __fmul_rn(g[3 * i + 1], 255.f)), __fmul_rn(g[3 * i + 2], 255.f));
+}
+
+__global__ void __launch_bounds__(256) maxnorm_input_bwd_part_kernel(const float* __restrict__ img,
+                                                                     const float* __restrict__ gmax,
+                                                                     const float* __restrict__ g_x,
+                                                                     float* __restrict__ part, int n) {
+  __shared__ float red[16];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  const float* gx = g_x + (int64_t)blockIdx.y * n * 3;
+  const float m = gmax[blockIdx.y];
+  float s = 0.f, ties = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    s += input_grad_sum(gx, i) * xi;
+    ties += (xi == m) ? 1.f : 0.f;
+  }
+  s = block_sum(s, red);
+  ties = block_sum(ties, red);
+  if (threadIdx.x == 0) {
+    part[((int64_t)blockIdx.y * MN_NB + blockIdx.x) * 2] = s;
+    part[((int64_t)blockIdx.y * MN_NB + blockIdx.x) * 2 + 1] = ties;
+  }
+}
+
+__global__ void __launch_bounds__(256) maxnorm_input_bwd_apply_kernel(const float* __restrict__ img,
+                                                                      const float* __restrict__ gmax,
+                                                                      const float* __restrict__ g_x,
+                                                                      const float* __restrict__ part,
+                                                                      float* __restrict__ g_img, int n) {
+  const float* x = img + (int64_t)blockIdx.y * n;
+  const float* gx = g_x + (int64_t)blockIdx.y * n * 3;
+  float* go = g_img + (int64_t)blockIdx.y * n;
+  const float m = gmax[blockIdx.y];
+  float s = 0.f, ties = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < MN_NB; ++k) {
+    s += part[((int64_t)blockIdx.y * MN_NB + k) * 2];
+    ties += part[((int64_t)blockIdx.y * MN_NB + k) * 2 + 1];
+  }
+  const float corr = s / (m * m) / ties;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float g = input_grad_sum(gx, i) / m;
+    if (x[i] == m) g -= corr;
+    go[i] = g;
   }
 }
 
@@ -738,16 +832,37 @@ int nfs_maxnorm_fwd(const float* img, float* out, float* gmax, int G, int n, nfs
   NFS_REQUIRE(img && out && gmax, "nfs_maxnorm_fwd: null pointer");
   NFS_REQUIRE(G > 0 && n > 0, "nfs_maxnorm_fwd: non-positive size");
   if (n >= 16384) {
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gmax), (int)0xff800000, G, as_stream(stream)) != hipSuccess) {
-      set_error("nfs_maxnorm_fwd: memset failed");
-      return NFS_ELAUNCH;
-    }
+    hipLaunchKernelGGL(maxnorm_init_kernel, dim3((G + 63) / 64), dim3(64), 0, as_stream(stream), gmax, G);
     hipLaunchKernelGGL(maxnorm_max_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, n);
     hipLaunchKernelGGL(maxnorm_div_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, out, n);
     return check_launch("nfs_maxnorm_fwd(multi-block)");
   }
   hipLaunchKernelGGL(maxnorm_fwd_kernel, dim3(G), dim3(1024), 0, as_stream(stream), img, out, gmax, n);
   return check_launch("nfs_maxnorm_fwd");
+}
+
+int nfs_maxnorm_input_fwd(const float* img, float* x, float* gmax, int G, int n, nfs_stream_t stream) {
+  NFS_REQUIRE(img && x && gmax, "nfs_maxnorm_input_fwd: null pointer");
+  NFS_REQUIRE(G > 0 && n > 0, "nfs_maxnorm_input_fwd: non-positive size");
+  if (n < 16384) {
+    hipLaunchKernelGGL(maxnorm_input_small_kernel, dim3(G), dim3(1024), 0, as_stream(stream), img, gmax, x, n);
+    return check_launch("nfs_maxnorm_input_fwd");
+  }
+  hipLaunchKernelGGL(maxnorm_init_kernel, dim3((G + 63) / 64), dim3(64), 0, as_stream(stream), gmax, G);
+  hipLaunchKernelGGL(maxnorm_max_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, n);
+  hipLaunchKernelGGL(maxnorm_input_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, x, n);
+  return check_launch("nfs_maxnorm_input_fwd");
+}
+
+int nfs_maxnorm_input_bwd(const float* img, const float* gmax, const float* g_x, float* g_img, int G, int n,
+                          float* workspace, nfs_stream_t stream) {
+  NFS_REQUIRE(img && gmax && g_x && g_img && workspace, "nfs_maxnorm_input_bwd: null pointer");
+  NFS_REQUIRE(G > 0 && n > 0, "nfs_maxnorm_input_bwd: non-positive size");
+  hipLaunchKernelGGL(maxnorm_input_bwd_part_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, g_x,
+                     workspace, n);
+  hipLaunchKernelGGL(maxnorm_input_bwd_apply_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, g_x,
+                     workspace, g_img, n);
+  return check_launch("nfs_maxnorm_input_bwd");
 }
 
 int nfs_maxnorm_bwd(const float* img, const float* gmax, const float* g_out, float* g_img, int G, int n,

@@ -155,7 +155,7 @@ class RenderStyleLoss(object):
         return self.style_grams
 
     # -- forward only (rendered image, used for the final inference) ------------------------
-    def render(self, d, rot, keep_rotated=False):
+    def render(self, d, rot, keep_rotated=False, normalise=True):
         self.d_rot = None
         if self.rotate:
             if keep_rotated:
@@ -167,8 +167,10 @@ class RenderStyleLoss(object):
         V = img.shape[0]
         if self.liquid:
             norm = img
-        else:
+        elif normalise:
             norm, gmax = ops.maxnorm_fwd(img, max(V // self.v_batch, 1))
+        else:
+            norm = None                              # (the caller normalises: _chain's fused max-norm + loss-net input)
         return img, rs, norm, gmax
 
     def d_img(self, d, rot):
@@ -297,13 +299,21 @@ class RenderStyleLoss(object):
         """render -> loss net -> Gram losses -> full adjoint for the views ``rot`` on the CURRENT stream;
         g_d [D,H,W] += dL/dd (= with ``overwrite``, two-pass rotate adjoint only); returns the per-view losses"""
         D, H, W = d.shape
-        img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint)
+        H2, W2 = self.out_hw(H, W)
+        hist_in = any("input" in n for n in self.hist_layers)
+        # smoke render at the loss net's own size with nothing reading d_img: max-normalisation and the loss-net input
+        # in one pass each way (same arithmetic; two launches and the [V,H,W] intermediates less per direction)
+        fused_in = (not self.liquid and (H2, W2) == (H, W) and not (self.w_tv > 0 or hist_in)
+                    and os.environ.get("NFS_FUSE_INPUT", "1") != "0")
+        img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint, normalise=not fused_in)
         d_rot = self.d_rot
         self.d_rot = None
         V = img.shape[0]
-        H2, W2 = self.out_hw(H, W)
-        hist_in = any("input" in n for n in self.hist_layers)
-        dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
+        if fused_in:
+            dimg = None
+            x, gmax = ops.maxnorm_input_fwd(img, max(V // self.v_batch, 1))
+        else:
+            dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
         g_x, loss = self._vgg_loss_grad(x)
         if hist_in:
             self._hist_input(dimg, loss, g_x)
@@ -316,8 +326,11 @@ class RenderStyleLoss(object):
             tv = torch.zeros(1, dtype=torch.float32, device=d.device)
             ops.tv_loss(dimg, self.w_tv * V / self._batch_views(V), tv, g_x)
             loss = loss + tv / V
-        g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
-        g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
+        if fused_in:
+            g_img = ops.maxnorm_input_bwd(img, gmax, g_x)
+        else:
+            g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
+            g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
         if self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
@@ -700,6 +713,10 @@ class GridStylizer(object):
         self._apply_binding()
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)
+        elif self.pg is None:
+            losses, g_ds = self.field_gradient(rot_local)
+            total = None
+            total_new = losses.sum()                                         # (one kernel, a fresh tensor: no slot, no copy)
         else:
             losses, g_ds = self.field_gradient(rot_local)
             torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
@@ -709,7 +726,7 @@ class GridStylizer(object):
             # the 4*G^3-byte density gradient, not on the 12*G^3-byte velocity gradient: everything below it is
             # linear and replicated, so reducing early moves 3x fewer bytes over the links.
             parallel.all_reduce_sum_([self._gbuf], group=self.pg)
-        total = total[0].clone()
+        total = total[0].clone() if total is not None else total_new
         D, H, W = self.d0.shape
         if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)

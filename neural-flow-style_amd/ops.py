@@ -327,6 +327,26 @@ def maxnorm_bwd(img, gmax, g_out, g_img=None):
     return g_img
 
 
+def maxnorm_input_fwd(img, groups):
+    """img [V,H,W] (grey render) -> (x [V,H,W,3] = (img / max) * 255 - mean, gmax [groups]): nfs_maxnorm_fwd +
+    nfs_loss_net_input_fwd in one pass (loss net at the render's size)"""
+    V, H, W = img.shape
+    x = _empty((V, H, W, 3), img)
+    gmax = _empty((groups,), img)
+    _lib.call("nfs_maxnorm_input_fwd", _ptr(img), _ptr(x), _ptr(gmax), groups, img.numel() // groups, _stream())
+    return x, gmax
+
+
+def maxnorm_input_bwd(img, gmax, g_x):
+    """adjoint of maxnorm_input_fwd: g_x [V,H,W,3] -> g_img [V,H,W]"""
+    groups = gmax.numel()
+    g_img = _empty(img.shape, img)
+    ws = _empty((64 * groups,), img)
+    _lib.call("nfs_maxnorm_input_bwd", _ptr(img), _ptr(gmax), _ptr(g_x), _ptr(g_img), groups, img.numel() // groups,
+              _ptr(ws), _stream())
+    return g_img
+
+
 # ---- A5 -----------------------------------------------------------------------------
 
 def loss_net_input_fwd(img, H2=None, W2=None, want_d_img=True, want_x=True):

@@ -153,6 +153,6 @@ def test_particle_sequence_sharded_by_frames_reproduces_the_single_rank_run(tmp_
     np.testing.assert_allclose(b["l"], a["l"], rtol=2e-5)
     # (the splat adds with float atomics: the two runs agree to rounding, which TF-Adam's m / sqrt(v) amplifies a little)
     assert np.linalg.norm(b["opt"] - a["opt"]) <= 1e-4 * np.linalg.norm(a["opt"])
-    np.testing.assert_allclose(b["p"], a["p"], atol=1e-6)
+    np.testing.assert_allclose(b["p"], a["p"], atol=2e-5)      # (float-atomic splat sums -> rounding-level noise, Adam-amplified)
     np.testing.assert_allclose(b["d"], a["d"], rtol=1e-4, atol=1e-6)
     assert b["di"].shape == a["di"].shape

@@ -162,6 +162,34 @@ def test_graph_replay_equals_eager_steps():
         assert rel(a, b) < 1e-6
 
 
+def test_graph_replay_with_large_images_uses_no_memset_nodes():
+    """a captured step whose render is >= 16384 pixels per normalisation group (the multi-block max-normalisation with
+    its -inf initialisation and float atomics, fused with the loss-net input): the replayed trajectory must equal the
+    eager one -- as a memset NODE of the hipGraph that initialisation ran out of order with the atomics behind it"""
+    import neural_flow_style_amd.vgg as vgg
+    import neural_flow_style_amd.engine as eng
+    import neural_flow_style_amd.transform as T
+    rng = np.random.RandomState(3)
+    D, H = 8, 136
+    d0 = blob_density(H, rng)[H // 2 - D // 2: H // 2 + D // 2].copy()          # [8,136,136]
+    vel0 = (rng.randn(D, H, H, 3) * 0.3 / (H - 1)).astype(np.float32)
+    simg = style_image(H, H, rng)
+    layers = ["conv1_1", "conv2_1"]
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv2_1"), "cuda")
+    rot = T.rot_to_device(uniform_views(2), "cuda")
+    out = []
+    for graph in (False, True):
+        loss = eng.RenderStyleLoss(net, layers, [1.0, 1.0], 1.0, transmit=0.05)
+        loss.set_style_image(simg)
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3, graph=graph)
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(6)]
+        assert (gs._graph is not None) == graph
+        out.append((ls, gs.var.clone()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
+    assert rel(out[0][1], out[1][1]) < 1e-6
+
+
 @pytest.mark.parametrize("variant", ["channel", "all", "image", "content_only"])
 def test_gradient_parity_with_content_loss(variant):
     """the content term of _loss (styler_base.py:135-150) on a VGG layer, added to the style loss:

@@ -709,6 +709,30 @@ def test_hist_loss_matches_the_oracle_restatement():
         assert rel(g.cpu(), go) < 3e-2
 
 
+def test_maxnorm_input_fused_equals_the_two_step_form():
+    """nfs_maxnorm_input_fwd / _bwd (max-normalisation + loss-net input in one pass each way) against nfs_maxnorm_fwd +
+    nfs_loss_net_input_fwd and nfs_loss_net_input_bwd + nfs_maxnorm_bwd: the same arithmetic value for value, incl. a
+    tie at the maximum; one group per view and one group over all views"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(2)
+    V, H, W = 4, 150, 140
+    img = rng.rand(V, H, W).astype(np.float32)
+    img[1, 3, 5] = img[1, 70, 9] = 2.0                        # a tie at the maximum of view 1
+    g_x = rng.randn(V, H, W, 3).astype(np.float32)
+    it, gt = torch.tensor(img).cuda(), torch.tensor(g_x).cuda()
+    for groups in (V, 1, 2):
+        norm, gmax = ops.maxnorm_fwd(it, groups)
+        _, x_ref = ops.loss_net_input_fwd(norm.unsqueeze(-1), H, W, want_d_img=False)
+        g_norm = ops.loss_net_input_bwd(gt, H, W, 1).reshape(V, H, W)
+        gi_ref = ops.maxnorm_bwd(it, gmax, g_norm)
+        x, gmax2 = ops.maxnorm_input_fwd(it, groups)
+        gi = ops.maxnorm_input_bwd(it, gmax2, gt)
+        torch.cuda.synchronize()
+        # (the same operations; the compiler may contract a multiply-add in one form and not in the other: last-bit)
+        assert torch.equal(gmax, gmax2) and float((x - x_ref).abs().max()) <= 4e-5          # |x| <= 255: 2 ulp
+        assert rel(gi.cpu(), gi_ref.cpu()) < 1e-6
+
+
 def test_gram_style_group_equals_the_per_layer_chain():
     """nfs_gram_style_group_fwd + nfs_gram_group_bwd (all style layers in three launches, the style loss as per-block
     partial sums) against the per-layer entry points nfs_gram_fwd -> nfs_style_loss_fwd -> nfs_gram_bwd: slab layers,
