@@ -204,7 +204,10 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d,
  * d [V,D,H,W] (C=1), img [V,H,W]: smoke (liquid=0) I = sum_z d[z]*exp(-tau*sum_{z'>=z} d[z'])
  * (un-normalised; the global-max division is nfs_maxnorm_*), liquid=1: 1-exp(-tau*sum_z d).
  * raysum [V,H,W] = sum_z d is saved for the adjoint.  bwd overwrites g_d [V,D,H,W] (may alias d);
- * gmax_out (device, nullable, 4 bytes) receives max |g_d| for nfs_rotate_bwd's fixed-point scale. */
+ * gmax_out (device, nullable, 4 bytes) receives max |g_d| for nfs_rotate_bwd's fixed-point scale.
+ * `liquid` doubles as the ray mode: 2 = reduce_max along the ray (the line the reference keeps commented out,
+ * styler_3p.py:149; raysum then carries the maximum, its gradient is split equally among ties like TF's), 3 =
+ * reduce_mean (raysum = the sum); tau is ignored for both.  The fused rotate + render entry points take 0 / 1 only. */
 int nfs_render_fwd(const float* d, float* img, float* raysum,
                    int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream);
 int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d,

@@ -5,8 +5,11 @@ defaults, so a reference driver's ``config`` Namespace drops in.  ``get_config()
 
 Build-specific additions (not in the reference): ``--views_mode`` (``sequential`` = the reference's
 one-Adam-step-per-view loop, ``sum`` = gradient of the summed view losses, shardable over GPUs),
-``--grid_variable`` / ``--transport_recursive`` for the grid (TNST-style) path and ``--synthetic_weights`` (explicit
-opt-in to seeded synthetic VGG filters when no converted checkpoint exists).
+``--grid_variable`` / ``--transport_recursive`` for the grid (TNST-style) path, ``--synthetic_weights`` (explicit
+opt-in to seeded synthetic VGG filters when no converted checkpoint exists), ``--ray_mode`` (``max`` / ``mean``: the
+per-ray reductions north_star names beside the reference's transmittance / liquid integrals; '' follows
+``render_liquid``).  The reference's own ``--optimizer`` flag (config.py:78, default 'adam', the only value its code
+honours) additionally takes ``lbfgs`` here: limited-memory BFGS, north_star's other outer loop (engine.LBFGSState).
 """
 from __future__ import annotations
 
@@ -95,6 +98,7 @@ _FLAGS = [
     ("MI355X", "grid_variable", dict(type=str, default="", choices=["", "v", "d"])),
     ("MI355X", "synthetic_weights", dict(type=str2bool, default=False)),
     ("MI355X", "transport_recursive", dict(type=str2bool, default=True)),
+    ("MI355X", "ray_mode", dict(type=str, default="", choices=["", "transmit", "liquid", "max", "mean"])),
 ]
 
 
@@ -133,4 +137,7 @@ def complete(config):
         config.synthetic_weights = False
     if not hasattr(config, "transport_recursive"):
         config.transport_recursive = True
+    if not hasattr(config, "ray_mode"):
+        config.ray_mode = ""
+
     return config

@@ -19,6 +19,21 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(const float* __restrict
   const int v = (int)(gid / HW);
   const int px = (int)(gid - (int64_t)v * HW);
   const float* col = d + (int64_t)v * D * HW + px;
+  if (liquid >= 2) {
+    // ray modes of north_star beside the reference's two: 2 = reduce_max along the ray (the line the reference keeps
+    // commented out, styler_3p.py:149), 3 = reduce_mean.  One thread per ray, neighbouring threads on W: the reduction is
+    // a register loop over coalesced planes.  raysum carries what the adjoint needs: the maximum / the sum.
+    float m = -INFINITY, sum = 0.f;
+#pragma unroll 4
+    for (int z = 0; z < D; ++z) {
+      const float s = col[(int64_t)z * HW];
+      m = fmaxf(m, s);
+      sum += s;
+    }
+    img[gid] = liquid == 2 ? m : sum / (float)D;
+    if (raysum) raysum[gid] = liquid == 2 ? m : sum;
+    return;
+  }
   float acc = 0.f, I = 0.f;
   // T[z] = exp(-tau * sum_{z' >= z} d[z'])  (reverse cumsum incl. own cell, styler_3p.py:155)
 #pragma unroll 4
@@ -48,7 +63,22 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(const float* d,
     const float total = raysum[gid];
     const float g = g_img[gid];
     const float ntau = -tau * 1.44269504088896341f;                 // exp(-tau a) = exp2(ntau a)
-    if (liquid) {
+    if (liquid == 2) {
+      // reduce_max: the gradient goes to the cells that hold the maximum, split equally among ties (TF's rule); the
+      // column is read once to count them and once more as it is overwritten (g_d may be d itself)
+      float ties = 0.f;
+      for (int z = 0; z < D; ++z) ties += d[base + (int64_t)z * HW] == total ? 1.f : 0.f;
+      const float gd = g / ties;
+      for (int z = 0; z < D; ++z) {
+        const float sv = d[base + (int64_t)z * HW];
+        g_d[base + (int64_t)z * HW] = sv == total ? gd : 0.f;
+      }
+      amax = fabsf(gd);
+    } else if (liquid == 3) {
+      const float gd = g / (float)D;                                  // reduce_mean
+      for (int z = 0; z < D; ++z) g_d[base + (int64_t)z * HW] = gd;
+      amax = fabsf(gd);
+    } else if (liquid) {
       const float gd = g * tau * __builtin_amdgcn_exp2f(total * ntau);
       for (int z = 0; z < D; ++z) g_d[base + (int64_t)z * HW] = gd;
       amax = fabsf(gd);
@@ -708,6 +738,7 @@ int nfs_render_fwd(const float* d, float* img, float* raysum, int V, int D, int 
                    nfs_stream_t stream) {
   NFS_REQUIRE(d && img, "nfs_render_fwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_render_fwd: non-positive dimension");
+  NFS_REQUIRE(liquid >= 0 && liquid <= 3, "nfs_render_fwd: mode must be 0 (transmittance), 1 (liquid), 2 (max) or 3 (mean)");
   const int64_t n = (int64_t)V * H * W;
   hipLaunchKernelGGL(render_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, img, raysum, V, D,
                      H * W, tau, liquid);
@@ -778,6 +809,7 @@ int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, floa
     return NFS_ELAUNCH;
   }
   static const bool no_seg = getenv("NFS_RB_NOSEG") != nullptr;   // timing comparisons only
+  NFS_REQUIRE(liquid >= 0 && liquid <= 3, "nfs_render_bwd: mode must be 0 (transmittance), 1 (liquid), 2 (max) or 3 (mean)");
   if (!liquid && !no_seg && D >= 4 * RR_SEG && (int64_t)V * D * H * W <= ((int64_t)16 << 20)) {
     hipLaunchKernelGGL(render_bwd_seg_kernel, dim3(blocks_for(n, 64)), dim3(256), 0, as_stream(stream), d, raysum,
                        g_img, g_d, V, D, H * W, tau, reinterpret_cast<unsigned*>(gmax_out));
@@ -792,6 +824,7 @@ int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* r
                           int H, int W, float tau, int liquid, nfs_stream_t stream) {
   NFS_REQUIRE(d && rot && img, "nfs_rotate_render_fwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_rotate_render_fwd: non-positive dimension");
+  NFS_REQUIRE(liquid == 0 || liquid == 1, "nfs_rotate_render_fwd: ray modes 2 / 3 go through nfs_rotate_fwd + nfs_render_fwd");
   const int64_t n = (int64_t)V * H * W;
   static const bool no_seg = getenv("NFS_RR_NOSEG") != nullptr;   // timing comparisons only
   static const bool no_reuse = getenv("NFS_RR_NOREUSE") != nullptr;   // timing comparisons only
@@ -822,6 +855,7 @@ int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,
                           int V, int D, int H, int W, float tau, int liquid, nfs_stream_t stream) {
   NFS_REQUIRE(d && rot && raysum && g_img && g_d_acc, "nfs_rotate_render_bwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_rotate_render_bwd: non-positive dimension");
+  NFS_REQUIRE(liquid == 0 || liquid == 1, "nfs_rotate_render_bwd: ray modes 2 / 3 go through nfs_render_bwd + nfs_rotate_bwd");
   const int64_t n = (int64_t)V * H * W;
   hipLaunchKernelGGL(rotate_render_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, rot, raysum,
                      g_img, g_d_acc, V, D, H, W, tau, liquid);

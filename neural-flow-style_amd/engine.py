@@ -21,14 +21,20 @@ class RenderStyleLoss(object):
 
     def __init__(self, net, style_layer, w_style_layer, w_style=1.0, transmit=0.01, render_liquid=False,
                  resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1, w_content=0.0, content_layer=None,
-                 content_channel=0, w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=()):
+                 content_channel=0, w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=(), ray_mode=""):
         self.net = net
         self.layers = list(style_layer)
         self.w_layers = [float(w) for w in w_style_layer]
         assert len(self.layers) == len(self.w_layers)
         self.w_style = float(w_style)
         self.tau = float(transmit)
-        self.liquid = bool(render_liquid)
+        # ray integral: the reference's transmittance (smoke, max-normalised) / liquid forms, or -- north_star's "per-ray
+        # max / mean" -- reduce_max (the line the reference keeps commented out, styler_3p.py:149) / reduce_mean along the
+        # ray; like the liquid form these are not max-normalised
+        if ray_mode not in ("", None, "transmit", "liquid", "max", "mean"):
+            raise ValueError("ray_mode %r: '', 'transmit', 'liquid', 'max' or 'mean'" % (ray_mode,))
+        self.mode = {"max": 2, "mean": 3, "liquid": 1, "transmit": 0}.get(ray_mode or "", 1 if render_liquid else 0)
+        self.liquid = self.mode != 0                 # (no max-normalisation)
         self.resize_scale = float(resize_scale)
         self.rotate = bool(rotate)
         self.w_tv = float(w_tv)
@@ -160,9 +166,15 @@ class RenderStyleLoss(object):
         if self.rotate:
             if keep_rotated:
                 self.d_rot = torch.empty((rot.shape[0],) + tuple(d.shape), dtype=torch.float32, device=d.device)
-            img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.liquid, d_rot=self.d_rot)
+            if self.mode >= 2:                       # max / mean: rotate, then the ray reduction on the kept volume
+                self.d_rot = ops.rotate_fwd(d.unsqueeze(-1), rot).squeeze(-1)
+                img, rs = ops.render_fwd(self.d_rot, self.tau, self.mode)
+                if not keep_rotated:
+                    self.d_rot = None
+            else:
+                img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.mode, d_rot=self.d_rot)
         else:
-            img, rs = ops.render_fwd(d.unsqueeze(0), self.tau, self.liquid)
+            img, rs = ops.render_fwd(d.unsqueeze(0), self.tau, self.mode)
         gmax = None
         V = img.shape[0]
         if self.liquid:
@@ -334,12 +346,13 @@ class RenderStyleLoss(object):
         if self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
-            g_rot, g_max = ops.render_bwd(d_rot, rs, g_img, self.tau, self.liquid, g_d=d_rot, want_max=True)
+            g_rot, g_max = ops.render_bwd(d_rot, rs, g_img, self.tau, self.mode, g_d=d_rot, want_max=True)
             ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_d_acc=g_d.unsqueeze(-1), g_max=g_max, overwrite=overwrite)
         elif self.rotate:
-            ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.liquid, g_d_acc=g_d)
+            assert self.mode < 2, "the max / mean ray modes use the two-pass adjoint"
+            ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.mode, g_d_acc=g_d)
         else:
-            g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.liquid)[0])
+            g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.mode)[0])
         return loss
 
     def writes_gradient(self, V):
@@ -433,6 +446,62 @@ class TFAdamState(object):
                                  float(self.b2), float(self.eps))
 
 
+class LBFGSState(object):
+    """Limited-memory BFGS for the outer loop (north_star names L-BFGS beside Adam; the mounted reference only has Adam):
+    one quasi-Newton step per ``step(x, g, lr)`` from the gradient the HIP chain delivers -- two-loop recursion over the
+    last ``history`` (s, y) pairs, initial Hessian scale y.s / y.y, a pair kept only when y.s > 1e-10, fixed step
+    ``lr`` (the first step min(1, 1/|g|_1) lr), no line search: the arithmetic of ``torch.optim.LBFGS(lr, max_iter=1,
+    history_size=history, line_search_fn=None)`` called once per iteration, against which tests/test_optim_cpu.py holds
+    it.  Everything stays on the variable's device (elementwise torch kernels and reductions); same call surface as
+    ``TFAdamState.step``, so the stylizers take either."""
+
+    def __init__(self, history=10):
+        self.history = int(history)
+        self.n = 0
+        self.S, self.Y, self.ro = [], [], []
+        self.d = self.prev_g = None
+        self.t = None
+        self.H = 1.0
+
+    def step(self, x, g, lr):
+        g = g.reshape(-1)
+        self.n += 1
+        if self.n == 1:
+            d = g.neg()
+            self.H = 1.0
+        else:
+            y = g - self.prev_g
+            s_ = self.d * self.t
+            ys = float((y * s_).sum())
+            if ys > 1e-10:
+                if len(self.S) == self.history:
+                    self.S.pop(0); self.Y.pop(0); self.ro.pop(0)
+                self.S.append(s_); self.Y.append(y); self.ro.append(1.0 / ys)
+                self.H = ys / float((y * y).sum())
+            q = g.neg()
+            al = [0.0] * len(self.S)
+            for i in range(len(self.S) - 1, -1, -1):
+                al[i] = float((self.S[i] * q).sum()) * self.ro[i]
+                q.add_(self.Y[i], alpha=-al[i])
+            d = q.mul(self.H)
+            for i in range(len(self.S)):
+                be = float((self.Y[i] * d).sum()) * self.ro[i]
+                d.add_(self.S[i], alpha=al[i] - be)
+        self.prev_g = g.clone()
+        self.t = min(1.0, 1.0 / float(g.abs().sum())) * float(lr) if self.n == 1 else float(lr)
+        self.d = d
+        x.reshape(-1).add_(d, alpha=self.t)
+
+
+def make_optimizer(kind="adam"):
+    """one optimiser state per ``opt_id`` (styler_3p.py:315-323): TF ApplyAdam (the reference) or L-BFGS (config.optimizer)"""
+    if kind in (None, "", "adam"):
+        return TFAdamState()
+    if kind == "lbfgs":
+        return LBFGSState()
+    raise ValueError("optimizer %r: 'adam' or 'lbfgs'" % (kind,))
+
+
 class GridStylizer(object):
     """TNST-style grid path assembled from the reference's operators:
         d^ = advect(d0, vel)  ->  smooth+max  ->  RenderStyleLoss
@@ -446,15 +515,16 @@ class GridStylizer(object):
     ``bind`` swaps the frame (density, variable, Adam state) under the same
     stylizer: the frame loop of a sequence (styler_grid.py) re-uses one instance."""
 
-    def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None, graph=None):
+    def __init__(self, loss, d0, k=3, target="v", lr=0.1, process_group=None, graph=None, optimizer="adam"):
         self.loss = loss
         self.d0 = d0.contiguous()
         self.k = float(k)
         self.target = target
         self.lr = float(lr)
         self.pg = process_group
-        self.adam = TFAdamState()
-        self.fuse_adam = os.environ.get("NFS_FUSE_ADAM", "1") != "0"
+        self.adam = make_optimizer(optimizer)        # (named after the reference's optimiser; L-BFGS on request)
+        # the advect adjoint consumed inside the Adam kernel: only when the optimiser IS Adam
+        self.fuse_adam = os.environ.get("NFS_FUSE_ADAM", "1") != "0" and isinstance(self.adam, TFAdamState)
         # hipGraph replay of the forward + adjoint (about 130 launches a step; the host needs 1.25 ms to issue
         # them one by one, which is the whole step at one view per rank)
         # (measured: 200^3 x 8 views 3.98 -> 3.90 ms, 200^3 x 1 view 1.35 -> 1.41 ms, 100^3 x 1 view 1.20 -> 1.06 ms:
@@ -598,6 +668,7 @@ class GridStylizer(object):
         self._pending = (d0, var)
         if adam is not None:
             self.adam = adam
+            self.fuse_adam = self.fuse_adam and isinstance(adam, TFAdamState)
 
     def _apply_binding(self):
         if self._pending is None:
@@ -661,7 +732,7 @@ class GridStylizer(object):
         L = self.loss
         grams = tuple(int(t.data_ptr()) for t in (L.style_grams or {}).values())
         cf = getattr(L, "content_feature", None)
-        hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "liquid", "resize_scale", "rotate", "w_tv",
+        hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "mode", "resize_scale", "rotate", "w_tv",
                                                     "v_batch", "w_content", "content_layer", "content_channel",
                                                     "w_content_amp"))
         # histogram term: template tensors by address, its weights and layer list by value

@@ -99,7 +99,7 @@ class Styler(StylerBase):
                     var = g_opt[t].clone().requires_grad_(True)
                     opt_id = t // self.frames_per_opt
                     if opt_id not in opt_:
-                        opt_[opt_id] = engine.TFAdamState()
+                        opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                     d, _ = self._colour(p[t], r[t], var, res)
                     with torch.no_grad():
                         d_gray = self._density(p[t], res)

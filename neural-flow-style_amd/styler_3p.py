@@ -246,7 +246,7 @@ class Styler(StylerBase):
                     var = g_opt[t].clone()                       # variable re-assigned from g_opt (312)
                     opt_id = t // self.frames_per_opt
                     if opt_id not in opt_:
-                        opt_[opt_id] = engine.TFAdamState()
+                        opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                     adam = opt_[opt_id]
 
                     if self.rotate and mode == "sequential":

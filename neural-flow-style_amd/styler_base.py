@@ -68,7 +68,7 @@ class StylerBase(object):
             w_content=getattr(self, "w_content", 0), content_layer=getattr(self, "content_layer", None),
             content_channel=getattr(self, "content_channel", 0), w_content_amp=getattr(self, "w_content_amp", 100),
             w_hist=getattr(self, "w_hist", 0), hist_layer=getattr(self, "hist_layer", ()),
-            w_hist_layer=getattr(self, "w_hist_layer", ()))
+            w_hist_layer=getattr(self, "w_hist_layer", ()), ray_mode=getattr(self, "ray_mode", ""))
 
     # -- _hist_feature (styler_base.py:280-309): the style image at the loss-net input size -------------------------
     def _hist_feature(self, style_target, style_shp=None):

@@ -202,7 +202,8 @@ class Styler(StylerBase):
         # (a rank beyond the number of optimiser groups owns no frame: it only takes part in the collectives)
         first = st.d[st.mine[0]] if st.mine else (next(iter(st.d.values())) if st.d else
                                                   torch.zeros(tuple(self.resolution), device=self.device))
-        st.gs = engine.GridStylizer(self.loss, first, k=self.k, target=self.target, lr=st.lr)
+        st.gs = engine.GridStylizer(self.loss, first, k=self.k, target=self.target, lr=st.lr,
+                                    optimizer=getattr(self, "optimizer", "adam"))
         st.opt_ = {}
         st.hist = []
         return st
@@ -227,7 +228,9 @@ class Styler(StylerBase):
         upd = {}
         for j, t in enumerate(st.keys):
             if st.owner[t] == st.rank:
-                adam = st.opt_.setdefault(t // self.frames_per_opt, engine.TFAdamState())
+                adam = st.opt_.get(t // self.frames_per_opt)
+                if adam is None:
+                    adam = st.opt_[t // self.frames_per_opt] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                 st.work.copy_(st.g_opt[t])
                 st.gs.bind(st.d[t], st.work.view(D, H, W_, 3) if self.target == "v" else st.work.view(D, H, W_), adam)
                 losses[j] = st.gs.step(self._rot())

@@ -349,7 +349,14 @@ def render(d, transmit, liquid=False):
     (156-157); I /= max over the WHOLE tensor (158, gradient flows through
     the max, ties split equally as TF's reduce_max gradient does).
     liquid: 1 - exp(-tau * sum_z d) (150-152).
+    ``liquid`` = 'max' / 'mean' (north_star's ray modes; not in the mounted reference beyond the commented-out
+    ``d = tf.reduce_max(d, axis=1)`` of line 149): reduce_max / reduce_mean along the ray, un-normalised like the liquid
+    form; torch's amax splits its gradient equally among ties, as TF's reduce_max does.
     """
+    if liquid == "max":
+        return d.amax(dim=1)
+    if liquid == "mean":
+        return d.mean(dim=1)
     if liquid:
         tr = torch.exp(-torch.cumsum(d.flip(1), dim=1) * transmit)
         return 1 - tr[:, -1]
@@ -826,7 +833,7 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
     per_view = []
     for v in range(rot.shape[0]):
         dr = rotate(d_out, rot[v:v + 1]) if cfg.get("rotate", True) else d_out
-        img = render(dr, cfg["transmit"], cfg.get("render_liquid", False))
+        img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
         feats = vgg19_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"])
         l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
@@ -896,7 +903,7 @@ def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
     total = 0
     for v in range(rot.shape[0]):
         dr = rotate(d_out, rot[v:v + 1]) if cfg["rotate"] else d_out
-        img = render(dr, cfg["transmit"], cfg.get("render_liquid", False))
+        img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
         use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
         feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] +

@@ -89,7 +89,7 @@ def test_config_surface_matches_the_reference_defaults():
         assert k in mine, k
         got = mine[k]
         assert (list(got) if isinstance(got, (list, tuple)) else got) == v, (k, got, v)
-    assert set(mine) - set(ref) == {"views_mode", "grid_variable", "synthetic_weights", "transport_recursive"}
+    assert set(mine) - set(ref) == {"views_mode", "grid_variable", "synthetic_weights", "transport_recursive", "ray_mode"}
 
 
 def test_product_library_has_no_wrong_result_ablation_switches():

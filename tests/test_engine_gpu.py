@@ -162,6 +162,32 @@ def test_graph_replay_equals_eager_steps():
         assert rel(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["max", "mean"])
+def test_gradient_parity_with_max_and_mean_ray_modes(mode):
+    """north_star's per-ray max / mean render (reduce_max -- the line the reference keeps commented out, styler_3p.py:149
+    -- and reduce_mean along the ray, un-normalised) through the whole chain: rotate -> ray reduction -> VGG -> Gram
+    losses and the adjoint back to the velocity variable, vs the oracle; the max gradient goes to the arg-max cells"""
+    G, V = 24, 3
+    layers = ["conv1_1", "conv2_1", "conv3_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(G, V, layers)
+    loss = eng.RenderStyleLoss(loss.net, layers, [1.0] * 3, 1.0, transmit=cfg["transmit"], ray_mode=mode)
+    simg = style_image(G, G, np.random.RandomState(123 + 1))
+    loss.set_style_image(simg)
+    sfe = O.style_target_features(torch.tensor(simg)[None], w_or, layers, upto=cfg["upto"])
+    cfg = dict(cfg, ray_mode=mode)
+    d0_o = torch.tensor(d0)[None, ..., None]
+    vel_o = torch.tensor(vel0)[None].requires_grad_()
+    total, per_view, _ = O.grid_forward(d0_o, vel_o, torch.tensor(np.asarray(mats, np.float32)), cfg, w_or, sfe)
+    (g_o,) = torch.autograd.grad(total, vel_o)
+    gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v")
+    gs.var.copy_(torch.tensor(vel0))
+    losses, g_h = gs.gradient(T.rot_to_device(mats, "cuda"))
+    assert rel(losses, torch.stack(per_view)) < 1e-4
+    assert rel(g_h, g_o[0]) < 1e-3
+    # and the step runs (two-pass adjoint on the kept rotated volume)
+    assert np.isfinite(float(gs.step(T.rot_to_device(mats, "cuda"))))
+
+
 def test_graph_replay_with_large_images_uses_no_memset_nodes():
     """a captured step whose render is >= 16384 pixels per normalisation group (the multi-block max-normalisation with
     its -inf initialisation and float atomics, fused with the loss-net input): the replayed trajectory must equal the
@@ -482,3 +508,31 @@ def test_slab_sharded_field_work_reproduces_the_single_rank_trajectory(tmp_path,
     # variables; with three the collectives may add the ranks in different orders
     if world == 2:
         assert np.array_equal(b["var"], c["var"])
+
+
+def test_grid_stylizer_with_lbfgs_decreases_the_loss_and_matches_a_host_replay():
+    """config.optimizer = 'lbfgs' (north_star's other outer loop): GridStylizer drives engine.LBFGSState with the
+    gradient of the HIP chain; the trajectory equals a replay of the same gradients through torch.optim.LBFGS and the
+    loss goes down"""
+    layers = ["conv1_1", "conv2_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 2, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=2e-4, optimizer="lbfgs")
+    assert isinstance(gs.adam, eng.LBFGSState) and not gs.fuse_adam
+    gs.var.copy_(torch.tensor(vel0))
+    ref = torch.tensor(vel0).cuda().clone().requires_grad_()
+    opt = torch.optim.LBFGS([ref], lr=2e-4, max_iter=1, history_size=10, tolerance_grad=0.0, tolerance_change=0.0)
+    ls = []
+    for _ in range(6):
+        x_before = gs.var.clone()
+        _, g = gs.gradient(rot)
+        g = g.clone()
+
+        def closure():
+            ref.grad = g.clone()
+            return torch.zeros((), device="cuda")
+        assert rel(ref.detach(), x_before) < 1e-6
+        opt.step(closure)
+        ls.append(float(gs.step(rot)))
+        assert rel(gs.var, ref.detach()) < 1e-5
+    assert ls[-1] < ls[0]

@@ -709,6 +709,32 @@ def test_hist_loss_matches_the_oracle_restatement():
         assert rel(g.cpu(), go) < 3e-2
 
 
+def test_render_max_and_mean_ray_modes():
+    """nfs_render_fwd / _bwd with mode 2 (reduce_max along the ray, gradient split equally among ties like TF's) and 3
+    (reduce_mean) against autograd, in place on the volume as the engine calls them"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(8)
+    V, D, H, W = 2, 9, 7, 6
+    d = rng.rand(V, D, H, W).astype(np.float32)
+    d[0, 2, 3, 4] = d[0, 7, 3, 4] = 1.5                      # a two-way tie at the maximum of one ray
+    g = rng.randn(V, H, W).astype(np.float32)
+    for mode, fn in ((2, lambda x: x.amax(dim=1)), (3, lambda x: x.mean(dim=1))):
+        dt = torch.tensor(d, requires_grad=True)
+        want = fn(dt)
+        (gd_ref,) = torch.autograd.grad((want * torch.tensor(g)).sum(), dt)
+        dv = torch.tensor(d).cuda()
+        img, rs = ops.render_fwd(dv, 0.3, mode)
+        assert rel(img.cpu(), want.detach()) < 1e-6
+        gd, gmax = ops.render_bwd(dv, rs, torch.tensor(g).cuda(), 0.3, mode, g_d=dv, want_max=True)     # in place
+        assert rel(gd.cpu(), gd_ref) < 1e-6
+        assert abs(float(gmax) - float(gd_ref.abs().max())) < 1e-6
+    assert float(gd_ref.sum()) != 0.0
+    dv = torch.tensor(d).cuda()
+    _, rs = ops.render_fwd(dv, 0.3, 2)
+    gd = ops.render_bwd(dv, rs, torch.tensor(g).cuda(), 0.3, 2)
+    assert float(gd[0, 2, 3, 4]) == float(gd[0, 7, 3, 4]) == 0.5 * g[0, 3, 4]
+
+
 def test_maxnorm_input_fused_equals_the_two_step_form():
     """nfs_maxnorm_input_fwd / _bwd (max-normalisation + loss-net input in one pass each way) against nfs_maxnorm_fwd +
     nfs_loss_net_input_fwd and nfs_loss_net_input_bwd + nfs_maxnorm_bwd: the same arithmetic value for value, incl. a
