@@ -375,6 +375,55 @@ int nfs_gram_group_bwd(const nfs_gram_layer_t* layers, int n, nfs_stream_t strea
  *   mode 2: mean((F - amp * target[b % Bt])^2)         (content image; target [Bt,HW,C], amp = w_content_amp) */
 int nfs_content_loss(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt,
                      int HW, int C, int channel, int mode, float weight, float amp, nfs_stream_t stream);
+/* the same term on a tensor that is NOT a ReLU output (the Inception graph's '*_pre_relu' content layers of
+ * run.bat:14-20): |F| with d|F| = sign(F), and the gradient is wrt F itself (no ReLU mask) */
+int nfs_content_loss_signed(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt,
+                            int HW, int C, int channel, int mode, float weight, float amp, nfs_stream_t stream);
+
+/* ---- the Inception-v1 loss network (styler_base.py:17-23, 51-57, 91-94) ------------
+ * The reference imports ``tensorflow_inception_graph.pb`` with tf.import_graph_def and reads feature tensors by
+ * node name ('conv2d2', 'mixed3b', 'mixed4b_pool_reduce_pre_relu' ...: test_smokegun.py:141, run.bat:14-20).  These
+ * are the node types of that graph between its input and its feature tensors; neural-flow-style_amd/inception.py
+ * assembles them under the graph's own node names.  All tensors NHWC float32, TF SAME padding
+ * (out = ceil(in / stride), pad_before = max((out - 1) stride + k - in, 0) / 2).  "ld*" = floats per pixel of the
+ * buffer a pointer points INTO: operands may be channel ranges of wider rows, so that the branches of an inception
+ * module write straight into the module's concatenated output (ConcatV2 never runs).
+ *
+ * nfs_conv2d_pack: HWIO filters [kh,kw,Ci,Co] -> the layout nfs_conv2d_fwd reads (opaque,
+ *   nfs_conv2d_packed_floats floats).  transpose = 1 packs the DATA-GRADIENT filters of a stride-1 convolution (taps
+ *   flipped, channels swapped): its data gradient is nfs_conv2d_fwd(gy, ..., Cin = Co, Cout = Ci).
+ * nfs_conv2d_fwd: Conv2D (+ BiasAdd, + Relu).  y[b,oy,ox,n] (+)= relu(bias[n] + sum x'[b,oy s+dy-pt,ox s+dx-pl,c] w),
+ *   x' = x * (x_mask > 0) when x_mask is given (the ReLU adjoint applied while a gradient is consumed; x_mask has the
+ *   indexing of x with row stride ldm).  y_pre (nullable) receives the value before the ReLU (the graph's
+ *   '*_pre_relu' tensors).  accumulate: y += (branch gradients meeting at a module input).  Cin <= 4 (the image) or
+ *   a multiple of 4; Cout, ld* multiples of 4; filters up to 7x7; stride 1 or 2.
+ * nfs_conv2d_dgrad_small: data gradient of a convolution with <= 4 input channels (the 7x7 stride-2 first layer, down
+ *   to the image): gx [B,H,W,Ci] = sum gy (y_act > 0) w, w_hwio unpacked; y_act nullable.
+ * nfs_maxpool3_fwd/bwd: MaxPool 3x3, stride 1 or 2, SAME (padding taps do not take part).  arg [B,Ho,Wo,C] bytes =
+ *   window position (0..8 row-major) of the FIRST maximum (TF's CPU kernel; ties only matter at exact equality, and
+ *   zero ties after a ReLU carry no gradient past that ReLU).  C = floats per pixel (multiple of 4).
+ * nfs_lrn_fwd/bwd: tf.nn.lrn, y = x / (bias + alpha sum_{|j-c| <= radius} x_j^2)^beta; scale = the bracket, kept
+ *   for the adjoint.  C channels in rows of ld floats.
+ * nfs_relu_mask_add: out = g (act > 0) + addend (each of g / act / addend nullable): a gradient injected at a
+ *   '*_pre_relu' tensor joins the chain after the ReLU adjoint. */
+int64_t nfs_conv2d_packed_floats(int kh, int kw, int Ci, int Co, int transpose);
+int nfs_conv2d_pack(const float* w_hwio, float* packed, int kh, int kw, int Ci, int Co, int transpose,
+                    nfs_stream_t stream);
+int nfs_conv2d_fwd(const float* x, int ldx, const float* x_mask, int ldm, const float* packed, const float* bias,
+                   float* y, int ldy, float* y_pre, int ldp, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                   int stride, int relu, int accumulate, nfs_stream_t stream);
+int nfs_conv2d_dgrad_small(const float* gy, int ldg, const float* y_act, int lda, const float* w_hwio, float* gx,
+                           int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, nfs_stream_t stream);
+int nfs_maxpool3_fwd(const float* x, float* y, uint8_t* arg, int B, int H, int W, int C, int stride,
+                     nfs_stream_t stream);
+int nfs_maxpool3_bwd(const float* gy, const uint8_t* arg, float* gx, int B, int H, int W, int C, int stride,
+                     int accumulate, nfs_stream_t stream);
+int nfs_lrn_fwd(const float* x, float* y, float* scale, int64_t npix, int C, int ld, int radius, float bias,
+                float alpha, float beta, nfs_stream_t stream);
+int nfs_lrn_bwd(const float* x, const float* y, const float* scale, const float* gy, float* gx, int64_t npix, int C,
+                int ld, int radius, float alpha, float beta, int accumulate, nfs_stream_t stream);
+int nfs_relu_mask_add(const float* g, int ldg, const float* act, int lda, const float* addend, int ldadd, float* out,
+                      int ldo, int64_t npix, int C, nfs_stream_t stream);
 
 /* ---- A12: TV loss (styler_base.py:211-213) --------------------------------------------
  * loss_acc[0] += weight * mean_b(sum|dh| + sum|dw|) on d_img [B,H,W,3]; g_acc (nullable) +=. */

@@ -87,9 +87,19 @@ SIGNATURES = {
     "nfs_gram_fwd": [_P, _P, _I, _I, _I, _P, _F, _P, _L, _P],
     "nfs_style_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "nfs_content_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+    "nfs_content_loss_signed": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "nfs_gram_bwd": [_P, _P, _P, _I, _I, _I, _P, _F, _I, _P],
     "nfs_hist_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "nfs_conv3x3_executed_flops": [_I, _I, _I, _I, _I, _I],
+    "nfs_conv2d_packed_floats": [_I, _I, _I, _I, _I],
+    "nfs_conv2d_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_conv2d_fwd": [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_conv2d_dgrad_small": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_maxpool3_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_maxpool3_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_lrn_fwd": [_P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P],
+    "nfs_lrn_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _I, _P],
+    "nfs_relu_mask_add": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P],
     "nfs_gram_style_group_workspace_floats": [_P, _I],
     "nfs_gram_style_group_parts": [_P, _I],
     "nfs_gram_style_group_fwd": [_P, _I, _P, _P, _L, _P],
@@ -111,7 +121,7 @@ SIGNATURES = {
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
             "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64,
-            "nfs_conv3x3_executed_flops": C.c_double}
+            "nfs_conv3x3_executed_flops": C.c_double, "nfs_conv2d_packed_floats": C.c_int64}
 
 _lib = None
 

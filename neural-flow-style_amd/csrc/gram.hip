@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256) style_loss_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) content_loss_kernel(const float* __restrict__ F, const float* __restrict__ target,
                                                            float* __restrict__ loss, float* __restrict__ g_acc,
                                                            int B, int Bt, int64_t HWC, int C, int channel, int mode,
-                                                           float weight, float amp) {
+                                                           float weight, float amp, int signed_f) {
   __shared__ float red[16];
   const int b = blockIdx.y;
   const float n_all = (float)B * (float)HWC;
@@ -370,8 +370,13 @@ __global__ void __launch_bounds__(256) content_loss_kernel(const float* __restri
     if (mode == 0) {
       const int ch = (int)(e % C);
       const float k = ch == channel ? c_on : (ch < channel ? c_lo : c_hi);
-      l = k * f;                                   // f >= 0 (post-ReLU): |f| = f
-      g = k;
+      if (ch == channel || !signed_f) {
+        l = k * f;                                 // post-ReLU (f >= 0): |f| = f
+        g = k;
+      } else {                                     // a tensor that is not a ReLU output: |f|, d|f| = sign(f) (0 at 0, as TF)
+        l = k * fabsf(f);
+        g = f > 0.f ? k : (f < 0.f ? -k : 0.f);
+      }
     } else if (mode == 1) {
       l = -weight / n_all * f;
       g = -weight / n_all;
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(256) content_loss_kernel(const float* __restri
       g = 2.f * weight / n_all * diff;
     }
     part += l;
-    if (f > 0.f) g_acc[i] += g;
+    if (signed_f || f > 0.f) g_acc[i] += g;        // post-ReLU: the gradient wrt the pre-activation
   }
   part = block_sum(part, red);
   if (threadIdx.x == 0) atomicAdd(loss + b, part);
@@ -577,18 +582,31 @@ int nfs_style_loss_fwd(const float* G, const float* Gs, float* loss_acc, float* 
   return check_launch("nfs_style_loss_fwd");
 }
 
-int nfs_content_loss(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt, int HW, int C,
-                     int channel, int mode, float weight, float amp, nfs_stream_t stream) {
-  NFS_REQUIRE(F && loss_acc && g_acc, "nfs_content_loss: null pointer");
-  NFS_REQUIRE(B > 0 && HW > 0 && C > 0, "nfs_content_loss: non-positive dimension");
-  NFS_REQUIRE(mode >= 0 && mode <= 2, "nfs_content_loss: mode must be 0 (channel), 1 (all) or 2 (target)");
-  NFS_REQUIRE(mode != 0 || (channel > 0 && channel < C), "nfs_content_loss: channel out of range");
-  NFS_REQUIRE(mode != 2 || (target && Bt > 0), "nfs_content_loss: mode 2 needs the target features");
+static int content_loss_launch(const char* who, const float* F, const float* target, float* loss_acc, float* g_acc, int B,
+                               int Bt, int HW, int C, int channel, int mode, float weight, float amp, int signed_f,
+                               nfs_stream_t stream) {
+  NFS_REQUIRE(F && loss_acc && g_acc, "%s: null pointer", who);
+  NFS_REQUIRE(B > 0 && HW > 0 && C > 0, "%s: non-positive dimension", who);
+  NFS_REQUIRE(mode >= 0 && mode <= 2, "%s: mode must be 0 (channel), 1 (all) or 2 (target)", who);
+  NFS_REQUIRE(mode != 0 || (channel > 0 && channel < C), "%s: channel out of range", who);
+  NFS_REQUIRE(mode != 2 || (target && Bt > 0), "%s: mode 2 needs the target features", who);
   const int64_t HWC = (int64_t)HW * C;
   const unsigned nb = blocks_for(HWC, 256) < 64u ? blocks_for(HWC, 256) : 64u;
   hipLaunchKernelGGL(content_loss_kernel, dim3(nb, B), dim3(256), 0, as_stream(stream), F, target, loss_acc, g_acc, B,
-                     Bt > 0 ? Bt : 1, HWC, C, channel, mode, weight, amp);
-  return check_launch("nfs_content_loss");
+                     Bt > 0 ? Bt : 1, HWC, C, channel, mode, weight, amp, signed_f);
+  return check_launch(who);
+}
+
+int nfs_content_loss(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt, int HW, int C,
+                     int channel, int mode, float weight, float amp, nfs_stream_t stream) {
+  return content_loss_launch("nfs_content_loss", F, target, loss_acc, g_acc, B, Bt, HW, C, channel, mode, weight, amp, 0,
+                             stream);
+}
+
+int nfs_content_loss_signed(const float* F, const float* target, float* loss_acc, float* g_acc, int B, int Bt, int HW,
+                            int C, int channel, int mode, float weight, float amp, nfs_stream_t stream) {
+  return content_loss_launch("nfs_content_loss_signed", F, target, loss_acc, g_acc, B, Bt, HW, C, channel, mode, weight,
+                             amp, 1, stream);
 }
 
 int nfs_gram_bwd(const float* F, const float* Dmat, float* dF, int B, int HW, int C, const float* scale_dev,

@@ -15,6 +15,34 @@ import torch
 from . import ops, parallel
 
 
+def _channels(acts, name, F):
+    """logical channel count of a loss-network tensor: Inception module outputs come in rows padded to a multiple of 64
+    floats (``acts.channels``); VGG activations are what their shape says"""
+    ch = getattr(acts, "channels", None)
+    return int(ch[name]) if ch is not None and name in ch else int(F.shape[-1])
+
+
+def _post_relu(name):
+    """True for tensors that are ReLU outputs (or pools / concatenations of them): a gradient injected there may carry
+    the ReLU mask.  The Inception graph's '*_pre_relu' tensors are not."""
+    return not name.endswith("_pre_relu")
+
+
+def _logical(acts, name):
+    """(contiguous tensor of the logical channels, padded?)"""
+    F = acts[name]
+    c = _channels(acts, name, F)
+    return (F, False) if c == F.shape[-1] else (F[..., :c].contiguous(), True)
+
+
+def _add_logical(sg, name, F, g_log):
+    """add a gradient over the logical channels into the (padded) entry of the adjoint chain"""
+    g = sg.get(name)
+    if g is None:
+        g = sg[name] = torch.zeros_like(F)
+    g[..., :g_log.shape[-1]].add_(g_log)
+
+
 class RenderStyleLoss(object):
     """loss(d) = w_style * sum_v sum_l w_l * || G_l(vgg(render(rotate(d, R_v)))) - G_l^style ||^2
     (+ w_tv * TV).  ``loss_and_grad`` returns the per-view losses and ADDS dL/dd to ``g_d``."""
@@ -23,8 +51,10 @@ class RenderStyleLoss(object):
                  resize_scale=1.0, rotate=True, w_tv=0.0, v_batch=1, w_content=0.0, content_layer=None,
                  content_channel=0, w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=(), ray_mode=""):
         self.net = net
-        self.layers = list(style_layer)
-        self.w_layers = [float(w) for w in w_style_layer]
+        # styler_base.py:152: the style term exists only with w_style != 0 (the semantic-transfer runs of run.bat:14-20
+        # have w_style 0, the flag default, and no style image)
+        self.layers = list(style_layer) if float(w_style) else []
+        self.w_layers = [float(w) for w in w_style_layer][:len(self.layers)] if self.layers else []
         assert len(self.layers) == len(self.w_layers)
         self.w_style = float(w_style)
         self.tau = float(transmit)
@@ -34,7 +64,6 @@ class RenderStyleLoss(object):
         if ray_mode not in ("", None, "transmit", "liquid", "max", "mean"):
             raise ValueError("ray_mode %r: '', 'transmit', 'liquid', 'max' or 'mean'" % (ray_mode,))
         self.mode = {"max": 2, "mean": 3, "liquid": 1, "transmit": 0}.get(ray_mode or "", 1 if render_liquid else 0)
-        self.liquid = self.mode != 0                 # (no max-normalisation)
         self.resize_scale = float(resize_scale)
         self.rotate = bool(rotate)
         self.w_tv = float(w_tv)
@@ -77,8 +106,24 @@ class RenderStyleLoss(object):
                 raise KeyError("hist_layer %r is not a layer of the loss network" % (name,))
         self.hist_targets = None
         vgg_hist = [n for n in self.hist_layers if "input" not in n]
-        self.top = max(self.layers + vgg_hist + ([self.content_layer] if self.content_layer else []), key=order.index)
+        wanted = self.layers + vgg_hist + ([self.content_layer] if self.content_layer else [])
+        if not wanted:
+            raise ValueError("no loss term reaches the loss network: w_style 0 (or no style layer) and no content / "
+                             "histogram layer")
+        for n in wanted:
+            if n not in order:
+                raise KeyError("%r is not a tensor of the loss network" % (n,))
+        self.top = max(wanted, key=order.index)
         self.style_grams = None
+
+    @property
+    def liquid(self):
+        """True for every ray integral that is not max-normalised (all but the transmittance form)"""
+        return self.mode != 0
+
+    @liquid.setter
+    def liquid(self, on):
+        self.mode = (1 if on else 0) if self.mode < 2 else self.mode
 
     def set_hist_image(self, style_img):
         """template features of the histogram term: style_img float32 [h,w,3] in 0..255 at the loss-net input size
@@ -94,7 +139,7 @@ class RenderStyleLoss(object):
         if vgg_hist:
             order = [q[0] for q in self.net.seq]
             acts = self.net.forward((s - mean).unsqueeze(0).contiguous(), max(vgg_hist, key=order.index))
-        self.hist_targets = {n: (s.unsqueeze(0).contiguous() if "input" in n else acts[n].clone())
+        self.hist_targets = {n: (s.unsqueeze(0).contiguous() if "input" in n else _logical(acts, n)[0].clone())
                              for n in self.hist_layers}
         return self.hist_targets
 
@@ -112,12 +157,17 @@ class RenderStyleLoss(object):
             if "input" in name:
                 continue
             assert self.hist_targets is not None, "call set_hist_image first"
-            F = acts[name]
-            g = sg.get(name)
-            if g is None:
-                g = sg[name] = torch.zeros_like(F)
+            F, padded = _logical(acts, name)
             m = None if d_gray is None else ops.resize_bicubic_tf1(d_gray.contiguous(), F.shape[1], F.shape[2])
-            ops.hist_loss(F, self.hist_targets[name], wl * self.w_hist, loss, g, relu_mask=True, mask=m)
+            if padded:
+                g = torch.zeros_like(F)
+            else:
+                g = sg.get(name)
+                if g is None:
+                    g = sg[name] = torch.zeros_like(F)
+            ops.hist_loss(F, self.hist_targets[name], wl * self.w_hist, loss, g, relu_mask=_post_relu(name), mask=m)
+            if padded:
+                _add_logical(sg, name, acts[name], g)
 
     def _hist_input(self, dimg, loss, g_x, d_gray=None):
         """hist_layer 'input': the term on d_img itself (gradient wrt d_img = gradient wrt the mean-subtracted x)"""
@@ -136,7 +186,7 @@ class RenderStyleLoss(object):
         s = torch.as_tensor(np.asarray(content_img, np.float32)).to(dev)
         mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255], dtype=torch.float32, device=dev)
         acts = self.net.forward((s - mean).unsqueeze(0).contiguous(), self.content_layer)
-        self.content_feature = acts[self.content_layer].clone()
+        self.content_feature = _logical(acts, self.content_layer)[0].clone()
         return self.content_feature
 
     # -- style targets (styler_base.py:249-278: the style image enters at d_img) -------------
@@ -156,8 +206,8 @@ class RenderStyleLoss(object):
         self.style_grams = {}
         for name in self.layers:
             F = acts[name]
-            _, h, w, c = F.shape
-            self.style_grams[name] = ops.gram_fwd(F, 1.0 / (2.0 * h * w * c))
+            _, h, w, _ = F.shape
+            self.style_grams[name] = ops.gram_fwd(F, 1.0 / (2.0 * h * w * _channels(acts, name, F)))
         return self.style_grams
 
     # -- forward only (rendered image, used for the final inference) ------------------------
@@ -193,19 +243,19 @@ class RenderStyleLoss(object):
         dimg, _ = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_x=False)
         return dimg
 
-    def _gram_job(self, name, F, loss, unmasked=None):
+    def _gram_job(self, name, F, loss, unmasked=None, channels=None):
         """Gram matrix, style loss and the Gram gradient dF of one style layer.  dF carries the layer's ReLU mask unless
         the data gradient that will add it applies that mask anyway (then the name is recorded in ``unmasked`` and the
         GEMM epilogue does not read F a second time)."""
         wl = self.w_layers[self.layers.index(name)]
         _, h, w, c = F.shape
-        scale = 1.0 / (2.0 * h * w * c)
+        scale = 1.0 / (2.0 * h * w * (channels or c))
         G = ops.gram_fwd(F, scale)
         Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
         defer = unmasked is not None and self._defers_mask(name, F)
         if defer:
             unmasked.add(name)
-        return ops.gram_bwd(F, Dm, scale, relu_mask=not defer)
+        return ops.gram_bwd(F, Dm, scale, relu_mask=_post_relu(name) and not defer)
 
     def _defers_mask(self, name, F):
         """True when dF of style layer ``name`` is handed over WITHOUT its ReLU mask: the data gradient that adds it
@@ -223,6 +273,12 @@ class RenderStyleLoss(object):
         side stream as soon as a layer exists (``gram_side_stream``)."""
         sg = {}
         unmasked = set()                            # style layers whose dF is handed over without its ReLU mask
+        if not self.layers:                          # content / histogram terms only (run.bat:14-20: w_style 0)
+            acts = self.net.forward(x, self.top, keep=self._keep())
+            loss = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+            self._content_job(acts, sg, loss)
+            self._hist_job(acts, sg, loss)
+            return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
         if self.gram_grouped:
             acts = self.net.forward(x, self.top, keep=self._keep())
             Fs = [acts[n] for n in self.layers]
@@ -231,9 +287,10 @@ class RenderStyleLoss(object):
                 d = self._defers_mask(n, F)
                 if d:
                     unmasked.add(n)
-                masks.append(not d)
+                masks.append(_post_relu(n) and not d)
             parts, dFs, _ = ops.gram_style_group(Fs, [self.style_grams[n] for n in self.layers],
-                                                 [w * self.w_style for w in self.w_layers], masks)
+                                                 [w * self.w_style for w in self.w_layers], masks,
+                                                 channels=[_channels(acts, n, F) for n, F in zip(self.layers, Fs)])
             sg.update(zip(self.layers, dFs))
             loss = parts.sum(0)
             self._content_job(acts, sg, loss)
@@ -243,7 +300,7 @@ class RenderStyleLoss(object):
         if not self.gram_side_stream:
             acts = self.net.forward(x, self.top, keep=self._keep())
             for name in self.layers:
-                sg[name] = self._gram_job(name, acts[name], loss, unmasked)
+                sg[name] = self._gram_job(name, acts[name], loss, unmasked, _channels(acts, name, acts[name]))
             self._content_job(acts, sg, loss)
             self._hist_job(acts, sg, loss)
             return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
@@ -296,15 +353,20 @@ class RenderStyleLoss(object):
         """adds the content term's per-view losses into ``loss`` and its gradient into the layer's entry of ``sg``"""
         if self.content_layer is None:
             return
-        F = acts[self.content_layer]
+        F, padded = _logical(acts, self.content_layer)
         V = F.shape[0]
         # the reference's means run over one loss-net batch (v_batch views); here all V views share the batch
         w = self.w_content * V / self._batch_views(V)
-        g = sg.get(self.content_layer)
-        if g is None:
-            g = sg[self.content_layer] = torch.zeros_like(F)
+        if padded:
+            g = torch.zeros_like(F)
+        else:
+            g = sg.get(self.content_layer)
+            if g is None:
+                g = sg[self.content_layer] = torch.zeros_like(F)
         ops.content_loss(F, w, loss, g, channel=self.content_channel, target=self.content_feature,
-                         amp=self.w_content_amp)
+                         amp=self.w_content_amp, signed=not _post_relu(self.content_layer))
+        if padded:
+            _add_logical(sg, self.content_layer, acts[self.content_layer], g)
 
     # -- the hot step -----------------------------------------------------------------------
     def _chain(self, d, rot, g_d, overwrite=False):
@@ -368,7 +430,7 @@ class RenderStyleLoss(object):
         With >= 4 local views (and per-view normalisation, v_batch == 1) the views are split into groups
         whose whole chains run on separate HIP streams: the MFMA-bound conv launches of one group overlap
         the VALU/LDS-bound render and rotate-adjoint kernels and the fill/drain phases of the other."""
-        assert self.style_grams is not None, "call set_style_image first"
+        assert self.style_grams is not None or not self.layers, "call set_style_image first"
         V = rot.shape[0] if self.rotate else 1
         ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
         ngroups = min(ngroups, V)
@@ -875,10 +937,15 @@ class ImageStyleLoss(object):
         sg = {}
         for name, wl in zip(self.layers, self.w_layers):
             F = acts[name]
-            _, h, w, c = F.shape
+            _, h, w, cpad = F.shape
+            c = _channels(acts, name, F)
             if self.style_mask:
+                if not _post_relu(name):
+                    raise NotImplementedError("style_mask on a '*_pre_relu' style layer (the mask adjoint folds the ReLU in)")
                 m = ops.resize_bicubic_tf1(d_gray.contiguous(), h, w)      # [B,h,w,1], constant (no gradient to it)
                 Fm, scale_dev = ops.style_mask_apply(F, m)                 # F * m, 1 / (2 area C)
+                if c != cpad:
+                    scale_dev = scale_dev * (float(cpad) / float(c))       # (rows padded with zero channels)
                 G = ops.gram_fwd(Fm, 1.0, scale_dev=scale_dev)
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
                 dFm = ops.gram_bwd(Fm, Dm, 1.0, scale_dev=scale_dev, relu_mask=False)
@@ -887,7 +954,7 @@ class ImageStyleLoss(object):
                 scale = 1.0 / (2.0 * h * w * c)
                 G = ops.gram_fwd(F, scale)
                 Dm = ops.style_loss_fwd(G, self.style_grams[name], wl * self.w_style, loss)
-                sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=True)
+                sg[name] = ops.gram_bwd(F, Dm, scale, relu_mask=_post_relu(name))
         self._content_job(acts, sg, loss)
         hmask = d_gray if self.style_mask else None     # masked histogram branch (styler_base.py:196-201)
         self._hist_job(acts, sg, loss, hmask)

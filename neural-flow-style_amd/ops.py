@@ -514,7 +514,7 @@ def style_loss_fwd(G, Gs, weight, loss_acc, Dmat=None):
     return Dmat
 
 
-def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False):
+def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False, channels=None):
     """Gram matrix, style loss and Gram gradient of SEVERAL style layers in three launches (the loop of
     styler_base.py:152-185): ``Fs`` list of [B,h,w,C] activations, ``Gss`` their style Grams [Bs,C,C] (scaled by
     1/(2 h w C) like G), ``weights`` w_layer * w_style, ``relu_masks`` whether dF carries the layer's ReLU mask.
@@ -523,8 +523,8 @@ def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False):
     import ctypes
     n = len(Fs)
     if n > 8:                                          # the descriptor table of one launch holds 8 layers
-        a = gram_style_group(Fs[:8], Gss[:8], weights[:8], relu_masks[:8], want_G)
-        b = gram_style_group(Fs[8:], Gss[8:], weights[8:], relu_masks[8:], want_G)
+        a = gram_style_group(Fs[:8], Gss[:8], weights[:8], relu_masks[:8], want_G, channels and channels[:8])
+        b = gram_style_group(Fs[8:], Gss[8:], weights[8:], relu_masks[8:], want_G, channels and channels[8:])
         return torch.cat([a[0], b[0]]), a[1] + b[1], (a[2] + b[2] if want_G else None)
     arr = (_lib.GramLayer * n)()
     keep = []
@@ -539,7 +539,8 @@ def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False):
         y = arr[l]
         y.F, y.Gs, y.G, y.Dmat, y.dF = _ptr(F), _ptr(Gs), _ptr(G), _ptr(Dm), _ptr(dF)
         y.B, y.Bs, y.HW, y.C = B, Gs.shape[0], HW, Cn
-        y.scale, y.weight, y.relu_mask = 1.0 / (2.0 * HW * Cn), float(w), int(bool(rm))
+        # (rows padded with zero channels -- Inception module outputs --: the denominator counts the logical ones)
+        y.scale, y.weight, y.relu_mask = 1.0 / (2.0 * HW * (channels[l] if channels else Cn)), float(w), int(bool(rm))
     L = _lib.lib()
     ap = ctypes.cast(arr, ctypes.c_void_p)
     P = L.nfs_gram_style_group_parts(ap, n)
@@ -553,7 +554,7 @@ def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False):
     return parts, [k[1] for k in keep], ([k[2] for k in keep] if want_G else None)
 
 
-def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
+def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0, signed=False):
     """content loss of the post-ReLU activation F [B,h,w,C] (styler_base.py:135-150): with ``target`` [Bt,h,w,C]
     mean((F - amp*target)^2), else channel maximisation (channel != 0) or -mean(F); loss_acc [B] and
     g_acc [B,h,w,C] (gradient wrt the pre-activation) are accumulated into"""
@@ -561,7 +562,9 @@ def content_loss(F, weight, loss_acc, g_acc, channel=0, target=None, amp=100.0):
     HW = F.numel() // (B * Cn)
     mode = 2 if target is not None else (0 if channel else 1)
     Bt = target.shape[0] if target is not None else 0
-    _lib.call("nfs_content_loss", _ptr(F), _ptr(target), _ptr(loss_acc), _ptr(g_acc), B, Bt, HW, Cn, int(channel or 0),
+    # ``signed``: F is not a ReLU output (an Inception '*_pre_relu' tensor): |F| proper, gradient wrt F itself
+    _lib.call("nfs_content_loss_signed" if signed else "nfs_content_loss", _ptr(F), _ptr(target), _ptr(loss_acc),
+              _ptr(g_acc), B, Bt, HW, Cn, int(channel or 0),
               mode, float(weight), float(amp), _stream())
     return g_acc
 
@@ -707,3 +710,128 @@ def g2p_fwd(g, p, cubic=True):
     _lib.call("nfs_g2p_fwd", _ptr(g), _ptr(p), _ptr(out), nd, X, Y, Z, Cn, N, int(bool(cubic)), _stream())
     return out
 
+
+
+# ---- node types of the Inception-v1 loss network ------------------------------------------------------
+# Operands are channel RANGES of contiguous [B,H,W,ld] buffers: (tensor, first channel, channels).
+
+def _rows(t):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4):
+        raise ValueError("expected a contiguous float32 CUDA tensor [B,H,W,ld]")
+    return t
+
+
+def same_out(n, k, stride):
+    """TF SAME: (output size, padding before)"""
+    out = -(-n // stride)
+    return out, max((out - 1) * stride + k - n, 0) // 2
+
+
+def conv2d_pack(w_hwio, transpose=False):
+    """HWIO filters -> the layout ``conv2d_fwd`` reads; ``transpose``: the data-gradient filters of a stride-1 conv"""
+    w = w_hwio.contiguous()
+    kh, kw, Ci, Co = w.shape
+    n = _lib.lib().nfs_conv2d_packed_floats(kh, kw, Ci, Co, int(transpose))
+    packed = _empty((n,), w)
+    _lib.call("nfs_conv2d_pack", _ptr(w), _ptr(packed), kh, kw, Ci, Co, int(transpose), _stream())
+    return packed
+
+
+def conv2d_fwd(x, cx, Cin, packed, bias, y, cy, Cout, kh, kw, stride=1, relu=True, y_pre=None, cp=0, x_mask=None, cm=0,
+               accumulate=False):
+    """y[..., cy:cy+Cout] (+)= relu(conv_SAME(x[..., cx:cx+Cin] * (x_mask[..., cm:cm+Cin] > 0)) + bias);
+    y_pre[..., cp:cp+Cout] = the value before the ReLU"""
+    _rows(x), _rows(y)
+    B, H, W, ldx = x.shape
+    Ho, _ = same_out(H, kh, stride)
+    Wo, _ = same_out(W, kw, stride)
+    assert tuple(y.shape[:3]) == (B, Ho, Wo), (tuple(y.shape), (B, Ho, Wo))
+    assert cx + Cin <= ldx and cy + Cout <= y.shape[3]
+    xm = None if x_mask is None else _rows(x_mask).data_ptr() + 4 * cm
+    yp = None if y_pre is None else _rows(y_pre).data_ptr() + 4 * cp
+    if x_mask is not None:
+        assert tuple(x_mask.shape[:3]) == (B, H, W) and cm + Cin <= x_mask.shape[3]
+    if y_pre is not None:
+        assert tuple(y_pre.shape[:3]) == (B, Ho, Wo) and cp + Cout <= y_pre.shape[3]
+    _lib.call("nfs_conv2d_fwd", x.data_ptr() + 4 * cx, ldx, xm, 0 if x_mask is None else x_mask.shape[3], _ptr(packed),
+              _ptr(bias), y.data_ptr() + 4 * cy, y.shape[3], yp, 0 if y_pre is None else y_pre.shape[3], B, H, W, Cin,
+              Cout, kh, kw, stride, int(relu), int(accumulate), _stream())
+    return y
+
+
+def conv2d_dgrad_small(gy, cg, Co, w_hwio, in_hw, stride, y_act=None, ca=0):
+    """data gradient of a convolution with <= 4 input channels down to the image [B,H,W,Ci]"""
+    _rows(gy)
+    kh, kw, Ci, Co_w = w_hwio.shape
+    assert Co_w == Co
+    B = gy.shape[0]
+    H, W = in_hw
+    assert tuple(gy.shape[1:3]) == (same_out(H, kh, stride)[0], same_out(W, kw, stride)[0])
+    gx = _empty((B, H, W, Ci), gy)
+    ya = None if y_act is None else _rows(y_act).data_ptr() + 4 * ca
+    _lib.call("nfs_conv2d_dgrad_small", gy.data_ptr() + 4 * cg, gy.shape[3], ya, 0 if y_act is None else y_act.shape[3],
+              _ptr(w_hwio.contiguous()), _ptr(gx), B, H, W, Ci, Co, kh, kw, stride, _stream())
+    return gx
+
+
+def maxpool3_fwd(x, stride):
+    """3x3 SAME max pool over every float of the rows: (y [B,Ho,Wo,ld], arg uint8 [B,Ho,Wo,ld])"""
+    _rows(x)
+    B, H, W, ld = x.shape
+    Ho, Wo = same_out(H, 3, stride)[0], same_out(W, 3, stride)[0]
+    y = _empty((B, Ho, Wo, ld), x)
+    arg = torch.empty((B, Ho, Wo, ld), dtype=torch.uint8, device=x.device)
+    _lib.call("nfs_maxpool3_fwd", _ptr(x), _ptr(y), arg.data_ptr(), B, H, W, ld, stride, _stream())
+    return y, arg
+
+
+def maxpool3_bwd(gy, arg, in_hw, stride, gx=None):
+    """gx (+)= the pool adjoint; ``gx`` given: accumulate into it"""
+    _rows(gy)
+    B, Ho, Wo, ld = gy.shape
+    H, W = in_hw
+    acc = gx is not None
+    if gx is None:
+        gx = _empty((B, H, W, ld), gy)
+    assert tuple(gx.shape) == (B, H, W, ld) and arg.dtype == torch.uint8 and arg.is_contiguous()
+    _lib.call("nfs_maxpool3_bwd", _ptr(gy), arg.data_ptr(), _ptr(gx), B, H, W, ld, stride, int(acc), _stream())
+    return gx
+
+
+def lrn_fwd(x, C, radius, bias, alpha, beta):
+    """tf.nn.lrn over the first C channels of the rows: (y, scale), both shaped like x (padding channels zero)"""
+    _rows(x)
+    ld = x.shape[3]
+    y = _zeros(x.shape, x) if ld > C else _empty(x.shape, x)
+    scale = _empty(x.shape, x)
+    _lib.call("nfs_lrn_fwd", _ptr(x), _ptr(y), _ptr(scale), x.numel() // ld, C, ld, int(radius), float(bias),
+              float(alpha), float(beta), _stream())
+    return y, scale
+
+
+def lrn_bwd(x, y, scale, gy, C, radius, alpha, beta, gx=None):
+    _rows(gy)
+    ld = x.shape[3]
+    acc = gx is not None
+    if gx is None:
+        gx = _zeros(x.shape, x) if ld > C else _empty(x.shape, x)
+    _lib.call("nfs_lrn_bwd", _ptr(x), _ptr(y), _ptr(scale), _ptr(gy), _ptr(gx), x.numel() // ld, C, ld, int(radius),
+              float(alpha), float(beta), int(acc), _stream())
+    return gx
+
+
+def relu_mask_add(g, cg, act, ca, addend, cadd, C, out=None, co=0):
+    """out[..., co:co+C] = g[..., cg:cg+C] * (act[..., ca:ca+C] > 0) + addend[..., cadd:cadd+C]; g / act / addend may
+    be None"""
+    ref = g if g is not None else addend
+    _rows(ref)
+    npix = ref.numel() // ref.shape[3]
+    if out is None:
+        out = _empty(tuple(ref.shape[:3]) + (C,), ref)
+        co = 0
+
+    def at(t, c):
+        return (None, 0) if t is None else (_rows(t).data_ptr() + 4 * c, t.shape[3])
+    (pg, lg), (pa, la), (pd, ldd) = at(g, cg), at(act, ca), at(addend, cadd)
+    _lib.call("nfs_relu_mask_add", pg, lg, pa, la, pd, ldd, out.data_ptr() + 4 * co, out.shape[3], npix, C, _stream())
+    return out

@@ -37,18 +37,23 @@ class StylerBase(object):
         self.device = torch.device("cuda", gpu)
         torch.cuda.set_device(self.device)
         self.model_path = os.path.join(self.data_dir, self.model_dir, self.network)
-        if "vgg" not in self.model_path:
-            raise NotImplementedError(
-                "network=%r: only the VGG loss network (vgg_19.ckpt) is on the MI355X hot path; the "
-                "Inception-v1 graph (tensorflow_inception_graph.pb) is out of scope" % self.network)
         if getattr(self, "w_density", 0) and "d" not in getattr(self, "target_field", ""):
             raise NotImplementedError("the density-preservation loss acts on the particle-density variable "
                                       "(target_field 'd'), as in the reference (styler_3p.py:75)")
-        self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123),
-                                   synthetic=True if getattr(self, "synthetic_weights", False) else None)
+        synthetic = True if getattr(self, "synthetic_weights", False) else None
+        if "vgg" in self.model_path:
+            self.net = vggmod.load_vgg(self.model_path, self.device, seed=getattr(self, "seed", 123), synthetic=synthetic)
+        elif "inception" in self.model_path:
+            # styler_base.py:17-30: the Inception-v1 GraphDef, its first stride set to 1 with ``pool1``
+            from . import inception as incmod
+            self.net = incmod.load_inception(self.model_path, self.device, seed=getattr(self, "seed", 123),
+                                             synthetic=synthetic, pool1=bool(getattr(self, "pool1", False)))
+        else:
+            raise NotImplementedError("network=%r: 'vgg_19.ckpt' / 'vgg_16.ckpt' or 'tensorflow_inception_graph.pb'"
+                                      % self.network)
         if getattr(self, "w_content", 0):
-            # _layer(content_layer) is a dict lookup on the VGG end points (styler_base.py:91-94): an Inception
-            # layer name (the config default) is a KeyError there too
+            # _layer(content_layer) is a lookup among the tensors of the chosen network (styler_base.py:91-94): a name
+            # of the other network is an error there too
             names = [s_[0] for s_ in self.net.seq if s_[1] == "conv"]
             if self.content_layer not in names:
                 raise KeyError("content_layer %r is not a layer of %s (w_content=%g; pass --w_content 0 for pure "

@@ -18,6 +18,9 @@ Pinning status -- "parity unpinned" except for the warp kernel:
   * Everything else is pinned only to (a) the cited lines, (b) float64
     ``torch.autograd.gradcheck`` of each operator, (c) closed-form adjoints
     (render), (d) an independent NumPy loop restatement for the splat.
+  * The Inception-v1 loss network (section 8(f)-3 below): PARITY UNPINNED -- the
+    GraphDef is not in the reference tree and cannot be parsed here; the
+    restatement follows the published topology of that file.
   The arithmetic of the reference lives in TensorFlow 1.15 (un-vendored, pinned
   by setup.bat:8 ``pip install tensorflow==1.15``); the TF1 op semantics that
   differ from PyTorch defaults are restated explicitly below (ApplyAdam epsilon
@@ -506,6 +509,117 @@ def vgg19_features(d_img, weights, upto="conv5_1"):
 
 
 # --------------------------------------------------------------------------
+# 8(f)-3  Inception-v1 ("inception5h", tensorflow_inception_graph.pb)
+#                                          styler_base.py:17-30, 51-57, 91-94
+# --------------------------------------------------------------------------
+# The reference imports the GraphDef and fetches tensors by node name.  The file is not in the reference tree (it is
+# downloaded by setup.bat) and TensorFlow is not in this image: PARITY UNPINNED.  What is restated is the published
+# topology of that file -- node names, SAME padding, 3x3 max pools, two LRNs, four-branch modules concatenated in the
+# order (1x1, 3x3, 5x5, pool_reduce) -- with the TF op semantics written out (asymmetric SAME padding, max pool over
+# in-range taps only, tf.nn.lrn's depth window).  Channel widths come from the weights handed in.
+
+INCEPTION_UNITS = ([("conv", "conv2d0"), ("maxpool", "maxpool0", 2), ("lrn", "localresponsenorm0"),
+                    ("conv", "conv2d1"), ("conv", "conv2d2"), ("lrn", "localresponsenorm1"), ("maxpool", "maxpool1", 2),
+                    ("mixed", "mixed3a"), ("mixed", "mixed3b"), ("maxpool", "maxpool4", 2)]
+                   + [("mixed", "mixed4" + c) for c in "abcde"]
+                   + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b")])
+INCEPTION_LRN = (5, 2.0, 1e-4, 0.5)          # depth_radius, bias, alpha, beta of both LRN nodes of the 5h graph
+
+
+def _tf_same(n, k, stride):
+    out = -(-n // stride)
+    total = max((out - 1) * stride + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def tf_conv2d_same(x, w_hwio, b=None, stride=1):
+    """tf.nn.conv2d(padding='SAME') + BiasAdd on NCHW x with HWIO filters (padding split low = total // 2)"""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    pt, pb = _tf_same(x.shape[2], kh, stride)
+    pl, pr = _tf_same(x.shape[3], kw, stride)
+    w = torch.as_tensor(w_hwio, dtype=x.dtype).permute(3, 2, 0, 1)
+    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None if b is None else torch.as_tensor(b, dtype=x.dtype), stride=stride)
+
+
+def tf_maxpool3_same(x, stride):
+    """tf.nn.max_pool(ksize 3, SAME): padding taps do not take part (= -inf padding)"""
+    pt, pb = _tf_same(x.shape[2], 3, stride)
+    pl, pr = _tf_same(x.shape[3], 3, stride)
+    return F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), 3, stride)
+
+
+def tf_lrn(x, depth_radius, bias, alpha, beta):
+    """tf.nn.lrn on NCHW: x / (bias + alpha * sum_{|j-c| <= r} x_j^2)^beta"""
+    sq = F.pad(x * x, (0, 0, 0, 0, depth_radius, depth_radius))
+    s = sum(sq[:, j:j + x.shape[1]] for j in range(2 * depth_radius + 1))
+    return x / (bias + alpha * s) ** beta
+
+
+def inception_v1_features(d_img, weights, upto, lrn=None, pool1=False):
+    """d_img [B,H,W,3] 0..255 -> OrderedDict node name -> [B,h,w,C] for every addressable tensor down to the unit
+    that produces ``upto``: ``U_pre_relu`` (BiasAdd) and ``U`` (Relu) of every convolution unit, the pools, the LRNs,
+    the module outputs.  Input = vgg.preprocess(d) (styler_base.py:54: the VGG mean is what the reference subtracts
+    for this network too); ``pool1``: first stride 1 (styler_base.py:28-30)."""
+    lrn = dict(lrn or {})
+    x = (d_img - torch.tensor(VGG_MEAN, dtype=d_img.dtype)).permute(0, 3, 1, 2)
+    feats = OrderedDict()
+
+    def put(name, t):
+        feats[name] = t.permute(0, 2, 3, 1)
+
+    def conv(name, t, stride=1):
+        w, b = weights[name]
+        pre = tf_conv2d_same(t, w, b, stride)
+        put(name + "_pre_relu", pre)
+        y = F.relu(pre)
+        put(name, y)
+        return y
+
+    base = upto[:-len("_pre_relu")] if upto.endswith("_pre_relu") else upto
+    for u in INCEPTION_UNITS:
+        kind, name = u[0], u[1]
+        if kind == "conv":
+            x = conv(name, x, (1 if pool1 else 2) if name == "conv2d0" else 1)
+        elif kind == "maxpool":
+            x = tf_maxpool3_same(x, u[2])
+            put(name, x)
+        elif kind == "lrn":
+            x = tf_lrn(x, *lrn.get(name, INCEPTION_LRN))
+            put(name, x)
+        else:
+            b1 = conv(name + "_1x1", x)
+            b3 = conv(name + "_3x3", conv(name + "_3x3_bottleneck", x))
+            b5 = conv(name + "_5x5", conv(name + "_5x5_bottleneck", x))
+            pool = tf_maxpool3_same(x, 1)
+            put(name + "_pool", pool)
+            bp = conv(name + "_pool_reduce", pool)
+            x = torch.cat([b1, b3, b5, bp], dim=1)
+            put(name, x)
+        if base == name or (kind == "mixed" and base.startswith(name + "_")):
+            return feats
+    raise KeyError(upto)
+
+
+def inception_last_layer(layers):
+    """the tensor of ``layers`` whose unit comes last in the graph"""
+    def unit_index(n):
+        b = n[:-len("_pre_relu")] if n.endswith("_pre_relu") else n
+        for i, u in enumerate(INCEPTION_UNITS):
+            if b == u[1] or (u[0] == "mixed" and b.startswith(u[1] + "_")):
+                return i
+        raise KeyError(n)
+    return max(layers, key=unit_index)
+
+
+def loss_net_features(d_img, weights, upto, cfg=None):
+    """the loss network ``cfg['network']`` selects (styler_base.py:47-57): VGG-19 unless it names the Inception graph"""
+    cfg = cfg or {}
+    if "inception" in str(cfg.get("network", "vgg")):
+        return inception_v1_features(d_img, weights, upto, cfg.get("lrn"), cfg.get("pool1", False))
+    return vgg19_features(d_img, weights, upto)
+
+
+# --------------------------------------------------------------------------
 # A7  Gram + style loss                           styler_base.py:96-102, 152-185
 # --------------------------------------------------------------------------
 
@@ -835,7 +949,7 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
         dr = rotate(d_out, rot[v:v + 1]) if cfg.get("rotate", True) else d_out
         img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
-        feats = vgg19_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"])
+        feats = loss_net_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"], cfg)
         l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
         if cfg.get("w_content", 0):
             # one view per loss-net batch here (v_batch = 1): the content means are per view
@@ -851,16 +965,28 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
     return total, per_view, d_out
 
 
-def style_target_features(style_img, weights, layers, upto=None):
+def style_target_features(style_img, weights, layers, upto=None, cfg=None):
     """_style_feature (styler_base.py:249-278): the style image is fed directly
     at d_img (0..255, before mean subtraction)."""
-    feats = vgg19_features(style_img, weights, layers[-1] if upto is None else upto)
+    feats = loss_net_features(style_img, weights, layers[-1] if upto is None else upto, cfg)
     return {k: feats[k].detach() for k in layers}
 
 
-def last_layer(layers):
+def last_layer(layers, cfg=None):
+    if cfg is not None and "inception" in str(cfg.get("network", "vgg")):
+        return inception_last_layer(layers)
     order = vgg19_layer_names("conv5_4")
     return max(layers, key=order.index)
+
+
+def uses_content(cfg):
+    """the content term is on when its layer is a tensor of the chosen network (the config default names an Inception
+    tensor: with the VGG network the drivers of this build switch the term off)"""
+    if not cfg.get("w_content", 0):
+        return False
+    if "inception" in str(cfg.get("network", "vgg")):
+        return True
+    return str(cfg.get("content_layer", "")).startswith("conv")
 
 
 # --------------------------------------------------------------------------
@@ -905,9 +1031,9 @@ def particle_loss(p, r, var, cfg, res, rot, weights, style_feats):
         dr = rotate(d_out, rot[v:v + 1]) if cfg["rotate"] else d_out
         img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
         d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
-        use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
-        feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] +
-                                                          ([cfg["content_layer"]] if use_content else [])))
+        use_content = uses_content(cfg)
+        feats = loss_net_features(d_img, weights, last_layer(cfg["style_layer"] +
+                                                             ([cfg["content_layer"]] if use_content else []), cfg), cfg)
         l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"])
         if use_content:                                           # styler_base.py:135-150, total_loss order: content first
             l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
@@ -942,7 +1068,7 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
     for octave in range(cfg["octave_n"]):
         res = [int(v) for v in oct_size[octave]]
         simg = torch.tensor(np.asarray(style_img[octave], np.float32))[None]
-        sfe = style_target_features(simg, weights, cfg["style_layer"])
+        sfe = style_target_features(simg, weights, cfg["style_layer"], upto=last_layer(cfg["style_layer"], cfg), cfg=cfg)
         h_o = []
         for step in range(cfg["iter"]):
             g_tmp = [None] * F_
@@ -1018,7 +1144,7 @@ def grid_sequence_run(cfg, d_frames, u_frames, weights, style_img, rot_mats, v_i
     u = torch.tensor(np.asarray(u_frames), dtype=dt) if u_frames is not None else None
     rot = torch.tensor(np.asarray(rot_mats, np.float32)) if cfg.get("rotate", True) else torch.eye(3)[None]
     sfe = style_target_features(torch.tensor(np.asarray(style_img, np.float32))[None], weights, cfg["style_layer"],
-                                upto=cfg.get("upto"))
+                                upto=cfg.get("upto"), cfg=cfg)
     keys = list(range(0, F_, interp))
     g_opt = {}
     for t in keys:
@@ -1097,10 +1223,10 @@ def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
     """style (optionally masked by d_gray, styler_base.py:165-169) + TV (211-213) of the colour image"""
     d, d_gray, _ = colour_field2d(p, r, var, cfg, res)
     d_img = plugin_to_loss_net(d, cfg.get("resize_scale", 1.0), is_color=True)
-    use_content = bool(cfg.get("w_content", 0)) and str(cfg.get("content_layer", "")).startswith("conv")
+    use_content = uses_content(cfg)
     vgg_hist = [n for n in cfg.get("hist_layer", []) if "input" not in n] if cfg.get("w_hist", 0) else []
-    feats = vgg19_features(d_img, weights, last_layer(cfg["style_layer"] + vgg_hist +
-                                                      ([cfg["content_layer"]] if use_content else [])))
+    feats = loss_net_features(d_img, weights, last_layer(cfg["style_layer"] + vgg_hist +
+                                                         ([cfg["content_layer"]] if use_content else []), cfg), cfg)
     l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"],
                       d_gray=d_gray if cfg.get("style_mask") else None)
     if use_content:
@@ -1140,7 +1266,7 @@ def styler2p_run(cfg, params, weights, style_img, c_init):
     for octave in range(cfg["octave_n"]):
         res = [int(v) for v in oct_size[octave]]
         simg = torch.tensor(np.asarray(style_img[octave], np.float32))[None]
-        sfe = style_target_features(simg, weights, cfg["style_layer"])
+        sfe = style_target_features(simg, weights, cfg["style_layer"], upto=last_layer(cfg["style_layer"], cfg), cfg=cfg)
         lr = cfg["lr"][octave] if isinstance(cfg["lr"], (list, tuple)) else cfg["lr"]
         h_o = []
         for step in range(cfg["iter"]):

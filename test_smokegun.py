@@ -2,11 +2,14 @@
 MI355X build: same ``run(config)`` body -- build the Styler, load the style image, read the
 particle frames, ``styler.run(params)``, save ``%03d.png`` / ``%03d.npz`` (key ``x`` = ``d[:, ::-1]``)
 / ``loss_plot.png`` -- with two differences: particles come from ``.npz`` files (keys ``position``
-[N,3] in world units (x,y,z), ``density`` [N,num_kernels]) instead of partio ``.bgeo``, and the
-``main()`` overrides select the VGG-19 style loss with rotated views (the reference hard-codes the
-Inception graph, which is out of scope).  Without a dataset it runs on seeded synthetic particles.
+[N,3] in world units (x,y,z), ``density`` [N,num_kernels]) or partio ``.bgeo`` through ``io_bgeo``, and the
+``main()`` override block yields to flags given on the command line (the reference hard-codes the Inception graph
+and a single view; BASELINE's configuration is the VGG-19 style loss over 8 rotated views).  Without a dataset it
+runs on seeded synthetic particles.
 
-    python test_smokegun.py --style_target data/image/fire_new.jpg --w_style 1 --iter 20
+    python test_smokegun.py --style_target data/image/fire_new.jpg --w_style 1 --w_content 0          (run.bat:22)
+    python test_smokegun.py --content_layer mixed3b_3x3_bottleneck_pre_relu --content_channel 44      (run.bat:14)
+    python test_smokegun.py --network vgg_19.ckpt --rotate true --n_views 8 --w_style 1 --w_content 0 --style_target ...
 """
 import os
 
@@ -61,11 +64,12 @@ def synthetic_frames(config):
 def run(config):
     prepare_dirs_and_logger(config)
     config.rng = np.random.RandomState(config.seed)
-    if not config.style_target:
-        # demo mode: no style image given -> seeded synthetic style image AND (explicitly) synthetic VGG filters; a real
-        # run needs --style_target and data/model/vgg_19.npz (vgg.load_vgg raises without it)
+    if not config.style_target and (config.w_style > 0 or not config.w_content):
+        # demo mode: a style term without a style image -> seeded synthetic style image AND (explicitly) synthetic
+        # loss-network filters; a real run needs --style_target and data/model/vgg_19.npz or
+        # tensorflow_inception_graph.npz (the loaders raise without them)
         from neural_flow_style_amd import synthetic as S
-        print("DEMO MODE: synthetic style image and synthetic (random) VGG-19 filters -- not a stylisation by VGG-19")
+        print("DEMO MODE: synthetic style image and synthetic (random) loss-network filters -- not a real stylisation")
         config.style_target = S.style_image(256, 256, np.random.RandomState(config.seed))
         config.w_style = 1
         config.synthetic_weights = True
@@ -99,20 +103,27 @@ def run(config):
 
 
 def main(config):
-    """The reference's main() (test_smokegun.py:111-197) sets these unconditionally; kept verbatim:
-    dataset, num_kernels 2, kernel_scale 2, support 4, disc 1, radius 0.5, nsize 1, rest_density 1000, clip False,
-    w_density 0, k 3, window_sigma 3, batch_size 1, frames_per_opt 1, target_field 'd', lr 0.1, octave_n 1,
-    octave_scale 1.8, transmit 0.01, iter 20, interp 1.
-    Deliberate differences (each because the reference's value cannot run here):
-      * d_path 'pt_low_o2/%03d.npz' instead of '.bgeo' (io_bgeo reads .bgeo too when the file exists);
-      * network 'vgg_19.ckpt' with style layers conv1_1..conv5_1 instead of the Inception graph ('conv2d2','mixed3b',
-        'mixed4b': weights not available), w_content 0 unless a VGG content layer is named;
-      * rotate True with 8 views instead of False (the benchmark's multi-view path); pass --rotate false to get the
-        reference's single view;
-      * resolution/domain [200,300,200] and resize_scale 300/resolution[0] are applied only when --resolution is left
-        at its flag default (so that a smaller grid can be asked for on the command line)."""
+    """The reference's main() (test_smokegun.py:111-197), value for value: dataset, num_kernels 2, kernel_scale 2,
+    support 4, disc 1, radius 0.5, nsize 1, rest_density 1000, resolution / domain [200,300,200], clip False, w_density
+    0, k 3, window_sigma 3, batch_size 1, frames_per_opt 1, target_field 'd', lr 0.1, network
+    'tensorflow_inception_graph.pb' with style layers ['conv2d2','mixed3b','mixed4b'] x [1,1,1], octave_n 1,
+    octave_scale 1.8, transmit 0.01, iter 20, resize_scale 300/resolution[0], rotate False, interp 1.
+
+    The reference sets them unconditionally; here a flag given on the command line wins over the block (SURVEY.md
+    section 0.1: the block must let BASELINE's configuration through), for these flags only: ``--network``,
+    ``--style_layer`` / ``--w_style_layer``, ``--rotate`` / ``--n_views``, ``--resolution``, ``--iter``, ``--transmit``,
+    ``--d_path``.  BASELINE configs[2] is
+
+        python test_smokegun.py --network vgg_19.ckpt --rotate true --n_views 8 --w_style 1 --w_content 0 ...
+
+    (with ``--network vgg_19.ckpt`` and no ``--style_layer`` the style layers are conv1_1 ... conv5_1, and a content
+    layer that is not a VGG end point switches the content term off).  d_path defaults to 'pt_low_o2/%03d.npz'
+    (``io_bgeo`` reads the reference's '.bgeo' when that file exists instead)."""
+    import sys
+    given = set(a.split("=")[0] for a in sys.argv[1:] if a.startswith("--"))
     config.dataset = "smokegun"
-    config.d_path = "pt_low_o2/%03d.npz"
+    if "--d_path" not in given:
+        config.d_path = "pt_low_o2/%03d.npz"
     config.num_kernels = 2
     config.kernel_scale = 2
     config.support = 4
@@ -120,9 +131,8 @@ def main(config):
     config.radius = 1 / config.disc / 2
     config.nsize = 1
     config.rest_density = 1000
-    if config.resolution == [384, 288]:          # flag default -> the driver's grid (test_smokegun.py:128)
+    if "--resolution" not in given:
         config.resolution = [200, 300, 200]
-        config.resize_scale = 300 / config.resolution[0]
     config.domain = list(config.resolution)
     config.clip = False
     config.w_density = 0
@@ -132,21 +142,27 @@ def main(config):
     config.frames_per_opt = 1
     config.target_field = "d"
     config.lr = 0.1
-    config.network = "vgg_19.ckpt"
-    if config.style_layer == ["conv3_1"]:
-        config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
-        config.w_style_layer = [1, 1, 1, 1, 1]
-    if not str(config.content_layer).startswith("conv"):
-        config.w_content = 0          # the default content layer is an Inception-v1 name: style transfer only
+    if "--network" not in given:
+        config.network = "tensorflow_inception_graph.pb"
+    if "--style_layer" not in given:
+        if "vgg" in config.network:
+            config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
+        else:
+            config.style_layer = ["conv2d2", "mixed3b", "mixed4b"]
+    if "--w_style_layer" not in given:
+        config.w_style_layer = [1] * len(config.style_layer)
+    if "vgg" in config.network and not str(config.content_layer).startswith("conv"):
+        config.w_content = 0          # the default content layer is an Inception-v1 tensor: style transfer only
     config.octave_n = 1
     config.octave_scale = 1.8
-    config.transmit = 0.01
-    config.iter = 20
+    if "--transmit" not in given:
+        config.transmit = 0.01
+    if "--iter" not in given:
+        config.iter = 20
+    config.resize_scale = 300 / config.resolution[0]
+    if "--rotate" not in given:
+        config.rotate = False
     config.interp = 1
-    import sys
-    if not any(a.startswith("--rotate") for a in sys.argv[1:]):
-        config.rotate = True
-        config.n_views = 8
     return run(config)
 
 
