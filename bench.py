@@ -389,7 +389,7 @@ def sustained(step, barrier, units, device, world, seconds=2.0, window=20):
 
 def other_configs(device, base):
     """short, driver-visible side numbers for the other BASELINE configurations (each a few seconds)"""
-    from neural_flow_style_amd import engine, ops, vgg
+    from neural_flow_style_amd import _lib, engine, ops, vgg
     from neural_flow_style_amd import synthetic as S
     from neural_flow_style_amd import transform as T
     out = []
@@ -617,6 +617,52 @@ def other_configs(device, base):
         del st
     except Exception as e:  # pragma: no cover
         out.append({"config": "configs[3]", "error": repr(e)})
+
+    # the reference driver's OWN configuration (test_smokegun.py:128-148): 200 x 300 x 200 density field, one unrotated
+    # view, render resized by 1.5 to 300 x 450, Inception-v1 style layers conv2d2 / mixed3b / mixed4b
+    try:
+        from neural_flow_style_amd import inception
+        rng = np.random.RandomState(3)
+        net = inception.InceptionV1(inception.synthetic_weights(123, upto="mixed4b"), device)
+        layers = ["conv2d2", "mixed3b", "mixed4b"]
+        il = engine.RenderStyleLoss(net, layers, [1.0] * 3, 1.0, transmit=0.01, resize_scale=1.5, rotate=False)
+        il.set_style_image(S.style_image(300, 450, rng))
+        dd = torch.tensor(S.blob_density(200, rng), device=device)
+        dd = torch.nn.functional.pad(dd, (0, 0, 50, 50)).contiguous()                    # [200,300,200]
+        g_d = torch.zeros_like(dd)
+
+        def inc_step():
+            g_d.zero_()
+            return il.loss_and_grad(dd, None, g_d)
+        ms = ev_time(inc_step, 50)
+        _lib.PROFILE = {}
+        for _ in range(5):
+            inc_step()
+        torch.cuda.synchronize()
+        prof, _lib.PROFILE = _lib.PROFILE, None
+        shapes = prof.pop("shapes:nfs_conv2d_group", [])
+
+        def fl(B, H, W, Cin, Cout, kh, kw, stride):
+            Ho, Wo = ops.same_out(H, kh, stride)[0], ops.same_out(W, kw, stride)[0]
+            K = (kh * kw + 3) // 4 * 16 if Cin <= 4 else kh * kw * ((Cin + 15) // 16 * 16)
+            return 2.0 * B * Ho * Wo * ((Cout + 63) // 64 * 64) * K
+        ex = (sum(fl(*r[2][10:18]) for r in prof.get("nfs_conv2d_fwd", []))
+              + sum(fl(*(sh + (1,))) for call in shapes for sh in call)) / 5
+        tc = sum(r[0].elapsed_time(r[1]) for k in ("nfs_conv2d_fwd", "nfs_conv2d_group") for r in prof.get(k, [])) / 5
+        out.append({"config": "the reference driver's own test_smokegun.py configuration: 200x300x200 density field, one "
+                              "unrotated view, render resized x1.5 to 300x450, Inception-v1 (tensorflow_inception_graph) "
+                              "style layers conv2d2 / mixed3b / mixed4b: loss + gradient of the density field",
+                    "value": 1e3 / ms, "unit": "iters/s", "ms_per_step": ms,
+                    "inception_conv": {"ms_per_step": tc, "executed_tflops": ex / tc / 1e9,
+                                       "frac_mfma_f32": ex / tc / 1e9 / MFMA_F32_PEAK_TF,
+                                       "launches_per_step": (len(prof.get("nfs_conv2d_fwd", []))
+                                                             + 2 * len(prof.get("nfs_conv2d_group", []))) / 5,
+                                       "note": "nfs_conv2d_fwd + nfs_conv2d_group calls (implicit-GEMM SAME convolutions on "
+                                               "the f32 MFMA, the branches of a module as grouped launches), executed "
+                                               "flops incl. the padding of K to 16 and N to 64, HIP event pairs"}})
+        del il, net
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "reference test_smokegun.py configuration (Inception-v1)", "error": repr(e)})
     return out
 
 

@@ -396,12 +396,15 @@ int nfs_content_loss_signed(const float* F, const float* target, float* loss_acc
  *   x' = x * (x_mask > 0) when x_mask is given (the ReLU adjoint applied while a gradient is consumed; x_mask has the
  *   indexing of x with row stride ldm).  y_pre (nullable) receives the value before the ReLU (the graph's
  *   '*_pre_relu' tensors).  accumulate: y += (branch gradients meeting at a module input).  Cin <= 4 (the image) or
- *   a multiple of 4; Cout, ld* multiples of 4; filters up to 7x7; stride 1 or 2.
+ *   a multiple of 4; Cout, ld* multiples of 4; filters up to 7x7; stride 1 or 2.  workspace (nullable):
+ *   nfs_conv2d_workspace_floats floats of scratch; with it, calls that would leave most CUs idle (a few hundred
+ *   pixels, K in the thousands) split K over blocks and finish with a fixed-order reduction (deterministic).
  * nfs_conv2d_dgrad_small: data gradient of a convolution with <= 4 input channels (the 7x7 stride-2 first layer, down
  *   to the image): gx [B,H,W,Ci] = sum gy (y_act > 0) w, w_hwio unpacked; y_act nullable.
  * nfs_maxpool3_fwd/bwd: MaxPool 3x3, stride 1 or 2, SAME (padding taps do not take part).  arg [B,Ho,Wo,C] bytes =
  *   window position (0..8 row-major) of the FIRST maximum (TF's CPU kernel; ties only matter at exact equality, and
- *   zero ties after a ReLU carry no gradient past that ReLU).  C = floats per pixel (multiple of 4).
+ *   zero ties after a ReLU carry no gradient past that ReLU).  C = floats per pixel (multiple of 4).  relu_of
+ *   (nullable, shaped like gx): the result is multiplied by (relu_of > 0) -- the pooled tensor's own ReLU adjoint.
  * nfs_lrn_fwd/bwd: tf.nn.lrn, y = x / (bias + alpha sum_{|j-c| <= radius} x_j^2)^beta; scale = the bracket, kept
  *   for the adjoint.  C channels in rows of ld floats.
  * nfs_relu_mask_add: out = g (act > 0) + addend (each of g / act / addend nullable): a gradient injected at a
@@ -409,15 +412,36 @@ int nfs_content_loss_signed(const float* F, const float* target, float* loss_acc
 int64_t nfs_conv2d_packed_floats(int kh, int kw, int Ci, int Co, int transpose);
 int nfs_conv2d_pack(const float* w_hwio, float* packed, int kh, int kw, int Ci, int Co, int transpose,
                     nfs_stream_t stream);
+int64_t nfs_conv2d_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride);
 int nfs_conv2d_fwd(const float* x, int ldx, const float* x_mask, int ldm, const float* packed, const float* bias,
                    float* y, int ldy, float* y_pre, int ldp, int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                   int stride, int relu, int accumulate, nfs_stream_t stream);
+                   int stride, int relu, int accumulate, float* workspace, int64_t workspace_floats,
+                   nfs_stream_t stream);
+/* Several stride-1 convolutions of one batch in ONE launch (+ one reduction launch): the branches of an inception
+ * module are a few hundred pixels each and would leave most of the chip idle one by one.  Fields as the arguments of
+ * nfs_conv2d_fwd.  sum_with_prev: the result is added to the previous problem's (same pixels, Cout and y) -- the data
+ * gradients of a module's three 1x1 branches meet in one tensor; they leave as partial sums and one fixed-order
+ * reduction writes y (no race, deterministic).  K is split over blocks until the launch fills the chip.  n <= 6. */
+typedef struct {
+  const float* x;
+  const float* x_mask;
+  const float* packed;
+  const float* bias;
+  float* y;
+  float* y_pre;
+  int ldx, ldm, ldy, ldp;
+  int H, W, Cin, Cout, kh, kw;
+  int relu, accumulate, sum_with_prev;
+} nfs_conv2d_desc_t;
+int64_t nfs_conv2d_group_workspace_floats(const nfs_conv2d_desc_t* descs, int n, int B);
+int nfs_conv2d_group(const nfs_conv2d_desc_t* descs, int n, int B, float* workspace, int64_t workspace_floats,
+                     nfs_stream_t stream);
 int nfs_conv2d_dgrad_small(const float* gy, int ldg, const float* y_act, int lda, const float* w_hwio, float* gx,
                            int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, nfs_stream_t stream);
 int nfs_maxpool3_fwd(const float* x, float* y, uint8_t* arg, int B, int H, int W, int C, int stride,
                      nfs_stream_t stream);
 int nfs_maxpool3_bwd(const float* gy, const uint8_t* arg, float* gx, int B, int H, int W, int C, int stride,
-                     int accumulate, nfs_stream_t stream);
+                     int accumulate, const float* relu_of, nfs_stream_t stream);
 int nfs_lrn_fwd(const float* x, float* y, float* scale, int64_t npix, int C, int ld, int radius, float bias,
                 float alpha, float beta, nfs_stream_t stream);
 int nfs_lrn_bwd(const float* x, const float* y, const float* scale, const float* gy, float* gx, int64_t npix, int C,

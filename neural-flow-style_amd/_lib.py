@@ -31,6 +31,15 @@ class GramLayer(C.Structure):
                 ("scale", C.c_float), ("weight", C.c_float), ("relu_mask", C.c_int)]
 
 
+class ConvDesc(C.Structure):
+    """nfs_conv2d_desc_t (include/nfs_hip.h): one convolution of a grouped launch"""
+    _fields_ = [("x", C.c_void_p), ("x_mask", C.c_void_p), ("packed", C.c_void_p), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("y_pre", C.c_void_p),
+                ("ldx", C.c_int), ("ldm", C.c_int), ("ldy", C.c_int), ("ldp", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("relu", C.c_int), ("accumulate", C.c_int), ("sum_with_prev", C.c_int)]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes (all return int unless listed in _RESTYPE)
@@ -93,10 +102,13 @@ SIGNATURES = {
     "nfs_conv3x3_executed_flops": [_I, _I, _I, _I, _I, _I],
     "nfs_conv2d_packed_floats": [_I, _I, _I, _I, _I],
     "nfs_conv2d_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "nfs_conv2d_fwd": [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_conv2d_workspace_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "nfs_conv2d_fwd": [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "nfs_conv2d_group_workspace_floats": [_P, _I, _I],
+    "nfs_conv2d_group": [_P, _I, _I, _P, _L, _P],
     "nfs_conv2d_dgrad_small": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "nfs_maxpool3_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "nfs_maxpool3_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "nfs_maxpool3_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nfs_lrn_fwd": [_P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P],
     "nfs_lrn_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _I, _P],
     "nfs_relu_mask_add": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P],
@@ -121,7 +133,8 @@ SIGNATURES = {
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
             "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64,
-            "nfs_conv3x3_executed_flops": C.c_double, "nfs_conv2d_packed_floats": C.c_int64}
+            "nfs_conv3x3_executed_flops": C.c_double, "nfs_conv2d_packed_floats": C.c_int64,
+            "nfs_conv2d_workspace_floats": C.c_int64, "nfs_conv2d_group_workspace_floats": C.c_int64}
 
 _lib = None
 

@@ -40,17 +40,27 @@ struct Conv2dArgs {
   int B, H, W, Ho, Wo, Cin, Cout, kh, kw, stride, pad_t, pad_l;
   int relu, accumulate;
   int M, nchunks, cchunks, Npad;
+  float* ws;            // partial sums [ztotal][M][Npad] (partial != 0)
+  int ksplit, cps;      // K chunks per split
+  int partial;          // the tile leaves as a raw partial sum in ws; conv2d_reduce finishes (split K, or several
+  int zbase, ztotal;    // convolutions summed into one output: first partial of this problem / all partials of the sum)
+};
+
+constexpr int IC_GMAX = 6;   // problems per grouped launch
+struct Conv2dGroupArgs {
+  Conv2dArgs p[IC_GMAX];
+  int bstart[IC_GMAX + 1];   // first block of each problem
+  int n;
 };
 
 template <int BM, int CMODE>
-__global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
+__device__ __forceinline__ void conv2d_tile(const Conv2dArgs& a, int mtile, int ntile, int zsplit, float* smem) {
   constexpr int MT = BM / 64;   // 32x32 MFMA tiles per wave along M (= A float4 per thread and chunk)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [2][BM][20]
   float* Bs = smem + 2 * BM * IC_LS;       // [2][64][20]
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * IC_BN;
+  const int m0 = mtile * BM, n0 = ntile * IC_BN;
   const int srow = t >> 2, kq = t & 3;
 
   int pixbase[MT], iy0[MT], ix0[MT];
@@ -125,12 +135,15 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  load(0);
+  // split-K (the late layers have a few hundred pixels and K in the thousands): blockIdx.z owns a range of chunks
+  const int it0 = zsplit * a.cps;
+  const int it1 = it0 + a.cps < a.nchunks ? it0 + a.cps : a.nchunks;
+  load(it0);
   stage(0);
   __syncthreads();
-  for (int it = 0; it < a.nchunks; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < a.nchunks) load(it + 1);          // in flight under this chunk's MFMAs
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    if (it + 1 < it1) load(it + 1);                // in flight under this chunk's MFMAs
     const float* Ab = As + buf * BM * IC_LS + (wm * (BM / 2) + i) * IC_LS + 4 * h;
     const float* Bb = Bs + buf * IC_BN * IC_LS + (wn * 32 + i) * IC_LS + 4 * h;
     // a lane fetches 4 consecutive k with one b128 and feeds 4 MFMA steps with them: the k order inside the chunk is
@@ -147,7 +160,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.w, bq.w, acc[mt], 0, 0, 0);
       }
     }
-    if (it + 1 < a.nchunks) stage(buf ^ 1);        // (read during chunk it-1: every wave is past that barrier)
+    if (it + 1 < it1) stage(buf ^ 1);              // (read during chunk it-1: every wave is past that barrier)
     __syncthreads();
   }
 
@@ -170,6 +183,10 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
     const int m = m0 + row, n = n0 + 4 * q;
     if (m >= a.M || n >= a.Cout) continue;
     float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    if (a.partial) {                                 // raw partial sum; conv2d_reduce finishes
+      *reinterpret_cast<float4*>(a.ws + ((int64_t)(a.zbase + zsplit) * a.M + m) * a.Npad + n) = v;
+      continue;
+    }
     if (a.bias) {
       const float4 bb = *reinterpret_cast<const float4*>(a.bias + n);
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -183,6 +200,64 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
     }
     *dst = v;
   }
+}
+
+template <int BM, int CMODE>
+__global__ void __launch_bounds__(256) conv2d_mfma_kernel(Conv2dArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv2d_tile<BM, CMODE>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Several convolutions in ONE launch (the branches of an inception module are a few hundred pixels each: alone a branch
+// fills a tenth of the chip): block -> (problem, m tile, n tile, K split) through a table in the kernel argument.
+// Problems are ordered longest block first by the host.
+__global__ void __launch_bounds__(256) conv2d_group_kernel(Conv2dGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.n && bid >= g.bstart[j + 1]) ++j;
+  const Conv2dArgs& a = g.p[j];
+  const int local = bid - g.bstart[j];
+  const int mtiles = (a.M + 63) / 64, ntiles = a.Npad / IC_BN;
+  const int mt = local % mtiles, r = local / mtiles;
+  conv2d_tile<64, 0>(a, mt, r % ntiles, r / ntiles, smem);
+}
+
+// second pass of the partial-sum path: y = epilogue(sum_z ws[z]) in a fixed order (deterministic)
+__device__ __forceinline__ void conv2d_reduce(const Conv2dArgs& a, int64_t idx) {
+  const int C4 = a.Cout >> 2;
+  if (idx >= (int64_t)a.M * C4) return;
+  const int m = (int)(idx / C4), n = (int)(idx - (int64_t)m * C4) * 4;
+  const float* p = a.ws + (int64_t)m * a.Npad + n;
+  const int64_t zs = (int64_t)a.M * a.Npad;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int z = 1; z < a.ztotal; ++z) {
+    const float4 o = *reinterpret_cast<const float4*>(p + z * zs);
+    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  }
+  if (a.bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(a.bias + n);
+    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+  }
+  if (a.ypre) *reinterpret_cast<float4*>(a.ypre + (int64_t)m * a.ldp + n) = v;
+  if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  float4* dst = reinterpret_cast<float4*>(a.y + (int64_t)m * a.ldy + n);
+  if (a.accumulate) {
+    const float4 o = *dst;
+    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  }
+  *dst = v;
+}
+
+__global__ void __launch_bounds__(256) conv2d_reduce_kernel(Conv2dArgs a) {
+  conv2d_reduce(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ void __launch_bounds__(256) conv2d_group_reduce_kernel(Conv2dGroupArgs g) {
+  const int bid = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.n && bid >= g.bstart[j + 1]) ++j;
+  conv2d_reduce(g.p[j], (int64_t)(bid - g.bstart[j]) * 256 + threadIdx.x);
 }
 
 // packed[(chunk * Npad + n) * 16 + kk]; transpose = data-gradient filters (taps flipped, channels swapped)
@@ -209,60 +284,65 @@ __global__ void __launch_bounds__(256) conv2d_pack_kernel(const float* __restric
 }
 
 // data gradient of a convolution down to <= 4 input channels: gx[p][c] = sum over the taps (ky, kx) whose output pixel
-// exists, sum_co gy[o][co] (y_act[o][co] > 0) w[ky][kx][c][co]
+// exists, sum_co gy[o][co] (y_act[o][co] > 0) w[ky][kx][c][co].
+// A wave holds pixels of ONE parity class (iy mod stride, ix mod stride): the taps that reach a pixel depend only on
+// its class, so the tap loop and every filter address are uniform across the wave -- the filters arrive through the
+// scalar cache as SGPR operands of the FMAs (no LDS, no per-lane filter traffic); per (tap, 4 channels) a lane issues
+// one 16-byte load of gy and 4 CI FMAs.
+template <int CI, bool MASK>
 __global__ void __launch_bounds__(256) conv2d_small_dgrad_kernel(const float* __restrict__ gy, int ldg,
                                                                  const float* __restrict__ yact, int lda,
                                                                  const float* __restrict__ w, float* __restrict__ gx,
-                                                                 int B, int H, int W, int Ho, int Wo, int Ci, int Co,
+                                                                 int B, int H, int W, int Ho, int Wo, int Co,
                                                                  int kh, int kw, int stride, int pad_t, int pad_l) {
-  extern __shared__ __attribute__((aligned(16))) float sw[];   // [taps][Co][4]
-  const int t = threadIdx.x;
-  for (int idx = t; idx < kh * kw * Co; idx += 256) {
-    const int tap = idx / Co, co = idx - tap * Co;
+  const int cls = blockIdx.y;
+  const int py = cls / stride, px = cls - py * stride;
+  const int nqy = (H - py + stride - 1) / stride, nqx = (W - px + stride - 1) / stride;
+  const int64_t nq = (int64_t)B * nqy * nqx;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < nq;
+  const int64_t qq = live ? q : 0;
+  const int per = nqy * nqx > 0 ? nqy * nqx : 1;
+  const int b = (int)(qq / per);
+  const int rem = (int)(qq - (int64_t)b * per);
+  const int qy = rem / (nqx > 0 ? nqx : 1), qx = rem - qy * (nqx > 0 ? nqx : 1);
+  const int ky0 = (py + pad_t) % stride, kx0 = (px + pad_l) % stride;
+  const int cy = (py + pad_t - ky0) / stride, cx = (px + pad_l - kx0) / stride;
+  float acc[CI];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sw[idx * 4 + c] = c < Ci ? w[((int64_t)tap * Ci + c) * Co + co] : 0.f;
-  }
-  __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * 256 + t;
-  if (p >= (int64_t)B * H * W) return;
-  const int b = (int)(p / ((int64_t)H * W));
-  const int rem = (int)(p - (int64_t)b * H * W);
-  const int iy = rem / W, ix = rem - iy * W;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int ky = 0; ky < kh; ++ky) {
-    const int ny = iy + pad_t - ky;
-    if (ny < 0 || ny % stride) continue;
-    const int oy = ny / stride;
-    if (oy >= Ho) continue;
-    for (int kx = 0; kx < kw; ++kx) {
-      const int nx = ix + pad_l - kx;
-      if (nx < 0 || nx % stride) continue;
-      const int ox = nx / stride;
-      if (ox >= Wo) continue;
-      const int64_t o = ((int64_t)b * Ho + oy) * Wo + ox;
+  for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+  for (int ky = ky0, jy = 0; ky < kh; ky += stride, ++jy) {
+    const int oy = qy + cy - jy;
+    for (int kx = kx0, jx = 0; kx < kw; kx += stride, ++jx) {
+      const int ox = qx + cx - jx;
+      const bool ok = live && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
+      const int64_t o = ok ? ((int64_t)b * Ho + oy) * Wo + ox : 0;
       const float* gp = gy + o * ldg;
-      const float* ap = yact ? yact + o * lda : nullptr;
-      const float4* wt = reinterpret_cast<const float4*>(sw) + (ky * kw + kx) * Co;
+      const float* ap = MASK ? yact + o * lda : nullptr;
+      const float* wt = w + (int64_t)(ky * kw + kx) * CI * Co;       // [CI][Co], uniform
+#pragma unroll 4
       for (int co = 0; co < Co; co += 4) {
         float4 g = *reinterpret_cast<const float4*>(gp + co);
-        if (ap) {
+        if (MASK) {
           const float4 m = *reinterpret_cast<const float4*>(ap + co);
           g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
           g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
         }
-        const float4 w0 = wt[co], w1 = wt[co + 1], w2 = wt[co + 2], w3 = wt[co + 3];
-        acc.x += g.x * w0.x + g.y * w1.x + g.z * w2.x + g.w * w3.x;
-        acc.y += g.x * w0.y + g.y * w1.y + g.z * w2.y + g.w * w3.y;
-        acc.z += g.x * w0.z + g.y * w1.z + g.z * w2.z + g.w * w3.z;
-        acc.w += g.x * w0.w + g.y * w1.w + g.z * w2.w + g.w * w3.w;
+        if (!ok) g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          const float* wc = wt + c * Co + co;
+          acc[c] = fmaf(g.x, wc[0], fmaf(g.y, wc[1], fmaf(g.z, wc[2], fmaf(g.w, wc[3], acc[c]))));
+        }
       }
     }
   }
-  float* o = gx + p * Ci;
-  o[0] = acc.x;
-  if (Ci > 1) o[1] = acc.y;
-  if (Ci > 2) o[2] = acc.z;
-  if (Ci > 3) o[3] = acc.w;
+  if (live) {
+    const int iy = py + stride * qy, ix = px + stride * qx;
+    float* o = gx + (((int64_t)b * H + iy) * W + ix) * CI;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) o[c] = acc[c];
+  }
 }
 
 // ---- 3x3 max pool, SAME (TF: out-of-range taps do not take part) ------------------------------------------------------
@@ -297,7 +377,8 @@ __global__ void __launch_bounds__(256) maxpool3_fwd_kernel(const float* __restri
 // thread = (input pixel, 4 channels): gather over the windows that contain the pixel
 __global__ void __launch_bounds__(256) maxpool3_bwd_kernel(const float* __restrict__ gy, const uint32_t* __restrict__ arg,
                                                            float* __restrict__ gx, int B, int H, int W, int Ho, int Wo,
-                                                           int C4, int stride, int pad_t, int pad_l, int accumulate) {
+                                                           int C4, int stride, int pad_t, int pad_l, int accumulate,
+                                                           const float* __restrict__ relu_of) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)B * H * W * C4) return;
   const int c4 = (int)(idx % C4);
@@ -327,6 +408,11 @@ __global__ void __launch_bounds__(256) maxpool3_bwd_kernel(const float* __restri
       if (((a >> 16) & 255u) == tap) acc.z += g.z;
       if ((a >> 24) == tap) acc.w += g.w;
     }
+  }
+  if (relu_of) {                                   // the pooled tensor is a ReLU output and this is the last term of
+    const float4 m = reinterpret_cast<const float4*>(relu_of)[idx];   // its gradient: hand it on with the ReLU adjoint
+    acc.x = m.x > 0.f ? acc.x : 0.f; acc.y = m.y > 0.f ? acc.y : 0.f;
+    acc.z = m.z > 0.f ? acc.z : 0.f; acc.w = m.w > 0.f ? acc.w : 0.f;
   }
   reinterpret_cast<float4*>(gx)[idx] = acc;
 }
@@ -400,6 +486,26 @@ static inline int conv2d_nchunks(int kh, int kw, int Cin) {
 }
 static inline int conv2d_npad(int Cout) { return (Cout + IC_BN - 1) / IC_BN * IC_BN; }
 
+// tile height and K split of one call: 128-row tiles once they still give every CU two blocks, 64-row tiles below;
+// when even those leave CUs idle and K is long, split K until ~512 blocks exist (>= 8 chunks per split, <= 16 splits)
+struct Conv2dPlan { int bm, ksplit, cps; };
+static Conv2dPlan conv2d_plan(int64_t M, int Npad, int nchunks) {
+  Conv2dPlan p;
+  const int ntiles = Npad / IC_BN;
+  p.bm = (M / 128) * ntiles >= 512 ? 128 : 64;
+  const int64_t blocks = ((M + p.bm - 1) / p.bm) * ntiles;
+  int ks = 1;
+  if (blocks < 384 && nchunks >= 16) {
+    ks = (int)((512 + blocks - 1) / blocks);
+    if (ks > nchunks / 8) ks = nchunks / 8;
+    if (ks > 16) ks = 16;
+    if (ks < 1) ks = 1;
+  }
+  p.cps = (nchunks + ks - 1) / ks;
+  p.ksplit = (nchunks + p.cps - 1) / p.cps;
+  return p;
+}
+
 }  // namespace nfs
 
 using namespace nfs;
@@ -424,9 +530,20 @@ int nfs_conv2d_pack(const float* w_hwio, float* packed, int kh, int kw, int Ci, 
   return check_launch("nfs_conv2d_pack");
 }
 
+int64_t nfs_conv2d_workspace_floats(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || (stride != 1 && stride != 2)) return 0;
+  int Ho, Wo, pt, pl;
+  same_pad(H, kh, stride, Ho, pt);
+  same_pad(W, kw, stride, Wo, pl);
+  const int64_t M = (int64_t)B * Ho * Wo;
+  const Conv2dPlan p = conv2d_plan(M, conv2d_npad(Cout), conv2d_nchunks(kh, kw, Cin));
+  return p.ksplit > 1 ? (int64_t)p.ksplit * M * conv2d_npad(Cout) : 0;
+}
+
 int nfs_conv2d_fwd(const float* x, int ldx, const float* x_mask, int ldm, const float* packed, const float* bias,
                    float* y, int ldy, float* y_pre, int ldp, int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                   int stride, int relu, int accumulate, nfs_stream_t stream) {
+                   int stride, int relu, int accumulate, float* workspace, int64_t workspace_floats,
+                   nfs_stream_t stream) {
   NFS_REQUIRE(x && packed && y, "nfs_conv2d_fwd: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "nfs_conv2d_fwd: non-positive dimension");
   NFS_REQUIRE(kh > 0 && kw > 0 && kh <= 7 && kw <= 7 && (stride == 1 || stride == 2),
@@ -456,21 +573,156 @@ int nfs_conv2d_fwd(const float* x, int ldx, const float* x_mask, int ldm, const 
   a.nchunks = conv2d_nchunks(kh, kw, Cin);
   a.Npad = conv2d_npad(Cout);
   const int ntiles = a.Npad / IC_BN;
-  // 128-row tiles once they still give every CU two blocks; 64-row tiles for the small late layers
-  const bool big = (M / 128) * ntiles >= 512;
+  Conv2dPlan p = conv2d_plan(M, a.Npad, a.nchunks);
+  if (p.ksplit > 1 && (!workspace || workspace_floats < (int64_t)p.ksplit * M * a.Npad)) {
+    p.ksplit = 1;                                   // no (or too small a) scratch buffer: one block per tile
+    p.cps = a.nchunks;
+  }
+  NFS_REQUIRE(p.ksplit == 1 || ((uintptr_t)workspace & 15) == 0, "nfs_conv2d_fwd: workspace must be 16-byte aligned");
+  a.ws = workspace; a.ksplit = p.ksplit; a.cps = p.cps;
+  a.partial = p.ksplit > 1; a.zbase = 0; a.ztotal = p.ksplit;
   hipStream_t s = as_stream(stream);
-  if (big) {
+  if (p.bm == 128) {
     const size_t lds = sizeof(float) * (size_t)(128 * (IC_BN + 4));          // >= 2 * (128 + 64) * 20
-    dim3 grid((unsigned)((M + 127) / 128), ntiles);
+    dim3 grid((unsigned)((M + 127) / 128), ntiles, p.ksplit);
     if (Cin <= 4) conv2d_mfma_kernel<128, 1><<<grid, 256, lds, s>>>(a);
     else conv2d_mfma_kernel<128, 0><<<grid, 256, lds, s>>>(a);
   } else {
     const size_t lds = sizeof(float) * (size_t)(2 * (64 + IC_BN) * IC_LS);   // >= 64 * 68
-    dim3 grid((unsigned)((M + 63) / 64), ntiles);
+    dim3 grid((unsigned)((M + 63) / 64), ntiles, p.ksplit);
     if (Cin <= 4) conv2d_mfma_kernel<64, 1><<<grid, 256, lds, s>>>(a);
     else conv2d_mfma_kernel<64, 0><<<grid, 256, lds, s>>>(a);
   }
+  if (p.ksplit > 1)
+    conv2d_reduce_kernel<<<blocks_for(M * (Cout / 4), 256), 256, 0, s>>>(a);
   return check_launch("nfs_conv2d_fwd");
+}
+
+// ---- grouped launch -------------------------------------------------------------------------------------------------
+namespace {
+struct GroupPlan {
+  Conv2dGroupArgs conv, red;
+  int64_t ws_floats;
+};
+
+// fills plan (pointers into `workspace` when given); returns 0, or a message
+const char* conv2d_group_plan(const nfs_conv2d_desc_t* d, int n, int B, float* workspace, GroupPlan& P) {
+  if (!d || n < 1 || n > IC_GMAX) return "1..6 problems";
+  if (B <= 0) return "non-positive batch";
+  Conv2dArgs a[IC_GMAX];
+  int mtiles[IC_GMAX], ntiles[IC_GMAX], ks[IC_GMAX];
+  for (int j = 0; j < n; ++j) {
+    const nfs_conv2d_desc_t& q = d[j];
+    if (!q.x || !q.packed || !q.y) return "null pointer";
+    if (q.H <= 0 || q.W <= 0 || q.Cin <= 4 || q.Cout <= 0 || q.kh <= 0 || q.kw <= 0 || q.kh > 7 || q.kw > 7)
+      return "bad dimension (Cin > 4, filters up to 7x7)";
+    if (q.Cin % 4 || q.Cout % 4 || q.ldx % 4 || q.ldy % 4 || q.ldx < q.Cin || q.ldy < q.Cout) return "channel counts and row strides must be multiples of 4";
+    if (q.x_mask && (q.ldm % 4 || q.ldm < q.Cin)) return "bad ldm";
+    if (q.y_pre && (q.ldp % 4 || q.ldp < q.Cout)) return "bad ldp";
+    if ((((uintptr_t)q.x | (uintptr_t)q.x_mask | (uintptr_t)q.packed | (uintptr_t)q.bias | (uintptr_t)q.y | (uintptr_t)q.y_pre) & 15) != 0)
+      return "pointers must be 16-byte aligned";
+    if ((int64_t)B * q.H * q.W >= ((int64_t)1 << 31)) return "too many pixels";
+    Conv2dArgs& c = a[j];
+    c.x = q.x; c.xmask = q.x_mask; c.wp = q.packed; c.bias = q.bias; c.y = q.y; c.ypre = q.y_pre;
+    c.ldx = q.ldx; c.ldm = q.ldm; c.ldy = q.ldy; c.ldp = q.ldp;
+    c.B = B; c.H = q.H; c.W = q.W; c.Cin = q.Cin; c.Cout = q.Cout; c.kh = q.kh; c.kw = q.kw; c.stride = 1;
+    same_pad(q.H, q.kh, 1, c.Ho, c.pad_t);
+    same_pad(q.W, q.kw, 1, c.Wo, c.pad_l);
+    c.relu = q.relu; c.accumulate = q.accumulate;
+    c.M = B * c.Ho * c.Wo;
+    c.cchunks = conv2d_cchunks(q.Cin);
+    c.nchunks = conv2d_nchunks(q.kh, q.kw, q.Cin);
+    c.Npad = conv2d_npad(q.Cout);
+    mtiles[j] = (c.M + 63) / 64;
+    ntiles[j] = c.Npad / IC_BN;
+    if (q.sum_with_prev) {
+      if (j == 0) return "the first problem cannot be summed with a previous one";
+      const Conv2dArgs& f = a[j - 1];
+      if (f.M != c.M || f.Cout != c.Cout || f.y != c.y || f.ldy != c.ldy) return "summed problems must share pixels, Cout and y";
+    }
+  }
+  // K chunks per block: the largest T of the ladder that yields >= 512 blocks (>= 8 chunks per block, <= 16 splits)
+  static const int ladder[] = {1 << 30, 256, 128, 64, 32, 16, 8};
+  for (int li = 0; li < 7; ++li) {
+    int64_t blocks = 0;
+    for (int j = 0; j < n; ++j) {
+      int k = (a[j].nchunks + ladder[li] - 1) / ladder[li];
+      if (k > 16) k = 16;
+      if (k < 1) k = 1;
+      ks[j] = k;
+      blocks += (int64_t)mtiles[j] * ntiles[j] * k;
+    }
+    if (blocks >= 512) break;
+  }
+  // partial-sum regions: a run of summed problems, or a single split problem
+  int64_t off = 0;
+  int nred = 0;
+  for (int j = 0; j < n;) {
+    int e = j + 1;
+    while (e < n && d[e].sum_with_prev) ++e;
+    const bool joint = e - j > 1;
+    int ztot = 0;
+    for (int i = j; i < e; ++i) {
+      a[i].cps = (a[i].nchunks + ks[i] - 1) / ks[i];
+      a[i].ksplit = (a[i].nchunks + a[i].cps - 1) / a[i].cps;
+      a[i].partial = joint || a[i].ksplit > 1;
+      a[i].zbase = ztot;
+      ztot += a[i].ksplit;
+    }
+    for (int i = j; i < e; ++i) {
+      a[i].ztotal = ztot;
+      a[i].ws = a[i].partial && workspace ? workspace + off : nullptr;
+    }
+    if (a[j].partial) {
+      P.red.p[nred++] = a[j];
+      off += (int64_t)ztot * a[j].M * a[j].Npad;
+    }
+    j = e;
+  }
+  P.ws_floats = off;
+  // reduce table
+  P.red.n = nred;
+  int b0 = 0;
+  for (int i = 0; i < nred; ++i) {
+    P.red.bstart[i] = b0;
+    b0 += (int)blocks_for((int64_t)P.red.p[i].M * (P.red.p[i].Cout / 4), 256);
+  }
+  P.red.bstart[nred] = b0;
+  // conv table: longest blocks first
+  int order[IC_GMAX];
+  for (int j = 0; j < n; ++j) order[j] = j;
+  for (int i = 1; i < n; ++i)
+    for (int k = i; k > 0 && a[order[k]].cps > a[order[k - 1]].cps; --k) { const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
+  b0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const int j = order[i];
+    P.conv.p[i] = a[j];
+    P.conv.bstart[i] = b0;
+    b0 += mtiles[j] * ntiles[j] * a[j].ksplit;
+  }
+  P.conv.bstart[n] = b0;
+  P.conv.n = n;
+  return nullptr;
+}
+}  // namespace
+
+int64_t nfs_conv2d_group_workspace_floats(const nfs_conv2d_desc_t* descs, int n, int B) {
+  GroupPlan P;
+  return conv2d_group_plan(descs, n, B, nullptr, P) ? -1 : P.ws_floats;
+}
+
+int nfs_conv2d_group(const nfs_conv2d_desc_t* descs, int n, int B, float* workspace, int64_t workspace_floats,
+                     nfs_stream_t stream) {
+  GroupPlan P;
+  const char* err = conv2d_group_plan(descs, n, B, workspace, P);
+  NFS_REQUIRE(!err, "nfs_conv2d_group: %s", err);
+  NFS_REQUIRE(P.ws_floats == 0 || (workspace && workspace_floats >= P.ws_floats && ((uintptr_t)workspace & 15) == 0),
+              "nfs_conv2d_group: workspace of %lld floats needed (16-byte aligned)", (long long)P.ws_floats);
+  hipStream_t s = as_stream(stream);
+  const size_t lds = sizeof(float) * (size_t)(2 * (64 + IC_BN) * IC_LS);
+  conv2d_group_kernel<<<P.conv.bstart[P.conv.n], 256, lds, s>>>(P.conv);
+  if (P.red.n > 0) conv2d_group_reduce_kernel<<<P.red.bstart[P.red.n], 256, 0, s>>>(P.red);
+  return check_launch("nfs_conv2d_group");
 }
 
 int nfs_conv2d_dgrad_small(const float* gy, int ldg, const float* y_act, int lda, const float* w_hwio, float* gx, int B,
@@ -481,14 +733,28 @@ int nfs_conv2d_dgrad_small(const float* gy, int ldg, const float* y_act, int lda
   NFS_REQUIRE(kh > 0 && kw > 0 && kh <= 7 && kw <= 7 && (stride == 1 || stride == 2),
               "nfs_conv2d_dgrad_small: filter up to 7x7, stride 1 or 2");
   NFS_REQUIRE(ldg % 4 == 0 && ldg >= Co && (!y_act || (lda % 4 == 0 && lda >= Co)), "nfs_conv2d_dgrad_small: bad row stride");
-  NFS_REQUIRE((((uintptr_t)gy | (uintptr_t)y_act) & 15) == 0, "nfs_conv2d_dgrad_small: pointers must be 16-byte aligned");
-  const size_t lds = sizeof(float) * (size_t)kh * kw * Co * 4;
-  NFS_REQUIRE(lds <= 64 * 1024, "nfs_conv2d_dgrad_small: filters do not fit 64 KB of LDS");
+  NFS_REQUIRE((((uintptr_t)gy | (uintptr_t)y_act | (uintptr_t)w_hwio) & 15) == 0,
+              "nfs_conv2d_dgrad_small: pointers must be 16-byte aligned");
   int Ho, Wo, pt, pl;
   same_pad(H, kh, stride, Ho, pt);
   same_pad(W, kw, stride, Wo, pl);
-  conv2d_small_dgrad_kernel<<<blocks_for((int64_t)B * H * W, 256), 256, lds, as_stream(stream)>>>(
-      gy, ldg, y_act, lda, w_hwio, gx, B, H, W, Ho, Wo, Ci, Co, kh, kw, stride, pt, pl);
+  const int nqy = (H + stride - 1) / stride, nqx = (W + stride - 1) / stride;      // class (0, 0) is the largest
+  dim3 grid(blocks_for((int64_t)B * nqy * nqx, 256), stride * stride);
+  hipStream_t s = as_stream(stream);
+#define NFS_LAUNCH(CI_)                                                                                               \
+  do {                                                                                                                \
+    if (y_act)                                                                                                        \
+      conv2d_small_dgrad_kernel<CI_, true><<<grid, 256, 0, s>>>(gy, ldg, y_act, lda, w_hwio, gx, B, H, W, Ho, Wo, Co, \
+                                                                kh, kw, stride, pt, pl);                              \
+    else                                                                                                              \
+      conv2d_small_dgrad_kernel<CI_, false><<<grid, 256, 0, s>>>(gy, ldg, y_act, lda, w_hwio, gx, B, H, W, Ho, Wo,    \
+                                                                 Co, kh, kw, stride, pt, pl);                         \
+  } while (0)
+  if (Ci == 1) NFS_LAUNCH(1);
+  else if (Ci == 2) NFS_LAUNCH(2);
+  else if (Ci == 3) NFS_LAUNCH(3);
+  else NFS_LAUNCH(4);
+#undef NFS_LAUNCH
   return check_launch("nfs_conv2d_dgrad_small");
 }
 
@@ -506,16 +772,17 @@ int nfs_maxpool3_fwd(const float* x, float* y, uint8_t* arg, int B, int H, int W
 }
 
 int nfs_maxpool3_bwd(const float* gy, const uint8_t* arg, float* gx, int B, int H, int W, int C, int stride,
-                     int accumulate, nfs_stream_t stream) {
+                     int accumulate, const float* relu_of, nfs_stream_t stream) {
   NFS_REQUIRE(gy && gx && arg, "nfs_maxpool3_bwd: null pointer");
   NFS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nfs_maxpool3_bwd: C must be a positive multiple of 4");
   NFS_REQUIRE(stride == 1 || stride == 2, "nfs_maxpool3_bwd: stride 1 or 2");
-  NFS_REQUIRE((((uintptr_t)gx | (uintptr_t)gy) & 15) == 0 && ((uintptr_t)arg & 3) == 0, "nfs_maxpool3_bwd: misaligned pointer");
+  NFS_REQUIRE((((uintptr_t)gx | (uintptr_t)gy | (uintptr_t)relu_of) & 15) == 0 && ((uintptr_t)arg & 3) == 0,
+              "nfs_maxpool3_bwd: misaligned pointer");
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, Ho, pt);
   same_pad(W, 3, stride, Wo, pl);
   maxpool3_bwd_kernel<<<blocks_for((int64_t)B * H * W * (C / 4), 256), 256, 0, as_stream(stream)>>>(
-      gy, reinterpret_cast<const uint32_t*>(arg), gx, B, H, W, Ho, Wo, C / 4, stride, pt, pl, accumulate);
+      gy, reinterpret_cast<const uint32_t*>(arg), gx, B, H, W, Ho, Wo, C / 4, stride, pt, pl, accumulate, relu_of);
   return check_launch("nfs_maxpool3_bwd");
 }
 

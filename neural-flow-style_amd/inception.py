@@ -58,6 +58,9 @@ UNITS = ([("conv", "conv2d0"), ("maxpool", "maxpool0", 2), ("lrn", "localrespons
           ("mixed", "mixed3b"), ("maxpool", "maxpool4", 2)] + [("mixed", "mixed4" + c) for c in "abcde"]
          + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b")])
 BRANCHES = ("1x1", "3x3_bottleneck", "3x3", "5x5_bottleneck", "5x5", "pool_reduce")
+# modules of up to this many pixels (batch x h x w) run their branches as grouped launches (64-row tiles, K split until
+# the launch fills the chip); above it every branch is a full launch of its own
+GROUP_MAX_PIXELS = 1 << 16
 
 
 def conv_units():
@@ -246,7 +249,8 @@ class InceptionV1(object):
         cur, ccur = x.contiguous(), 3                     # current tensor (padded rows) and its logical channels
         acts.aux["input_hw"] = (x.shape[1], x.shape[2])
 
-        def conv(name, src, csrc, dst, cdst, stride=1):
+        def conv(name, src, csrc, dst, cdst, stride=1, group=None):
+            """one convolution unit; with ``group`` (a list) the call is queued for a grouped launch"""
             p = self.params[name]
             pre = None
             if want_pre(name):
@@ -256,8 +260,12 @@ class InceptionV1(object):
                 acts[name + "_pre_relu"] = pre
                 acts.channels[name + "_pre_relu"] = p["cout"]
                 acts.where[name + "_pre_relu"] = (pre, 0, p["cout"])
-            ops.conv2d_fwd(src, csrc, p["cin"], p["fwd"], p["bias"], dst, cdst, p["cout"], p["k"], p["k"], stride,
-                           relu=True, y_pre=pre)
+            if group is not None:
+                group.append(dict(x=src, cx=csrc, Cin=p["cin"], packed=p["fwd"], bias=p["bias"], y=dst, cy=cdst,
+                                  Cout=p["cout"], k=p["k"], relu=True, y_pre=pre))
+            else:
+                ops.conv2d_fwd(src, csrc, p["cin"], p["fwd"], p["bias"], dst, cdst, p["cout"], p["k"], p["k"], stride,
+                               relu=True, y_pre=pre)
             acts.where[name] = (dst, cdst, p["cout"])
 
         def new(b, h, w, c):
@@ -295,17 +303,26 @@ class InceptionV1(object):
                 ps = [self.params["%s_%s" % (name, b)] for b in BRANCHES]
                 c1, c3, c5, cp = ps[0]["cout"], ps[2]["cout"], ps[4]["cout"], ps[5]["cout"]
                 out = new(B, H, W, c1 + c3 + c5 + cp)
-                conv(name + "_1x1", cur, 0, out, 0)
                 b3 = new(B, H, W, ps[1]["cout"])
-                conv(name + "_3x3_bottleneck", cur, 0, b3, 0)
-                conv(name + "_3x3", b3, 0, out, c1)
                 b5 = new(B, H, W, ps[3]["cout"])
-                conv(name + "_5x5_bottleneck", cur, 0, b5, 0)
-                conv(name + "_5x5", b5, 0, out, c1 + c3)
+                # a module = two grouped launches (the three 1x1 convolutions on the module input; 3x3, 5x5 and the
+                # pool projection) + the pool: one by one the branches leave most of the chip idle
+                grouped = B * H * W <= GROUP_MAX_PIXELS
+                g1 = [] if grouped else None
+                conv(name + "_1x1", cur, 0, out, 0, group=g1)
+                conv(name + "_3x3_bottleneck", cur, 0, b3, 0, group=g1)
+                conv(name + "_5x5_bottleneck", cur, 0, b5, 0, group=g1)
+                if grouped:
+                    ops.conv2d_group(g1)
                 pool, arg = ops.maxpool3_fwd(cur, 1)
                 acts.aux[name + "_pool"] = (arg, (H, W), 1)
                 acts.where[name + "_pool"] = (pool, 0, ccur)
-                conv(name + "_pool_reduce", pool, 0, out, c1 + c3 + c5)
+                g2 = [] if grouped else None
+                conv(name + "_3x3", b3, 0, out, c1, group=g2)
+                conv(name + "_5x5", b5, 0, out, c1 + c3, group=g2)
+                conv(name + "_pool_reduce", pool, 0, out, c1 + c3 + c5, group=g2)
+                if grouped:
+                    ops.conv2d_group(g2)
                 acts.aux[name + "/in"] = (cur, ccur)
                 cur, ccur = out, c1 + c3 + c5 + cp
                 acts.where[name] = (out, 0, ccur)
@@ -331,6 +348,7 @@ class InceptionV1(object):
         post-ReLU tensor already carries that ReLU's mask makes no difference).  Returns dL/dx [B,H,W,3]."""
         G = {}                                              # id(buffer) -> gradient buffer of the same shape
         pre_inject = {}
+        premasked = set()                                   # gradient buffers that already carry their ReLU adjoint
 
         def gbuf(buf):
             g = G.get(id(buf))
@@ -351,8 +369,9 @@ class InceptionV1(object):
             else:
                 gb[..., c0:c0 + c].add_(g[..., :c])
 
-        def conv_bwd(name, src, csrc):
-            """data gradient of unit ``name`` into the gradient of its input (src buffer, logical channels csrc)"""
+        def conv_bwd(name, src, csrc, group=None):
+            """data gradient of unit ``name`` into the gradient of its input (src buffer, logical channels csrc); with
+            ``group`` (a list) the call is queued for a grouped launch"""
             p = self.params[name]
             buf, c0, c = acts.where[name]
             g = G.get(id(buf))
@@ -363,8 +382,12 @@ class InceptionV1(object):
                 g_in, cg, mask, cm = ops.relu_mask_add(g, c0, buf if g is not None else None, c0, inj, 0, c), 0, None, 0
             else:
                 g_in, cg, mask, cm = g, c0, buf, c0
-            ops.conv2d_fwd(g_in, cg, c, p["dgrad"], None, gbuf(src), 0, csrc, p["k"], p["k"], 1, relu=False,
-                           x_mask=mask, cm=cm, accumulate=True)
+            if group is not None:
+                group.append(dict(x=g_in, cx=cg, Cin=c, packed=p["dgrad"], bias=None, y=gbuf(src), cy=0, Cout=csrc,
+                                  k=p["k"], relu=False, x_mask=mask, cm=cm, accumulate=True))
+            else:
+                ops.conv2d_fwd(g_in, cg, c, p["dgrad"], None, gbuf(src), 0, csrc, p["k"], p["k"], 1, relu=False,
+                               x_mask=mask, cm=cm, accumulate=True)
 
         last = self._last_unit(upto)
         for u in reversed(self.units[:last + 1]):
@@ -378,9 +401,10 @@ class InceptionV1(object):
                 if g is None and inj is None:
                     return torch.zeros(tuple(src.shape[:3]) + (3,), dtype=torch.float32, device=src.device)
                 if inj is not None:
-                    g, mask = ops.relu_mask_add(g, 0, buf if g is not None else None, 0, inj, 0, c), None
+                    g, mask = ops.relu_mask_add(g, 0, buf if (g is not None and id(buf) not in premasked) else None, 0,
+                                                inj, 0, c), None
                 else:
-                    mask = buf
+                    mask = None if id(buf) in premasked else buf
                 return ops.conv2d_dgrad_small(g, 0, c, p["w"], acts.aux["input_hw"], self.stride0, y_act=mask)
             if kind == "conv":
                 conv_bwd(name, src, csrc)
@@ -388,7 +412,12 @@ class InceptionV1(object):
                 arg, hw, stride = acts.aux[name]
                 g = G.get(id(acts.where[name][0]))
                 if g is not None:
-                    ops.maxpool3_bwd(g, arg, hw, stride, gx=gbuf(src))
+                    # the pool over conv2d0's output is the last term of that gradient: it hands it on with the ReLU
+                    # adjoint, and the data gradient down to the image (16 taps per pixel) reads it unmasked
+                    first = name == "maxpool0"
+                    ops.maxpool3_bwd(g, arg, hw, stride, gx=gbuf(src), relu_of=src if first else None)
+                    if first:
+                        premasked.add(id(src))
             elif kind == "lrn":
                 xin, y, scale = acts.aux[name]
                 g = G.get(id(y))
@@ -399,12 +428,24 @@ class InceptionV1(object):
                 b3 = acts.where[name + "_3x3_bottleneck"][0]
                 b5 = acts.where[name + "_5x5_bottleneck"][0]
                 pool = acts.where[name + "_pool"][0]
-                conv_bwd(name + "_1x1", src, csrc)
-                conv_bwd(name + "_3x3", b3, self.params[name + "_3x3_bottleneck"]["cout"])
-                conv_bwd(name + "_5x5", b5, self.params[name + "_5x5_bottleneck"]["cout"])
-                conv_bwd(name + "_pool_reduce", pool, csrc)
-                conv_bwd(name + "_3x3_bottleneck", src, csrc)
-                conv_bwd(name + "_5x5_bottleneck", src, csrc)
+                grouped = src.shape[0] * src.shape[1] * src.shape[2] <= GROUP_MAX_PIXELS
+                # the three data gradients that end in other tensors in one launch; then the three 1x1 data gradients
+                # that meet in the gradient of the module input as ONE sum (partial sums + a fixed-order reduction: no
+                # race between them, deterministic)
+                g2 = [] if grouped else None
+                conv_bwd(name + "_3x3", b3, self.params[name + "_3x3_bottleneck"]["cout"], group=g2)
+                conv_bwd(name + "_5x5", b5, self.params[name + "_5x5_bottleneck"]["cout"], group=g2)
+                conv_bwd(name + "_pool_reduce", pool, csrc, group=g2)
+                if g2:
+                    ops.conv2d_group(g2)
+                g1 = [] if grouped else None
+                conv_bwd(name + "_1x1", src, csrc, group=g1)
+                conv_bwd(name + "_3x3_bottleneck", src, csrc, group=g1)
+                conv_bwd(name + "_5x5_bottleneck", src, csrc, group=g1)
+                if g1:
+                    for q in g1[1:]:
+                        q["sum_with_prev"] = True
+                    ops.conv2d_group(g1)
                 gp = G.get(id(pool))
                 if gp is not None:
                     arg, hw, stride = acts.aux[name + "_pool"]

@@ -24,8 +24,16 @@ def _ptr(t):
     return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device=None):
+    """the current HIP stream's handle (the raw getter is ~20x cheaper than building a torch.cuda.Stream object: the
+    one-view and small-grid steps are bound by what the host needs per launch)"""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _empty(shape, like):
@@ -68,7 +76,7 @@ _workspaces = {}
 
 def workspace(device):
     """small per-device scratch (64 floats) for entry points that need a device-side scalar"""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)   # one per stream
+    key = (device.type, device.index, _stream(device))   # one per stream
     if key not in _workspaces:
         _workspaces[key] = torch.zeros(64, dtype=torch.float32, device=device)
     return _workspaces[key]
@@ -391,7 +399,7 @@ _conv_ws = {}
 def conv_workspace(device, floats):
     """split-K scratch, grown on demand and shared by all conv calls of a device (calls on one stream
     are ordered, so sharing is safe)"""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)   # one per stream
+    key = (device.type, device.index, _stream(device))   # one per stream
     cur = _conv_ws.get(key)
     if cur is None or cur.numel() < floats:
         cur = torch.empty(int(floats), dtype=torch.float32, device=device)
@@ -753,10 +761,52 @@ def conv2d_fwd(x, cx, Cin, packed, bias, y, cy, Cout, kh, kw, stride=1, relu=Tru
         assert tuple(x_mask.shape[:3]) == (B, H, W) and cm + Cin <= x_mask.shape[3]
     if y_pre is not None:
         assert tuple(y_pre.shape[:3]) == (B, Ho, Wo) and cp + Cout <= y_pre.shape[3]
+    nws = _lib.lib().nfs_conv2d_workspace_floats(B, H, W, Cin, Cout, kh, kw, stride)
+    ws = conv_workspace(x.device, nws) if nws > 0 else None     # shared scratch (calls on one stream are ordered)
     _lib.call("nfs_conv2d_fwd", x.data_ptr() + 4 * cx, ldx, xm, 0 if x_mask is None else x_mask.shape[3], _ptr(packed),
               _ptr(bias), y.data_ptr() + 4 * cy, y.shape[3], yp, 0 if y_pre is None else y_pre.shape[3], B, H, W, Cin,
-              Cout, kh, kw, stride, int(relu), int(accumulate), _stream())
+              Cout, kh, kw, stride, int(relu), int(accumulate), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return y
+
+
+_group_ws = {}
+
+
+def conv2d_group(problems):
+    """Several stride-1 SAME convolutions of one batch in one launch.  ``problems``: dicts with the arguments of
+    ``conv2d_fwd`` (x, cx, Cin, packed, bias, y, cy, Cout, k, relu, y_pre, cp, x_mask, cm, accumulate) and
+    ``sum_with_prev`` (added to the previous problem's result: same pixels, Cout and output range)"""
+    import ctypes
+    n = len(problems)
+    arr = (_lib.ConvDesc * n)()
+    B = problems[0]["x"].shape[0]
+    for q, pr in zip(arr, problems):
+        x, y = _rows(pr["x"]), _rows(pr["y"])
+        assert x.shape[0] == B and tuple(y.shape[:3]) == tuple(x.shape[:3])
+        cx, cy, Cin, Cout = pr.get("cx", 0), pr.get("cy", 0), pr["Cin"], pr["Cout"]
+        assert cx + Cin <= x.shape[3] and cy + Cout <= y.shape[3]
+        xm, yp = pr.get("x_mask"), pr.get("y_pre")
+        q.x, q.ldx = x.data_ptr() + 4 * cx, x.shape[3]
+        q.y, q.ldy = y.data_ptr() + 4 * cy, y.shape[3]
+        q.x_mask, q.ldm = (None, 0) if xm is None else (_rows(xm).data_ptr() + 4 * pr.get("cm", 0), xm.shape[3])
+        q.y_pre, q.ldp = (None, 0) if yp is None else (_rows(yp).data_ptr() + 4 * pr.get("cp", 0), yp.shape[3])
+        q.packed, q.bias = _ptr(pr["packed"]), _ptr(pr.get("bias"))
+        q.H, q.W, q.Cin, q.Cout, q.kh, q.kw = x.shape[1], x.shape[2], Cin, Cout, pr["k"], pr["k"]
+        q.relu, q.accumulate = int(bool(pr.get("relu", True))), int(bool(pr.get("accumulate", False)))
+        q.sum_with_prev = int(bool(pr.get("sum_with_prev", False)))
+    ap = ctypes.cast(arr, ctypes.c_void_p)
+    key = (B,) + tuple((q.H, q.W, q.Cin, q.Cout, q.kh, q.sum_with_prev) for q in arr)
+    nws = _group_ws.get(key)
+    if nws is None:
+        nws = _lib.lib().nfs_conv2d_group_workspace_floats(ap, n, B)
+        if nws < 0:
+            _lib.call("nfs_conv2d_group", ap, n, B, None, 0, _stream())     # raises with the planner's message
+        _group_ws[key] = nws
+    ws = conv_workspace(x.device, nws) if nws > 0 else None
+    if _lib.PROFILE is not None:                          # (bench: the shapes behind this call's event pair)
+        _lib.PROFILE.setdefault("shapes:nfs_conv2d_group", []).append(
+            [(B, q.H, q.W, q.Cin, q.Cout, q.kh, q.kw) for q in arr])
+    _lib.call("nfs_conv2d_group", ap, n, B, _ptr(ws), 0 if ws is None else ws.numel(), _stream())
 
 
 def conv2d_dgrad_small(gy, cg, Co, w_hwio, in_hw, stride, y_act=None, ca=0):
@@ -785,8 +835,9 @@ def maxpool3_fwd(x, stride):
     return y, arg
 
 
-def maxpool3_bwd(gy, arg, in_hw, stride, gx=None):
-    """gx (+)= the pool adjoint; ``gx`` given: accumulate into it"""
+def maxpool3_bwd(gy, arg, in_hw, stride, gx=None, relu_of=None):
+    """gx (+)= the pool adjoint; ``gx`` given: accumulate into it; ``relu_of`` (the pooled tensor, a ReLU output): the
+    result also carries that ReLU's adjoint"""
     _rows(gy)
     B, Ho, Wo, ld = gy.shape
     H, W = in_hw
@@ -794,7 +845,9 @@ def maxpool3_bwd(gy, arg, in_hw, stride, gx=None):
     if gx is None:
         gx = _empty((B, H, W, ld), gy)
     assert tuple(gx.shape) == (B, H, W, ld) and arg.dtype == torch.uint8 and arg.is_contiguous()
-    _lib.call("nfs_maxpool3_bwd", _ptr(gy), arg.data_ptr(), _ptr(gx), B, H, W, ld, stride, int(acc), _stream())
+    assert relu_of is None or tuple(relu_of.shape) == tuple(gx.shape)
+    _lib.call("nfs_maxpool3_bwd", _ptr(gy), arg.data_ptr(), _ptr(gx), B, H, W, ld, stride, int(acc), _ptr(relu_of),
+              _stream())
     return gx
 
 

@@ -116,6 +116,10 @@ def test_maxpool3_same_and_its_adjoint(stride, B, H, W, C):
     assert rel(gx - 0.5, nhwc(xt.grad)) < 1e-6
     gx2 = ops.maxpool3_bwd(torch.tensor(gy, device=DEV), arg, (H, W), stride)
     assert rel(gx2, nhwc(xt.grad)) < 1e-6
+    # ... handing the gradient on with the pooled tensor's own ReLU adjoint
+    gx3 = ops.maxpool3_bwd(torch.tensor(gy, device=DEV), arg, (H, W), stride, gx=base.clone().fill_(0.5),
+                           relu_of=torch.tensor(x, device=DEV))
+    assert rel(gx3, (nhwc(xt.grad) + 0.5) * torch.tensor(x > 0)) < 1e-6
 
 
 def test_maxpool3_gives_the_gradient_to_the_first_maximum():
