@@ -7,11 +7,9 @@ Same ``run(config)`` body as the reference: build the Styler, ``load_img(resolut
 (``id, position``; slots of absent particles stay at -1, i.e. outside the domain), ``styler.run(params)``, save
 ``loss_plot.png``, ``%03d.bgeo`` (``position`` de-normalised back to (x,y,z) world units + ``radius``; padded slots
 skipped), ``%03d.png`` (``result['r']``), ``o%02d_%03d.png``.  ``main()`` reproduces the reference's override block
-value for value.  Differences, each because the reference's choice cannot run here:
-  * loss network: the reference hard-codes ``tensorflow_inception_graph.pb`` with style layers ('conv2d2', 'mixed3b',
-    'mixed4b'); that graph's weights are not in this image and the build's hot path is the VGG-19 network, so the
-    driver selects ``vgg_19.ckpt`` with conv1_1 ... conv4_1 (printed) -- the substitution test_dambreak2d.py:183 makes
-    itself;
+value for value (``tensorflow_inception_graph.pb`` with style layers 'conv2d2', 'mixed3b', 'mixed4b';
+``--network vgg_19.ckpt`` selects VGG-19 conv1_1 ... conv4_1).  Differences, each because the reference's choice cannot
+run here:
   * particle files go through ``io_bgeo`` or ``.npz`` (keys ``position`` [N,3] world (x,y,z), optional ``id``); without
     a dataset the run uses seeded synthetic particles (DEMO MODE, printed);
   * ``np.float`` (test_chocolate.py:121, removed from NumPy) is ``float``; no open3d viewer at the end.
@@ -70,7 +68,7 @@ def synthetic_frames(config, n=50000):
 def run(config):
     prepare_dirs_and_logger(config)
     config.rng = np.random.RandomState(config.seed)
-    if not config.style_target and not (config.w_content > 0 and not getattr(config, "content_target", "")):
+    if not config.style_target and (config.w_style > 0 or not config.w_content):
         from neural_flow_style_amd import synthetic as S
         print("DEMO MODE: synthetic style image and synthetic (random) loss-network filters -- not a real stylisation")
         config.style_target = S.style_image(256, 256, np.random.RandomState(config.seed))
@@ -186,12 +184,18 @@ def main(config):
     config.render_liquid = True
     config.rotate = False
 
-    print("loss network: VGG-19 conv1_1..conv4_1 in place of the Inception-v1 graph ('conv2d2','mixed3b','mixed4b')")
-    config.network = "vgg_19.ckpt"
+    # test_chocolate.py:173-180: the Inception graph with conv2d2 / mixed3b / mixed4b; ``--network vgg_19.ckpt`` selects
+    # the VGG-19 end points conv1_1 ... conv4_1 instead
+    if "--network" not in given:
+        config.network = "tensorflow_inception_graph.pb"
     if "--style_layer" not in given:
-        config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1"]
-        config.w_style_layer = [1, 1, 1, 1]
-    if not str(config.content_layer).startswith("conv"):
+        if "vgg" in config.network:
+            config.style_layer = ["conv1_1", "conv2_1", "conv3_1", "conv4_1"]
+        else:
+            config.style_layer = ["conv2d2", "mixed3b", "mixed4b"]
+    if "--w_style_layer" not in given:
+        config.w_style_layer = [1] * len(config.style_layer)
+    if "vgg" in config.network and not str(config.content_layer).startswith("conv"):
         config.w_content = 0
 
     # frame range setting

@@ -62,8 +62,8 @@ def test_dambreak2d_driver_reproduces_the_override_block_and_writes_its_outputs(
 
 def test_chocolate_driver_reproduces_the_override_block_and_writes_its_outputs(tmp_path, monkeypatch):
     """main() of test_chocolate.py:148-252 value for value (200^3 render grid on the 128^3 x 0.1 domain, liquid render,
-    transmit 0.2, 'p' field, 2 octaves, lr 0.002, frames_per_opt 120, window_sigma 9; VGG in place of the Inception
-    graph), then a short demo run on a 32^3 grid with the pressure term"""
+    transmit 0.2, 'p' field, 2 octaves, lr 0.002, frames_per_opt 120, window_sigma 9, the Inception graph with conv2d2 /
+    mixed3b / mixed4b; VGG through --network), then a short demo run on a 32^3 grid with the pressure term"""
     import test_chocolate as drv
     seen = {}
     monkeypatch.setattr(drv, "run", lambda c: seen.update(vars(c)))
@@ -75,11 +75,17 @@ def test_chocolate_driver_reproduces_the_override_block_and_writes_its_outputs(t
     assert seen["target_field"] == "p" and seen["lr"] == 0.002 and seen["iter"] == 20 and seen["octave_n"] == 2
     assert seen["octave_scale"] == 1.8 and seen["k"] == 3 and seen["num_kernels"] == 1 and seen["clip"] is False
     assert seen["frames_per_opt"] == 120 and seen["window_sigma"] == 9 and seen["batch_size"] == 1
-    assert seen["network"] == "vgg_19.ckpt"
+    assert seen["network"] == "tensorflow_inception_graph.pb" and seen["style_layer"] == ["conv2d2", "mixed3b", "mixed4b"]
+    assert seen["w_style_layer"] == [1, 1, 1]
+    seen.clear()
+    monkeypatch.setattr(sys, "argv", ["test_chocolate.py", "--network", "vgg_19.ckpt"])
+    drv.main(_cfg(tmp_path, ["--network", "vgg_19.ckpt"]))
+    assert seen["network"] == "vgg_19.ckpt" and seen["style_layer"] == ["conv1_1", "conv2_1", "conv3_1", "conv4_1"]
+    assert seen["w_content"] == 0
     monkeypatch.undo()
 
     argv = ["--resolution", "32", "32", "32", "--iter", "2", "--octave_n", "2", "--num_frames", "2", "--target_frame",
-            "90", "--w_pressure", "1000"]
+            "90", "--w_pressure", "1000", "--w_style", "1", "--w_content", "0"]
     monkeypatch.setattr(sys, "argv", ["test_chocolate.py"] + argv)
     cfg = _cfg(tmp_path, argv)
     res = drv.main(cfg)
