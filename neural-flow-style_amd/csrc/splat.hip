@@ -5,6 +5,8 @@
 // (backward, no atomics).  HBM-bound: N*(4*nd+4*C) B of particle data + the touched cells.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace nfs {
 
 struct SplatDev {
@@ -100,6 +102,115 @@ __global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* _
     } else {
       for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * attr[a * C + ch]);
       if (s.mode == 2) atomicAdd(wsum + ci, w);
+    }
+  }
+}
+
+// The same scatter with the block's cells privatised in LDS.  Particles arrive in grid-cell order (Styler.run sorts
+// them once per sequence), so the own cells of a block's 256 particles span a short interval [cmin, cmax] of the
+// linear cell index, and every cell they touch lies in 2 nsize + 1 intervals ("bands", one per plane offset) of length
+// cmax - cmin + 2 (nsize W + nsize) + 1.  When those fit 48 KB the block accumulates into LDS (ds_add_f32: neighbouring
+// particles share 18 of their 27 cells) and flushes each touched cell ONCE with a global atomic; otherwise (unsorted or
+// very sparse particles) it falls back to the per-cell global atomics above.  Same arithmetic per contribution.
+constexpr int SPL_LDS = 12288;     // floats of LDS accumulators
+
+template <int SPL_PB>              // particles per block
+__global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const float* __restrict__ p,
+                                                          const float* __restrict__ attr, const float* __restrict__ pd,
+                                                          float* __restrict__ grid, float* __restrict__ wsum, int N,
+                                                          int C, int allow_lds) {
+  extern __shared__ float acc[];
+  __shared__ int red[2 * 4];
+  const int t = threadIdx.x;
+  const int64_t a0 = (int64_t)blockIdx.x * SPL_PB;
+  Particle P[SPL_PB / 256];
+  int cmin = 0x7fffffff, cmax = -1;
+#pragma unroll
+  for (int j = 0; j < SPL_PB / 256; ++j) {
+    const int64_t a = a0 + t + 256 * j;
+    P[j].valid = false;
+    if (a < N) {
+      P[j] = load_particle(s, p, a);
+      if (P[j].valid) {
+        const int ci = (int)cell_index(s, P[j].idx);
+        if (ci >= 0) { cmin = min(cmin, ci); cmax = max(cmax, ci); }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cmin = min(cmin, __shfl_xor(cmin, o, 64));
+    cmax = max(cmax, __shfl_xor(cmax, o, 64));
+  }
+  if ((t & 63) == 0) { red[t >> 6] = cmin; red[4 + (t >> 6)] = cmax; }
+  __syncthreads();
+  cmin = min(min(red[0], red[1]), min(red[2], red[3]));
+  cmax = max(max(red[4], red[5]), max(red[6], red[7]));
+  const int Wd = s.res[s.nd - 1];
+  const int HW = s.nd == 3 ? s.res[1] * s.res[2] : 0;
+  const int R = s.nsize * Wd + s.nsize;
+  const int nb = s.nd == 3 ? 2 * s.nsize + 1 : 1;
+  const int nch = s.mode == 0 ? 1 : (s.mode == 2 ? C + 1 : C);
+  const int64_t L64 = (int64_t)cmax - cmin + 2 * R + 1;
+  const bool use_lds = allow_lds && cmax >= cmin && L64 * nb * nch <= SPL_LDS;
+  const int L = (int)L64;
+  if (use_lds) {
+    for (int i = t; i < nb * L * nch; i += 256) acc[i] = 0.f;
+    __syncthreads();
+  }
+  const int span = 2 * s.nsize + 1;
+  const int total = s.nd == 2 ? span * span : span * span * span;
+#pragma unroll
+  for (int j = 0; j < SPL_PB / 256; ++j) {
+    if (!P[j].valid) continue;
+    const int64_t a = a0 + t + 256 * j;
+    float coef = 1.f;
+    if (s.mode == 0) coef = s.mass;
+    if (s.mode == 1) coef = s.mass / (pd ? pd[a] : s.rest_density);
+    for (int o = 0; o < total; ++o) {
+      int n[3] = {0, 0, 0};
+      if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
+      else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
+      float d2 = 0.f;
+      int c[3];
+      for (int k = 0; k < s.nd; ++k) {
+        const float rr = P[j].r[k] - (float)n[k] * s.cell;
+        d2 += rr * rr;
+        c[k] = P[j].idx[k] + n[k];
+      }
+      const float w = cubic_w(sqrtf(d2) / s.h, s.sigma);
+      if (w == 0.f) continue;
+      const int64_t ci = cell_index(s, c);
+      if (ci < 0) continue;
+      if (use_lds) {
+        const int band = s.nd == 3 ? n[0] + s.nsize : 0;
+        float* dst = acc + ((int64_t)band * L + ((int)ci - (cmin + (band - (s.nd == 3 ? s.nsize : 0)) * HW - R))) * nch;
+        if (s.mode == 0) {
+          atomicAdd(dst, coef * w);
+        } else {
+          for (int ch = 0; ch < C; ++ch) atomicAdd(dst + ch, coef * w * attr[a * C + ch]);
+          if (s.mode == 2) atomicAdd(dst + C, w);
+        }
+      } else if (s.mode == 0) {
+        atomicAdd(grid + ci, coef * w);
+      } else {
+        for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * attr[a * C + ch]);
+        if (s.mode == 2) atomicAdd(wsum + ci, w);
+      }
+    }
+  }
+  if (!use_lds) return;
+  __syncthreads();
+  for (int i = t; i < nb * L; i += 256) {
+    const int band = i / L, off = i - band * L;
+    const int64_t cell = (int64_t)cmin + (int64_t)(band - (s.nd == 3 ? s.nsize : 0)) * HW - R + off;
+    const float* src = acc + (int64_t)i * nch;
+    if (s.mode == 0) {
+      if (src[0] != 0.f) atomicAdd(grid + cell, src[0]);
+    } else {
+      for (int ch = 0; ch < C; ++ch)
+        if (src[ch] != 0.f) atomicAdd(grid + cell * C + ch, src[ch]);
+      if (s.mode == 2 && src[C] != 0.f) atomicAdd(wsum + cell, src[C]);
     }
   }
 }
@@ -297,8 +408,17 @@ int nfs_p2g_fwd(const float* p, const float* attr, const float* pd, float* grid,
   NFS_REQUIRE(s.mode == 0 || attr, "nfs_p2g_fwd: attr required for mode 1/2");
   NFS_REQUIRE(s.mode != 2 || wsum, "nfs_p2g_fwd: wsum required for mode 2");
   NFS_REQUIRE(s.mode != 0 || C == 1, "nfs_p2g_fwd: density mode has C=1");
-  hipLaunchKernelGGL(p2g_fwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, grid,
-                     wsum, N, C);
+  int64_t cells = 1;
+  for (int k = 0; k < s.nd; ++k) cells *= s.res[k];
+  if (cells >= ((int64_t)1 << 31)) {                 // (the LDS form keeps linear cell indices in 32 bits)
+    hipLaunchKernelGGL(p2g_fwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, grid,
+                       wsum, N, C);
+    return check_launch("nfs_p2g_fwd");
+  }
+  static const int allow_lds = [] { const char* e = getenv("NFS_SPLAT_LDS"); return e ? atoi(e) : 1; }();
+  // 256 particles per block: measured 0.156 ms against 0.184 (512) and 0.247 (1024) on the 5e5-particle blob set
+  hipLaunchKernelGGL(p2g_fwd_lds_kernel<256>, dim3(blocks_for(N, 256)), dim3(256), SPL_LDS * sizeof(float),
+                     as_stream(stream), s, p, attr, pd, grid, wsum, N, C, allow_lds);
   return check_launch("nfs_p2g_fwd");
 }
 

@@ -420,6 +420,35 @@ def test_p2g_density(ops, nd):
     assert rel(gp_h, gp[0]) < 5e-4
 
 
+@pytest.mark.parametrize("mode", ["density", "wavg"])
+def test_p2g_cell_ordered_particles_accumulate_in_lds_and_agree_with_the_scattered_form(ops, mode):
+    """particles in grid-cell order (as Styler.run sorts them) take the LDS-privatised path of the splat (a block's
+    cells span a short interval of the linear index); the same particles shuffled span the whole grid and fall back to
+    per-cell global atomics: both must give the oracle's grid"""
+    rng = np.random.RandomState(31)
+    N, G = 30000, 48
+    p = np.clip(0.5 + rng.randn(N, 3) * 0.12, 0.02, 0.98).astype(np.float32)
+    cell = np.floor(p * G).astype(np.int64)
+    order = np.argsort((cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2], kind="stable")
+    x = rng.uniform(0, 1, (N, 2)).astype(np.float32)
+    res, dom = [G, G, G], [float(G)] * 3
+    outs = []
+    for perm in (order, rng.permutation(N)):
+        pp, xx = torch.tensor(p[perm]), torch.tensor(x[perm])
+        if mode == "density":
+            cfg = ops.make_splat_cfg(3, res, dom, 0.5, 4, 1000., 1, False, 0)
+            outs.append(ops.p2g_fwd(dev(pp), cfg))
+        else:
+            cfg = ops.make_splat_cfg(3, res, dom, 0.5, 4, 1000., 1, False, 2)
+            xs, ws = ops.p2g_fwd(dev(pp), cfg, attr=dev(xx))
+            outs.append(ops.p2g_wavg_finish(xs, ws))
+    pt = torch.tensor(p)[None]
+    ref = O.p2g(pt, dom, res, 0.5, 1000., 1, is_2d=False, clip=False) if mode == "density" else \
+        O.p2g_wavg(pt, torch.tensor(x)[None], dom, res, 0.5, 1, is_2d=False, clip=False, support=4)
+    assert rel(outs[0], ref[0]) < TOL and rel(outs[1], ref[0]) < TOL
+    assert rel(outs[0], outs[1]) < 1e-6
+
+
 def test_p2g_colour_2d(ops):
     rng = np.random.RandomState(13)
     N = 400
