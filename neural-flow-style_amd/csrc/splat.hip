@@ -106,12 +106,13 @@ __global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* _
   }
 }
 
-// The same scatter with the block's cells privatised in LDS.  Particles arrive in grid-cell order (Styler.run sorts
-// them once per sequence), so the own cells of a block's 256 particles span a short interval [cmin, cmax] of the
-// linear cell index, and every cell they touch lies in 2 nsize + 1 intervals ("bands", one per plane offset) of length
-// cmax - cmin + 2 (nsize W + nsize) + 1.  When those fit 48 KB the block accumulates into LDS (ds_add_f32: neighbouring
-// particles share 18 of their 27 cells) and flushes each touched cell ONCE with a global atomic; otherwise (unsorted or
-// very sparse particles) it falls back to the per-cell global atomics above.  Same arithmetic per contribution.
+// The same scatter with the block's cells privatised in LDS.  Particles arrive in the order of the grid (Styler.run
+// sorts them once per sequence, by 8-cell bricks), so the own cells of a block's 256 particles sit in a small box
+// [lo, hi] per axis -- and stay in one while a Lagrangian run moves them by a few cells.  When the box, widened by
+// nsize, fits 48 KB the block accumulates into LDS (ds_add_f32: neighbouring particles share 18 of their 27 cells) and
+// flushes each touched cell ONCE with a global atomic; otherwise (unsorted or very sparse particles: decided per block
+// from a min / max reduction of the cell coordinates) it falls back to the per-cell global atomics above.  Same
+// arithmetic per contribution.
 constexpr int SPL_LDS = 12288;     // floats of LDS accumulators
 
 template <int SPL_PB>              // particles per block
@@ -120,42 +121,56 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
                                                           float* __restrict__ grid, float* __restrict__ wsum, int N,
                                                           int C, int allow_lds) {
   extern __shared__ float acc[];
-  __shared__ int red[2 * 4];
+  __shared__ int red[6 * 4];
   const int t = threadIdx.x;
   const int64_t a0 = (int64_t)blockIdx.x * SPL_PB;
   Particle P[SPL_PB / 256];
-  int cmin = 0x7fffffff, cmax = -1;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
 #pragma unroll
   for (int j = 0; j < SPL_PB / 256; ++j) {
     const int64_t a = a0 + t + 256 * j;
     P[j].valid = false;
     if (a < N) {
       P[j] = load_particle(s, p, a);
-      if (P[j].valid) {
-        const int ci = (int)cell_index(s, P[j].idx);
-        if (ci >= 0) { cmin = min(cmin, ci); cmax = max(cmax, ci); }
-      }
+      if (P[j].valid)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], P[j].idx[k]); hi[k] = max(hi[k], P[j].idx[k]); }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    cmin = min(cmin, __shfl_xor(cmin, o, 64));
-    cmax = max(cmax, __shfl_xor(cmax, o, 64));
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], o, 64));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], o, 64));
+    }
+    if ((t & 63) == 0) { red[(2 * k) * 4 + (t >> 6)] = lo[k]; red[(2 * k + 1) * 4 + (t >> 6)] = hi[k]; }
   }
-  if ((t & 63) == 0) { red[t >> 6] = cmin; red[4 + (t >> 6)] = cmax; }
   __syncthreads();
-  cmin = min(min(red[0], red[1]), min(red[2], red[3]));
-  cmax = max(max(red[4], red[5]), max(red[6], red[7]));
-  const int Wd = s.res[s.nd - 1];
-  const int HW = s.nd == 3 ? s.res[1] * s.res[2] : 0;
-  const int R = s.nsize * Wd + s.nsize;
-  const int nb = s.nd == 3 ? 2 * s.nsize + 1 : 1;
+  int ext[3] = {1, 1, 1};
+  bool any = true;
+  int64_t vol = 1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int* r0 = red + (2 * k) * 4;
+    const int* r1 = red + (2 * k + 1) * 4;
+    lo[k] = min(min(r0[0], r0[1]), min(r0[2], r0[3]));
+    hi[k] = max(max(r1[0], r1[1]), max(r1[2], r1[3]));
+    if (k < s.nd) {
+      any = any && hi[k] >= lo[k];
+      lo[k] = max(lo[k] - s.nsize, 0);
+      hi[k] = min(hi[k] + s.nsize, s.res[k] - 1);
+      ext[k] = hi[k] - lo[k] + 1;
+      vol *= ext[k] > 0 ? ext[k] : 1;
+    } else {
+      lo[k] = 0; hi[k] = 0;
+    }
+  }
   const int nch = s.mode == 0 ? 1 : (s.mode == 2 ? C + 1 : C);
-  const int64_t L64 = (int64_t)cmax - cmin + 2 * R + 1;
-  const bool use_lds = allow_lds && cmax >= cmin && L64 * nb * nch <= SPL_LDS;
-  const int L = (int)L64;
+  const bool use_lds = allow_lds && any && vol * nch <= SPL_LDS;
+  const int nvol = (int)vol;
   if (use_lds) {
-    for (int i = t; i < nb * L * nch; i += 256) acc[i] = 0.f;
+    for (int i = t; i < nvol * nch; i += 256) acc[i] = 0.f;
     __syncthreads();
   }
   const int span = 2 * s.nsize + 1;
@@ -172,7 +187,7 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
       if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
       else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
       float d2 = 0.f;
-      int c[3];
+      int c[3] = {0, 0, 0};
       for (int k = 0; k < s.nd; ++k) {
         const float rr = P[j].r[k] - (float)n[k] * s.cell;
         d2 += rr * rr;
@@ -180,18 +195,22 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
       }
       const float w = cubic_w(sqrtf(d2) / s.h, s.sigma);
       if (w == 0.f) continue;
-      const int64_t ci = cell_index(s, c);
-      if (ci < 0) continue;
       if (use_lds) {
-        const int band = s.nd == 3 ? n[0] + s.nsize : 0;
-        float* dst = acc + ((int64_t)band * L + ((int)ci - (cmin + (band - (s.nd == 3 ? s.nsize : 0)) * HW - R))) * nch;
+        bool in = true;
+        for (int k = 0; k < s.nd; ++k) in = in && c[k] >= lo[k] && c[k] <= hi[k];   // (the box is clipped to the grid)
+        if (!in) continue;
+        float* dst = acc + (((c[0] - lo[0]) * ext[1] + (c[1] - lo[1])) * ext[2] + (c[2] - lo[2])) * nch;
         if (s.mode == 0) {
           atomicAdd(dst, coef * w);
         } else {
           for (int ch = 0; ch < C; ++ch) atomicAdd(dst + ch, coef * w * attr[a * C + ch]);
           if (s.mode == 2) atomicAdd(dst + C, w);
         }
-      } else if (s.mode == 0) {
+        continue;
+      }
+      const int64_t ci = cell_index(s, c);
+      if (ci < 0) continue;
+      if (s.mode == 0) {
         atomicAdd(grid + ci, coef * w);
       } else {
         for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * attr[a * C + ch]);
@@ -201,12 +220,19 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
   }
   if (!use_lds) return;
   __syncthreads();
-  for (int i = t; i < nb * L; i += 256) {
-    const int band = i / L, off = i - band * L;
-    const int64_t cell = (int64_t)cmin + (int64_t)(band - (s.nd == 3 ? s.nsize : 0)) * HW - R + off;
+  for (int i = t; i < nvol; i += 256) {
+    int c[3];
+    c[2] = lo[2] + i % ext[2];
+    const int r = i / ext[2];
+    c[1] = lo[1] + r % ext[1];
+    c[0] = lo[0] + r / ext[1];
     const float* src = acc + (int64_t)i * nch;
+    bool nz = false;
+    for (int ch = 0; ch < nch; ++ch) nz = nz || src[ch] != 0.f;
+    if (!nz) continue;
+    const int64_t cell = cell_index(s, c);
     if (s.mode == 0) {
-      if (src[0] != 0.f) atomicAdd(grid + cell, src[0]);
+      atomicAdd(grid + cell, src[0]);
     } else {
       for (int ch = 0; ch < C; ++ch)
         if (src[ch] != 0.f) atomicAdd(grid + cell * C + ch, src[ch]);

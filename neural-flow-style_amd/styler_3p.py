@@ -168,15 +168,13 @@ class Styler(StylerBase):
         p = [self._dev(x) for x in params["p"]]
         r = [self._dev(x) for x in params["r"]] if "d" in self.target_field else [None] * self.num_frames
         # Particles in grid-cell order (one permutation for all frames, from the first frame's positions: the temporal
-        # filter and the frame interpolation need particle i to be the same particle in every frame).  The splat's
-        # 27-125 atomic adds per particle then fall into the cache lines its neighbours in the wave are updating
-        # (5e5 particles on 200^3: 0.69 -> 0.37 ms per splat); the outputs are returned in the caller's order.
+        # filter and the frame interpolation need particle i to be the same particle in every frame).  A block of
+        # consecutive particles then touches a small box of cells and the splat accumulates it in LDS
+        # (5e5 particles on 200^3: 0.69 ms unordered, 0.37 ordered with global atomics, 0.16 in LDS); the outputs are
+        # returned in the caller's order.
         inv = None
         if getattr(self, "sort_particles", True) and len(set(int(x.shape[0]) for x in p)) == 1 and p[0].shape[0] > 1:
-            dims = torch.tensor([float(v) for v in self.resolution], device=self.device)
-            cell = torch.minimum((p[0].clamp(min=0) * dims).floor(), dims - 1).long()
-            key = (cell[:, 0] * int(self.resolution[1]) + cell[:, 1]) * int(self.resolution[2]) + cell[:, 2]
-            perm = torch.argsort(key, stable=True)
+            perm = T.grid_order(p[0], self.resolution)
             inv = torch.empty_like(perm)
             inv[perm] = torch.arange(perm.numel(), device=self.device)
             p = [x[perm].contiguous() for x in p]

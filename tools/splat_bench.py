@@ -32,6 +32,18 @@ key = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
 ps = p[torch.argsort(key)].contiguous()
 cfg = ops.make_splat_cfg(3, [G, G, G], [G, G, G], 0.5, 4, 1000.0, 1, False, 0)
 g = torch.randn(G, G, G, 1, device="cuda")
-print("cell-sorted particles, nsize 1: fwd %.3f ms  bwd %.3f ms" % (t(lambda: ops.p2g_fwd(ps, cfg)), t(lambda: ops.p2g_bwd(ps, cfg, g, need_p=True))))
+print("cell-sorted particles (row-major cells), nsize 1: fwd %.3f ms  bwd %.3f ms" % (t(lambda: ops.p2g_fwd(ps, cfg)), t(lambda: ops.p2g_bwd(ps, cfg, g, need_p=True))))
+from neural_flow_style_amd import transform as T
+for brick in (4, 8, 16):
+    pb = p[T.grid_order(p, [G, G, G], brick)].contiguous()
+    line = "grid order in %d-cell bricks, nsize 1: fwd %.3f ms  bwd %.3f ms" % (
+        brick, t(lambda: ops.p2g_fwd(pb, cfg)), t(lambda: ops.p2g_bwd(pb, cfg, g, need_p=True)))
+    # ... and after a Lagrangian run has moved every particle by up to +-2 / +-4 cells
+    for drift in (2, 4):
+        pd_ = (pb + (torch.rand_like(pb) * 2 - 1) * drift / G).clamp(0.01, 0.99)
+        line += "; drifted +-%d cells: fwd %.3f" % (drift, t(lambda: ops.p2g_fwd(pd_, cfg)))
+    print(line)
+psd = (ps + (torch.rand_like(ps) * 2 - 1) * 2 / G).clamp(0.01, 0.99)
+print("row-major cell order drifted +-2 cells: fwd %.3f ms" % t(lambda: ops.p2g_fwd(psd, cfg)))
 pu = torch.rand(N, 3, device="cuda") * 0.9 + 0.05
 print("uniform random particles, nsize 1: fwd %.3f ms  bwd %.3f ms" % (t(lambda: ops.p2g_fwd(pu, cfg)), t(lambda: ops.p2g_bwd(pu, cfg, g, need_p=True))))
