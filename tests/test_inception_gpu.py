@@ -351,3 +351,53 @@ def test_smokegun_driver_follows_the_reference_override_block(tmp_path, monkeypa
     res = drv.main(cfg)                                   # the reference's default: semantic transfer, no style image
     assert res["d"][0].shape[:3] == (24, 36, 24) and len(res["l"][0]) == 2 and np.isfinite(res["l"][0]).all()
     assert os.path.exists(os.path.join(cfg.log_dir, "070.png")) and os.path.exists(os.path.join(cfg.log_dir, "070.npz"))
+
+
+def test_grid_stylizer_steps_with_the_inception_network_replayed_as_a_hipgraph():
+    """small grids replay forward + adjoint as one hipGraph (GridStylizer decides by problem size): the Inception
+    network's grouped launches, zero fills and channel-range copies must capture and replay to the eager trajectory"""
+    from neural_flow_style_amd import engine, transform as T
+    net, _ = _net("mixed4b", seed=123)
+    d0, vel0, simg, mats = _grid_case()
+    layers = ["conv2d2", "mixed3b", "mixed4b"]
+    rot = T.rot_to_device(mats, DEV)
+    hist = {}
+    for graph in (False, True):
+        loss = engine.RenderStyleLoss(net, layers, [1.0, 0.5, 2.0], 1.0, transmit=0.05, resize_scale=1.5,
+                                      w_content=3e3, content_layer="mixed3b_3x3_bottleneck_pre_relu", content_channel=44)
+        loss.set_style_image(simg)
+        gs = engine.GridStylizer(loss, torch.tensor(d0, device=DEV), k=3, target="v", lr=2e-3, graph=graph)
+        gs.var.copy_(torch.tensor(vel0))
+        hist[graph] = ([float(gs.step(rot)) for _ in range(5)], gs.var.clone())
+        assert bool(gs.use_graph) == graph
+    np.testing.assert_allclose(hist[True][0], hist[False][0], rtol=1e-5)
+    assert rel(hist[True][1], hist[False][1]) < 1e-5
+    assert hist[False][0][-1] < hist[False][0][0]
+
+
+@pytest.mark.parametrize("style_mask", [False, True])
+def test_image_style_loss_2d_with_the_inception_network(style_mask):
+    """the 2-D colour path (styler_2p.py:91-102) on the Inception graph: Gram style loss on conv2d2 / mixed3a / the
+    480-channel mixed3b (padded rows), TV, optionally the density mask on the features (styler_base.py:165-169)"""
+    from neural_flow_style_amd import engine, synthetic as S
+    net, w = _net("mixed3b", seed=5)
+    rng = np.random.RandomState(2)
+    H, W = 40, 56
+    layers, wl = ["conv2d2", "mixed3a", "mixed3b"], [1.0, 2.0, 0.5]
+    simg = S.style_image(H, W, rng)
+    d = rng.rand(1, H, W, 3).astype(np.float32)
+    dg = (rng.rand(1, H, W, 1) > 0.3).astype(np.float32)
+    il = engine.ImageStyleLoss(net, layers, wl, 1.0, w_tv=0.01, style_mask=style_mask)
+    il.set_style_image(simg)
+    loss, g = il.loss_and_grad(torch.tensor(d, device=DEV), torch.tensor(dg, device=DEV) if style_mask else None)
+
+    cfg = dict(network="tensorflow_inception_graph.pb")
+    dt = torch.tensor(d).requires_grad_()
+    d_img = O.plugin_to_loss_net(dt, 1.0, is_color=True)
+    feats = O.loss_net_features(d_img, w, "mixed3b", cfg)
+    sfe = O.style_target_features(torch.tensor(simg)[None], w, layers, upto="mixed3b", cfg=cfg)
+    ls, _ = O.style_loss(feats, sfe, layers, wl, 1.0, d_gray=torch.tensor(dg) if style_mask else None)
+    total = ls + 0.01 * O.tv_loss(d_img)
+    total.backward()
+    assert abs(float(loss.sum()) - float(total.detach())) < 2e-4 * abs(float(total.detach()))
+    assert rel(g, dt.grad) < 1e-3
