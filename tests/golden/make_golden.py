@@ -45,9 +45,32 @@ def make_g2p():
          d_diff=r["d_diff"], cfg_keys=np.array(sorted(cfg)), cfg_vals=np.array([str(cfg[k]) for k in sorted(cfg)]))
 
 
+def make_inception():
+    """(7) SURVEY 8(f)-3: the Inception-v1 restatement down to mixed3b on a 32 x 40 image -- four tensor kinds (a ReLU
+    output, two module outputs incl. the 480-channel one, a '*_pre_relu' tensor) and the gradient of a fixed
+    functional of them with respect to the image.  Weights: the seeded synthetic set (seed 17) of
+    neural-flow-style_amd/inception.py, regenerated from the seed by the tests (the arrays would be 2.7 MB)."""
+    from neural_flow_style_amd import inception
+    w = inception.synthetic_weights(17, upto="mixed3b")
+    rng = np.random.RandomState(17)
+    img = (rng.rand(1, 32, 40, 3) * 255).astype(np.float32)
+    names = ["conv2d2", "mixed3a", "mixed3b", "mixed3b_3x3_bottleneck_pre_relu"]
+    x = torch.tensor(img, requires_grad=True)
+    feats = O.inception_v1_features(x, w, "mixed3b")
+    proj = {n: rng.randn(*feats[n].shape).astype(np.float32) for n in names}
+    total = sum((feats[n] * torch.tensor(proj[n])).sum() / float(feats[n].detach().abs().mean()) for n in names)
+    (gx,) = torch.autograd.grad(total, x)
+    save("inception_mixed3b.npz", seed=17, img=img, grad_img=gx,
+         scale=np.array([float(feats[n].detach().abs().mean()) for n in names], np.float64),
+         **{"feat_" + n: feats[n].detach() for n in names}, **{"proj_" + n: proj[n] for n in names})
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g2p":      # regenerate only the 8(f)-1 fixture
         make_g2p()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "inception":   # ... only the 8(f)-3 fixture
+        make_inception()
         return
     # (1) the reference's own known-answer vector
     save("warp2d_kat.npz", img=np.arange(25, dtype=np.float32).reshape(5, 5),
