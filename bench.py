@@ -492,6 +492,8 @@ def other_configs(device, base):
             losses, g = stp._value_and_grad(pp, None, var, [G, G, G], stp._identity)
             adam.step(var, g.contiguous(), cfg.lr)
             return losses
+        for _ in range(4):            # (lazy state, then the stylizer's measured eager-vs-hipGraph choice for the loss chain)
+            p_iter()
         ms_it = ev_time(p_iter, 10)
         # stage split (each stage alone, same operands)
         v_ = var.detach().clone().requires_grad_(True)
@@ -514,8 +516,10 @@ def other_configs(device, base):
                     "stages_ms": {"field forward (splat p2g + smooth/clamp, through autograd)": ms_f,
                                   "render + VGG + Gram losses + adjoint down to the grid": ms_l,
                                   "field forward + backward (smooth adjoint + splat gather adjoint)": ms_fb},
+                    "loss_chain_mode": getattr(stp._graph_loss, "mode", None) if stp._graph_loss else "eager",
                     "note": "stages timed alone on the same operands (their sum exceeds the iteration by the forward "
-                            "pass counted twice)"})
+                            "pass counted twice); loss_chain_mode: what the stylizer measured to be faster on this "
+                            "box for its one-view loss chain, eager submission or hipGraph replay"})
         del stp
     except Exception as e:  # pragma: no cover
         out.append({"config": "configs[4] end to end", "error": repr(e)})

@@ -458,6 +458,89 @@ class RenderStyleLoss(object):
         return loss
 
 
+def loss_capture_key(L):
+    """what a captured graph of ``L.loss_and_grad`` has baked in by address or by value (style / content / histogram
+    targets are device tensors, the loss weights are kernel arguments)"""
+    grams = tuple(int(t.data_ptr()) for t in (L.style_grams or {}).values())
+    cf = getattr(L, "content_feature", None)
+    hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "mode", "resize_scale", "rotate", "w_tv",
+                                                "v_batch", "w_content", "content_layer", "content_channel",
+                                                "w_content_amp"))
+    # histogram term: template tensors by address, its weights and layer list by value
+    hist = (tuple(sorted((n, int(t.data_ptr())) for n, t in (getattr(L, "hist_targets", None) or {}).items())),
+            getattr(L, "w_hist", 0.0), tuple(getattr(L, "hist_layers", ())), tuple(getattr(L, "w_hist_layers", ())),
+            getattr(L, "style_mask", False))
+    return (grams, tuple(getattr(L, "layers", ())), tuple(getattr(L, "w_layers", ())), hyper,
+            None if cf is None else int(cf.data_ptr()), hist, id(getattr(L, "net", None)))
+
+
+class GraphedLoss(object):
+    """``loss.loss_and_grad(d, rot, g_d)`` of a few views, replayed as ONE hipGraph where the host cannot keep up with
+    it.  A one-view chain is 60-110 small launches: on a box with a slow host the host needs 1.1-1.4 ms to issue what
+    the GPU runs in 0.58-0.97 (tools/loss_chain_host.py: the chocolate-scale VGG chain 1.39 -> 0.58 ms, the reference
+    smokegun configuration on Inception-v1 1.11 -> 0.97 ms); on a box whose host keeps up, eager submission is the
+    faster of the two by ~10 % (graph nodes do not overlap their launch latencies the way back-to-back stream packets
+    do).  Hosts differ by 2x between boxes of one pool, so the choice is MEASURED: call 1 runs eagerly (lazy state:
+    packed filters, tile tuner, workspaces); call 2 eagerly between two synchronisations, timing both what the host
+    needed to issue it and when the GPU finished -- if the GPU finished as soon as the host did (issue time > 85 % of the
+    wall time) the chain is host-bound and calls 3.. are replays of a captured graph, otherwise it stays eager (``mode``
+    = 'graph' | 'eager'; ``force`` = True / False skips the trial).  A change of anything the capture bakes in
+    (``loss_capture_key``, shapes) starts over.  Inputs are copied into static buffers; the returned loss and gradient
+    tensors are valid until the next call."""
+
+    def __init__(self, loss, force=None):
+        self.loss = loss
+        self.force = force
+        self._reset()
+
+    def _reset(self):
+        self._graph = None
+        self._key = None
+        self._calls = 0
+        self.mode = None if self.force is None else ("graph" if self.force else "eager")
+        self.trial = None
+
+    def _eager(self, d, rot):
+        g_d = torch.zeros_like(d)
+        return self.loss.loss_and_grad(d, rot, g_d), g_d
+
+    def __call__(self, d, rot):
+        import time
+        key = (loss_capture_key(self.loss), tuple(d.shape), None if rot is None else tuple(rot.shape))
+        if self._key is not None and key != self._key:
+            self._reset()
+        self._key = key
+        self._calls += 1
+        if self.mode == "eager" or self._calls == 1:
+            return self._eager(d, rot)
+        if self.mode is None:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = self._eager(d, rot)
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_wall = time.perf_counter() - t0
+            self.trial = (t_issue, t_wall)
+            self.mode = "graph" if t_issue > 0.85 * t_wall else "eager"
+            return out
+        if self._graph is None:
+            self._d = d.clone()
+            self._rot = None if rot is None else rot.clone()
+            self._gd = torch.zeros_like(d)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._gd.zero_()
+                self._losses = self.loss.loss_and_grad(self._d, self._rot, self._gd)
+            self._graph = g
+        else:
+            self._d.copy_(d)
+            if rot is not None and rot.data_ptr() != self._rot.data_ptr():
+                self._rot.copy_(rot)
+        self._graph.replay()
+        return self._losses, self._gd
+
+
 class argparse_ns(object):
     """plain attribute bag"""
 
@@ -791,18 +874,8 @@ class GridStylizer(object):
         """everything a captured graph has baked in by address or by value: a mismatch forces a re-capture
         (set_style_image / set_content_image / set_hist_image allocate new targets; loss weights are kernel
         arguments)"""
-        L = self.loss
-        grams = tuple(int(t.data_ptr()) for t in (L.style_grams or {}).values())
-        cf = getattr(L, "content_feature", None)
-        hyper = tuple(getattr(L, a, None) for a in ("w_style", "tau", "mode", "resize_scale", "rotate", "w_tv",
-                                                    "v_batch", "w_content", "content_layer", "content_channel",
-                                                    "w_content_amp"))
-        # histogram term: template tensors by address, its weights and layer list by value
-        hist = (tuple(sorted((n, int(t.data_ptr())) for n, t in (getattr(L, "hist_targets", None) or {}).items())),
-                getattr(L, "w_hist", 0.0), tuple(getattr(L, "hist_layers", ())), tuple(getattr(L, "w_hist_layers", ())),
-                getattr(L, "style_mask", False))
-        return (grams, tuple(getattr(L, "w_layers", ())), hyper, None if cf is None else int(cf.data_ptr()), hist,
-                int(self.d0.data_ptr()), int(self.var.data_ptr()), tuple(rot_local.shape), self.k, self.target)
+        return loss_capture_key(self.loss) + (int(self.d0.data_ptr()), int(self.var.data_ptr()),
+                                              tuple(rot_local.shape), self.k, self.target)
 
     def _loss_gradient_graphed(self, rot_local):
         """the graph without the field ops (slab mode: their all-gather stays outside the capture)"""

@@ -76,6 +76,10 @@ _workspaces = {}
 
 def workspace(device):
     """small per-device scratch (64 floats) for entry points that need a device-side scalar"""
+    if torch.cuda.is_current_stream_capturing():
+        # a capture owns what it allocates (its private pool keeps it for the replays); a buffer cached here would be
+        # shared by every later capture on the same capture stream, whatever became of the graph that allocated it
+        return torch.zeros(64, dtype=torch.float32, device=device)
     key = (device.type, device.index, _stream(device))   # one per stream
     if key not in _workspaces:
         _workspaces[key] = torch.zeros(64, dtype=torch.float32, device=device)
@@ -399,6 +403,10 @@ _conv_ws = {}
 def conv_workspace(device, floats):
     """split-K scratch, grown on demand and shared by all conv calls of a device (calls on one stream
     are ordered, so sharing is safe)"""
+    if torch.cuda.is_current_stream_capturing():
+        # (see ``workspace``: a capture owns its scratch.)  A fresh buffer per call: the graph's private pool hands the
+        # block back to later allocations of the same capture in stream order and keeps it for the replays
+        return torch.empty(int(floats), dtype=torch.float32, device=device)
     key = (device.type, device.index, _stream(device))   # one per stream
     cur = _conv_ws.get(key)
     if cur is None or cur.numel() < floats:

@@ -23,6 +23,8 @@ Differences from the reference, all deliberate and documented:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -63,6 +65,7 @@ class Styler(StylerBase):
             print("# vps:", self.n_views)
             assert self.n_views % self.v_batch == 0
         self.loss = self._make_loss(rotate=self.rotate)
+        self._graph_loss = None                      # engine.GraphedLoss, decided at the first loss call
         self._identity = T.rot_to_device([np.identity(3)], self.device)
         # multi-GPU (set by the driver): ``pg`` = the process group; ``shard_by`` = 'views' (views=sum: the views of every
         # frame over the ranks, ONE all-reduce of the variable's gradient + loss per frame step) or 'frames' (SURVEY 8(e)
@@ -111,8 +114,19 @@ class Styler(StylerBase):
         v = var.detach().clone().requires_grad_(True)
         _, d_out, extra = self._field(p, r, v, res)
         d3 = d_out.detach().reshape(d_out.shape[1:4]).contiguous()
-        g_d = torch.zeros_like(d3)
-        losses = self.loss.loss_and_grad(d3, rot, g_d)
+        nviews = int(rot.shape[0]) if (self.rotate and rot is not None) else 1
+        if self._graph_loss is None:
+            # hipGraph replay of the loss chain where the host cannot keep up with it: tried (and timed against eager
+            # submission) with one or two views per call; NFS_GRAPH=0 / 1 forces it off / on
+            env = os.environ.get("NFS_GRAPH")
+            self._graph_loss = (engine.GraphedLoss(self.loss, force=True) if env == "1" else
+                                engine.GraphedLoss(self.loss) if (env is None and nviews <= 2) else False)
+        if self._graph_loss:
+            losses, g_d = self._graph_loss(d3, rot)
+            losses = losses.clone()
+        else:
+            g_d = torch.zeros_like(d3)
+            losses = self.loss.loss_and_grad(d3, rot, g_d)
         # view-independent terms (pressure / density preservation) belong to the iteration, not to a view: with the
         # views sharded over ranks (views=sum) only rank 0 adds them, so that the all-reduced loss and gradient
         # contain them ONCE (every rank would otherwise contribute a copy: world x the single-rank weight)

@@ -536,3 +536,41 @@ def test_grid_stylizer_with_lbfgs_decreases_the_loss_and_matches_a_host_replay()
         ls.append(float(gs.step(rot)))
         assert rel(gs.var, ref.detach()) < 1e-5
     assert ls[-1] < ls[0]
+
+
+def test_graphed_loss_replays_equal_eager_calls_with_several_graphs_alive():
+    """engine.GraphedLoss (the particle stylers' one-view loss chain as a hipGraph): replays on changing inputs equal
+    eager calls; two graphs of different sizes alive at once and used in turn (their scratch buffers are the captures'
+    own); a graph dropped and re-captured after set_style_image; the measured choice picks one of the two modes"""
+    out = {}
+    for G in (20, 32):
+        d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(G, 2, ["conv1_1", "conv2_1", "conv3_1"], seed=G)
+        out[G] = (loss, T.rot_to_device(mats, "cuda"), eng)
+    eng = out[20][2]
+    graphed = {G: eng.GraphedLoss(out[G][0], force=True) for G in out}
+    rng = np.random.RandomState(0)
+    for it in range(5):
+        for G in (20, 32, 20):
+            loss, rot, _ = out[G]
+            d = torch.tensor(blob_density(G, rng) * (1 + 0.1 * it), device="cuda")
+            l_g, g_g = graphed[G](d, rot)
+            l_g, g_g = l_g.clone(), g_g.clone()
+            g_e = torch.zeros_like(d)
+            l_e = loss.loss_and_grad(d, rot, g_e)
+            assert rel(l_g, l_e) < 1e-5 and rel(g_g, g_e) < 1e-5, (it, G)
+    assert graphed[20].mode == "graph" and graphed[20]._graph is not None
+    # new style targets: the capture is dropped, warmed and taken again
+    loss, rot, _ = out[20]
+    old = graphed[20]._graph
+    loss.set_style_image(style_image(20, 20, rng))
+    d = torch.tensor(blob_density(20, rng), device="cuda")
+    for _ in range(3):
+        l_g, g_g = graphed[20](d, rot)
+    g_e = torch.zeros_like(d)
+    l_e = loss.loss_and_grad(d, rot, g_e)
+    assert graphed[20]._graph is not old and rel(l_g, l_e) < 1e-5 and rel(g_g, g_e) < 1e-5
+    auto = eng.GraphedLoss(loss)
+    for _ in range(4):
+        l_a, g_a = auto(d, rot)
+    assert auto.mode in ("graph", "eager") and auto.trial is not None
+    assert rel(l_a, l_e) < 1e-5 and rel(g_a, g_e) < 1e-5
