@@ -911,9 +911,33 @@ class GridStylizer(object):
         self._graph.replay()
         return self._loss_slot, self.g_ds
 
+    def _loss_chain_host_bound(self, rot_local):
+        """one extra evaluation of the loss chain between two synchronisations: True when the GPU finishes it as soon as
+        the host has issued it (issue time > 85 % of the wall time), i.e. when a hipGraph replay would be faster"""
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self._loss_gradient(self.d_s, rot_local)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_wall = time.perf_counter() - t0
+        self.graph_trial = (t_issue, t_wall)
+        return t_issue > 0.85 * t_wall
+
     def step(self, rot_local):
-        if self.use_graph is None:                  # host-bound regime only: small volumes, few views
-            self.use_graph = self.d0.numel() * max(int(rot_local.shape[0]), 1) <= (2 << 20)
+        if self.use_graph is None:
+            nv = max(int(rot_local.shape[0]), 1)
+            if self.d0.numel() * nv <= (2 << 20):    # small volumes, few views: the host needs longer than the GPU
+                self.use_graph = True
+            elif nv > 2:                             # full view batches are bound by their kernels
+                self.use_graph = False
+            else:
+                # one or two views of a large volume (a rank of a view-sharded run): 80 launches of ~14 us -- kernel-bound
+                # on a fast host, host-bound on a slow one, and the hosts of one pool differ by 2x.  Measured at the
+                # second step (the first has built the lazy state); until then the step runs eagerly.
+                self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+                if self._steps_seen == 2 and getattr(self, "d_s", None) is not None:
+                    self.use_graph = self._loss_chain_host_bound(rot_local)
         if self.slab is not None:
             return self._step_slab(rot_local)
         self._apply_binding()

@@ -559,8 +559,10 @@ def test_graphed_loss_replays_equal_eager_calls_with_several_graphs_alive():
             l_e = loss.loss_and_grad(d, rot, g_e)
             assert rel(l_g, l_e) < 1e-5 and rel(g_g, g_e) < 1e-5, (it, G)
     assert graphed[20].mode == "graph" and graphed[20]._graph is not None
-    # new style targets: the capture is dropped, warmed and taken again
+    # new style targets (new tensors: the capture is keyed on their addresses and taken again when they move -- when the
+    # allocator hands the new Grams the very addresses of the old ones the graph stays, and reads the new values)
     loss, rot, _ = out[20]
+    keep_alive = list(loss.style_grams.values())          # the old Grams stay allocated: the new ones must move
     old = graphed[20]._graph
     loss.set_style_image(style_image(20, 20, rng))
     d = torch.tensor(blob_density(20, rng), device="cuda")
@@ -569,6 +571,13 @@ def test_graphed_loss_replays_equal_eager_calls_with_several_graphs_alive():
     g_e = torch.zeros_like(d)
     l_e = loss.loss_and_grad(d, rot, g_e)
     assert graphed[20]._graph is not old and rel(l_g, l_e) < 1e-5 and rel(g_g, g_e) < 1e-5
+    del keep_alive
+    loss.set_style_image(style_image(20, 20, rng))        # ... and whatever the allocator does here, the values hold
+    l_g, g_g = graphed[20](d, rot)
+    l_g, g_g = graphed[20](d, rot)
+    g_e = torch.zeros_like(d)
+    l_e = loss.loss_and_grad(d, rot, g_e)
+    assert rel(l_g, l_e) < 1e-5 and rel(g_g, g_e) < 1e-5
     auto = eng.GraphedLoss(loss)
     for _ in range(4):
         l_a, g_a = auto(d, rot)
