@@ -303,8 +303,9 @@ class InceptionV1(object):
                 ps = [self.params["%s_%s" % (name, b)] for b in BRANCHES]
                 c1, c3, c5, cp = ps[0]["cout"], ps[2]["cout"], ps[4]["cout"], ps[5]["cout"]
                 out = new(B, H, W, c1 + c3 + c5 + cp)
-                b3 = new(B, H, W, ps[1]["cout"])
-                b5 = new(B, H, W, ps[3]["cout"])
+                # (the bottleneck outputs are read by their own branch only: exact width, no padding to fill)
+                b3 = torch.empty((B, H, W, ps[1]["cout"]), dtype=torch.float32, device=x.device)
+                b5 = torch.empty((B, H, W, ps[3]["cout"]), dtype=torch.float32, device=x.device)
                 # a module = two grouped launches (the three 1x1 convolutions on the module input; 3x3, 5x5 and the
                 # pool projection) + the pool: one by one the branches leave most of the chip idle
                 grouped = B * H * W <= GROUP_MAX_PIXELS
@@ -356,6 +357,16 @@ class InceptionV1(object):
                 g = G[id(buf)] = torch.zeros_like(buf)
             return g
 
+        def target(buf):
+            """(gradient buffer of ``buf``, accumulate?): the first term of a gradient is WRITTEN into a fresh buffer (no
+            zero fill: 25 fills per pass otherwise), later terms are added.  Channels behind the logical width of a
+            padded buffer are never written and never read as values."""
+            g = G.get(id(buf))
+            if g is None:
+                G[id(buf)] = g = torch.empty_like(buf)
+                return g, False
+            return g, True
+
         for n, g in grads.items():
             if g is None:
                 continue
@@ -363,6 +374,9 @@ class InceptionV1(object):
                 pre_inject[n[:-len("_pre_relu")]] = g
                 continue
             buf, c0, c = acts.where[n]
+            if c0 == 0 and tuple(g.shape) == tuple(buf.shape) and id(buf) not in G:
+                G[id(buf)] = g                              # the caller's tensor IS the gradient buffer (it is not kept)
+                continue
             gb = gbuf(buf)
             if c0 == 0 and tuple(g.shape) == tuple(gb.shape):
                 gb.add_(g)
@@ -382,12 +396,13 @@ class InceptionV1(object):
                 g_in, cg, mask, cm = ops.relu_mask_add(g, c0, buf if g is not None else None, c0, inj, 0, c), 0, None, 0
             else:
                 g_in, cg, mask, cm = g, c0, buf, c0
+            dst, acc = target(src)
             if group is not None:
-                group.append(dict(x=g_in, cx=cg, Cin=c, packed=p["dgrad"], bias=None, y=gbuf(src), cy=0, Cout=csrc,
-                                  k=p["k"], relu=False, x_mask=mask, cm=cm, accumulate=True))
+                group.append(dict(x=g_in, cx=cg, Cin=c, packed=p["dgrad"], bias=None, y=dst, cy=0, Cout=csrc,
+                                  k=p["k"], relu=False, x_mask=mask, cm=cm, accumulate=acc))
             else:
-                ops.conv2d_fwd(g_in, cg, c, p["dgrad"], None, gbuf(src), 0, csrc, p["k"], p["k"], 1, relu=False,
-                               x_mask=mask, cm=cm, accumulate=True)
+                ops.conv2d_fwd(g_in, cg, c, p["dgrad"], None, dst, 0, csrc, p["k"], p["k"], 1, relu=False,
+                               x_mask=mask, cm=cm, accumulate=acc)
 
         last = self._last_unit(upto)
         for u in reversed(self.units[:last + 1]):
@@ -415,7 +430,8 @@ class InceptionV1(object):
                     # the pool over conv2d0's output is the last term of that gradient: it hands it on with the ReLU
                     # adjoint, and the data gradient down to the image (16 taps per pixel) reads it unmasked
                     first = name == "maxpool0"
-                    ops.maxpool3_bwd(g, arg, hw, stride, gx=gbuf(src), relu_of=src if first else None)
+                    r = ops.maxpool3_bwd(g, arg, hw, stride, gx=G.get(id(src)), relu_of=src if first else None)
+                    G[id(src)] = r
                     if first:
                         premasked.add(id(src))
             elif kind == "lrn":
@@ -423,7 +439,7 @@ class InceptionV1(object):
                 g = G.get(id(y))
                 if g is not None:
                     r, bias, alpha, beta = self.lrn[name]
-                    ops.lrn_bwd(xin, y, scale, g, csrc, r, alpha, beta, gx=gbuf(src))
+                    G[id(src)] = ops.lrn_bwd(xin, y, scale, g, csrc, r, alpha, beta, gx=G.get(id(src)))
             else:
                 b3 = acts.where[name + "_3x3_bottleneck"][0]
                 b5 = acts.where[name + "_5x5_bottleneck"][0]
@@ -449,7 +465,7 @@ class InceptionV1(object):
                 gp = G.get(id(pool))
                 if gp is not None:
                     arg, hw, stride = acts.aux[name + "_pool"]
-                    ops.maxpool3_bwd(gp, arg, hw, stride, gx=gbuf(src))
+                    G[id(src)] = ops.maxpool3_bwd(gp, arg, hw, stride, gx=G.get(id(src)))
         raise AssertionError("unreachable")
 
 
