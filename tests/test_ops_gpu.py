@@ -447,6 +447,29 @@ def test_p2g_cell_ordered_particles_accumulate_in_lds_and_agree_with_the_scatter
         O.p2g_wavg(pt, torch.tensor(x)[None], dom, res, 0.5, 1, is_2d=False, clip=False, support=4)
     assert rel(outs[0], ref[0]) < TOL and rel(outs[1], ref[0]) < TOL
     assert rel(outs[0], outs[1]) < 1e-6
+    # the gather adjoint: the block's box of the grid gradient staged in LDS (ordered) or gathered from global memory
+    g = torch.tensor(rng.randn(G, G, G, 1).astype(np.float32))
+    grads = []
+    for perm in (order, rng.permutation(N)):
+        pp, xx = torch.tensor(p[perm]), torch.tensor(x[perm])
+        if mode == "density":
+            gp, _, _ = ops.p2g_bwd(dev(pp), ops.make_splat_cfg(3, res, dom, 0.5, 4, 1000., 1, False, 0), dev(g))
+            ga = None
+        else:
+            cfg = ops.make_splat_cfg(3, res, dom, 0.5, 4, 1000., 1, False, 2)
+            xs, ws = ops.p2g_fwd(dev(pp), cfg, attr=dev(xx))
+            g_xs, g_ws = ops.p2g_wavg_finish_bwd(xs, ws, dev(g.expand(G, G, G, 2).contiguous()))
+            gp, ga, _ = ops.p2g_bwd(dev(pp), cfg, g_xs, attr=dev(xx), g_wsum=g_ws, need_p=True, need_attr=True)
+        back = np.empty(N, np.int64)
+        back[perm] = np.arange(N)
+        grads.append((gp.cpu()[back], None if ga is None else ga.cpu()[back]))
+    assert rel(grads[0][0], grads[1][0]) < 1e-4
+    if mode == "wavg":
+        assert rel(grads[0][1], grads[1][1]) < 1e-4
+    if mode == "density":
+        pt_ = torch.tensor(p)[None].requires_grad_()
+        (gref,) = torch.autograd.grad(O.p2g(pt_, dom, res, 0.5, 1000., 1, is_2d=False, clip=False), pt_, g[None])
+        assert rel(grads[0][0], gref[0]) < 5e-4
 
 
 def test_p2g_colour_2d(ops):
