@@ -42,6 +42,7 @@ struct Conv2dArgs {
   int M, nchunks, cchunks, Npad;
   float* ws;            // partial sums [ztotal][M][Npad] (partial != 0)
   int ksplit, cps;      // K chunks per split
+  uint32_t x_bytes, m_bytes;   // extents of x / x_mask from their slice bases (buffer-load range checks)
   int partial;          // the tile leaves as a raw partial sum in ws; conv2d_reduce finishes (split K, or several
   int zbase, ztotal;    // convolutions summed into one output: first partial of this problem / all partials of the sum)
 };
@@ -80,53 +81,87 @@ __device__ __forceinline__ void conv2d_tile(const Conv2dArgs& a, int mtile, int 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp) + ((int64_t)n0 + srow) * 4 + kq;
   const int64_t slab4 = (int64_t)a.Npad * 4;
 
-  float4 av[MT], bv;
-  // every load goes out unconditionally from a clamped address and is zeroed by a select: a branch around a load
-  // makes hipcc drain vmcnt at the join, i.e. serialises the prefetch
-  auto load = [&](int it) {
-    int tap, c;
-    bool kvalid;
-    if (CMODE == 0) {
-      tap = it / a.cchunks;
-      c = (it - tap * a.cchunks) * 16 + 4 * kq;
-      kvalid = c < a.Cin;
-    } else {
-      tap = it * 4 + kq;
-      c = 0;
-      kvalid = tap < a.kh * a.kw;
-    }
-    if (!kvalid) { tap = 0; c = 0; }
-    const int dy = tap / a.kw, dx = tap - dy * a.kw;
+  // Operand loads (CMODE 0) go through buffer descriptors: one 32-bit byte offset per (lane, row) that changes only
+  // when the tap does, plus the chunk's channel offset; a pixel outside the image (SAME padding), a row beyond M or a
+  // channel beyond Cin gets an offset beyond num_records, which the hardware answers with zeros -- no select, no branch
+  // around a load (a branch makes hipcc drain vmcnt at the join, i.e. serialises the prefetch).  The ReLU mask of the
+  // data-gradient form is applied when the chunk is staged, not when it is requested: the select would otherwise wait
+  // for the load it belongs to.  The chunk counter advances through (tap, channel chunk) without divisions.
+  constexpr uint32_t OOB = 0x80000000u;           // the launcher keeps x and x_mask below 2 GB
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, CMODE == 0 ? a.x_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.xmask ? a.xmask : a.x), 0, (CMODE == 0 && a.xmask) ? a.m_bytes : 0u, 0x00020000);
+  struct Chunk { float4 x[MT]; float4 m[MT]; float4 b; };
+  int ld_tap = 0, ld_cc = 0, ld_dy = 0, ld_dx = 0;          // state of the next chunk to request (wave-uniform)
+  uint32_t xo[MT], mo[MT];                                  // byte offsets of the rows' pixels at the current tap
+  auto set_tap = [&]() {
 #pragma unroll
     for (int r = 0; r < MT; ++r) {
-      const int iy = iy0[r] + dy, ix = ix0[r] + dx;
-      const bool ok = rvalid[r] && kvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const int64_t off = ok ? (int64_t)(pixbase[r] + iy * a.W + ix) : 0;
-      float4 v;
-      if (CMODE == 0) {
-        v = *reinterpret_cast<const float4*>(a.x + off * a.ldx + c);
-        if (a.xmask) {
-          const float4 mk = *reinterpret_cast<const float4*>(a.xmask + off * a.ldm + c);
-          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-      } else {
+      const int iy = iy0[r] + ld_dy, ix = ix0[r] + ld_dx;
+      const bool ok = rvalid[r] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const uint32_t pix = (uint32_t)(pixbase[r] + iy * a.W + ix);
+      xo[r] = ok ? pix * (uint32_t)a.ldx * 4u + 16u * kq : OOB;
+      mo[r] = ok ? pix * (uint32_t)a.ldm * 4u + 16u * kq : OOB;
+    }
+  };
+  auto seek = [&](int it) {                                  // (once per tile: the first chunk of this K split)
+    ld_tap = it / a.cchunks;
+    ld_cc = it - ld_tap * a.cchunks;
+    ld_dy = ld_tap / a.kw;
+    ld_dx = ld_tap - ld_dy * a.kw;
+    set_tap();
+  };
+  auto load = [&](int it, Chunk& ch) {
+    if (CMODE == 0) {
+      const uint32_t cb = (uint32_t)ld_cc * 64u;             // 16 channels per chunk
+      const bool kvalid = ld_cc * 16 + 4 * kq < a.Cin;
+#pragma unroll
+      for (int r = 0; r < MT; ++r) {
+        ch.x[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, kvalid ? xo[r] : OOB, cb, 0));
+        if (a.xmask)
+          ch.m[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, kvalid ? mo[r] : OOB, cb, 0));
+      }
+      if (++ld_cc == a.cchunks) {
+        ld_cc = 0;
+        ++ld_tap;
+        if (++ld_dx == a.kw) { ld_dx = 0; ++ld_dy; }
+        set_tap();
+      }
+    } else {
+      const int tap0 = it * 4 + kq;
+      const bool kvalid = tap0 < a.kh * a.kw;
+      const int tap = kvalid ? tap0 : 0;
+      const int dy = tap / a.kw, dx = tap - dy * a.kw;
+#pragma unroll
+      for (int r = 0; r < MT; ++r) {
+        const int iy = iy0[r] + dy, ix = ix0[r] + dx;
+        const bool ok = rvalid[r] && kvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int64_t off = ok ? (int64_t)(pixbase[r] + iy * a.W + ix) : 0;
         const float* p = a.x + off * a.ldx;
+        float4 v;
         v.x = p[0];
         v.y = a.Cin > 1 ? p[a.Cin > 1 ? 1 : 0] : 0.f;
         v.z = a.Cin > 2 ? p[a.Cin > 2 ? 2 : 0] : 0.f;
         v.w = a.Cin > 3 ? p[a.Cin > 3 ? 3 : 0] : 0.f;
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        ch.x[r] = v;
       }
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      av[r] = v;
     }
-    bv = wp4[(int64_t)it * slab4];
+    ch.b = wp4[(int64_t)it * slab4];
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, const Chunk& ch) {
 #pragma unroll
-    for (int r = 0; r < MT; ++r)
-      *reinterpret_cast<float4*>(As + (buf * BM + srow + 64 * r) * IC_LS + 4 * kq) = av[r];
-    *reinterpret_cast<float4*>(Bs + (buf * IC_BN + srow) * IC_LS + 4 * kq) = bv;
+    for (int r = 0; r < MT; ++r) {
+      float4 v = ch.x[r];
+      if (CMODE == 0 && a.xmask) {
+        const float4 mk = ch.m[r];
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(As + (buf * BM + srow + 64 * r) * IC_LS + 4 * kq) = v;
+    }
+    *reinterpret_cast<float4*>(Bs + (buf * IC_BN + srow) * IC_LS + 4 * kq) = ch.b;
   };
 
   f32x16 acc[MT];
@@ -138,12 +173,16 @@ __device__ __forceinline__ void conv2d_tile(const Conv2dArgs& a, int mtile, int 
   // split-K (the late layers have a few hundred pixels and K in the thousands): blockIdx.z owns a range of chunks
   const int it0 = zsplit * a.cps;
   const int it1 = it0 + a.cps < a.nchunks ? it0 + a.cps : a.nchunks;
-  load(it0);
-  stage(0);
+  // three stages, two chunks of look-ahead: chunk it is multiplied from LDS while chunk it + 1 waits in registers for the
+  // other LDS buffer and chunk it + 2 is in flight from memory (one chunk of look-ahead -- 512 MFMA cycles of a wave --
+  // did not cover a load's latency with the 1-2 blocks per CU these layers give: conv2d2 42 -> see DESIGN.md)
+  Chunk cA, cB;
+  if (CMODE == 0) seek(it0);
+  load(it0, cA);
+  stage(0, cA);
+  if (it0 + 1 < it1) load(it0 + 1, cA);
   __syncthreads();
-  for (int it = it0; it < it1; ++it) {
-    const int buf = (it - it0) & 1;
-    if (it + 1 < it1) load(it + 1);                // in flight under this chunk's MFMAs
+  auto mma = [&](int buf) {
     const float* Ab = As + buf * BM * IC_LS + (wm * (BM / 2) + i) * IC_LS + 4 * h;
     const float* Bb = Bs + buf * IC_BN * IC_LS + (wn * 32 + i) * IC_LS + 4 * h;
     // a lane fetches 4 consecutive k with one b128 and feeds 4 MFMA steps with them: the k order inside the chunk is
@@ -160,7 +199,19 @@ __device__ __forceinline__ void conv2d_tile(const Conv2dArgs& a, int mtile, int 
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.w, bq.w, acc[mt], 0, 0, 0);
       }
     }
-    if (it + 1 < it1) stage(buf ^ 1);              // (read during chunk it-1: every wave is past that barrier)
+  };
+  // (unrolled by two so that the two register sets keep their names)
+  for (int it = it0; it < it1; it += 2) {
+    // chunk it: LDS buffer 0; registers A hold it + 1
+    if (it + 2 < it1) load(it + 2, cB);
+    mma(0);
+    if (it + 1 < it1) stage(1, cA);                // (buffer 1 was read during chunk it - 1: every wave is past that barrier)
+    __syncthreads();
+    if (it + 1 >= it1) break;
+    // chunk it + 1: LDS buffer 1; registers B hold it + 2
+    if (it + 3 < it1) load(it + 3, cA);
+    mma(1);
+    if (it + 2 < it1) stage(0, cB);
     __syncthreads();
   }
 
@@ -569,6 +620,11 @@ int nfs_conv2d_fwd(const float* x, int ldx, const float* x_mask, int ldm, const 
               "nfs_conv2d_fwd: too many pixels");
   NFS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31), "nfs_conv2d_fwd: too many pixels");
   a.M = (int)M;
+  {
+    const int64_t xb = (((int64_t)B * H * W - 1) * ldx + Cin) * 4, mb = x_mask ? (((int64_t)B * H * W - 1) * ldm + Cin) * 4 : 0;
+    NFS_REQUIRE(xb < ((int64_t)1 << 31) && mb < ((int64_t)1 << 31), "nfs_conv2d_fwd: operands must stay below 2 GB");
+    a.x_bytes = (uint32_t)xb; a.m_bytes = (uint32_t)mb;
+  }
   a.cchunks = conv2d_cchunks(Cin);
   a.nchunks = conv2d_nchunks(kh, kw, Cin);
   a.Npad = conv2d_npad(Cout);
@@ -630,6 +686,12 @@ const char* conv2d_group_plan(const nfs_conv2d_desc_t* d, int n, int B, float* w
     same_pad(q.W, q.kw, 1, c.Wo, c.pad_l);
     c.relu = q.relu; c.accumulate = q.accumulate;
     c.M = B * c.Ho * c.Wo;
+    {
+      const int64_t xb = (((int64_t)B * q.H * q.W - 1) * q.ldx + q.Cin) * 4;
+      const int64_t mb = q.x_mask ? (((int64_t)B * q.H * q.W - 1) * q.ldm + q.Cin) * 4 : 0;
+      if (xb >= ((int64_t)1 << 31) || mb >= ((int64_t)1 << 31)) return "operands must stay below 2 GB";
+      c.x_bytes = (uint32_t)xb; c.m_bytes = (uint32_t)mb;
+    }
     c.cchunks = conv2d_cchunks(q.Cin);
     c.nchunks = conv2d_nchunks(q.kh, q.kw, q.Cin);
     c.Npad = conv2d_npad(q.Cout);
