@@ -396,6 +396,73 @@ __global__ void __launch_bounds__(256) conv2d_small_dgrad_kernel(const float* __
   }
 }
 
+// The stride-2 case (the graph's own first layer) with the output-gradient tile in LDS: a block owns 16 x 16 image
+// pixels, i.e. 8 x 8 pixels of each parity class = one wave per class (filters stay wave-uniform SGPR operands), and the
+// 12 x 12 outputs x Co channels those pixels draw from are staged once, masked, with zeros where no output exists -- the
+// first form read every output 12 times through the vector memory path (256 16-byte loads per pixel), which is what
+// bounded it.  Pixel stride Co + 4 floats and a row stride = 32 mod 64 keep the 16-lane groups of a b128 read (two
+// rows of eight neighbours) on distinct banks.
+constexpr int SD_T = 16, SD_TO = 12;   // (15 + 7 - 1) / 2 + 2 output rows / columns reach a 16-pixel tile
+template <int CI, bool MASK>
+__global__ void __launch_bounds__(256) conv2d_small_dgrad_s2_kernel(const float* __restrict__ gy, int ldg,
+                                                                    const float* __restrict__ yact, int lda,
+                                                                    const float* __restrict__ w, float* __restrict__ gx,
+                                                                    int H, int W, int Ho, int Wo, int Co, int kh, int kw,
+                                                                    int pad_t, int pad_l, int tiles_x, int tiles_y,
+                                                                    int cs, int rs) {
+  extern __shared__ __attribute__((aligned(16))) float gt[];    // [12][rs], pixel stride cs
+  const int t = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int iy0 = ty * SD_T, ix0 = tx * SD_T;
+  const int oy_lo = (iy0 + pad_t - kh + 1) >> 1, ox_lo = (ix0 + pad_l - kw + 1) >> 1;      // (arithmetic shift = floor)
+  const int q4 = Co >> 2;
+  for (int idx = t; idx < SD_TO * SD_TO * q4; idx += 256) {
+    const int pix = idx / q4, q = idx - pix * q4;
+    const int ry = pix / SD_TO, rx = pix - ry * SD_TO;
+    const int oy = oy_lo + ry, ox = ox_lo + rx;
+    const bool ok = (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
+    const int64_t o = ok ? ((int64_t)b * Ho + oy) * Wo + ox : 0;
+    float4 g = *reinterpret_cast<const float4*>(gy + o * ldg + 4 * q);
+    if (MASK) {
+      const float4 m = *reinterpret_cast<const float4*>(yact + o * lda + 4 * q);
+      g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
+      g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+    }
+    if (!ok) g = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(gt + ry * rs + rx * cs + 4 * q) = g;
+  }
+  __syncthreads();
+  const int cls = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int py = cls >> 1, px = cls & 1;
+  const int iy = iy0 + py + 2 * (lane >> 3), ix = ix0 + px + 2 * (lane & 7);
+  const int ky0 = (py + pad_t) & 1, kx0 = (px + pad_l) & 1;
+  float acc[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+  for (int ky = ky0; ky < kh; ky += 2) {
+    const int ry = ((iy + pad_t - ky) >> 1) - oy_lo;                      // in [0, 12) by construction
+    for (int kx = kx0; kx < kw; kx += 2) {
+      const int rx = ((ix + pad_l - kx) >> 1) - ox_lo;
+      const float* gp = gt + ry * rs + rx * cs;
+      const float* wt = w + (int64_t)(ky * kw + kx) * CI * Co;            // [CI][Co], wave-uniform
+#pragma unroll 4
+      for (int co = 0; co < Co; co += 4) {
+        const float4 g = *reinterpret_cast<const float4*>(gp + co);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          const float* wc = wt + c * Co + co;
+          acc[c] = fmaf(g.x, wc[0], fmaf(g.y, wc[1], fmaf(g.z, wc[2], fmaf(g.w, wc[3], acc[c]))));
+        }
+      }
+    }
+  }
+  if (iy < H && ix < W) {
+    float* o = gx + (((int64_t)b * H + iy) * W + ix) * CI;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) o[c] = acc[c];
+  }
+}
+
 // ---- 3x3 max pool, SAME (TF: out-of-range taps do not take part) ------------------------------------------------------
 // thread = (output pixel, 4 channels); arg = window position (0..8, row-major) of the first maximum
 __global__ void __launch_bounds__(256) maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -800,9 +867,32 @@ int nfs_conv2d_dgrad_small(const float* gy, int ldg, const float* y_act, int lda
   int Ho, Wo, pt, pl;
   same_pad(H, kh, stride, Ho, pt);
   same_pad(W, kw, stride, Wo, pl);
+  hipStream_t s = as_stream(stream);
+  if (stride == 2 && Co <= 64 && (int64_t)B * ((H + 15) / 16) * ((W + 15) / 16) < ((int64_t)1 << 31)) {
+    // 16 x 16-pixel tiles with the 12 x 12 outputs they draw from in LDS
+    const int tiles_x = (W + SD_T - 1) / SD_T, tiles_y = (H + SD_T - 1) / SD_T;
+    const int cs = Co + 4;
+    int rs = SD_TO * cs;
+    rs += ((32 - rs % 64) + 64) % 64;                                             // row stride = 32 mod 64 floats
+    const size_t lds = sizeof(float) * (size_t)SD_TO * rs;
+#define NFS_LAUNCH_S2(CI_)                                                                                              \
+  do {                                                                                                                    \
+    if (y_act)                                                                                                            \
+      conv2d_small_dgrad_s2_kernel<CI_, true><<<B * tiles_x * tiles_y, 256, lds, s>>>(                                    \
+          gy, ldg, y_act, lda, w_hwio, gx, H, W, Ho, Wo, Co, kh, kw, pt, pl, tiles_x, tiles_y, cs, rs);                   \
+    else                                                                                                                  \
+      conv2d_small_dgrad_s2_kernel<CI_, false><<<B * tiles_x * tiles_y, 256, lds, s>>>(                                   \
+          gy, ldg, y_act, lda, w_hwio, gx, H, W, Ho, Wo, Co, kh, kw, pt, pl, tiles_x, tiles_y, cs, rs);                   \
+  } while (0)
+    if (Ci == 1) NFS_LAUNCH_S2(1);
+    else if (Ci == 2) NFS_LAUNCH_S2(2);
+    else if (Ci == 3) NFS_LAUNCH_S2(3);
+    else NFS_LAUNCH_S2(4);
+#undef NFS_LAUNCH_S2
+    return check_launch("nfs_conv2d_dgrad_small");
+  }
   const int nqy = (H + stride - 1) / stride, nqx = (W + stride - 1) / stride;      // class (0, 0) is the largest
   dim3 grid(blocks_for((int64_t)B * nqy * nqx, 256), stride * stride);
-  hipStream_t s = as_stream(stream);
 #define NFS_LAUNCH(CI_)                                                                                               \
   do {                                                                                                                \
     if (y_act)                                                                                                        \
