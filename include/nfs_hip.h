@@ -446,6 +446,12 @@ int nfs_lrn_fwd(const float* x, float* y, float* scale, int64_t npix, int C, int
                 float alpha, float beta, nfs_stream_t stream);
 int nfs_lrn_bwd(const float* x, const float* y, const float* scale, const float* gy, float* gx, int64_t npix, int C,
                 int ld, int radius, float alpha, float beta, int accumulate, nfs_stream_t stream);
+/* AvgPool k x k, stride 1, VALID on rows of C floats (the graph's avgpool0, 7 x 7, in front of the classifier whose
+ * logits 'softmax2_pre_activation' the reference's top_k content target reads: styler_base.py:240-245); the fully
+ * connected layer behind it is nfs_conv2d_fwd with a 1 x 1 filter */
+int nfs_avgpool_valid_fwd(const float* x, float* y, int B, int H, int W, int C, int k, nfs_stream_t stream);
+int nfs_avgpool_valid_bwd(const float* gy, float* gx, int B, int H, int W, int C, int k, int accumulate,
+                          nfs_stream_t stream);
 int nfs_relu_mask_add(const float* g, int ldg, const float* act, int lda, const float* addend, int ldadd, float* out,
                       int ldo, int64_t npix, int C, nfs_stream_t stream);
 

@@ -111,6 +111,8 @@ SIGNATURES = {
     "nfs_maxpool3_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nfs_lrn_fwd": [_P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P],
     "nfs_lrn_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _I, _P],
+    "nfs_avgpool_valid_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_avgpool_valid_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_relu_mask_add": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P],
     "nfs_gram_style_group_workspace_floats": [_P, _I],
     "nfs_gram_style_group_parts": [_P, _I],

@@ -570,6 +570,50 @@ __global__ void __launch_bounds__(256) lrn_bwd_kernel(const float* __restrict__ 
   gx[o + c] = v;
 }
 
+// ---- AvgPool k x k, stride 1, VALID (the graph's avgpool0 in front of the classifier) -----------------------------------
+__global__ void __launch_bounds__(256) avgpool_valid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                                int H, int W, int C4, int k) {
+  const int Ho = H - k + 1, Wo = W - k + 1;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo * C4) return;
+  const int c4 = (int)(idx % C4);
+  const int64_t o = idx / C4;
+  const int ox = (int)(o % Wo), oy = (int)((o / Wo) % Ho), b = (int)(o / ((int64_t)Wo * Ho));
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const float4 v = reinterpret_cast<const float4*>(x)[(((int64_t)b * H + oy + dy) * W + ox + dx) * C4 + c4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  const float inv = 1.f / (float)(k * k);
+  reinterpret_cast<float4*>(y)[idx] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+}
+
+__global__ void __launch_bounds__(256) avgpool_valid_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                int B, int H, int W, int C4, int k, int accumulate) {
+  const int Ho = H - k + 1, Wo = W - k + 1;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * C4) return;
+  const int c4 = (int)(idx % C4);
+  const int64_t p = idx / C4;
+  const int ix = (int)(p % W), iy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oy0 = iy - k + 1 < 0 ? 0 : iy - k + 1, oy1 = iy < Ho - 1 ? iy : Ho - 1;
+  const int ox0 = ix - k + 1 < 0 ? 0 : ix - k + 1, ox1 = ix < Wo - 1 ? ix : Wo - 1;
+  for (int oy = oy0; oy <= oy1; ++oy)
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const float4 v = reinterpret_cast<const float4*>(gy)[(((int64_t)b * Ho + oy) * Wo + ox) * C4 + c4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  const float inv = 1.f / (float)(k * k);
+  float4 r = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  if (accumulate) {
+    const float4 o = reinterpret_cast<const float4*>(gx)[idx];
+    r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+  }
+  reinterpret_cast<float4*>(gx)[idx] = r;
+}
+
 // out = g (act > 0) + addend   (gradient injected at a *_pre_relu tensor: added AFTER the ReLU adjoint)
 __global__ void __launch_bounds__(256) relu_mask_add_kernel(const float* __restrict__ g, int ldg,
                                                             const float* __restrict__ act, int lda,
@@ -953,6 +997,27 @@ int nfs_lrn_bwd(const float* x, const float* y, const float* scale, const float*
   lrn_bwd_kernel<<<blocks_for(npix * C, 256), 256, 0, as_stream(stream)>>>(x, y, scale, gy, gx, npix, C, ld, radius, alpha,
                                                                          beta, accumulate);
   return check_launch("nfs_lrn_bwd");
+}
+
+int nfs_avgpool_valid_fwd(const float* x, float* y, int B, int H, int W, int C, int k, nfs_stream_t stream) {
+  NFS_REQUIRE(x && y, "nfs_avgpool_valid_fwd: null pointer");
+  NFS_REQUIRE(B > 0 && k > 0 && H >= k && W >= k && C > 0 && C % 4 == 0,
+              "nfs_avgpool_valid_fwd: the image must hold one k x k window; C a multiple of 4");
+  NFS_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "nfs_avgpool_valid_fwd: misaligned pointer");
+  avgpool_valid_fwd_kernel<<<blocks_for((int64_t)B * (H - k + 1) * (W - k + 1) * (C / 4), 256), 256, 0,
+                             as_stream(stream)>>>(x, y, B, H, W, C / 4, k);
+  return check_launch("nfs_avgpool_valid_fwd");
+}
+
+int nfs_avgpool_valid_bwd(const float* gy, float* gx, int B, int H, int W, int C, int k, int accumulate,
+                          nfs_stream_t stream) {
+  NFS_REQUIRE(gy && gx, "nfs_avgpool_valid_bwd: null pointer");
+  NFS_REQUIRE(B > 0 && k > 0 && H >= k && W >= k && C > 0 && C % 4 == 0,
+              "nfs_avgpool_valid_bwd: the image must hold one k x k window; C a multiple of 4");
+  NFS_REQUIRE((((uintptr_t)gx | (uintptr_t)gy) & 15) == 0, "nfs_avgpool_valid_bwd: misaligned pointer");
+  avgpool_valid_bwd_kernel<<<blocks_for((int64_t)B * H * W * (C / 4), 256), 256, 0, as_stream(stream)>>>(
+      gy, gx, B, H, W, C / 4, k, accumulate);
+  return check_launch("nfs_avgpool_valid_bwd");
 }
 
 int nfs_relu_mask_add(const float* g, int ldg, const float* act, int lda, const float* addend, int ldadd, float* out,

@@ -25,7 +25,7 @@ def _channels(acts, name, F):
 def _post_relu(name):
     """True for tensors that are ReLU outputs (or pools / concatenations of them): a gradient injected there may carry
     the ReLU mask.  The Inception graph's '*_pre_relu' tensors are not."""
-    return not name.endswith("_pre_relu")
+    return not (name.endswith("_pre_relu") or name.endswith("_pre_activation"))
 
 
 def _logical(acts, name):
@@ -177,8 +177,10 @@ class RenderStyleLoss(object):
                 m = None if d_gray is None else ops.resize_bicubic_tf1(d_gray.contiguous(), dimg.shape[1], dimg.shape[2])
                 ops.hist_loss(dimg, self.hist_targets[name], wl * self.w_hist, loss, g_x, relu_mask=False, mask=m)
 
-    def set_content_image(self, content_img):
-        """content_img: float32 [h,w,3] in 0..255 at the loss-net input size, or None (styler_base.py:232-247)"""
+    def set_content_image(self, content_img, top_k=0):
+        """content_img: float32 [h,w,3] in 0..255 at the loss-net input size, or None (styler_base.py:232-247);
+        ``top_k`` > 0 (with the classifier logits as content layer): only the k largest |logits| of every row of the
+        fetched feature survive, the others are zeroed (styler_base.py:240-245)"""
         if content_img is None or self.content_layer is None:
             self.content_feature = None
             return None
@@ -186,7 +188,15 @@ class RenderStyleLoss(object):
         s = torch.as_tensor(np.asarray(content_img, np.float32)).to(dev)
         mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255], dtype=torch.float32, device=dev)
         acts = self.net.forward((s - mean).unsqueeze(0).contiguous(), self.content_layer)
-        self.content_feature = _logical(acts, self.content_layer)[0].clone()
+        cf = _logical(acts, self.content_layer)[0].clone()
+        if top_k and top_k > 0:
+            if "softmax2_pre_activation" not in self.content_layer:
+                raise AssertionError("top_k > 0 needs content_layer softmax2_pre_activation (styler_base.py:241)")
+            rows = cf.reshape(-1, cf.shape[-1])
+            keep = torch.zeros_like(rows, dtype=torch.bool)
+            keep.scatter_(1, rows.abs().topk(int(top_k), dim=1).indices, True)
+            cf = (rows * keep).reshape(cf.shape).contiguous()
+        self.content_feature = cf
         return self.content_feature
 
     # -- style targets (styler_base.py:249-278: the style image enters at d_img) -------------
@@ -980,8 +990,8 @@ class ImageStyleLoss(object):
                  w_content_amp=100.0, w_hist=0.0, hist_layer=(), w_hist_layer=()):
         assert not style_mask_on_ref, "style_mask_on_ref is not used by any reference driver"
         self.net = net
-        self.layers = list(style_layer)
-        self.w_layers = [float(w) for w in w_style_layer]
+        self.layers = list(style_layer) if float(w_style) else []        # (styler_base.py:152: no style term at w_style 0)
+        self.w_layers = [float(w) for w in w_style_layer][:len(self.layers)] if self.layers else []
         self.w_style, self.w_tv = float(w_style), float(w_tv)
         self.resize_scale = float(resize_scale)
         self.style_mask = bool(style_mask)
@@ -1004,7 +1014,11 @@ class ImageStyleLoss(object):
                              % (len(self.w_hist_layers), len(self.hist_layers)))
         self.hist_targets = None
         vgg_hist = [n for n in self.hist_layers if "input" not in n]
-        self.top = max(self.layers + vgg_hist + ([self.content_layer] if self.content_layer else []), key=order.index)
+        wanted = self.layers + vgg_hist + ([self.content_layer] if self.content_layer else [])
+        if not wanted:
+            raise ValueError("no loss term reaches the loss network: w_style 0 (or no style layer) and no content / "
+                             "histogram layer")
+        self.top = max(wanted, key=order.index)
         self.style_grams = None
 
     set_style_image = RenderStyleLoss.set_style_image

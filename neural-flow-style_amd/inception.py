@@ -16,7 +16,9 @@ Every convolution unit ``U`` is the node triple ``U_pre_relu/conv`` (Conv2D, SAM
 (Relu), with constants ``U_w`` [kh,kw,Cin,Cout] and ``U_b``.  Channel widths are NOT hard-wired: they are read from the
 weight shapes (the table below only feeds the synthetic initialisation), and the LRN attributes come from the weight
 file when it carries them.  Addressable tensors: ``U``, ``U_pre_relu``, the pools, the LRNs and the module outputs.
-The classifier heads (avgpool0, softmax*) are not on the path to any feature tensor and are not built.
+The main classifier (``avgpool0`` -> ``softmax2_pre_activation``, the logits the reference's ``top_k`` content target
+reads) is built; the two auxiliary heads (head0 / head1, nn*, softmax0 / softmax1) are on the path to no tensor the
+reference asks for and are not.
 
 Weights: ``tensorflow_inception_graph.npz`` next to the ``.pb`` path, converted offline with keys
 ``<unit>_w`` / ``<unit>_b`` (the names of the graph's Const nodes) and optionally ``localresponsenorm0`` /
@@ -56,7 +58,10 @@ LRN_DEFAULT = (5, 2.0, 1e-4, 0.5)
 UNITS = ([("conv", "conv2d0"), ("maxpool", "maxpool0", 2), ("lrn", "localresponsenorm0"), ("conv", "conv2d1"),
           ("conv", "conv2d2"), ("lrn", "localresponsenorm1"), ("maxpool", "maxpool1", 2), ("mixed", "mixed3a"),
           ("mixed", "mixed3b"), ("maxpool", "maxpool4", 2)] + [("mixed", "mixed4" + c) for c in "abcde"]
-         + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b")])
+         + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b"),
+            # the main classifier: AvgPool 7x7 VALID, reshape to [-1, 1024], MatMul + BiasAdd -> the logits the reference's
+            # top_k content target reads (styler_base.py:240-245); needs >= 193 input pixels a side (7 x 7 at mixed5b)
+            ("avgpool", "avgpool0", 7), ("fc", "softmax2_pre_activation")])
 BRANCHES = ("1x1", "3x3_bottleneck", "3x3", "5x5_bottleneck", "5x5", "pool_reduce")
 # modules of up to this many pixels (batch x h x w) run their branches as grouped launches (64-row tiles, K split until
 # the launch fills the chip); above it every branch is a full launch of its own
@@ -99,6 +104,8 @@ def synthetic_weights(seed=123, upto=None):
             draw(u[1] + "_5x5", 5, c5b, c5)
             draw(u[1] + "_pool_reduce", 1, cin, cp)
             cin = c1 + c3 + c5 + cp
+        elif u[0] == "fc":
+            draw("softmax2", 1, cin, 1008)
         if u[1] == upto:
             break
     return out
@@ -110,6 +117,8 @@ def unit_of(name):
     for u in UNITS:
         if base == u[1] or (u[0] == "mixed" and base.startswith(u[1] + "_")):
             return u[1]
+    if name == "avgpool0/reshape":
+        return "avgpool0"
     raise KeyError("%r is not a tensor of the Inception-v1 graph" % (name,))
 
 
@@ -122,6 +131,9 @@ def load_npz_weights(path, upto=None):
     stop = False
     for u in UNITS:
         names = [u[1]] if u[0] == "conv" else ["%s_%s" % (u[1], b) for b in BRANCHES] if u[0] == "mixed" else []
+        if u[0] == "fc" and "softmax2_w" in z and "softmax2_b" in z:      # (the classifier is optional in a weight file)
+            w2 = np.asarray(z["softmax2_w"], np.float32)
+            out["softmax2"] = (w2.reshape((1, 1) + w2.shape[-2:]), np.asarray(z["softmax2_b"], np.float32).reshape(-1))
         for name in names:
             wk, bk = name + "_w", name + "_b"
             if wk not in z or bk not in z:
@@ -216,6 +228,19 @@ class InceptionV1(object):
                 cin = ps[0]["cout"] + ps[2]["cout"] + ps[4]["cout"] + ps[5]["cout"]
                 self.cout[u[1]] = cin
                 self.seq.append((u[1], "conv", cin, cin))
+            elif u[0] == "fc":
+                if "softmax2" not in have:
+                    break
+                w2, b2 = weights["softmax2"]
+                if w2.shape[:3] != (1, 1, cin) or w2.shape[3] % 4:
+                    raise ValueError("softmax2: weights %s do not fit the %d pooled channels" % (tuple(w2.shape), cin))
+                wt = torch.as_tensor(w2, dtype=torch.float32).to(self.device).contiguous()
+                self.params["softmax2"] = dict(k=1, cin=cin, cout=w2.shape[3], w=wt, fwd=ops.conv2d_pack(wt, False),
+                                               dgrad=ops.conv2d_pack(wt, True),
+                                               bias=torch.as_tensor(b2, dtype=torch.float32).to(self.device).contiguous())
+                cin = w2.shape[3]
+                self.cout[u[1]] = cin
+                self.seq.append((u[1], "conv", self.params["softmax2"]["cin"], cin))
             else:
                 self.cout[u[1]] = cin
                 self.seq.append((u[1], "pool", cin, cin))
@@ -291,6 +316,22 @@ class InceptionV1(object):
                 acts.aux[name] = (arg, (H, W), u[2])
                 acts.aux[name + "/in"] = (cur, ccur)
                 cur = out
+                acts.where[name] = (out, 0, ccur)
+            elif kind == "avgpool":
+                if H < u[2] or W < u[2]:
+                    raise ValueError("%s: the %d x %d map in front of the classifier is smaller than its %d x %d window "
+                                     "(the graph classifies 224 x 224 images)" % (name, H, W, u[2], u[2]))
+                out = ops.avgpool_valid_fwd(cur, u[2])
+                acts.aux[name] = ((H, W), u[2])
+                acts.aux[name + "/in"] = (cur, ccur)
+                cur = out
+                acts.where[name] = (out, 0, ccur)
+            elif kind == "fc":
+                p = self.params["softmax2"]
+                out = new(B, H, W, p["cout"])
+                ops.conv2d_fwd(cur, 0, p["cin"], p["fwd"], p["bias"], out, 0, p["cout"], 1, 1, 1, relu=False)
+                acts.aux[name + "/in"] = (cur, ccur)
+                cur, ccur = out, p["cout"]
                 acts.where[name] = (out, 0, ccur)
             elif kind == "lrn":
                 r, bias, alpha, beta = self.lrn[name]
@@ -434,6 +475,18 @@ class InceptionV1(object):
                     G[id(src)] = r
                     if first:
                         premasked.add(id(src))
+            elif kind == "avgpool":
+                hw, k = acts.aux[name]
+                g = G.get(id(acts.where[name][0]))
+                if g is not None:
+                    G[id(src)] = ops.avgpool_valid_bwd(g, hw, k, gx=G.get(id(src)))
+            elif kind == "fc":
+                p = self.params["softmax2"]
+                g = G.get(id(acts.where[name][0]))
+                if g is not None:
+                    dst, acc = target(src)
+                    ops.conv2d_fwd(g, 0, p["cout"], p["dgrad"], None, dst, 0, p["cin"], 1, 1, 1, relu=False,
+                                   accumulate=acc)
             elif kind == "lrn":
                 xin, y, scale = acts.aux[name]
                 g = G.get(id(y))

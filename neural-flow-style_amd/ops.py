@@ -881,6 +881,26 @@ def lrn_bwd(x, y, scale, gy, C, radius, alpha, beta, gx=None):
     return gx
 
 
+def avgpool_valid_fwd(x, k):
+    """k x k average pool, stride 1, VALID, over every float of the rows"""
+    _rows(x)
+    B, H, W, ld = x.shape
+    y = _empty((B, H - k + 1, W - k + 1, ld), x)
+    _lib.call("nfs_avgpool_valid_fwd", _ptr(x), _ptr(y), B, H, W, ld, int(k), _stream())
+    return y
+
+
+def avgpool_valid_bwd(gy, in_hw, k, gx=None):
+    _rows(gy)
+    B, _, _, ld = gy.shape
+    H, W = in_hw
+    acc = gx is not None
+    if gx is None:
+        gx = _empty((B, H, W, ld), gy)
+    _lib.call("nfs_avgpool_valid_bwd", _ptr(gy), _ptr(gx), B, H, W, ld, int(k), int(acc), _stream())
+    return gx
+
+
 def relu_mask_add(g, cg, act, ca, addend, cadd, C, out=None, co=0):
     """out[..., co:co+C] = g[..., cg:cg+C] * (act[..., ca:ca+C] > 0) + addend[..., cadd:cadd+C]; g / act / addend may
     be None"""

@@ -91,7 +91,7 @@ class Styler(StylerBase):
                 if getattr(self, "w_hist", 0) > 0:               # styler_2p.py:220-225
                     self.loss.set_hist_image(self._hist_feature(self.style_img, res))
             if self.content_img is not None:                     # styler_2p.py:209-211
-                self.loss.set_content_image(self._content_feature(self.content_img, res))
+                self.loss.set_content_image(self._content_feature(self.content_img, res), top_k=self._content_top_k())
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames

@@ -243,7 +243,7 @@ class Styler(StylerBase):
                 if getattr(self, "w_hist", 0) > 0:                # styler_3p.py:288-293
                     self.loss.set_hist_image(self._hist_feature(self.style_img, res[1:]))
             if self.content_img is not None:                     # styler_3p.py:277-279
-                self.loss.set_content_image(self._content_feature(self.content_img, res[1:]))
+                self.loss.set_content_image(self._content_feature(self.content_img, res[1:]), top_k=self._content_top_k())
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
 
             for step in range(self.iter):

@@ -95,6 +95,11 @@ class StylerBase(object):
             content_target = util.resize(content_target, content_shp, order=3)
         return content_target
 
+    def _content_top_k(self):
+        """styler_base.py:240-245: with a content image, ``top_k`` > 0 keeps the k strongest logits of the fetched
+        feature (the flag default is 5, and the reference asserts the content layer is the classifier's logits)"""
+        return int(getattr(self, "top_k", 0) or 0)
+
     # -- _style_feature (styler_base.py:249-278) -----------------------------------------------------
     def _style_feature(self, style_target, style_shp=None):
         style_target = np.array(style_target, np.float32)

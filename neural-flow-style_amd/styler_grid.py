@@ -191,7 +191,7 @@ class Styler(StylerBase):
             if getattr(self, "w_hist", 0) > 0:
                 self.loss.set_hist_image(self._hist_feature(self.style_img, [H, W_]))
         if self.content_img is not None:
-            self.loss.set_content_image(self._content_feature(self.content_img, [H, W_]))
+            self.loss.set_content_image(self._content_feature(self.content_img, [H, W_]), top_k=self._content_top_k())
         st.lr = self.lr[0] if isinstance(self.lr, list) else self.lr
         # the variable per key frame: stylisation velocity (zero, or params['v_init'][t]) / the density itself.
         # NOTE: at velocity == 0 every back-traced point sits exactly on a grid node, where the trilinear stencil has a

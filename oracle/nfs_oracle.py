@@ -522,7 +522,8 @@ INCEPTION_UNITS = ([("conv", "conv2d0"), ("maxpool", "maxpool0", 2), ("lrn", "lo
                     ("conv", "conv2d1"), ("conv", "conv2d2"), ("lrn", "localresponsenorm1"), ("maxpool", "maxpool1", 2),
                     ("mixed", "mixed3a"), ("mixed", "mixed3b"), ("maxpool", "maxpool4", 2)]
                    + [("mixed", "mixed4" + c) for c in "abcde"]
-                   + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b")])
+                   + [("maxpool", "maxpool10", 2), ("mixed", "mixed5a"), ("mixed", "mixed5b"),
+                      ("avgpool", "avgpool0", 7), ("fc", "softmax2_pre_activation")])
 INCEPTION_LRN = (5, 2.0, 1e-4, 0.5)          # depth_radius, bias, alpha, beta of both LRN nodes of the 5h graph
 
 
@@ -586,6 +587,13 @@ def inception_v1_features(d_img, weights, upto, lrn=None, pool1=False):
         elif kind == "lrn":
             x = tf_lrn(x, *lrn.get(name, INCEPTION_LRN))
             put(name, x)
+        elif kind == "avgpool":                      # AvgPool 7x7, stride 1, VALID
+            x = F.avg_pool2d(x, u[2], 1)
+            put(name, x)
+        elif kind == "fc":                           # reshape [-1, 1024] -> MatMul + BiasAdd: a 1x1 convolution of the map
+            w2, b2 = weights["softmax2"]
+            x = tf_conv2d_same(x, np.asarray(w2).reshape((1, 1) + np.asarray(w2).shape[-2:]), b2)
+            put(name, x)
         else:
             b1 = conv(name + "_1x1", x)
             b3 = conv(name + "_3x3", conv(name + "_3x3_bottleneck", x))
@@ -598,6 +606,22 @@ def inception_v1_features(d_img, weights, upto, lrn=None, pool1=False):
         if base == name or (kind == "mixed" and base.startswith(name + "_")):
             return feats
     raise KeyError(upto)
+
+
+def content_target_feature(content_img, weights, layer, cfg=None, top_k=0):
+    """_content_feature (styler_base.py:232-247): the content image fed at d_img, ``layer`` fetched; with ``top_k`` > 0
+    (asserted to be the classifier's logits, line 241) every row of the fetched [rows, classes] array keeps its k
+    largest |values| and the rest is zeroed (242-245)"""
+    feats = loss_net_features(content_img, weights, layer, cfg)
+    f = feats[layer].detach().clone()
+    if top_k and top_k > 0:
+        assert "softmax2_pre_activation" in layer
+        rows = f.reshape(-1, f.shape[-1])
+        idx = rows.abs().topk(int(top_k), dim=1).indices
+        keep = torch.zeros_like(rows, dtype=torch.bool)
+        keep.scatter_(1, idx, True)
+        f = (rows * keep).reshape(f.shape)
+    return f
 
 
 def inception_last_layer(layers):

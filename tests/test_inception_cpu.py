@@ -41,8 +41,9 @@ def test_published_tensor_shapes_of_the_graph_at_its_native_input():
     14^2 x 508, mixed4b .. 4c 512, mixed4d 528, mixed4e 832, mixed5a 7^2 x 832, mixed5b 1024; run.bat's content tensors
     exist with room for their channel numbers (run.bat:14-20)"""
     w = inception.synthetic_weights(0)
-    assert len(w) == len(inception.conv_units()) == 3 + 9 * 6
-    feats = O.inception_v1_features(torch.zeros(1, 224, 224, 3), w, "mixed5b")
+    assert len(w) == len(inception.conv_units()) + 1 == 3 + 9 * 6 + 1 and w["softmax2"][0].shape == (1, 1, 1024, 1008)
+    feats = O.inception_v1_features(torch.zeros(1, 224, 224, 3), w, "softmax2_pre_activation")
+    assert tuple(feats["avgpool0"].shape) == (1, 1, 1, 1024) and tuple(feats["softmax2_pre_activation"].shape) == (1, 1, 1, 1008)
     want = {"conv2d0": (112, 64), "maxpool0": (56, 64), "conv2d1": (56, 64), "conv2d2": (56, 192), "maxpool1": (28, 192),
             "mixed3a": (28, 256), "mixed3b": (28, 480), "maxpool4": (14, 480), "mixed4a": (14, 508), "mixed4b": (14, 512),
             "mixed4c": (14, 512), "mixed4d": (14, 528), "mixed4e": (14, 832), "maxpool10": (7, 832), "mixed5a": (7, 832),

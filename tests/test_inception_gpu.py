@@ -401,3 +401,89 @@ def test_image_style_loss_2d_with_the_inception_network(style_mask):
     total.backward()
     assert abs(float(loss.sum()) - float(total.detach())) < 2e-4 * abs(float(total.detach()))
     assert rel(g, dt.grad) < 1e-3
+
+
+# ---- the main classifier: avgpool0 -> softmax2_pre_activation (styler_base.py:240-245) ---------------------------------
+
+@pytest.mark.parametrize("B,H,W,C,k", [(2, 9, 11, 64, 7), (1, 7, 7, 1024, 7), (1, 10, 15, 128, 3)])
+def test_avgpool_valid_and_its_adjoint(B, H, W, C, k):
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(H)
+    x = rng.randn(B, H, W, C).astype(np.float32)
+    xt = nchw(x).double().requires_grad_()
+    y = torch.nn.functional.avg_pool2d(xt, k, 1)
+    gy = rng.randn(*nhwc(y).shape).astype(np.float32)
+    (y * nchw(gy).double()).sum().backward()
+    got = ops.avgpool_valid_fwd(torch.tensor(x, device=DEV), k)
+    assert rel(got, nhwc(y)) < 1e-6
+    gx = ops.avgpool_valid_bwd(torch.tensor(gy, device=DEV), (H, W), k)
+    assert rel(gx, nhwc(xt.grad)) < 1e-6
+    base = torch.full((B, H, W, C), 0.25, device=DEV)
+    assert rel(ops.avgpool_valid_bwd(torch.tensor(gy, device=DEV), (H, W), k, gx=base) - 0.25, nhwc(xt.grad)) < 1e-6
+
+
+def test_inception_classifier_logits_and_their_data_gradient():
+    """the whole graph down to 'softmax2_pre_activation' at 224 x 256 (a 7 x 8 map in front of the 7 x 7 pool: two rows
+    of logits per image, as the graph's reshape to [-1, 1024] gives them) against the oracle, and its data gradient"""
+    net, w = _net("softmax2_pre_activation", seed=4)
+    rng = np.random.RandomState(8)
+    img = (rng.rand(1, 224, 256, 3) * 255).astype(np.float32)
+    x = torch.tensor(img, device=DEV) - torch.tensor(O.VGG_MEAN, dtype=torch.float32, device=DEV)
+    names = ["mixed4e", "mixed5b", "avgpool0", "softmax2_pre_activation"]
+    acts = net.forward(x.contiguous(), "softmax2_pre_activation", keep=set(names))
+    # (float64 oracle: in float32 the restatement itself routes a few max-pool near-ties differently, 7e-3 on the gradient)
+    xi = torch.tensor(img, dtype=torch.float64, requires_grad=True)
+    w64 = {k: (np.asarray(a, np.float64), np.asarray(b, np.float64)) for k, (a, b) in w.items()}
+    feats = O.inception_v1_features(xi, w64, "softmax2_pre_activation")
+    assert tuple(feats["softmax2_pre_activation"].shape) == (1, 1, 2, 1008)
+    total, grads = 0, {}
+    for i, n in enumerate(names):
+        c = acts.channels[n]
+        assert rel(acts[n][..., :c], feats[n]) < 5e-5, n
+        r = torch.tensor(np.random.RandomState(i).randn(*feats[n].shape)) / feats[n].detach().abs().mean()
+        total = total + (feats[n] * r).sum()
+        g = torch.zeros_like(acts[n])
+        g[..., :c] = r.float().to(DEV)
+        grads[n] = g
+    total.backward()
+    assert rel(net.backward(acts, grads, "softmax2_pre_activation"), xi.grad) < 5e-5
+    small = torch.zeros(1, 100, 100, 3, device=DEV)
+    with pytest.raises(ValueError, match="avgpool0"):
+        net.forward(small, "softmax2_pre_activation")
+
+
+def test_engine_gradient_with_the_top_k_content_target_on_the_classifier_logits():
+    """styler_base.py:232-247 with the flag defaults' mechanism: a content image, content_layer
+    softmax2_pre_activation, top_k 5 -- the target keeps the five strongest logits of the content image, the term is
+    mean((logits - amp * target)^2).  Through the 2-D colour loss on a textured 224 x 256 image: a smooth render has
+    large areas whose neighbouring pixels differ by less than a float32 ulp of the mean-subtracted input -- exact ties
+    in the graph's 16 max pools in float32, distinct values in a float64 oracle, i.e. the same loss with its gradient
+    routed to other pixels (measured: 1.4e-2 on a blob, 6e-3 on a noise volume; the subgradient of a max is not unique
+    there, in TF either; even on a textured image ONE near-tie among the ~10^6 pool windows moves 2e-3 of the gradient:
+    weight seed 123 has one for this image, seed 4 has none)"""
+    from neural_flow_style_amd import engine, synthetic as S
+    net, w = _net("softmax2_pre_activation", seed=4)
+    rng = np.random.RandomState(12)
+    H, W = 224, 256
+    d = rng.rand(1, H, W, 3).astype(np.float32)
+    cimg = S.style_image(H, W, rng)
+    il = engine.ImageStyleLoss(net, ["conv2d2"], [1.0], 0.0, w_content=1.0, content_layer="softmax2_pre_activation",
+                               w_content_amp=100.0)
+    cf = il.set_content_image(cimg, top_k=5)
+    assert tuple(cf.shape) == (1, 1, 2, 1008) and int((cf != 0).sum()) == 10
+    loss, g = il.loss_and_grad(torch.tensor(d, device=DEV))
+
+    cfg = dict(network="tensorflow_inception_graph.pb")
+    w64 = {k: (np.asarray(a, np.float64), np.asarray(b, np.float64)) for k, (a, b) in w.items()}
+    target = O.content_target_feature(torch.tensor(cimg, dtype=torch.float64)[None], w64, "softmax2_pre_activation", cfg,
+                                      top_k=5)
+    assert rel(cf, target) < 1e-5
+    dt = torch.tensor(d, dtype=torch.float64).requires_grad_()
+    feats = O.loss_net_features(O.plugin_to_loss_net(dt, 1.0, is_color=True), w64, "softmax2_pre_activation", cfg)
+    total = O.content_loss(feats["softmax2_pre_activation"], 0, target, 100.0)
+    total.backward()
+    assert abs(float(loss.sum()) - float(total.detach())) < 1e-5 * abs(float(total.detach()))
+    assert rel(g, dt.grad) < 1e-4
+    with pytest.raises(AssertionError, match="softmax2_pre_activation"):
+        engine.ImageStyleLoss(net, ["conv2d2"], [1.0], 0.0, w_content=1.0, content_layer="mixed3b").set_content_image(
+            cimg, top_k=5)
