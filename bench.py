@@ -737,6 +737,11 @@ def main():
         settle(views_step)
         dt, last = time_steps(views_step, barrier, args.warmup, args.steps, device, world)
         out.update(value=args.steps / dt, ms_per_step=1e3 * dt / args.steps, scaling="strong", final_loss=float(last))
+        # how the step was submitted: eagerly, or as a hipGraph replay -- the stylizer measures at its second step whether
+        # the host can issue the ~80 launches faster than the GPU runs them (hosts of one pool differ by 2x)
+        out["submission"] = {"hipgraph": bool(gs.use_graph),
+                             "trial_issue_ms": None if not getattr(gs, "graph_trial", None) else 1e3 * gs.graph_trial[0],
+                             "trial_wall_ms": None if not getattr(gs, "graph_trial", None) else 1e3 * gs.graph_trial[1]}
         out["config"] = dict(cfg_common, workload="smokegun %d^3 single-frame, %d rotated views, VGG-19 conv1_1..conv5_1 "
                              "Gram style loss, grid velocity variable through advect + TF-Adam (BASELINE configs[2])"
                              % (G, V), views_per_rank=V // world,
@@ -750,6 +755,7 @@ def main():
         def frames_step():
             return st.iterate()
 
+        settle(frames_step, 2)
         dt, last = time_steps(frames_step, barrier, args.warmup, args.steps, device, world)
         out.update(value=F_ * args.steps / dt, ms_per_step=1e3 * dt / args.steps, scaling="weak",
                    final_loss=float(last.sum()))

@@ -939,12 +939,12 @@ class GridStylizer(object):
             nv = max(int(rot_local.shape[0]), 1)
             if self.d0.numel() * nv <= (2 << 20):    # small volumes, few views: the host needs longer than the GPU
                 self.use_graph = True
-            elif nv > 2:                             # full view batches are bound by their kernels
-                self.use_graph = False
             else:
-                # one or two views of a large volume (a rank of a view-sharded run): 80 launches of ~14 us -- kernel-bound
-                # on a fast host, host-bound on a slow one, and the hosts of one pool differ by 2x.  Measured at the
-                # second step (the first has built the lazy state); until then the step runs eagerly.
+                # Large volumes: ~80 launches per step.  At 8 views the GPU needs 2.7 ms for them and a fast host 2.0 ms to
+                # issue them (tools/step_host_time.py: 35 us per C-ABI call, i.e. the HIP launches themselves) -- kernel-
+                # bound, but a host of the same pool that is 2x slower (measured: 20 us per launch instead of 9) turns
+                # the very same step host-bound, at 8 views as at 1.  So the choice is measured at the second step (the
+                # first has built the lazy state); until then the step runs eagerly.
                 self._steps_seen = getattr(self, "_steps_seen", 0) + 1
                 if self._steps_seen == 2 and getattr(self, "d_s", None) is not None:
                     self.use_graph = self._loss_chain_host_bound(rot_local)
