@@ -84,9 +84,20 @@ class Styler(StylerBase):
         p_ = p.unsqueeze(0)
         if "p" in self.target_field:
             p_ = p_ + var.unsqueeze(0)
+        p_all = p_
+        # a sequence keeps ONE particle order for all frames (frame 0's: the temporal filter needs particle i to be the
+        # same particle everywhere), so by frame 60 of a flowing liquid the neighbours of that order have dispersed and
+        # the splat would fall back to scattered global atomics; it therefore sees every frame through that frame's
+        # own grid order (a gather of the positions in, the scatter of their gradient out -- the splat does not care
+        # about the order of its particles)
+        order = getattr(self, "_orders", {}).get(p.data_ptr())
+        if order is not None:
+            p_ = p_[:, order]
         if "d" in self.target_field:
             r_opt = torch.clamp(var.unsqueeze(0), -1, 1)                    # "necessary!" (styler_3p.py:74)
             r_ = r.unsqueeze(0) + r_opt
+            if order is not None:
+                r_ = r_[:, order]
             if getattr(self, "w_density", 0) > 0:
                 # density preservation on the clipped offsets (self.d[i], styler_3p.py:75; styler_base.py:217-223)
                 d_loss = r_opt[0].sum() ** 2
@@ -106,7 +117,7 @@ class Styler(StylerBase):
                 pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
                 extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
         d_out = _SmoothRelu.apply(d_, float(self.k)) if self.k > 0 else _SmoothRelu.apply(d_, 0.0)
-        return p_[0], d_out, extra
+        return p_all[0], d_out, extra
 
     def _value_and_grad(self, p, r, var, res, rot, view_shard=True):
         """loss (per view, device) and d loss / d var for one frame.  ``view_shard``: the views are sharded over the
@@ -193,6 +204,11 @@ class Styler(StylerBase):
             inv[perm] = torch.arange(perm.numel(), device=self.device)
             p = [x[perm].contiguous() for x in p]
             r = [x[perm].contiguous() if x is not None else None for x in r]
+        self._orders = {}
+        if getattr(self, "sort_particles", True) and self.num_frames > 1:
+            for x in p[1:]:                                  # (frame 0 is in its own order already)
+                if x.shape[0] > 1:
+                    self._orders[x.data_ptr()] = T.grid_order(x, self.resolution)
         nvar = 3 if "p" in self.target_field else self.num_kernels
         g_opt = [torch.zeros(p[i].shape[0], nvar, device=self.device) for i in range(self.num_frames)]
         mode = getattr(self, "views_mode", "sequential")

@@ -47,3 +47,19 @@ psd = (ps + (torch.rand_like(ps) * 2 - 1) * 2 / G).clamp(0.01, 0.99)
 print("row-major cell order drifted +-2 cells: fwd %.3f ms" % t(lambda: ops.p2g_fwd(psd, cfg)))
 pu = torch.rand(N, 3, device="cuda") * 0.9 + 0.05
 print("uniform random particles, nsize 1: fwd %.3f ms  bwd %.3f ms" % (t(lambda: ops.p2g_fwd(pu, cfg)), t(lambda: ops.p2g_bwd(pu, cfg, g, need_p=True))))
+# a later frame of a sequence: the same particles carried along by a flow (here a rotation about the axis by 0.4 rad), still
+# in frame 0's order -- and seen through that frame's own grid order (what Styler.run does: gather in, scatter out)
+pb = p[T.grid_order(p, [G, G, G])].contiguous()
+c, s_ = float(np.cos(0.4)), float(np.sin(0.4))
+q = pb - 0.5
+moved = torch.stack([q[:, 0], c * q[:, 1] - s_ * q[:, 2], s_ * q[:, 1] + c * q[:, 2]], 1).mul(0.7).add(0.5).contiguous()
+order = T.grid_order(moved, [G, G, G])
+def via_order():
+    return ops.p2g_fwd(moved[order].contiguous(), cfg)
+print("frame carried by a coherent flow, frame-0 order: fwd %.3f ms; through its own grid order (incl. the gather): %.3f ms"
+      % (t(lambda: ops.p2g_fwd(moved, cfg)), t(via_order)))
+# ... and with mixing: every particle also wanders by up to +-10 cells relative to its frame-0 neighbours
+moved = (moved + (torch.rand_like(moved) * 2 - 1) * 10 / G).clamp(0.02, 0.98).contiguous()
+order = T.grid_order(moved, [G, G, G])
+print("frame with mixing (+-10 cells), frame-0 order: fwd %.3f ms; through its own grid order (incl. the gather): %.3f ms"
+      % (t(lambda: ops.p2g_fwd(moved, cfg)), t(via_order)))
