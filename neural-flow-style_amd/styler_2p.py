@@ -40,15 +40,31 @@ class Styler(StylerBase):
     def _dev(self, a):
         return torch.as_tensor(np.asarray(a, np.float32)).to(self.device).contiguous()
 
+    def _order(self, p):
+        """the frame's own grid order (computed once per frame and run): the splat accumulates a block of consecutive
+        particles in LDS when their cells sit in a small box, whatever order the caller's particles come in -- a
+        gather of positions / colours in, the scatter of the colour gradient out"""
+        if not getattr(self, "sort_particles", True) or p.shape[0] < 2:
+            return None
+        cache = self.__dict__.setdefault("_orders", {})
+        key = (p.data_ptr(), p.shape[0])
+        if key not in cache:
+            cache[key] = T.grid_order(p, self.resolution)
+        return cache[key]
+
     def _density(self, p, res):
-        d = T.p2g(p.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
+        o = self._order(p)
+        pp = p if o is None else p[o]
+        d = T.p2g(pp.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
                   support=self.support, clip=self.clip)
         return torch.clamp(d / self.rest_density, 0, 1)                      # [1,H,W,1]
 
     def _colour(self, p, r, var, res):
         c_ = torch.clamp(var.unsqueeze(0), 0, 1)
-        d = T.p2g(p.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
-                  support=self.support, clip=self.clip, pc=c_, pd=r.unsqueeze(0))
+        o = self._order(p)
+        pp, cc, rr = (p, c_, r) if o is None else (p[o], c_[:, o], r[o])
+        d = T.p2g(pp.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
+                  support=self.support, clip=self.clip, pc=cc, pd=rr.unsqueeze(0))
         return torch.clamp(d, 0, 1), c_[0]                                   # [1,H,W,3]
 
     def render_test(self, params):
@@ -72,6 +88,7 @@ class Styler(StylerBase):
 
         p = [self._dev(x) for x in params["p"]]
         r = [self._dev(x) for x in params["r"]]
+        self._orders = {}
         n = p[0].shape[0]
         # colour init: noise around the VGG mean / 255 (styler_2p.py:189-192)
         c_opt = self.rng.uniform(-5, 5, [self.num_frames, n, 3]).astype(np.float32)
