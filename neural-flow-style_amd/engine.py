@@ -511,6 +511,8 @@ class GraphedLoss(object):
         self.trial = None
 
     def _eager(self, d, rot):
+        if isinstance(self.loss, ImageStyleLoss):        # (d, d_gray) -> (losses, gradient)
+            return self.loss.loss_and_grad(d, rot)
         g_d = torch.zeros_like(d)
         return self.loss.loss_and_grad(d, rot, g_d), g_d
 
@@ -540,8 +542,11 @@ class GraphedLoss(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._gd.zero_()
-                self._losses = self.loss.loss_and_grad(self._d, self._rot, self._gd)
+                if isinstance(self.loss, ImageStyleLoss):
+                    self._losses, self._gd = self.loss.loss_and_grad(self._d, self._rot)
+                else:
+                    self._gd.zero_()
+                    self._losses = self.loss.loss_and_grad(self._d, self._rot, self._gd)
             self._graph = g
         else:
             self._d.copy_(d)

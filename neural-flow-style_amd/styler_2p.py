@@ -10,6 +10,8 @@ Forward graph (styler_2p.py:42-102):
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -89,6 +91,7 @@ class Styler(StylerBase):
         p = [self._dev(x) for x in params["p"]]
         r = [self._dev(x) for x in params["r"]]
         self._orders = {}
+        self._graph_loss = None
         n = p[0].shape[0]
         # colour init: noise around the VGG mean / 255 (styler_2p.py:189-192)
         c_opt = self.rng.uniform(-5, 5, [self.num_frames, n, 3]).astype(np.float32)
@@ -120,7 +123,17 @@ class Styler(StylerBase):
                     d, _ = self._colour(p[t], r[t], var, res)
                     with torch.no_grad():
                         d_gray = self._density(p[t], res)
-                    losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
+                    if self._graph_loss is None:
+                        # the loss chain of one colour image is ~40 small launches: hipGraph replay where a measured
+                        # trial finds the host cannot keep up with it (engine.GraphedLoss; NFS_GRAPH=0 / 1 forces)
+                        env = os.environ.get("NFS_GRAPH")
+                        self._graph_loss = (engine.GraphedLoss(self.loss, force=True) if env == "1" else
+                                            engine.GraphedLoss(self.loss) if env is None else False)
+                    if self._graph_loss:
+                        losses, g_d = self._graph_loss(d.detach().contiguous(), d_gray)
+                        losses = losses.clone()
+                    else:
+                        losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
                     d.backward(g_d)
                     x = var.detach().clone()
                     opt_[opt_id].step(x, var.grad.contiguous(), lr)
