@@ -444,6 +444,42 @@ def other_configs(device, base):
     except Exception as e:  # pragma: no cover
         out.append({"config": "configs[0]", "error": repr(e)})
 
+    # configs[0] end to end: Styler(config).run of the 2-D colour stylizer (particle colours -> splat -> masked style + TV ->
+    # adjoint -> TF-Adam), 50 iterations at 128 x 128 (tools/dambreak_bench.py)
+    try:
+        from neural_flow_style_amd.config import get_config as _gc
+        from neural_flow_style_amd.styler_2p import Styler as Styler2
+        rng = np.random.RandomState(7)
+        pp2 = S.dambreak_particles(80, rng)
+        rr2 = rng.uniform(900, 1100, (pp2.shape[0], 1)).astype(np.float32)
+        c2, _ = _gc([])
+        for k_, v_ in dict(network="vgg_19.ckpt", data_dir="/nonexistent", synthetic_weights=True, resolution=[128, 128],
+                           domain=[3.2, 3.2], radius=0.0125, nsize=2, support=4, rest_density=1000, clip=False,
+                           target_field="c", num_frames=1, batch_size=1, frames_per_opt=200, window_sigma=3, lr=0.01,
+                           iter=50, octave_n=1, octave_scale=1.7, style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0,
+                           w_content=0, style_mask=True, w_tv=0.01, style_target=S.style_image(128, 128, rng),
+                           resize_scale=1.0).items():
+            setattr(c2, k_, v_)
+        c2.rng = np.random.RandomState(c2.seed)
+        import contextlib, io as _io
+        with contextlib.redirect_stdout(_io.StringIO()):           # (the stylizer prints its octave sizes)
+            st2 = Styler2(c2)
+            st2.load_img([128, 128])
+            st2.run({"p": [pp2], "r": [rr2]})                       # warm-up (weight packing, workspaces)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res2 = st2.run({"p": [pp2], "r": [rr2]})
+            torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / c2.iter
+        out.append({"config": "configs[0] dambreak2d 128x128 END TO END: Styler(config).run of the 2-D colour stylizer, %d "
+                              "particles, conv3_1, style mask + TV, 50 Adam iterations" % pp2.shape[0],
+                    "value": 1.0 / dt2, "unit": "iters/s", "ms_per_step": 1e3 * dt2,
+                    "loss_first_last": [float(res2["l"][0][0]), float(res2["l"][0][-1])],
+                    "loss_chain_mode": getattr(st2._graph_loss, "mode", None) if st2._graph_loss else "eager"})
+        del st2
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "configs[0] end to end", "error": repr(e)})
+
     # configs[4]: chocolate-scale splat, 5e5 particles -> 200^3 (grid-cell order as Styler.run processes them)
     try:
         N, G = 500000, 200
