@@ -3,6 +3,6 @@
 cd neural-flow-style_amd; cp libnfs_hip.so /tmp/new.so
 F="--steps 40 --warmup 5 --no-cpu-baseline --no-kernel-profile --no-parity --no-sustained --no-other-configs --no-split-limb"
 for i in 1 2 3; do
-  cp libnfs_old.so libnfs_hip.so; (cd ..; python bench.py $F 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('r02_j lib', round(d['value'],1))")
+  cp libnfs_old.so libnfs_hip.so; (cd ..; python bench.py $F 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('old   lib', round(d['value'],1))")
   cp /tmp/new.so libnfs_hip.so; (cd ..; python bench.py $F 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('HEAD  lib', round(d['value'],1))")
 done
