@@ -157,8 +157,15 @@ def test_particle_sequence_sharded_by_frames_reproduces_the_single_rank_run(tmp_
                    check=True, env=env, timeout=900)
     a, b = np.load(one), np.load(two)
     np.testing.assert_allclose(b["l"], a["l"], rtol=2e-5)
-    # (the splat adds with float atomics: the two runs agree to rounding, which TF-Adam's m / sqrt(v) amplifies a little)
-    assert np.linalg.norm(b["opt"] - a["opt"]) <= 1e-4 * np.linalg.norm(a["opt"])
-    np.testing.assert_allclose(b["p"], a["p"], atol=2e-5)      # (float-atomic splat sums -> rounding-level noise, Adam-amplified)
-    np.testing.assert_allclose(b["d"], a["d"], rtol=1e-4, atol=1e-6)
+    # The splat adds with float atomics, so two runs of the SAME process layout agree to rounding only (1e-7) -- and the
+    # loss chain is not smooth: at the 20th loss evaluation of this sequence a last-bit change of the density flips one
+    # of its discrete decisions (a ReLU mask at a pre-activation on zero); the loss does not notice, the gradient of
+    # that call jumps by 6e-5 ... 2e-4, and the final variables then differ by 1e-4.  tools/flaky_knife_edge.py: the
+    # chain is bit-deterministic on a fixed input there, and 1 of 40 last-bit perturbations of its input lands on the
+    # other side; tools/flaky_trace.py: so does the one-rank run itself, 1 run in 10.  The bars below admit such an
+    # event and stay two orders of magnitude under what a sharding error does (a missing halo term or a different view
+    # sequence moves the variables by 10-50 %).
+    assert np.linalg.norm(b["opt"] - a["opt"]) <= 2e-3 * np.linalg.norm(a["opt"])
+    np.testing.assert_allclose(b["p"], a["p"], atol=3e-4)      # (one Adam step moves a coordinate by 2e-3)
+    np.testing.assert_allclose(b["d"], a["d"], rtol=2e-3, atol=1e-4)
     assert b["di"].shape == a["di"].shape
