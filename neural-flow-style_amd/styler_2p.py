@@ -25,7 +25,11 @@ from .util import denoise
 class Styler(StylerBase):
     def __init__(self, self_dict):
         StylerBase.__init__(self, self_dict)
-        assert self.batch_size == 1, "batch_size > 1 is not supported (frames are optimised one at a time)"
+        self.batch_size = max(int(self.batch_size), 1)
+        if self.batch_size > 1 and (getattr(self, "w_content", 0) and getattr(self, "content_layer", None)
+                                    or getattr(self, "w_hist", 0)):
+            raise NotImplementedError("batch_size > 1 with a content or histogram term: their means / matches run over "
+                                      "the whole batch tensor (styler_base.py:135-150, 203-207); style + TV only")
         w_layers = list(self.w_style_layer)
         if len(w_layers) == 1 and len(self.style_layer) > 1:
             w_layers = w_layers * len(self.style_layer)
@@ -115,14 +119,19 @@ class Styler(StylerBase):
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames
-                for t in range(0, self.num_frames, self.batch_size):
-                    var = g_opt[t].clone().requires_grad_(True)
+                B = self.batch_size
+                assert self.num_frames % B == 0, "num_frames must be a multiple of batch_size (styler_2p.py:239-244)"
+                for t in range(0, self.num_frames, B):
+                    # B frames share one sess.run (styler_2p.py:42-98: batch_size towers): one image batch through the
+                    # loss network -- style summed over the images, TV averaged (styler_base.py:181, 212) -- and ONE
+                    # optimiser step on the B colour variables (Adam slots per batch position, one step count)
+                    vars_ = [g_opt[t + i].clone().requires_grad_(True) for i in range(B)]
                     opt_id = t // self.frames_per_opt
                     if opt_id not in opt_:
                         opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
-                    d, _ = self._colour(p[t], r[t], var, res)
+                    d = torch.cat([self._colour(p[t + i], r[t + i], vars_[i], res)[0] for i in range(B)], 0)
                     with torch.no_grad():
-                        d_gray = self._density(p[t], res)
+                        d_gray = torch.cat([self._density(p[t + i], res) for i in range(B)], 0)
                     if self._graph_loss is None:
                         # the loss chain of one colour image is ~40 small launches: hipGraph replay where a measured
                         # trial finds the host cannot keep up with it (engine.GraphedLoss; NFS_GRAPH=0 / 1 forces)
@@ -135,13 +144,14 @@ class Styler(StylerBase):
                     else:
                         losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
                     d.backward(g_d)
-                    x = var.detach().clone()
-                    opt_[opt_id].step(x, var.grad.contiguous(), lr)
+                    x = torch.stack([v.detach() for v in vars_])                    # [B,N,3]
+                    opt_[opt_id].step(x, torch.stack([v.grad for v in vars_]).contiguous(), lr)
                     loss_history_o.append(float(losses.sum()))
-                    g_tmp[t] = torch.nan_to_num(x) - g_opt[t]
+                    for i in range(B):
+                        g_tmp[t + i] = torch.nan_to_num(x[i]) - g_opt[t + i]
                     if step == self.iter - 1 and octave < self.octave_n - 1:
                         with torch.no_grad():
-                            dd, _ = self._colour(p[t], r[t], x, res)
+                            dd = torch.cat([self._colour(p[t + i], r[t + i], x[i], res)[0] for i in range(B)], 0)
                             d_intm_o.append(((dd * d_gray) * 255).cpu().numpy().astype(np.uint8))
                 if self.window_sigma > 0 and self.num_frames > 1:
                     stack = denoise(np.stack([g.cpu().numpy() for g in g_tmp]), sigma=(self.window_sigma, 0, 0))

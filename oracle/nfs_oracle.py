@@ -1243,8 +1243,10 @@ def colour_field2d(p, r, var, cfg, res):
     return torch.clamp(d, 0, 1), d_gray.detach(), c_[0]
 
 
-def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
-    """style (optionally masked by d_gray, styler_base.py:165-169) + TV (211-213) of the colour image"""
+def colour_loss2d(p, r, var, cfg, res, weights, style_feats, batch=1):
+    """style (optionally masked by d_gray, styler_base.py:165-169) + TV (211-213) of the colour image.  ``batch``: the
+    image is one of ``batch`` frames of a sess.run (styler_2p.py:42-98 builds batch_size towers): the style term is a
+    reduce_sum over the batch (181: separable), the TV term a reduce_mean (212: this frame's share is TV / batch)"""
     d, d_gray, _ = colour_field2d(p, r, var, cfg, res)
     d_img = plugin_to_loss_net(d, cfg.get("resize_scale", 1.0), is_color=True)
     use_content = uses_content(cfg)
@@ -1264,13 +1266,17 @@ def colour_loss2d(p, r, var, cfg, res, weights, style_feats):
             m = tf1_resize_bicubic(d_gray, f.shape[1], f.shape[2]) if cfg.get("style_mask") else None
             l = l + cfg["w_hist"] * wl * hist_loss(f, cfg["hist_feature"][name], mask=m)
     if cfg.get("w_tv", 0):
-        l = l + tv_loss(d_img) * cfg["w_tv"]
+        l = l + tv_loss(d_img) * cfg["w_tv"] / batch
     return l
 
 
 def styler2p_run(cfg, params, weights, style_img, c_init):
-    """The reference's 2-D colour Styler.run (styler_2p.py:165-315) for batch_size 1: octaves coarse -> fine, one
-    TF-Adam state per frame group, temporal Gaussian smoothing of the per-frame updates.  ``style_img[octave]`` is
+    """The reference's 2-D colour Styler.run (styler_2p.py:165-315): octaves coarse -> fine, one TF-Adam state per
+    frame group, temporal Gaussian smoothing of the per-frame updates.  ``batch_size`` B > 1 (run.bat's last line): B
+    consecutive frames share one sess.run -- total loss = sum of their style terms + mean of their TV terms, ONE
+    optimiser step on the B colour variables (243-255: the Adam slots belong to the batch POSITION, the step count to
+    the optimiser), one loss entry per batch (258).  Style + TV only there: the content mean and the unmasked
+    histogram match run over the whole batch tensor and are not restated for B > 1.  ``style_img[octave]`` is
     the style image already resized for that octave, ``c_init`` [F,N,3] the colour initialisation (189-192).
     Returns (loss history per octave, optimised colours per frame, final uint8 images d*d_gray*255)."""
     from scipy.ndimage import gaussian_filter
@@ -1295,14 +1301,18 @@ def styler2p_run(cfg, params, weights, style_img, c_init):
         h_o = []
         for step in range(cfg["iter"]):
             g_tmp = [None] * F_
-            for t in range(F_):
+            B = int(cfg.get("batch_size", 1) or 1)
+            assert F_ % B == 0, "num_frames must be a multiple of batch_size (styler_2p.py:239-244 indexes p[t+i])"
+            assert B == 1 or not (uses_content(cfg) or cfg.get("w_hist", 0)), "batch_size > 1: style + TV only"
+            for t in range(0, F_, B):
                 opt = opt_.setdefault(t // cfg["frames_per_opt"], TFAdam())
-                vv = g_opt[t].clone().requires_grad_()
-                l = colour_loss2d(p[t], r[t], vv, cfg, res, weights, sfe)
-                (g,) = torch.autograd.grad(l, vv)
+                vv = [g_opt[t + i].clone().requires_grad_() for i in range(B)]
+                l = sum(colour_loss2d(p[t + i], r[t + i], vv[i], cfg, res, weights, sfe, batch=B) for i in range(B))
+                g = torch.autograd.grad(l, vv)
                 h_o.append(float(l.detach()))
-                new = torch.nan_to_num(opt.step(g_opt[t].clone(), g, lr))
-                g_tmp[t] = new - g_opt[t]
+                new = torch.nan_to_num(opt.step(torch.stack([g_opt[t + i] for i in range(B)]), torch.stack(g), lr))
+                for i in range(B):
+                    g_tmp[t + i] = new[i] - g_opt[t + i]
             if cfg["window_sigma"] > 0 and F_ > 1:
                 st = gaussian_filter(np.stack([g.numpy() for g in g_tmp]), sigma=(cfg["window_sigma"], 0, 0))
                 g_tmp = [torch.tensor(s) for s in st]

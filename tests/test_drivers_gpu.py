@@ -59,6 +59,15 @@ def test_dambreak2d_driver_reproduces_the_override_block_and_writes_its_outputs(
     np.testing.assert_allclose(pt.array("Cd"), res["c"][0], rtol=0, atol=0)
     assert float(pt.array("position")[:, 2].max()) == 0.0           # 2-component position, zero-padded
 
+    # run.bat's last line in miniature: ``--num_frames 20 --batch_size 4`` -> 4 frames in batches of 2 (one loss entry
+    # and one optimiser step per batch)
+    argv = ["--scale", "1", "--iter", "2", "--octave_n", "1", "--num_frames", "4", "--batch_size", "2", "--target_frame", "5",
+            "--w_style", "1", "--w_content", "0"]
+    monkeypatch.setattr(sys, "argv", ["test_dambreak2d.py"] + argv)
+    cfg = _cfg(tmp_path, argv)
+    res = drv.main(cfg)
+    assert res["d"].shape == (4, 128, 256, 3) and len(res["l"][0]) == 2 * 2 and np.isfinite(res["l"]).all()
+
 
 def test_chocolate_driver_reproduces_the_override_block_and_writes_its_outputs(tmp_path, monkeypatch):
     """main() of test_chocolate.py:148-252 value for value (200^3 render grid on the 128^3 x 0.1 domain, liquid render,
