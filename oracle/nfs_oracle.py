@@ -1134,6 +1134,14 @@ def styler3p_run(cfg, params, weights, style_img, rot_mats, views_mode="sequenti
             for i in idx:
                 g_opt[i] = g_opt[i] + g_tmp[i]
         hist.append(h_o)
+    # frame interpolation (styler_3p.py:392-397): the frames between two key frames get the linear blend of their
+    # variables (the reference indexes g_opt[t + interp] unguarded: num_frames - 1 is a multiple of interp in its runs)
+    if cfg.get("interp", 1) > 1:
+        w_ = np.linspace(0, 1, cfg["interp"] + 1)
+        for t in range(0, F_ - 1, cfg["interp"]):
+            for i in range(1, cfg["interp"]):
+                if t + cfg["interp"] < F_:
+                    g_opt[t + i] = g_opt[t] * float(1 - w_[i]) + g_opt[t + cfg["interp"]] * float(w_[i])
     res = [int(v) for v in oct_size[-1]]
     d_fin = [particle_field(p[t], r[t], g_opt[t], cfg, res)[1][0] for t in range(F_)]
     return hist, g_opt, d_fin

@@ -292,6 +292,42 @@ def test_chocolate_like_liquid_position_field():
     assert rel(res["d"][0], d_fin[0]) < 1e-3
 
 
+def test_chocolate_like_key_frames_and_interpolation():
+    """run.bat's interpolation test (``test_chocolate.py ... --num_frames 21 --interp 5``) in miniature: 5 frames of the
+    same particles, interp 2 -> key frames 0, 2, 4 are stylised (temporal filter over the KEY frames only,
+    styler_3p.py:380-386), frames 1 and 3 get the linear blend of their neighbours' variables (392-397); 'p' field,
+    liquid render, pressure loss"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_3p import Styler
+    G, n, F = 16, 1500, 5
+    rng = np.random.RandomState(19)
+    p0, r0 = _particles(G, n, 1, rng)
+    drift = rng.randn(n, 3).astype(np.float32) * 0.004
+    ps = [np.where(p0 >= 0, np.clip(p0 + drift * t, 0.05, 0.95), p0).astype(np.float32) for t in range(F)]
+    simg = S.style_image(G, G, rng)
+    layers = ["conv1_1", "conv2_1"]
+    cfg = _config(resolution=[G, G, G], domain=[G, G, G], radius=0.5, nsize=1, support=4, rest_density=1000, k=3,
+                  clip=False, target_field="p", num_frames=F, batch_size=1, frames_per_opt=2, window_sigma=0.8,
+                  interp=2, lr=0.002, iter=3, octave_n=1, style_layer=layers, w_style_layer=[1, 1], w_style=1.0,
+                  w_content=0, transmit=0.2, render_liquid=True, rotate=True, n_views=2, v_batch=1,
+                  sample_type="uniform", phi0=0, phi1=0, phi_unit=0, theta0=-10, theta1=10, theta_unit=20,
+                  resize_scale=1.0, views_mode="sum", style_target=simg, num_kernels=1, kernel_scale=2,
+                  w_pressure=1e2)
+    st = Styler(cfg)
+    st.load_img([G, G])
+    params = {"p": ps, "r": [r0] * F}
+    res = st.run(params)
+    w = O.synthetic_vgg19_weights(123, upto="conv2_1")
+    hist, g_opt, d_fin = O.styler3p_run(dict(vars(cfg)), params, w, [simg], st.rot_mat_, views_mode="sum")
+    assert len(res["l"][0]) == 3 * 3                                # three key frames per iteration
+    np.testing.assert_allclose(res["l"][0], hist[0], rtol=2e-3)
+    for t in range(F):
+        assert rel(res["v"][t], g_opt[t]) < 2e-3
+        assert rel(res["d"][t], d_fin[t]) < 1e-3
+    for t in (1, 3):                                                # the blend itself, exactly
+        np.testing.assert_allclose(res["v"][t], 0.5 * (res["v"][t - 1] + res["v"][t + 1]), rtol=0, atol=1e-7)
+
+
 def test_transport_matches_oracle():
     """StylerBase._transport (styler_base.py:59-89): chained advection a->b forward and backward."""
     import neural_flow_style_amd.ops as ops
