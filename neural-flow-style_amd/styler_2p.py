@@ -26,10 +26,9 @@ class Styler(StylerBase):
     def __init__(self, self_dict):
         StylerBase.__init__(self, self_dict)
         self.batch_size = max(int(self.batch_size), 1)
-        if self.batch_size > 1 and (getattr(self, "w_content", 0) and getattr(self, "content_layer", None)
-                                    or getattr(self, "w_hist", 0)):
-            raise NotImplementedError("batch_size > 1 with a content or histogram term: their means / matches run over "
-                                      "the whole batch tensor (styler_base.py:135-150, 203-207); style + TV only")
+        if self.batch_size > 1 and getattr(self, "w_hist", 0):
+            raise NotImplementedError("batch_size > 1 with a histogram term: the match runs over the whole batch "
+                                      "tensor (styler_base.py:203-207)")
         w_layers = list(self.w_style_layer)
         if len(w_layers) == 1 and len(self.style_layer) > 1:
             w_layers = w_layers * len(self.style_layer)

@@ -1264,8 +1264,9 @@ def colour_loss2d(p, r, var, cfg, res, weights, style_feats, batch=1):
     l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg["w_style"],
                       d_gray=d_gray if cfg.get("style_mask") else None)
     if use_content:
+        # (every form of the content term is a reduce_mean over the batch tensor, styler_base.py:135-150: 1 / batch)
         l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
-                                                cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
+                                                cfg.get("content_feature"), cfg.get("w_content_amp", 100.0)) / batch
     if cfg.get("w_hist", 0):
         # histogram term (styler_base.py:187-209); with style_mask the masked branch (196-201): the density mask,
         # bicubic-resized to the layer, removes its zero pixels from the source of the match
@@ -1283,8 +1284,8 @@ def styler2p_run(cfg, params, weights, style_img, c_init):
     frame group, temporal Gaussian smoothing of the per-frame updates.  ``batch_size`` B > 1 (run.bat's last line): B
     consecutive frames share one sess.run -- total loss = sum of their style terms + mean of their TV terms, ONE
     optimiser step on the B colour variables (243-255: the Adam slots belong to the batch POSITION, the step count to
-    the optimiser), one loss entry per batch (258).  Style + TV only there: the content mean and the unmasked
-    histogram match run over the whole batch tensor and are not restated for B > 1.  ``style_img[octave]`` is
+    the optimiser), one loss entry per batch (258).  Style, content (a mean over the batch) and TV there; the unmasked
+    histogram match runs over the whole batch tensor and is not restated for B > 1.  ``style_img[octave]`` is
     the style image already resized for that octave, ``c_init`` [F,N,3] the colour initialisation (189-192).
     Returns (loss history per octave, optimised colours per frame, final uint8 images d*d_gray*255)."""
     from scipy.ndimage import gaussian_filter
@@ -1311,7 +1312,7 @@ def styler2p_run(cfg, params, weights, style_img, c_init):
             g_tmp = [None] * F_
             B = int(cfg.get("batch_size", 1) or 1)
             assert F_ % B == 0, "num_frames must be a multiple of batch_size (styler_2p.py:239-244 indexes p[t+i])"
-            assert B == 1 or not (uses_content(cfg) or cfg.get("w_hist", 0)), "batch_size > 1: style + TV only"
+            assert B == 1 or not cfg.get("w_hist", 0), "batch_size > 1: no histogram term (it matches over the batch tensor)"
             for t in range(0, F_, B):
                 opt = opt_.setdefault(t // cfg["frames_per_opt"], TFAdam())
                 vv = [g_opt[t + i].clone().requires_grad_() for i in range(B)]

@@ -192,8 +192,8 @@ def test_styler2p_matches_oracle_loop():
         assert np.abs(res["d"][t].astype(np.int32) - imgs[t].astype(np.int32)).max() <= 1     # uint8 rounding
 
 
-@pytest.mark.parametrize("frames_per_opt", [200, 2])
-def test_styler2p_batches_of_two_frames_match_oracle_loop(frames_per_opt):
+@pytest.mark.parametrize("frames_per_opt,w_content", [(200, 0), (2, 0), (200, 1e3)])
+def test_styler2p_batches_of_two_frames_match_oracle_loop(frames_per_opt, w_content):
     """run.bat's last line (``test_dambreak2d.py ... --num_frames 20 --batch_size 4``): batch_size consecutive frames
     share one sess.run -- style summed over the images, TV averaged, ONE Adam step on the B colour variables (slots per
     batch position, shared by every batch that uses the optimiser), one loss entry per batch (styler_2p.py:42-98,
@@ -211,14 +211,17 @@ def test_styler2p_batches_of_two_frames_match_oracle_loop(frames_per_opt):
     cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.05, nsize=2, support=4,
                   rest_density=1000, clip=False, target_field="c", num_frames=F, batch_size=2,
                   frames_per_opt=frames_per_opt, window_sigma=1.0, lr=0.01, iter=3, octave_n=2, octave_scale=1.6,
-                  style_layer=layers, w_style_layer=[0.5, 0.5], w_style=1.0, w_content=0, style_mask=True, w_tv=0.01,
-                  style_target=simg, resize_scale=1.0)
+                  style_layer=layers, w_style_layer=[0.5, 0.5], w_style=1.0, w_content=w_content, content_layer="conv3_1",
+                  content_channel=65, style_mask=True, w_tv=0.01, style_target=simg, resize_scale=1.0)
     st = Styler(cfg)
     st.load_img([H, W])
     params = {"p": ps, "r": rs}
     res = st.run(params)
     w = O.synthetic_vgg19_weights(123, upto="conv3_1")
     hist, c_opt, imgs = O.styler2p_run(dict(vars(cfg)), params, w, res["style_per_octave"], res["c_init"])
+    if w_content:                                                  # (the content mean over the batch is not negligible)
+        h0, _, _ = O.styler2p_run(dict(vars(cfg), w_content=0), params, w, res["style_per_octave"], res["c_init"])
+        assert abs(hist[0][0] - h0[0][0]) > 1e-3 * abs(h0[0][0])
     for o in range(2):
         assert len(res["l"][o]) == 3 * F // 2                      # one entry per batch and iteration
         np.testing.assert_allclose(res["l"][o], hist[o], rtol=2e-3)
@@ -228,10 +231,10 @@ def test_styler2p_batches_of_two_frames_match_oracle_loop(frames_per_opt):
     assert res["d_intm"][0].shape[0] == F
 
 
-def test_styler2p_batch_with_content_term_is_refused():
+def test_styler2p_batch_with_histogram_term_is_refused():
     from neural_flow_style_amd.styler_2p import Styler
-    cfg = _config(resolution=[32, 32], domain=[3.2, 3.2], target_field="c", num_frames=2, batch_size=2, w_content=1.0,
-                  content_layer="conv3_1", style_layer=["conv2_1"], w_style_layer=[1.0])
+    cfg = _config(resolution=[32, 32], domain=[3.2, 3.2], target_field="c", num_frames=2, batch_size=2, w_hist=1.0,
+                  hist_layer=["conv2_1"], w_hist_layer=[1.0], style_layer=["conv2_1"], w_style_layer=[1.0], w_content=0)
     with pytest.raises(NotImplementedError):
         Styler(cfg)
 
