@@ -157,3 +157,99 @@ def lap_normalize(img, scale_n=3, is_3d=False, c=1):
     for hi in levels[1:]:                                       # lap_merge (util.py:77-84)
         out = ops.lap_up(out, k, hi.shape, s, addend=hi)
     return out
+
+
+# ---- small host helpers of the reference's ``from util import *`` surface (util.py:209-235, 401-431, 484-531) --------
+# NumPy / PIL only; none of them is on the hot path.  Viewers and external tools (draw_pt, draw_voxel, npz2vdb,
+# save_video, v2rgb) are out of scope.
+
+def str2bool(v):
+    """argparse type of the boolean flags (util.py:401-402): 'true' / '1' in any case are True, everything else False"""
+    return str(v).lower() in ("true", "1")
+
+
+def get_time():
+    """time stamp of the log directories (util.py:427-428)"""
+    from datetime import datetime
+    return datetime.now().strftime("%m%d_%H%M%S")
+
+
+def save_config(config):
+    """``params.json`` in ``config.log_dir`` (util.py:418-425); entries json cannot hold (the rng) are skipped"""
+    path = os.path.join(config.log_dir, "params.json")
+    print("[*] MODEL dir: %s" % config.log_dir)
+    print("[*] PARAM path: %s" % path)
+    keep = {k: v for k, v in vars(config).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None)))}
+    with open(path, "w") as fp:
+        json.dump(keep, fp, indent=4, sort_keys=True)
+
+
+def save_density(d, d_path):
+    """a [H,W] image in [0,1] as a grey 8-bit picture (util.py:209-213)"""
+    from PIL import Image
+    g = (np.asarray(d) * 255).astype(np.uint8)
+    Image.fromarray(np.repeat(g[..., None], 3, axis=-1)).save(d_path)
+
+
+_YUV_FROM_RGB = np.array([[0.299, 0.587, 0.114],
+                          [-0.14714119, -0.28886916, 0.43601035],
+                          [0.61497538, -0.51496512, -0.10001026]])
+_RGB_FROM_YUV = np.array([[1.0, 0.0, 1.13988303],
+                          [1.0, -0.394642334, -0.58062185],
+                          [1.0, 2.03206185, 0.0]])
+
+
+def rgb2yuv(r, g, b):
+    """TF's rgb_to_yuv matrix, channel by channel (util.py:229-233)"""
+    m = _YUV_FROM_RGB
+    return tuple(m[i, 0] * r + m[i, 1] * g + m[i, 2] * b for i in range(3))
+
+
+def yuv2rgb(y, u, v):
+    """its inverse as TF writes it (util.py:215-227)"""
+    m = _RGB_FROM_YUV
+    return tuple(m[i, 0] * y + m[i, 1] * u + m[i, 2] * v for i in range(3))
+
+
+def hsv2rgb(h, s, v):
+    """h, s, v in [0,1] (arrays of one shape) -> r, g, b (util.py:235-269: the six-sector construction)"""
+    h, s, v = (np.asarray(a, np.float32) for a in (h, s, v))
+    c = s * v
+    h6 = h * 6
+    x = c * (1 - np.abs(np.mod(h6, 2) - 1))
+    sector = h6.astype(np.int32)
+    zero = np.zeros_like(c)
+    # (r, g, b) before the offset, per sector 0..5; a sector outside 0..5 (h = 1 exactly) leaves zeros, as there
+    table = ((c, x, zero), (x, c, zero), (zero, c, x), (zero, x, c), (x, zero, c), (c, zero, x))
+    out = [np.zeros_like(c) for _ in range(3)]
+    for k, comps in enumerate(table):
+        hit = sector == k
+        for ch in range(3):
+            out[ch] = np.where(hit, comps[ch], out[ch])
+    m = v - c
+    return out[0] + m, out[1] + m, out[2] + m
+
+
+def make_grid(tensor, nrow=8, padding=2, normalize=False, scale_each=False, gray=True):
+    """[B,H,W(,3)] uint8 images tiled ``nrow`` per row with ``padding`` black pixels between them (util.py:484-515,
+    after torchvision's make_grid; ``normalize`` / ``scale_each`` are accepted and ignored, as there)"""
+    t = np.asarray(tensor)
+    n = t.shape[0]
+    cols = min(int(nrow), n)
+    rows = -(-n // cols)
+    ch, cw = int(t.shape[1] + padding), int(t.shape[2] + padding)
+    edge = (1 + padding // 2) if padding else 0
+    shape = [ch * rows + edge, cw * cols + edge] + ([] if gray else [3])
+    grid = np.zeros(shape, np.uint8)
+    for k in range(n):
+        y, x = divmod(k, cols)
+        grid[y * ch + edge:y * ch + edge + t.shape[1], x * cw + edge:x * cw + edge + t.shape[2]] = t[k]
+    return grid
+
+
+def save_image(tensor, filename, nrow=8, padding=2, normalize=False, scale_each=False, single=False, gray=True):
+    """a batch of uint8 images as one tiled picture, or (``single``) one image as it is (util.py:517-531)"""
+    from PIL import Image
+    arr = np.asarray(tensor) if single else make_grid(tensor, nrow=nrow, padding=padding, normalize=normalize,
+                                                      scale_each=scale_each, gray=gray)
+    Image.fromarray(arr).save(filename)

@@ -2,7 +2,8 @@
 """Golden vectors for the host helpers of the stylisation loop from the REFERENCE ITSELF: its util.py is imported in
 the build container and ``denoise`` (temporal smoothing of the per-frame updates, styler_3p.py:377-381) and
 ``crop_ratio`` (style / content image crop, styler_base.py:320-338) are run on seeded inputs; the Laplacian-pyramid
-kernels ``k5x5`` / ``k5x5x5`` (util.py:27-46) and ``cosine_decay`` values are dumped as the module computes them.  util.py imports
+kernels ``k5x5`` / ``k5x5x5`` (util.py:27-46) and ``cosine_decay`` values are dumped as the module computes them, and
+the small NumPy helpers of the drivers' surface (rgb2yuv / yuv2rgb, make_grid, str2bool) are run on seeded inputs.  util.py imports
 imageio, skimage, tensorflow, matplotlib and open3d at module level; modules of those names that are absent here are
 registered empty only to let the import statements pass -- neither function touches them (``resize`` does, through
 skimage, and therefore is not part of this fixture).   Run:  python tests/golden/make_util_fixture.py
@@ -62,6 +63,21 @@ for i, img in enumerate(imgs):
 out["k5x5"] = np.asarray(R.k5x5[1][:, :, 0, 0], np.float64)
 out["k5x5x5"] = np.asarray(R.k5x5x5[1][:, :, :, 0, 0], np.float64)
 out["cosine_decay"] = np.array([R.cosine_decay(s_, 20, 0.1, 2.0) for s_ in (0, 5, 10, 20, 30)], np.float64)
+# small host helpers of the drivers' ``from util import *`` surface (plain NumPy in the reference): colour conversions,
+# the image tiling of save_image, the boolean flag parser
+c = rng.rand(3, 11).astype(np.float64)
+out["rgb_in"] = c
+out["rgb2yuv"] = np.stack(R.rgb2yuv(c[0], c[1], c[2]))
+out["yuv2rgb"] = np.stack(R.yuv2rgb(c[0] - 0.2, c[1] - 0.5, c[2] - 0.5))
+tiles = (rng.rand(5, 6, 7) * 255).astype(np.uint8)
+out["grid_in"] = tiles
+out["grid_gray_n2_p2"] = R.make_grid(tiles, nrow=2, padding=2)
+out["grid_gray_n8_p0"] = R.make_grid(tiles, nrow=8, padding=0)
+tiles3 = (rng.rand(3, 4, 5, 3) * 255).astype(np.uint8)
+out["grid3_in"] = tiles3
+out["grid_rgb_n2_p3"] = R.make_grid(tiles3, nrow=2, padding=3, gray=False)
+words = ["true", "True", "1", "0", "false", "yes", "TRUE", ""]
+out["str2bool"] = np.array([R.str2bool(w_) for w_ in words])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "util_reference.npz")
 np.savez_compressed(path, **out)
 print(path, len(out), "arrays")
