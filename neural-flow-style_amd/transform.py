@@ -357,3 +357,13 @@ def g2p(g, p, is_2d=True, is_linear=False):
     consumer in the reference (the SimG2P resampler, test_smokegun_resim.py:36-47,96)."""
     assert g.shape[0] == 1 and p.shape[0] == 1
     return ops.g2p_fwd(g[0].detach().contiguous(), p[0].detach().contiguous(), cubic=not is_linear).unsqueeze(0)
+
+
+def g2p_cubic(g, p, is_2d=True):
+    """the Catmull-Rom branch under its own name (transform.py:778)"""
+    return g2p(g, p, is_2d=is_2d, is_linear=False)
+
+
+def g2p_linear(g, p, is_2d=True):
+    """the (bi/tri)linear branch under its own name (transform.py:1110)"""
+    return g2p(g, p, is_2d=is_2d, is_linear=True)
