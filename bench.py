@@ -701,6 +701,55 @@ def other_configs(device, base):
         del il, net
     except Exception as e:  # pragma: no cover
         out.append({"config": "reference test_smokegun.py configuration (Inception-v1)", "error": repr(e)})
+
+    # the operators either side of the path, each at the size its caller uses -- time per call and the
+    # fraction of 8 TB/s its ALGORITHMIC bytes make (compulsory reads + writes; gathers counted once per element read)
+    try:
+        from neural_flow_style_amd import util as U
+        G, N = 200, 1000000
+        rng = np.random.RandomState(5)
+        gen = torch.Generator(device=device).manual_seed(5)
+        ops_out = []
+
+        def add(name, ref, f, nbytes, reps=20):
+            ms = ev_time(f, reps)
+            ops_out.append({"op": name, "reference": ref, "ms": ms, "algorithmic_mb": nbytes / 1e6,
+                            "gb_s": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / HBM_PEAK_GBS})
+
+        grid1 = torch.rand(G, G, G, 1, device=device, generator=gen)
+        grid3 = torch.rand(G, G, G, 3, device=device, generator=gen)
+        pts = (torch.rand(N, 3, device=device, generator=gen) * 0.9 + 0.05).contiguous()
+        # grid -> particle sampling of the SimG2P resampler (test_smokegun_resim.py:36-47, 96): 1e6 particles in 200^3
+        add("g2p cubic, density (64 taps)", "transform.py:778-1108", lambda: ops.g2p_fwd(grid1, pts, cubic=True),
+            4.0 * G ** 3 + N * (12 + 4))
+        add("g2p linear, velocity (8 taps x 3)", "transform.py:1110-1231", lambda: ops.g2p_fwd(grid3, pts, cubic=False),
+            12.0 * G ** 3 + N * (12 + 12))
+        vel = torch.tensor(S.curl_velocity(G, rng, max_cells=2.0), device=device)
+        dens = grid1.contiguous()
+        add("advect order 2 (MacCormack: forward pass + corrected pass)", "transform.py:570-582",
+            lambda: ops.advect_maccormack(dens, vel), 2 * (4.0 + 12.0 + 4.0) * G ** 3 + 4.0 * G ** 3)
+        add("curl of a 3-component stream function", "transform.py:517-555", lambda: ops.curl_fwd(grid3), 24.0 * G ** 3)
+        add("curl adjoint", "adjoint of transform.py:517-555", lambda: ops.curl_bwd(grid3), 24.0 * G ** 3)
+        gfield = torch.randn(G, G, G, 3, device=device, generator=gen)
+        add("Laplacian-pyramid normalisation of a 200^3 x 3 gradient (3 levels)", "util.py:57-110",
+            lambda: U.lap_normalize(gfield, scale_n=3, is_3d=True, c=3), 2 * 12.0 * G ** 3, reps=5)
+        # histogram loss of one 300 x 450 x 256-channel feature map against a style feature of the same size
+        F_ = torch.rand(1, 75, 112, 256, device=device, generator=gen)
+        Ft = torch.rand(1, 75, 112, 256, device=device, generator=gen)
+        lacc = torch.zeros(1, device=device)
+        gacc = torch.zeros_like(F_)
+        add("histogram loss + gradient, 75 x 112 x 256 feature map", "styler_base.py:187-209, util.py:317-399",
+            lambda: ops.hist_loss(F_, Ft, 1.0, lacc, gacc), 4.0 * F_.numel() * 4)
+        img = torch.rand(4, 512, 1024, 3, device=device, generator=gen)
+        coords = (torch.rand(4, 2, 512, 1024, device=device, generator=gen) * 2 - 1).contiguous()
+        add("batch_warp2d of four 512 x 1024 x 3 images", "transform.py:206-236, 280-341", lambda: ops.warp2d_fwd(img, coords),
+            4.0 * img.numel() * 2 + 4.0 * coords.numel())
+        out.append({"config": "SURVEY 8(f) operators outside the iteration (resampler, order-2 advection, stream function, "
+                              "gradient normalisation, histogram loss, 2-D warp): one call each",
+                    "ops": ops_out})
+        del grid1, grid3, pts, vel, dens, gfield, F_, Ft, img, coords
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "SURVEY 8(f) operators", "error": repr(e)})
     return out
 
 
