@@ -718,12 +718,21 @@ def other_configs(device, base):
 
         grid1 = torch.rand(G, G, G, 1, device=device, generator=gen)
         grid3 = torch.rand(G, G, G, 3, device=device, generator=gen)
-        pts = (torch.rand(N, 3, device=device, generator=gen) * 0.9 + 0.05).contiguous()
-        # grid -> particle sampling of the SimG2P resampler (test_smokegun_resim.py:36-47, 96): 1e6 particles in 200^3
-        add("g2p cubic, density (64 taps)", "transform.py:778-1108", lambda: ops.g2p_fwd(grid1, pts, cubic=True),
-            4.0 * G ** 3 + N * (12 + 4))
-        add("g2p linear, velocity (8 taps x 3)", "transform.py:1110-1231", lambda: ops.g2p_fwd(grid3, pts, cubic=False),
-            12.0 * G ** 3 + N * (12 + 12))
+        # grid -> particle sampling of the SimG2P resampler (test_smokegun_resim.py:36-47, 96): 1e6 particles in 200^3,
+        # seeded the way the resampler seeds them -- cell by cell in grid order, jittered inside the cell (here the
+        # central 100^3 cells) -- and, as the worst case, the same number at uniformly random positions in random order
+        ax = torch.arange(50, 150, device=device, dtype=torch.float32)
+        cells = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+        pts = ((cells + torch.rand(N, 3, device=device, generator=gen)) / G).contiguous()
+        pts_rand = (torch.rand(N, 3, device=device, generator=gen) * 0.9 + 0.05).contiguous()
+        bytes_d = 4.0 * 104 ** 3 + N * (12 + 4)          # the cells the particles touch + positions in + values out
+        bytes_v = 12.0 * 102 ** 3 + N * (12 + 12)
+        add("g2p cubic, density (64 taps), particles in cell order", "transform.py:778-1108",
+            lambda: ops.g2p_fwd(grid1, pts, cubic=True), bytes_d)
+        add("g2p linear, velocity (8 taps x 3), particles in cell order", "transform.py:1110-1231",
+            lambda: ops.g2p_fwd(grid3, pts, cubic=False), bytes_v)
+        add("g2p cubic, density, random positions in random order", "transform.py:778-1108",
+            lambda: ops.g2p_fwd(grid1, pts_rand, cubic=True), 4.0 * G ** 3 + N * (12 + 4))
         vel = torch.tensor(S.curl_velocity(G, rng, max_cells=2.0), device=device)
         dens = grid1.contiguous()
         add("advect order 2 (MacCormack: forward pass + corrected pass)", "transform.py:570-582",
@@ -747,7 +756,7 @@ def other_configs(device, base):
         out.append({"config": "SURVEY 8(f) operators outside the iteration (resampler, order-2 advection, stream function, "
                               "gradient normalisation, histogram loss, 2-D warp): one call each",
                     "ops": ops_out})
-        del grid1, grid3, pts, vel, dens, gfield, F_, Ft, img, coords
+        del grid1, grid3, pts, pts_rand, cells, vel, dens, gfield, F_, Ft, img, coords
     except Exception as e:  # pragma: no cover
         out.append({"config": "SURVEY 8(f) operators", "error": repr(e)})
     return out

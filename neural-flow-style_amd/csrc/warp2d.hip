@@ -305,7 +305,7 @@ int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nf
 // TF 'SAME' geometry for stride 2, window 5, input n: out = ceil(n / 2), pad_before = (max((out-1)*2 + 5 - n, 0)) / 2.
 namespace nfs {
 
-__device__ __forceinline__ int same_pad_before(int n) {
+__host__ __device__ __forceinline__ int same_pad_before(int n) {
   const int out = (n + 1) / 2;
   const int total = (out - 1) * 2 + 5 - n;
   return total > 0 ? total / 2 : 0;
@@ -342,6 +342,48 @@ __global__ void __launch_bounds__(256) lap_down_kernel(const float* __restrict__
   out[gid] = s;
 }
 
+// The 3-D form of lap_down with the input staged: a block owns 4 x 4 x 16 output voxels and loads the 11 x 11 x 35 input
+// voxels (x C) they draw from into LDS once (zeros outside the volume = SAME padding), rows of 35 C consecutive floats;
+// 16.5 global loads per output instead of 125, the 125 taps come from LDS and the kernel from LDS too.  Same taps as the
+// gather form above (an out-of-range tap adds k * 0); equal to the rounding of the 125-term sum.
+constexpr int LD_TZ = 4, LD_TY = 4, LD_TX = 16;
+constexpr int LD_IZ = 2 * LD_TZ + 3, LD_IY = 2 * LD_TY + 3, LD_IX = 2 * LD_TX + 3;
+template <int C>
+__global__ void __launch_bounds__(256) lap_down3_tiled_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                              float* __restrict__ out, int D, int H, int W, int ntx,
+                                                              int nty) {
+  __shared__ float tile[LD_IZ * LD_IY * LD_IX * C];
+  __shared__ float ks[125];
+  const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int bx = blockIdx.x % ntx, by = (blockIdx.x / ntx) % nty, bz = blockIdx.x / (ntx * nty);
+  const int zo0 = bz * LD_TZ, yo0 = by * LD_TY, xo0 = bx * LD_TX;
+  const int zi0 = 2 * zo0 - same_pad_before(D), yi0 = 2 * yo0 - same_pad_before(H), xi0 = 2 * xo0 - same_pad_before(W);
+  if (threadIdx.x < 125) ks[threadIdx.x] = k[threadIdx.x];
+  constexpr int ROW = LD_IX * C;
+  for (int i = threadIdx.x; i < LD_IZ * LD_IY * ROW; i += 256) {
+    const int xc = i % ROW, iy = (i / ROW) % LD_IY, iz = i / (ROW * LD_IY);
+    const int gz = zi0 + iz, gy = yi0 + iy, gx = xi0 + xc / C;
+    float v = 0.f;
+    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+      v = x[(((int64_t)gz * H + gy) * W + gx) * C + xc % C];
+    tile[i] = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < LD_TZ * LD_TY * LD_TX * C; o += 256) {
+    const int c = o % C, xo = (o / C) % LD_TX, yo = (o / (C * LD_TX)) % LD_TY, zo = o / (C * LD_TX * LD_TY);
+    if (zo0 + zo >= Do || yo0 + yo >= Ho || xo0 + xo >= Wo) continue;
+    const float* t0 = tile + ((2 * zo) * LD_IY + 2 * yo) * ROW + 2 * xo * C + c;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) s += ks[(a * 5 + b) * 5 + e] * t0[(a * LD_IY + b) * ROW + e * C];
+    out[(((int64_t)(zo0 + zo) * Ho + yo0 + yo) * Wo + xo0 + xo) * C + c] = s;
+  }
+}
+
 // out [D,H,W,C] = scale * conv_transpose(lo [Do,Ho,Wo,C], k) + addend (nullable): the adjoint of lap_down's geometry,
 // gathered per output element (taps of matching parity only: <= 3 per axis)
 __global__ void __launch_bounds__(256) lap_up_kernel(const float* __restrict__ lo, const float* __restrict__ k,
@@ -359,25 +401,21 @@ __global__ void __launch_bounds__(256) lap_up_kernel(const float* __restrict__ l
   const int pz = nd == 3 ? same_pad_before(D) : 0, py = same_pad_before(H), px = same_pad_before(W);
   const int nz = nd == 3 ? 5 : 1;
   float s = 0.f;
-  for (int a = 0; a < nz; ++a) {
-    int zo = 0;
-    if (nd == 3) {
-      const int tz = z + pz - a;                 // 2 zo = z + pz - a
-      if (tz < 0 || (tz & 1)) continue;
-      zo = tz >> 1;
-      if (zo >= Do) continue;
-    }
-    for (int b = 0; b < 5; ++b) {
-      const int ty = y + py - b;
-      if (ty < 0 || (ty & 1)) continue;
-      const int yo = ty >> 1;
-      if (yo >= Ho) continue;
-      for (int e = 0; e < 5; ++e) {
-        const int tx = x + px - e;
-        if (tx < 0 || (tx & 1)) continue;
-        const int xo = tx >> 1;
-        if (xo >= Wo) continue;
-        s += k[(a * 5 + b) * 5 + e] * lo[(((int64_t)zo * Ho + yo) * Wo + xo) * C + c];
+  // only the taps whose parity matches reach an output element (2 zo = z + pz - a): start at the first such tap and
+  // step by two -- at most 3 per axis instead of 5 tests per axis
+  const int a0 = nd == 3 ? ((z + pz) & 1) : 0, b0 = (y + py) & 1, e0 = (x + px) & 1;
+  for (int a = a0; a < nz; a += 2) {
+    const int zo = nd == 3 ? (z + pz - a) >> 1 : 0;
+    if (nd == 3 && (z + pz - a < 0 || zo >= Do)) continue;
+    for (int b = b0; b < 5; b += 2) {
+      const int yo = (y + py - b) >> 1;
+      if (y + py - b < 0 || yo >= Ho) continue;
+      const float* row = lo + (((int64_t)zo * Ho + yo) * Wo) * C + c;
+      const float* kr = k + (a * 5 + b) * 5;
+      for (int e = e0; e < 5; e += 2) {
+        const int xo = (x + px - e) >> 1;
+        if (x + px - e < 0 || xo >= Wo) continue;
+        s += kr[e] * row[(int64_t)xo * C];
       }
     }
   }
@@ -386,12 +424,86 @@ __global__ void __launch_bounds__(256) lap_up_kernel(const float* __restrict__ l
   out[gid] = s;
 }
 
+// The 3-D form of lap_up by 2 x 2 x 2 CELLS: the fine voxels 2m - p and 2m - p + 1 of an axis (p = the SAME pad) draw
+// from the coarse voxels m, m-1, m-2 with the even taps (k0, k2, k4) and from m, m-1 with the odd ones (k1, k3) -- so a
+// thread that owns one cell holds its 3 x 3 x 3 coarse neighbourhood in registers and forms its 8 outputs with
+// compile-time tap sets: 125 multiply-adds and 27 LDS reads per 8 outputs and channel, no parity tests, no index
+// arithmetic in the sums.  A block = 4 x 4 x 16 cells, the 6 x 6 x 18 coarse voxels (x C) they reach staged in LDS
+// (zeros outside the coarse volume: an out-of-range tap adds k * 0; equal to the gather form to rounding).
+constexpr int LU_CZ = 4, LU_CY = 4, LU_CX = 16;
+template <int C>
+__global__ void __launch_bounds__(256) lap_up3_cell_kernel(const float* __restrict__ lo, const float* __restrict__ k,
+                                                           const float* __restrict__ addend, float* __restrict__ out,
+                                                           int D, int H, int W, float scale, int nbx, int nby) {
+  constexpr int IZ = LU_CZ + 2, IY = LU_CY + 2, IX = LU_CX + 2, ROW = IX * C;
+  __shared__ float tile[IZ * IY * ROW];
+  __shared__ float ks[125];
+  const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
+  const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
+  const int mz0 = (pz >> 1) + bz * LU_CZ, my0 = (py >> 1) + by * LU_CY, mx0 = (px >> 1) + bx * LU_CX;
+  if (threadIdx.x < 125) ks[threadIdx.x] = k[threadIdx.x];
+  for (int i = threadIdx.x; i < IZ * IY * ROW; i += 256) {
+    const int xc = i % ROW, iy = (i / ROW) % IY, iz = i / (ROW * IY);
+    const int gz = mz0 - 2 + iz, gy = my0 - 2 + iy, gx = mx0 - 2 + xc / C;
+    float v = 0.f;
+    if (gz >= 0 && gz < Do && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo)
+      v = lo[(((int64_t)gz * Ho + gy) * Wo + gx) * C + xc % C];
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int ix = threadIdx.x % LU_CX, iy = (threadIdx.x / LU_CX) % LU_CY, iz = threadIdx.x / (LU_CX * LU_CY);
+  const int ze = 2 * (mz0 + iz) - pz, ye = 2 * (my0 + iy) - py, xe = 2 * (mx0 + ix) - px;
+  if (ze >= D || ye >= H || xe >= W) return;
+  // coarse neighbourhood, cq[jz][jy][jx][c] = coarse voxel (m - j) per axis
+  float cq[3][3][3][C];
+#pragma unroll
+  for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+    for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          cq[jz][jy][jx][c] = tile[((iz + 2 - jz) * IY + (iy + 2 - jy)) * ROW + (ix + 2 - jx) * C + c];
+#pragma unroll
+  for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+    for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+      for (int ex = 0; ex < 2; ++ex) {
+        const int z = ze + ez, y = ye + ey, x = xe + ex;
+        if (z < 0 || z >= D || y < 0 || y >= H || x < 0 || x >= W) continue;
+        const int64_t gid = (((int64_t)z * H + y) * W + x) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float s = 0.f;
+#pragma unroll
+          for (int tz = 0; tz < 3 - ez; ++tz)
+#pragma unroll
+            for (int ty = 0; ty < 3 - ey; ++ty)
+#pragma unroll
+              for (int tx = 0; tx < 3 - ex; ++tx)
+                s += ks[((ez + 2 * tz) * 5 + ey + 2 * ty) * 5 + ex + 2 * tx] * cq[tz][ty][tx][c];
+          s *= scale;
+          if (addend) s += addend[gid + c];
+          out[gid + c] = s;
+        }
+      }
+}
+
 // normalize_std / mean-abs normalisation: partial sums (fixed block order => deterministic) then scale
 __global__ void __launch_bounds__(256) norm_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part,
                                                            int use_abs) {
   __shared__ float red[16];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t n4 = ((uintptr_t)x & 15) == 0 ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    s += use_abs ? fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) : v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = x[i];
     s += use_abs ? fabsf(v) : v * v;
   }
@@ -402,17 +514,29 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const float* __restri
 __global__ void __launch_bounds__(256) norm_scale_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
                                                          const float* __restrict__ part, int nparts, int use_abs,
                                                          float eps) {
-  __shared__ float inv;
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < nparts; ++i) t += (double)part[i];
-    const float m = use_abs ? (float)(t / (double)n) : sqrtf((float)(t / (double)n));
-    inv = 1.f / fmaxf(m, eps);
-  }
+  // every block forms the total itself: each thread a strided slice of the partial sums in double, then a tree over
+  // the 256 slots -- a fixed order (the same bits in every block and every run), 4 dependent loads per thread instead
+  // of 1024 in one
+  __shared__ double tot[256];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) t += (double)part[i];
+  tot[threadIdx.x] = t;
   __syncthreads();
-  const float r = inv;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = x[i] * r;
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) tot[threadIdx.x] += tot[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double sum = tot[0];
+  const float m = use_abs ? (float)(sum / (double)n) : sqrtf((float)(sum / (double)n));
+  const float r = 1.f / fmaxf(m, eps);
+  const int64_t n4 = (((uintptr_t)x | (uintptr_t)out) & 15) == 0 ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = x[i] * r;
 }
 
 }  // namespace nfs
@@ -424,6 +548,13 @@ int nfs_lap_down(const float* x, const float* k, float* out, int D, int H, int W
   NFS_REQUIRE((nd == 2 && D == 1) || nd == 3, "nfs_lap_down: nd must be 2 (D == 1) or 3");
   if (int e = check_dims2(D, H, W, C)) return e;
   const int64_t n = (int64_t)(nd == 3 ? (D + 1) / 2 : 1) * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  if (nd == 3 && (C == 1 || C == 3)) {
+    const int ntx = ((W + 1) / 2 + LD_TX - 1) / LD_TX, nty = ((H + 1) / 2 + LD_TY - 1) / LD_TY,
+              ntz = ((D + 1) / 2 + LD_TZ - 1) / LD_TZ;
+    if (C == 1) hipLaunchKernelGGL(lap_down3_tiled_kernel<1>, dim3(ntx * nty * ntz), dim3(256), 0, as_stream(stream), x, k, out, D, H, W, ntx, nty);
+    else hipLaunchKernelGGL(lap_down3_tiled_kernel<3>, dim3(ntx * nty * ntz), dim3(256), 0, as_stream(stream), x, k, out, D, H, W, ntx, nty);
+    return check_launch("nfs_lap_down");
+  }
   hipLaunchKernelGGL(lap_down_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, k, out, D, H, W, C,
                      nd);
   return check_launch("nfs_lap_down");
@@ -435,6 +566,15 @@ int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend
   NFS_REQUIRE((nd == 2 && D == 1) || nd == 3, "nfs_lap_up: nd must be 2 (D == 1) or 3");
   if (int e = check_dims2(D, H, W, C)) return e;
   const int64_t n = (int64_t)D * H * W * C;
+  if (nd == 3 && (C == 1 || C == 3) && (int64_t)D * H * W >= ((int64_t)1 << 21)) {   // (small volumes: too few blocks)
+    const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
+    // cells m = (p >> 1) ... floor((n - 1 + p) / 2) per axis
+    const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
+    const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
+    if (C == 1) hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby);
+    else hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby);
+    return check_launch("nfs_lap_up");
+  }
   hipLaunchKernelGGL(lap_up_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W,
                      C, nd, scale);
   return check_launch("nfs_lap_up");

@@ -119,12 +119,36 @@ def test_curl_matches_the_reference_lines_and_its_adjoint():
     assert float(div.abs().max()) < 1e-5
 
 
+def test_laplacian_pyramid_3d_kernels_equal_the_gather_forms():
+    """the staged 3-D kernels (lap_down from an LDS tile, lap_up by 2 x 2 x 2 cells with compile-time tap sets; taken for
+    1 and 3 channels, lap_up from 2^21 voxels on) against the plain gather kernels (any other channel count): the same
+    taps, equal to the rounding of a 125-term float sum (measured: 6e-8 / 5e-7 absolute on O(1) data) -- odd sizes,
+    ragged tiles, both SAME-padding parities"""
+    import neural_flow_style_amd.ops as ops
+    from neural_flow_style_amd import util
+    k = torch.as_tensor(util.lap_kernel(True)).cuda().contiguous()
+    for shape in ((131, 129, 130), (128, 130, 127)):
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        x3 = torch.randn(*shape, 3, device="cuda", generator=gen)
+        x2 = x3[..., :2].contiguous()                                   # two channels: the gather kernels
+        lo3, lo2 = ops.lap_down(x3, k), ops.lap_down(x2, k)
+        assert float((lo3[..., :2] - lo2).abs().max()) < 5e-7
+        add3 = torch.randn(*shape, 3, device="cuda", generator=gen)
+        up3 = ops.lap_up(lo3, k, x3.shape, -5.0, addend=add3)
+        up2 = ops.lap_up(lo2, k, x2.shape, -5.0, addend=add3[..., :2].contiguous())
+        assert float((up3[..., :2] - up2).abs().max()) < 5e-6
+        up1 = ops.lap_up(lo3[..., 2:3].contiguous(), k, shape + (1,), 5.0)    # one channel, no addend
+        assert float((up1[..., 0] - ops.lap_up(lo3, k, x3.shape, 5.0)[..., 2]).abs().max()) < 5e-6
+
+
 def test_laplacian_pyramid_normalisation_matches_the_oracle():
     """util.lap_normalize on the HIP kernels (strided 'SAME' smoothing, its transpose, RMS normalisation) vs the oracle's
     restatement with torch convolutions; even / odd sizes exercise both TF padding cases, c = 1 and 3"""
     from neural_flow_style_amd import util
     rng = np.random.RandomState(31)
-    for shape, is_3d in (((12, 9, 10, 1), True), ((8, 8, 8, 3), True), ((17, 12, 3), False), ((9, 9, 1), False)):
+    # (21 x 19 x 37 and 40 x 18 x 34: several LDS tiles of the 3-D kernels per axis, ragged last tiles, odd sizes)
+    for shape, is_3d in (((12, 9, 10, 1), True), ((8, 8, 8, 3), True), ((21, 19, 37, 3), True), ((40, 18, 34, 1), True),
+                         ((17, 12, 3), False), ((9, 9, 1), False)):
         g = rng.randn(*shape).astype(np.float32)
         k = util.lap_kernel(is_3d)
         for scale_n in (0, 1, 3) if min(shape[:-1]) >= 8 else (0, 1):
