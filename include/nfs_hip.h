@@ -124,6 +124,16 @@ int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float*
  * tf.range(min, max, 0) has no defined result there), or every source pixel masked out -- adds loss 0, gradient 0. */
 int nfs_hist_loss_masked(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc,
                          int B, int Bt, int HW, int HWt, int C, float weight, int relu_mask, nfs_stream_t stream);
+/* The same loss (mask nullable) for images of 1..4 channels -- the default hist layer is the 3-channel loss-net INPUT
+ * (config.py:97 hist_layer ['input']): the per-(image, channel) kernels above would run 3 blocks for a whole image, so
+ * here the pixels are spread over the chip and the per-(image, channel) state (value range, the two histograms, the
+ * lookup table) lives in `workspace` (nfs_hist_loss_wide_workspace_floats(B, C, HW, HWt) floats, 16-byte aligned;
+ * -1 for unsupported arguments).  Integer atomics and fixed-order sums only: deterministic; the same bins, table and
+ * matched values as nfs_hist_loss_masked. */
+int64_t nfs_hist_loss_wide_workspace_floats(int B, int C, int HW, int HWt);
+int nfs_hist_loss_wide(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc,
+                       float* workspace, int64_t workspace_floats, int B, int Bt, int HW, int HWt, int C, float weight,
+                       int relu_mask, nfs_stream_t stream);
 
 /* ---- A7 mask variant (styler_base.py:165-173, style_mask = True) -------------------------------------------------
  * nfs_resize_bicubic_tf1: tf.compat.v1.image.resize(BICUBIC) (legacy kernel: align_corners False, no half-pixel

@@ -119,6 +119,8 @@ SIGNATURES = {
     "nfs_gram_style_group_fwd": [_P, _I, _P, _P, _L, _P],
     "nfs_gram_group_bwd": [_P, _I, _P],
     "nfs_hist_loss_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_hist_loss_wide_workspace_floats": [_I, _I, _I, _I],
+    "nfs_hist_loss_wide": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _I, _P],
     "nfs_resize_bicubic_tf1": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "nfs_style_mask_apply": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nfs_style_mask_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -134,7 +136,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
-            "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64,
+            "nfs_conv3x3_relu_bits_words": C.c_int64, "nfs_gram_style_group_workspace_floats": C.c_int64, "nfs_hist_loss_wide_workspace_floats": C.c_int64,
             "nfs_conv3x3_executed_flops": C.c_double, "nfs_conv2d_packed_floats": C.c_int64,
             "nfs_conv2d_workspace_floats": C.c_int64, "nfs_conv2d_group_workspace_floats": C.c_int64}
 

@@ -116,6 +116,213 @@ __global__ void __launch_bounds__(256) hist_loss_kernel(const float* __restrict_
   if (t == 0) atomicAdd(loss_acc + b, weight * part);
 }
 
+// ---- the same loss for images of FEW channels (the default hist layer is the loss-net INPUT: 3 channels) -------------
+// One block per (image, channel) is 3 blocks for a 300 x 450 image -- 0.7 ms, 3.9 ms at 512 x 1024 -- so for C <= 4 the
+// work is spread over the pixels instead: a thread owns whole pixels (C contiguous floats), the per-(image, channel)
+// state -- value range as order-preserving integers, the two 255-bin histograms, the lookup table -- lives in a
+// caller-provided workspace, and the steps of hist_loss_kernel become launches:
+//   init -> range (block min / max, integer atomics) -> histograms (LDS, flushed with integer atomics) -> quantiles +
+//   table (one block per (image, channel), the code of steps 3-4 above) -> apply (loss as per-block partial sums) ->
+//   fixed-order total.  Integer atomics and fixed-order sums only: deterministic, and the same bins, table and
+//   matched values as the per-channel kernel (the same float expressions per element).
+constexpr int HW_CMAX = 4;
+struct HistState {                         // per (image, channel), in the workspace
+  unsigned vmin_enc, vmax_enc, live, pad;
+  float vmin, delta;
+  unsigned skip, pad2;
+  unsigned hs[256], ht[256];
+  float lut[256];
+};
+__device__ __forceinline__ unsigned enc_ordered(float f) {      // monotone float -> unsigned
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned e) {
+  return __uint_as_float(e ^ ((e >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+__global__ void __launch_bounds__(256) hist_wide_init_kernel(HistState* st, int n) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (i >= n) return;
+  st[i].hs[t] = 0u; st[i].ht[t] = 0u;
+  if (t == 0) { st[i].vmin_enc = 0xffffffffu; st[i].vmax_enc = 0u; st[i].live = 0u; st[i].skip = 0u; }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) hist_wide_range_kernel(const float* __restrict__ feat, const float* __restrict__ templ,
+                                                              const float* __restrict__ mask, HistState* st, int Bt,
+                                                              int HW, int HWt, int ld) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, bt = b < Bt ? b : Bt - 1, t = threadIdx.x;
+  const int c0 = blockIdx.z * C;                     // this block's channel window of the ld-float rows
+  const float* s = feat + (int64_t)b * HW * ld + c0;
+  const float* tp = templ + (int64_t)bt * HWt * ld + c0;
+  const float* mk = mask ? mask + (int64_t)b * HW : nullptr;
+  float lo[C], hi[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { lo[c] = 3.0e38f; hi[c] = -3.0e38f; }
+  int live = 0;
+  const int stride = gridDim.x * 256;
+  for (int p = blockIdx.x * 256 + t; p < HW; p += stride) {
+    if (mk && mk[p] == 0.f) continue;
+    live = 1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = s[(int64_t)p * ld + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+  }
+  for (int p = blockIdx.x * 256 + t; p < HWt; p += stride) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float v = tp[(int64_t)p * ld + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+  }
+  const float any_live = block_max((float)live, red);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float vmax = block_max(hi[c], red);
+    const float vmin = block_min(lo[c], red);
+    if (t == 0) {
+      HistState& h = st[b * ld + c0 + c];
+      if (vmin < 3.0e38f) atomicMin(&h.vmin_enc, enc_ordered(vmin));
+      if (vmax > -3.0e38f) atomicMax(&h.vmax_enc, enc_ordered(vmax));
+      if (any_live != 0.f) atomicOr(&h.live, 1u);
+    }
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) hist_wide_count_kernel(const float* __restrict__ feat, const float* __restrict__ templ,
+                                                              const float* __restrict__ mask, HistState* st, int Bt,
+                                                              int HW, int HWt, int ld) {
+  __shared__ unsigned hs[C][256], ht[C][256];
+  __shared__ float smin[C], srange[C];
+  __shared__ unsigned sskip[C];
+  const int b = blockIdx.y, bt = b < Bt ? b : Bt - 1, t = threadIdx.x;
+  const int c0 = blockIdx.z * C;
+  if (t < C) {
+    HistState& h = st[b * ld + c0 + t];
+    const float vmin = dec_ordered(h.vmin_enc), vmax = dec_ordered(h.vmax_enc);
+    smin[t] = vmin; srange[t] = vmax - vmin;
+    sskip[t] = (!(vmax > vmin) || h.live == 0u) ? 1u : 0u;       // nothing to match: loss 0, gradient 0
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) { hs[c][t] = 0u; ht[c][t] = 0u; }
+  __syncthreads();
+  const float* s = feat + (int64_t)b * HW * ld + c0;
+  const float* tp = templ + (int64_t)bt * HWt * ld + c0;
+  const float* mk = mask ? mask + (int64_t)b * HW : nullptr;
+  const int stride = gridDim.x * 256;
+  for (int p = blockIdx.x * 256 + t; p < HW; p += stride) {
+    if (mk && mk[p] == 0.f) continue;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (sskip[c]) continue;
+      const float sc = (s[(int64_t)p * ld + c] - smin[c]) / srange[c];
+      int k = (int)floorf((float)HB * sc);
+      k = k < 0 ? 0 : (k > HB - 1 ? HB - 1 : k);
+      atomicAdd(&hs[c][k], 1u);
+    }
+  }
+  for (int p = blockIdx.x * 256 + t; p < HWt; p += stride) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (sskip[c]) continue;
+      const float sc = (tp[(int64_t)p * ld + c] - smin[c]) / srange[c];
+      int k = (int)floorf((float)HB * sc);
+      k = k < 0 ? 0 : (k > HB - 1 ? HB - 1 : k);
+      atomicAdd(&ht[c][k], 1u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (sskip[c]) continue;
+    if (hs[c][t]) atomicAdd(&st[b * ld + c0 + c].hs[t], hs[c][t]);
+    if (ht[c][t]) atomicAdd(&st[b * ld + c0 + c].ht[t], ht[c][t]);
+  }
+}
+
+// steps 3-4 of hist_loss_kernel on the global histograms: one block per (image, channel)
+__global__ void __launch_bounds__(256) hist_wide_table_kernel(HistState* st) {
+  __shared__ double sq[256], tq[256];
+  HistState& h = st[blockIdx.x];
+  const int t = threadIdx.x;
+  const float vmin = dec_ordered(h.vmin_enc), vmax = dec_ordered(h.vmax_enc);
+  if (!(vmax > vmin) || h.live == 0u) { if (t == 0) h.skip = 1u; return; }
+  const float range = vmax - vmin, delta = range / (float)HB;
+  if (t == 0) {
+    unsigned long long a = 0, bq = 0;
+    for (int k = 0; k < HB; ++k) { a += h.hs[k]; bq += h.ht[k]; sq[k] = (double)a; tq[k] = (double)bq; }
+    const double ta = (double)a, tb = (double)bq;
+    for (int k = 0; k < HB; ++k) { sq[k] /= ta; tq[k] /= tb; }
+    h.vmin = vmin; h.delta = delta; h.skip = 0u;
+  }
+  __syncthreads();
+  if (t < HB) {
+    const double x = sq[t];
+    int n;
+    if (x < tq[0]) n = 0;
+    else if (x >= tq[HB - 1]) n = HB - 1;
+    else {
+      int l = 0, r = HB;
+      while (l < r) { const int mid = (l + r) >> 1; if (tq[mid] <= x) l = mid + 1; else r = mid; }
+      const int j = l - 1;
+      const double y = (double)j + (x - tq[j]) / (tq[j + 1] - tq[j]);
+      n = (int)rint(y);
+      n = n < 0 ? 0 : (n > HB - 1 ? HB - 1 : n);
+    }
+    h.lut[t] = (vmin + delta * (float)n) + delta * 0.5f;
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) hist_wide_apply_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
+                                                              const HistState* __restrict__ st, float* __restrict__ g_acc,
+                                                              float* __restrict__ parts, int HW, int ld, float weight,
+                                                              int relu_mask) {
+  __shared__ float red[16];
+  __shared__ float lut[C][256];
+  __shared__ float smin[C], sdelta[C];
+  __shared__ unsigned sskip[C];
+  const int b = blockIdx.y, t = threadIdx.x, c0 = blockIdx.z * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) lut[c][t] = st[b * ld + c0 + c].lut[t];
+  if (t < C) { smin[t] = st[b * ld + c0 + t].vmin; sdelta[t] = st[b * ld + c0 + t].delta; sskip[t] = st[b * ld + c0 + t].skip; }
+  __syncthreads();
+  const float* s = feat + (int64_t)b * HW * ld + c0;
+  const float* mk = mask ? mask + (int64_t)b * HW : nullptr;
+  float part = 0.f;
+  const int stride = gridDim.x * 256;
+  for (int p = blockIdx.x * 256 + t; p < HW; p += stride) {
+    if (mk && mk[p] == 0.f) continue;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (sskip[c]) continue;
+      const int64_t o = (int64_t)p * ld + c;
+      const float v = s[o];
+      int k = (int)((v - smin[c]) / sdelta[c]);
+      k = k < 0 ? 0 : (k > HB - 1 ? HB - 1 : k);
+      const float d = v - lut[c][k];
+      part += d * d;
+      if (g_acc && (!relu_mask || v > 0.f)) g_acc[(int64_t)b * HW * ld + c0 + o] += 2.f * weight * d;
+    }
+  }
+  part = block_sum(part, red);
+  if (t == 0) parts[((int64_t)b * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = part;
+}
+
+__global__ void __launch_bounds__(256) hist_wide_total_kernel(const float* __restrict__ parts, float* __restrict__ loss_acc,
+                                                              int nblk, float weight) {
+  __shared__ double tot[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double a = 0.0;
+  for (int i = t; i < nblk; i += 256) a += (double)parts[(int64_t)b * nblk + i];
+  tot[t] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) tot[t] += tot[t + w];
+    __syncthreads();
+  }
+  if (t == 0) loss_acc[b] += weight * (float)tot[0];
+}
+
 // ---- style mask (styler_base.py:165-173): features weighted by the bicubic-resized density mask --------------------
 // TF-1 legacy ResizeBicubic (align_corners = False, no half-pixel centres): src = dst * in/out, taps floor-1..floor+2
 // clamped to the image, Keys weights (A = -0.75) from the 1024-entry table looked up at round(frac * 1024).
@@ -195,6 +402,27 @@ __global__ void __launch_bounds__(256) style_mask_bwd_kernel(const float* __rest
 
 using namespace nfs;
 
+static int hist_wide_blocks(int HW, int HWt) {
+  const int n = HW > HWt ? HW : HWt;
+  int nb = (n + 256 * 4 - 1) / (256 * 4);                 // ~4 pixels per thread
+  return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+}
+
+template <int C>
+static void hist_wide_launch(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc,
+                             HistState* st, float* parts, int B, int Bt, int HW, int HWt, int ld, float weight,
+                             int relu_mask, hipStream_t s) {
+  const int nb = hist_wide_blocks(HW, HWt), groups = ld / C;
+  const dim3 grid(nb, B, groups);
+  hipLaunchKernelGGL(hist_wide_init_kernel, dim3(B * ld), dim3(256), 0, s, st, B * ld);
+  hipLaunchKernelGGL(hist_wide_range_kernel<C>, grid, dim3(256), 0, s, feat, templ, mask, st, Bt, HW, HWt, ld);
+  hipLaunchKernelGGL(hist_wide_count_kernel<C>, grid, dim3(256), 0, s, feat, templ, mask, st, Bt, HW, HWt, ld);
+  hipLaunchKernelGGL(hist_wide_table_kernel, dim3(B * ld), dim3(256), 0, s, st);
+  hipLaunchKernelGGL(hist_wide_apply_kernel<C>, grid, dim3(256), 0, s, feat, mask, st, g_acc, parts, HW, ld, weight,
+                     relu_mask);
+  hipLaunchKernelGGL(hist_wide_total_kernel, dim3(B), dim3(256), 0, s, parts, loss_acc, nb * groups, weight);
+}
+
 extern "C" {
 
 int nfs_hist_loss_masked(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc, int B,
@@ -210,6 +438,34 @@ int nfs_hist_loss_masked(const float* feat, const float* templ, const float* mas
 int nfs_hist_loss(const float* feat, const float* templ, float* loss_acc, float* g_acc, int B, int Bt, int HW, int HWt,
                   int C, float weight, int relu_mask, nfs_stream_t stream) {
   return nfs_hist_loss_masked(feat, templ, nullptr, loss_acc, g_acc, B, Bt, HW, HWt, C, weight, relu_mask, stream);
+}
+
+int64_t nfs_hist_loss_wide_workspace_floats(int B, int C, int HW, int HWt) {
+  if (B <= 0 || C <= 0 || (C > HW_CMAX && C % HW_CMAX) || HW <= 0 || HWt <= 0) return -1;
+  const int groups = C <= HW_CMAX ? 1 : C / HW_CMAX;
+  return (int64_t)B * C * (int64_t)(sizeof(HistState) / sizeof(float)) + (int64_t)B * groups * hist_wide_blocks(HW, HWt);
+}
+
+int nfs_hist_loss_wide(const float* feat, const float* templ, const float* mask, float* loss_acc, float* g_acc,
+                       float* workspace, int64_t workspace_floats, int B, int Bt, int HW, int HWt, int C, float weight,
+                       int relu_mask, nfs_stream_t stream) {
+  NFS_REQUIRE(feat && templ && loss_acc && workspace, "nfs_hist_loss_wide: null pointer");
+  NFS_REQUIRE(B > 0 && Bt > 0 && HW > 0 && HWt > 0 && C > 0 && (C <= HW_CMAX || C % HW_CMAX == 0),
+              "nfs_hist_loss_wide: 1..4 channels or a multiple of 4, positive sizes");
+  NFS_REQUIRE(C <= HW_CMAX || (((uintptr_t)feat | (uintptr_t)templ) & 15) == 0, "nfs_hist_loss_wide: misaligned features");
+  NFS_REQUIRE(((uintptr_t)workspace & 15) == 0 && workspace_floats >= nfs_hist_loss_wide_workspace_floats(B, C, HW, HWt),
+              "nfs_hist_loss_wide: workspace too small or misaligned (nfs_hist_loss_wide_workspace_floats)");
+  HistState* st = reinterpret_cast<HistState*>(workspace);
+  float* parts = workspace + (int64_t)B * C * (sizeof(HistState) / sizeof(float));
+  hipStream_t s = as_stream(stream);
+  const int per = C <= HW_CMAX ? C : HW_CMAX;              // channels per thread; rows are C floats long
+  switch (per) {
+    case 1: hist_wide_launch<1>(feat, templ, mask, loss_acc, g_acc, st, parts, B, Bt, HW, HWt, C, weight, relu_mask, s); break;
+    case 2: hist_wide_launch<2>(feat, templ, mask, loss_acc, g_acc, st, parts, B, Bt, HW, HWt, C, weight, relu_mask, s); break;
+    case 3: hist_wide_launch<3>(feat, templ, mask, loss_acc, g_acc, st, parts, B, Bt, HW, HWt, C, weight, relu_mask, s); break;
+    default: hist_wide_launch<4>(feat, templ, mask, loss_acc, g_acc, st, parts, B, Bt, HW, HWt, C, weight, relu_mask, s); break;
+  }
+  return check_launch("nfs_hist_loss_wide");
 }
 
 int nfs_resize_bicubic_tf1(const float* x, float* out, int B, int H, int W, int C, int oh, int ow, nfs_stream_t stream) {

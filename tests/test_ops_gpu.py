@@ -885,6 +885,33 @@ def test_hist_loss_masked_branch_flat_channels_and_empty_masks():
     assert abs(float(loss2.sum()) - float(lo2)) < 2e-3 * float(lo2)
 
 
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_hist_loss_pixel_parallel_form_equals_the_per_channel_kernel(with_mask):
+    """images of <= 4 channels (the default hist layer, the 3-channel loss-net input) take nfs_hist_loss_wide -- pixels
+    spread over the chip, per-channel state in a workspace -- where one block per (image, channel) would run 3 blocks:
+    the same bins, table and matched values, so the SAME gradient bit for bit and the same loss to summation order;
+    two images of 150 x 225, one template of another size, a flat channel in image 1"""
+    from neural_flow_style_amd import _lib, ops
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, h, w, C = 2, 150, 225, 3
+    f = (torch.rand(B, h, w, C, device="cuda", generator=gen) * 255).contiguous()
+    f[1, ..., 1] = 12.0
+    t = (torch.rand(1, 120, 200, C, device="cuda", generator=gen) * 200 + 20).contiguous()
+    m = None
+    if with_mask:
+        m = (torch.rand(B, h, w, device="cuda", generator=gen) > 0.35).float().contiguous()
+    l_w, g_w = torch.zeros(B, device="cuda"), torch.zeros_like(f)
+    ops.hist_loss(f, t, 0.3, l_w, g_w, relu_mask=False, mask=m)
+    l_c, g_c = torch.zeros(B, device="cuda"), torch.zeros_like(f)
+    _lib.call("nfs_hist_loss_masked", ops._ptr(f), ops._ptr(t), ops._ptr(m), ops._ptr(l_c), ops._ptr(g_c), B, 1, h * w,
+              120 * 200, C, 0.3, 0, ops._stream())
+    assert torch.equal(g_w, g_c) and float(g_w.abs().max()) > 0
+    assert torch.allclose(l_w, l_c, rtol=1e-5)
+    l_2, g_2 = torch.zeros(B, device="cuda"), torch.zeros_like(f)       # deterministic: a second call, the same bits
+    ops.hist_loss(f, t, 0.3, l_2, g_2, relu_mask=False, mask=m)
+    assert torch.equal(l_2, l_w) and torch.equal(g_2, g_w)
+
+
 def test_style_mask_kernels():
     """legacy bicubic resize of the density mask, masked features with the 2*area*C denominator, masked gradient
     (styler_base.py:165-173) against the oracle's restatement"""
