@@ -749,6 +749,11 @@ def other_configs(device, base):
         gacc = torch.zeros_like(F_)
         add("histogram loss + gradient, 75 x 112 x 256 feature map", "styler_base.py:187-209, util.py:317-399",
             lambda: ops.hist_loss(F_, Ft, 1.0, lacc, gacc), 4.0 * F_.numel() * 4)
+        Fi = torch.rand(1, 300, 450, 3, device=device, generator=gen) * 255
+        Fit = torch.rand(1, 300, 450, 3, device=device, generator=gen) * 255
+        gacc_i = torch.zeros_like(Fi)
+        add("histogram loss + gradient, the 300 x 450 x 3 loss-net input (the default hist layer)",
+            "styler_base.py:187-209, config.py:97", lambda: ops.hist_loss(Fi, Fit, 1.0, lacc, gacc_i), 4.0 * Fi.numel() * 4)
         img = torch.rand(4, 512, 1024, 3, device=device, generator=gen)
         coords = (torch.rand(4, 2, 512, 1024, device=device, generator=gen) * 2 - 1).contiguous()
         add("batch_warp2d of four 512 x 1024 x 3 images", "transform.py:206-236, 280-341", lambda: ops.warp2d_fwd(img, coords),

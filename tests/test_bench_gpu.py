@@ -46,7 +46,7 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
     assert "64^3" in one["metric"] and one["sustained"]["windows"] >= 3
     assert len(one["other_configs"]) == 9 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
     widened = one["other_configs"][-1]["ops"]                         # SURVEY 8(f) operators: one timed call each
-    assert len(widened) == 9 and all(o["ms"] > 0 and 0 < o["frac_hbm"] < 1 for o in widened), widened
+    assert len(widened) == 10 and all(o["ms"] > 0 and 0 < o["frac_hbm"] < 1 for o in widened), widened
     fast = args + ["--no-kernel-profile", "--no-other-configs", "--no-sustained"]
     # (a) the launcher form the driver uses, views sharded (strong scaling): 2 ranks share the GPU over gloo
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
