@@ -90,7 +90,11 @@ __device__ __forceinline__ uint2 wf_ld2u(__amdgpu_buffer_rsrc_t r, uint32_t voff
 
 // POOLED: 0 plain operand; 1 pooled gradient masked from the ReLU bit cache; 2 ... from the float output (a template
 // parameter: a run-time choice is a branch around loads inside the MFMA stream)
-template <int K, int N, int MODE, int POOLED>
+// RAG: H or W is not a multiple of 4 -- the last tile row / column hangs over the image.  Staging already answers the
+// pixels outside with zeros (the halo's mechanism); the epilogue then tests every pixel of a tile against a 16-bit
+// validity mask (stores, addend / mask loads, pooling windows).  A template parameter: the aligned form keeps its
+// epilogue without per-pixel branches (they cost 13 % of the kernel when they were unconditional).
+template <int K, int N, int MODE, int POOLED, bool RAG>
 __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   constexpr int NIT = K / 16;         // k-slices of 16 input channels
   constexpr int NWT = N / 16;         // column tiles of the layer (a block takes four: blockIdx.y = 64-channel group)
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
   }
 
   // ---- output transform + layer epilogue, all in-lane: tiles 4 g + {0..3} of the run (as two pairs), channel n0 ----
-  // (H and W are multiples of 4 on this path: every pixel of a live tile is inside the image.  Staging the tile through
+  // (!RAG: H and W are multiples of 4, every pixel of a live tile is inside the image.  Staging the tile through
   // LDS to store 256-byte rows instead of these 64-byte pieces was measured: no gain, one more barrier.)
   const int n0 = 16 * wg + t;          // (t = lane & 15 is the C column)
   const int N2 = N >> 1;
@@ -348,6 +352,16 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
       const bool live = tile < a.T;
       const WfTile ot = wf_tile((uint32_t)(live ? tile : a.T - 1), a.TH, a.TW);
       const int64_t base = (((int64_t)ot.b * a.H + 4 * ot.ty) * a.W + 4 * ot.tx) * N + n0;
+      // pixels of this tile inside the image: bit px = (px >> 2) < rows left && (px & 3) < columns left
+      uint32_t vm = 0xffffu;
+      if (RAG) {
+        const int hy = min(4, a.H - 4 * ot.ty), wx = min(4, a.W - 4 * ot.tx);
+        const uint32_t rowm = (1u << wx) - 1u;
+        vm = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vm |= (r < hy ? rowm : 0u) << (4 * r);
+      }
+#define NFS_WF_IN(px_) (!RAG || ((vm >> (px_)) & 1u))
       float vv[16];
 #pragma unroll
       for (int px = 0; px < 16; ++px) vv[px] = e == 0 ? o[px >> 2][px & 3].x : o[px >> 2][px & 3].y;
@@ -363,7 +377,8 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
         if (a.y && live) {
           float* yt = a.y + base;
 #pragma unroll
-          for (int px = 0; px < 16; ++px) yt[(px >> 2) * rowN + (px & 3) * N] = vv[px];
+          for (int px = 0; px < 16; ++px)
+            if (NFS_WF_IN(px)) yt[(px >> 2) * rowN + (px & 3) * N] = vv[px];
         }
         if (a.out_bits) {
           // word = two channels (even, odd) of one tile: pair with the neighbouring lane
@@ -378,8 +393,10 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
           for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc)
-              yp[(pa * PW + pc) * N] = 0.25f * (vv[(2 * pa) * 4 + 2 * pc] + vv[(2 * pa) * 4 + 2 * pc + 1] +
-                                                vv[(2 * pa + 1) * 4 + 2 * pc] + vv[(2 * pa + 1) * 4 + 2 * pc + 1]);
+              // (VALID pooling: a window exists when its lower right pixel does)
+              if (NFS_WF_IN((2 * pa + 1) * 4 + 2 * pc + 1))
+                yp[(pa * PW + pc) * N] = 0.25f * (vv[(2 * pa) * 4 + 2 * pc] + vv[(2 * pa) * 4 + 2 * pc + 1] +
+                                                  vv[(2 * pa + 1) * 4 + 2 * pc] + vv[(2 * pa + 1) * 4 + 2 * pc + 1]);
         }
       } else if (live) {
         uint32_t wd = mbits ? (mbits[tile * N2 + (n0 >> 1)] >> (n0 & 1)) : 0x55555555u;
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
         if (a.aux1) {
           const float* at = a.aux1 + base;
 #pragma unroll
-          for (int px = 0; px < 16; ++px) ad[px] = at[(px >> 2) * rowN + (px & 3) * N];
+          for (int px = 0; px < 16; ++px) ad[px] = NFS_WF_IN(px) ? at[(px >> 2) * rowN + (px & 3) * N] : 0.f;
         } else {
 #pragma unroll
           for (int px = 0; px < 16; ++px) ad[px] = 0.f;
@@ -396,7 +413,8 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
           const float* xt = a.aux0 + base;
           wd = 0u;
 #pragma unroll
-          for (int px = 0; px < 16; ++px) wd |= (xt[(px >> 2) * rowN + (px & 3) * N] > 0.f ? 1u : 0u) << (px * 2);
+          for (int px = 0; px < 16; ++px)
+            if (NFS_WF_IN(px)) wd |= (xt[(px >> 2) * rowN + (px & 3) * N] > 0.f ? 1u : 0u) << (px * 2);
         }
         float* yt = a.y + base;
 #pragma unroll
@@ -405,9 +423,10 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
           if (a.relu) v += ad[px];            // addend not yet through the mask: add first
           v = ((wd >> (px * 2)) & 1u) ? v : 0.f;
           if (!a.relu) v += ad[px];
-          yt[(px >> 2) * rowN + (px & 3) * N] = v;
+          if (NFS_WF_IN(px)) yt[(px >> 2) * rowN + (px & 3) * N] = v;
         }
       }
+#undef NFS_WF_IN
     }
   }
 #ifdef NFS_ABLATE
@@ -431,16 +450,17 @@ bool winograd_fusable(int K, int N) {
   static const bool off = [] { const char* e = getenv("NFS_WG_FUSED"); return e && atoi(e) == 0; }();
   return !off && (K == 64 || K == 128) && (N == 64 || N == 128);
 }
-// ... and sizes: whole 4x4 tiles only (the epilogue has no per-pixel bounds checks), activations below 2 GB (32-bit
-// buffer offsets)
+// ... and sizes: activations below 2 GB (32-bit buffer offsets); H or W off a multiple of 4 takes the RAG instance
+// (per-pixel validity tests in the epilogue)
 // ... and enough of them: a block walks its K / 16 slices one after the other (~4 us each), so with K = 128 and fewer
 // than ~128 blocks (runs of 16 tiles x 64-channel groups) the three-kernel form, which spreads the same work over 36
 // components, finishes sooner (tools/small_conv_bench.py).  A static rule, not a measurement: the two forms differ in
 // rounding, and which one runs must not depend on timing noise.
 bool winograd_fused_takes(int B, int H, int W, int K, int N) {
-  if (!(H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31)))
-    return false;
-  const int64_t blocks = (((int64_t)B * (H / 4) * (W / 4) + 15) / 16) * (N / 64);
+  static const bool no_rag = [] { const char* e = getenv("NFS_WG_FUSED_RAG"); return e && atoi(e) == 0; }();
+  if (!(H >= 4 && W >= 4 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31))) return false;
+  if (no_rag && (H % 4 || W % 4)) return false;          // (ablation: ragged sizes on the three-kernel form)
+  const int64_t blocks = (((int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) + 15) / 16) * (N / 64);
   return K == 64 || blocks >= 128;
 }
 
@@ -451,23 +471,29 @@ int winograd_pack_fused(const float* up, float* uf, int K, int N, hipStream_t s)
   return check_launch("winograd_pack_fused");
 }
 
-template <int K, int N, int MODE, int POOLED>
+template <int K, int N, int MODE, int POOLED, bool RAG>
 static void launch_fused(const WfArgs& a, hipStream_t s) {
   const size_t lds = 2 * WF_BUF * sizeof(float);
   static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
   std::call_once(attr_once, [&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_fused_kernel<K, N, MODE, POOLED>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_fused_kernel<K, N, MODE, POOLED, RAG>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int grid = (a.runs + 7) / 8 * 8;
-  hipLaunchKernelGGL((winograd_fused_kernel<K, N, MODE, POOLED>), dim3(grid, N / 64), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((winograd_fused_kernel<K, N, MODE, POOLED, RAG>), dim3(grid, N / 64), dim3(256), lds, s, a);
+}
+
+template <int K, int N, bool RAG>
+static void launch_fused_knr(const WfArgs& a, int mode, bool pooled, hipStream_t s) {
+  if (mode == 0) launch_fused<K, N, 0, 0, RAG>(a, s);
+  else if (!pooled) launch_fused<K, N, 1, 0, RAG>(a, s);
+  else if (a.pool_bits) launch_fused<K, N, 1, 1, RAG>(a, s);
+  else launch_fused<K, N, 1, 2, RAG>(a, s);
 }
 
 template <int K, int N>
 static void launch_fused_kn(const WfArgs& a, int mode, bool pooled, hipStream_t s) {
-  if (mode == 0) launch_fused<K, N, 0, 0>(a, s);
-  else if (!pooled) launch_fused<K, N, 1, 0>(a, s);
-  else if (a.pool_bits) launch_fused<K, N, 1, 1>(a, s);
-  else launch_fused<K, N, 1, 2>(a, s);
+  if ((a.H & 3) || (a.W & 3)) launch_fused_knr<K, N, true>(a, mode, pooled, s);
+  else launch_fused_knr<K, N, false>(a, mode, pooled, s);
 }
 
 // same contract as winograd_conv (winograd.hip) for the shapes winograd_fusable() / winograd_fused_takes() accept; Uf from

@@ -250,7 +250,11 @@ def _conv_ref(x, w, b, relu=True):
                                           # 16 tiles that wrap rows and images, a ragged last run, both channel groups
                                           # (with 128 input channels it is taken from 128 blocks of 16 tiles x 64 channels on)
                                           (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
-                                          (1, 4, 4, 64, 128), (4, 64, 64, 128, 128), (8, 64, 64, 128, 64)])
+                                          (1, 4, 4, 64, 128), (4, 64, 64, 128, 128), (8, 64, 64, 128, 64),
+                                          # ... and its ragged instance (H or W off a multiple of 4: the last tile row /
+                                          # column hangs over the image; per-pixel validity in the epilogue)
+                                          (2, 30, 45, 64, 64), (2, 30, 45, 64, 128), (4, 62, 66, 128, 128),
+                                          (4, 61, 67, 128, 64), (1, 5, 6, 64, 64)])
 def test_conv3x3_fwd_and_dgrad(ops, B, H, W, Ci, Co):
     rng = np.random.RandomState(7)
     x = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32).requires_grad_()
@@ -298,7 +302,10 @@ def test_winograd_f5_error_budget(ops, B, H, W, Ci, Co):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128),
                                           (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
-                                          (4, 64, 64, 128, 128)])
+                                          (4, 64, 64, 128, 128),
+                                          # ragged single-kernel instances: odd sides floor in the pool (a window exists
+                                          # when its lower right pixel does), the pooled gradient is zero beyond them
+                                          (2, 30, 45, 64, 64), (4, 61, 66, 128, 128), (2, 150, 225, 128, 128)])
 def test_conv3x3_fused_pool(ops, B, H, W, Ci, Co):
     """conv + ReLU + 2x2 VALID average pool in one pass, and the data gradient taken from the POOLED gradient
     (pool adjoint + ReLU mask folded into the Winograd input transform); odd sizes floor like slim.avg_pool2d"""
