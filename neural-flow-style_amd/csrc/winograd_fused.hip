@@ -461,7 +461,10 @@ bool winograd_fused_takes(int B, int H, int W, int K, int N) {
   if (!(H >= 4 && W >= 4 && (int64_t)B * H * W * (K > N ? K : N) * 4 < ((int64_t)1 << 31))) return false;
   if (no_rag && (H % 4 || W % 4)) return false;          // (ablation: ragged sizes on the three-kernel form)
   const int64_t blocks = (((int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) + 15) / 16) * (N / 64);
-  return K == 64 || blocks >= 128;
+  // (the ragged instance's guarded epilogue moves the break-even up: 150 x 225, 272 blocks, 0.129 ms against 0.118 for
+  // the three-kernel form; 8 x 75 x 75, 362 blocks, 0.133 against 0.140 -- tools/ragged_conv_bench.py)
+  const bool ragged = (H % 4) || (W % 4);
+  return K == 64 || blocks >= (ragged ? 300 : 128);
 }
 
 int64_t winograd_fused_packed_floats(int K, int N) { return winograd_fusable(K, N) ? (int64_t)36 * K * N : 0; }
