@@ -493,8 +493,10 @@ class GraphedLoss(object):
     do).  Hosts differ by 2x between boxes of one pool, so the choice is MEASURED: call 1 runs eagerly (lazy state:
     packed filters, tile tuner, workspaces); call 2 eagerly between two synchronisations, timing both what the host
     needed to issue it and when the GPU finished -- if the GPU finished as soon as the host did (issue time > 85 % of the
-    wall time) the chain is host-bound and calls 3.. are replays of a captured graph, otherwise it stays eager (``mode``
-    = 'graph' | 'eager'; ``force`` = True / False skips the trial).  A change of anything the capture bakes in
+    wall time; calls 2-4 are timed this way and the MEDIAN ratio decides, so that one-off lazy work in one of them does
+    not) the chain is host-bound and calls 5.. are replays of a captured graph, otherwise it stays eager (``mode``
+    = 'graph' | 'eager'; ``force`` = True / False skips the trial: ``NFS_GRAPH=0/1`` is the reproducible setting, the
+    measured choice can differ between hosts and runs).  A change of anything the capture bakes in
     (``loss_capture_key``, shapes) starts over.  Inputs are copied into static buffers; the returned loss and gradient
     tensors are valid until the next call."""
 
@@ -509,6 +511,7 @@ class GraphedLoss(object):
         self._calls = 0
         self.mode = None if self.force is None else ("graph" if self.force else "eager")
         self.trial = None
+        self._trials = []
 
     def _eager(self, d, rot):
         if isinstance(self.loss, ImageStyleLoss):        # (d, d_gray) -> (losses, gradient)
@@ -526,14 +529,20 @@ class GraphedLoss(object):
         if self.mode == "eager" or self._calls == 1:
             return self._eager(d, rot)
         if self.mode is None:
+            # three timed eager calls (2, 3, 4), the median ratio decides: one trial can catch one-off lazy work
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = self._eager(d, rot)
             t_issue = time.perf_counter() - t0
             torch.cuda.synchronize()
             t_wall = time.perf_counter() - t0
-            self.trial = (t_issue, t_wall)
-            self.mode = "graph" if t_issue > 0.85 * t_wall else "eager"
+            self._trials.append((t_issue, t_wall))
+            if len(self._trials) == 3:
+                self.trial = sorted(self._trials, key=lambda tw: tw[0] / tw[1])[1]
+                self.mode = "graph" if self.trial[0] > 0.85 * self.trial[1] else "eager"
+                if os.environ.get("NFS_VERBOSE"):
+                    print("GraphedLoss: %s (issue %.3f ms of %.3f ms wall, median of 3; NFS_GRAPH=0/1 fixes the choice)"
+                          % (self.mode, 1e3 * self.trial[0], 1e3 * self.trial[1]))
             return out
         if self._graph is None:
             self._d = d.clone()
@@ -615,8 +624,12 @@ class LBFGSState(object):
     it.  Everything stays on the variable's device (elementwise torch kernels and reductions); same call surface as
     ``TFAdamState.step``, so the stylizers take either."""
 
-    def __init__(self, history=10):
+    def __init__(self, history=10, tolerance_grad=1e-7, tolerance_change=1e-9):
         self.history = int(history)
+        # torch.optim.LBFGS's stopping tests, applied per call: nothing moves when max|g| <= tolerance_grad (an empty or
+        # fully masked frame has g = 0: the first step's 1/|g|_1 would divide by zero) or when the quasi-Newton direction
+        # is not a descent direction (g.d > -tolerance_change)
+        self.tol_g, self.tol_c = float(tolerance_grad), float(tolerance_change)
         self.n = 0
         self.S, self.Y, self.ro = [], [], []
         self.d = self.prev_g = None
@@ -625,6 +638,12 @@ class LBFGSState(object):
 
     def step(self, x, g, lr):
         g = g.reshape(-1)
+        if self.prev_g is not None and self.prev_g.numel() != g.numel():
+            raise ValueError("LBFGSState: the variable changed size (%d -> %d elements): the curvature history belongs to "
+                             "ONE variable -- use one state per variable (engine.optimizer_slot)"
+                             % (self.prev_g.numel(), g.numel()))
+        if float(g.abs().max()) <= self.tol_g if g.numel() else True:
+            return
         self.n += 1
         if self.n == 1:
             d = g.neg()
@@ -650,7 +669,18 @@ class LBFGSState(object):
         self.prev_g = g.clone()
         self.t = min(1.0, 1.0 / float(g.abs().sum())) * float(lr) if self.n == 1 else float(lr)
         self.d = d
+        if float((g * d).sum()) > -self.tol_c:
+            self.t = 0.0                 # (no move; the pair of the next call is then s = 0: y.s = 0, not kept)
+            return
         x.reshape(-1).add_(d, alpha=self.t)
+
+
+def optimizer_slot(kind, t, frames_per_opt):
+    """key of the optimiser state frame ``t`` steps with.  Adam: ``t // frames_per_opt`` -- one (m, v, step count) shared
+    by the frames of a group, updated by them in turn (styler_3p.py:315-323; the moments are running averages and
+    tolerate it).  L-BFGS: one state PER FRAME -- its (s, y) pairs are differences of consecutive gradients of one
+    variable; pairs mixed across frames (or across particle counts) are not curvature of anything."""
+    return ("lbfgs", int(t)) if kind == "lbfgs" else int(t) // int(frames_per_opt)
 
 
 def make_optimizer(kind="adam"):

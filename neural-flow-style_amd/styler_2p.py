@@ -55,6 +55,7 @@ class Styler(StylerBase):
         key = (p.data_ptr(), p.shape[0])
         if key not in cache:
             cache[key] = T.grid_order(p, self.resolution)
+        assert cache[key].numel() == p.shape[0]
         return cache[key]
 
     def _density(self, p, res):
@@ -125,7 +126,7 @@ class Styler(StylerBase):
                     # loss network -- style summed over the images, TV averaged (styler_base.py:181, 212) -- and ONE
                     # optimiser step on the B colour variables (Adam slots per batch position, one step count)
                     vars_ = [g_opt[t + i].clone().requires_grad_(True) for i in range(B)]
-                    opt_id = t // self.frames_per_opt
+                    opt_id = engine.optimizer_slot(getattr(self, "optimizer", "adam"), t, self.frames_per_opt)
                     if opt_id not in opt_:
                         opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                     d = torch.cat([self._colour(p[t + i], r[t + i], vars_[i], res)[0] for i in range(B)], 0)
@@ -176,4 +177,5 @@ class Styler(StylerBase):
         # extras of this build (not in the reference's dict): what the run started from, for parity tests
         result["c_init"] = c_opt
         result["style_per_octave"] = style_per_octave
+        self._orders = {}        # keyed by device address: the frame tensors die with this call, the addresses get re-used
         return result

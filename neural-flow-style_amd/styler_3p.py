@@ -90,7 +90,7 @@ class Styler(StylerBase):
         # the splat would fall back to scattered global atomics; it therefore sees every frame through that frame's
         # own grid order (a gather of the positions in, the scatter of their gradient out -- the splat does not care
         # about the order of its particles)
-        order = getattr(self, "_orders", {}).get(p.data_ptr())
+        order = getattr(self, "_orders", {}).get((p.data_ptr(), p.shape[0]))
         if order is not None:
             p_ = p_[:, order]
         if "d" in self.target_field:
@@ -128,11 +128,13 @@ class Styler(StylerBase):
         nviews = int(rot.shape[0]) if (self.rotate and rot is not None) else 1
         if self._graph_loss is None:
             # hipGraph replay of the loss chain where the host cannot keep up with it: tried (and timed against eager
-            # submission) with one or two views per call; NFS_GRAPH=0 / 1 forces it off / on
+            # submission) with one or two views per call; NFS_GRAPH=0 / 1 forces it off / on.  The GraphedLoss object is
+            # made once; whether THIS call goes through it depends on this call's view count (it keys its capture on
+            # the shapes and starts over when they change)
             env = os.environ.get("NFS_GRAPH")
             self._graph_loss = (engine.GraphedLoss(self.loss, force=True) if env == "1" else
-                                engine.GraphedLoss(self.loss) if (env is None and nviews <= 2) else False)
-        if self._graph_loss:
+                                engine.GraphedLoss(self.loss) if env is None else False)
+        if self._graph_loss and (self._graph_loss.force or nviews <= 2):
             losses, g_d = self._graph_loss(d3, rot)
             losses = losses.clone()
         else:
@@ -208,10 +210,15 @@ class Styler(StylerBase):
         if getattr(self, "sort_particles", True) and self.num_frames > 1:
             for x in p[1:]:                                  # (frame 0 is in its own order already)
                 if x.shape[0] > 1:
-                    self._orders[x.data_ptr()] = T.grid_order(x, self.resolution)
+                    self._orders[(x.data_ptr(), x.shape[0])] = T.grid_order(x, self.resolution)
         nvar = 3 if "p" in self.target_field else self.num_kernels
         g_opt = [torch.zeros(p[i].shape[0], nvar, device=self.device) for i in range(self.num_frames)]
         mode = getattr(self, "views_mode", "sequential")
+        if getattr(self, "optimizer", "adam") == "lbfgs" and self.rotate and mode == "sequential" \
+                and self.n_views > self.v_batch:
+            raise ValueError("optimizer=lbfgs with views_mode='sequential': every step sees a different view batch, i.e. "
+                             "a different objective -- gradient differences across them are not curvature pairs.  Use "
+                             "views_mode='sum' (one objective per iteration) or optimizer=adam")
 
         # key frames (304-309) and who stylises them.  Frame sharding follows SURVEY 8(e): contiguous blocks of optimiser
         # groups per rank (one Adam state never straddles ranks), every rank keeps full view batches for its frames.
@@ -272,7 +279,7 @@ class Styler(StylerBase):
                             self._resample_views()
                         continue
                     var = g_opt[t].clone()                       # variable re-assigned from g_opt (312)
-                    opt_id = t // self.frames_per_opt
+                    opt_id = engine.optimizer_slot(getattr(self, "optimizer", "adam"), t, self.frames_per_opt)
                     if opt_id not in opt_:
                         opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                     adam = opt_[opt_id]
@@ -374,6 +381,7 @@ class Styler(StylerBase):
         result["d"] = np.array(d_sty)
         result["r"] = np.array(r_sty)
         result["opt"] = [(g if inv is None else g[inv]).cpu().numpy() for g in g_opt]   # build extension: the variables
+        self._orders = {}        # keyed by device address: the frame tensors die with this call, the addresses get re-used
         return result
 
     def loss_d_img(self, d_out):

@@ -228,9 +228,10 @@ class Styler(StylerBase):
         upd = {}
         for j, t in enumerate(st.keys):
             if st.owner[t] == st.rank:
-                adam = st.opt_.get(t // self.frames_per_opt)
+                slot = engine.optimizer_slot(getattr(self, "optimizer", "adam"), t, self.frames_per_opt)
+                adam = st.opt_.get(slot)
                 if adam is None:
-                    adam = st.opt_[t // self.frames_per_opt] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
+                    adam = st.opt_[slot] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
                 st.work.copy_(st.g_opt[t])
                 st.gs.bind(st.d[t], st.work.view(D, H, W_, 3) if self.target == "v" else st.work.view(D, H, W_), adam)
                 losses[j] = st.gs.step(self._rot())

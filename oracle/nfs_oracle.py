@@ -970,23 +970,31 @@ def grid_forward(d0, vel, rot, cfg, weights, style_feats, var="vel"):
     total = 0
     per_view = []
     for v in range(rot.shape[0]):
-        dr = rotate(d_out, rot[v:v + 1]) if cfg.get("rotate", True) else d_out
-        img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
-        d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
-        feats = loss_net_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"], cfg)
-        l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
-        if cfg.get("w_content", 0):
-            # one view per loss-net batch here (v_batch = 1): the content means are per view
-            l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
-                                                    cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
-        if cfg.get("w_hist", 0):
-            # histogram term (styler_base.py:187-209): 'input' = d_img, otherwise a layer of the loss network
-            for name, wl in zip(cfg["hist_layer"], cfg["w_hist_layer"]):
-                f = d_img if "input" in name else feats[name]
-                l = l + cfg["w_hist"] * wl * hist_loss(f, cfg["hist_feature"][name])
+        l = grid_view_loss(d_out, rot[v:v + 1], cfg, weights, style_feats)
         per_view.append(l)
         total = total + l
     return total, per_view, d_out
+
+
+def grid_view_loss(d_out, rot_v, cfg, weights, style_feats):
+    """the loss of ONE view of ``grid_forward`` from the smoothed density ``d_out`` [1,D,H,W,1]: rotate
+    (styler_3p.py:133) -> render (147-158) -> loss net (styler_base.py:33-57) -> style (152-185) / content /
+    histogram terms; ``rot_v`` [1,3,3]"""
+    dr = rotate(d_out, rot_v) if cfg.get("rotate", True) else d_out
+    img = render(dr, cfg["transmit"], cfg.get("ray_mode") or cfg.get("render_liquid", False))
+    d_img = plugin_to_loss_net(img, cfg.get("resize_scale", 1.0))
+    feats = loss_net_features(d_img, weights, cfg["style_layer"][-1] if cfg.get("upto") is None else cfg["upto"], cfg)
+    l, _ = style_loss(feats, style_feats, cfg["style_layer"], cfg["w_style_layer"], cfg.get("w_style", 1.0))
+    if cfg.get("w_content", 0):
+        # one view per loss-net batch here (v_batch = 1): the content means are per view
+        l = l + cfg["w_content"] * content_loss(feats[cfg["content_layer"]], cfg.get("content_channel", 0),
+                                                cfg.get("content_feature"), cfg.get("w_content_amp", 100.0))
+    if cfg.get("w_hist", 0):
+        # histogram term (styler_base.py:187-209): 'input' = d_img, otherwise a layer of the loss network
+        for name, wl in zip(cfg["hist_layer"], cfg["w_hist_layer"]):
+            f = d_img if "input" in name else feats[name]
+            l = l + cfg["w_hist"] * wl * hist_loss(f, cfg["hist_feature"][name])
+    return l
 
 
 def style_target_features(style_img, weights, layers, upto=None, cfg=None):

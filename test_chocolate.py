@@ -43,8 +43,11 @@ def load_frames(config):
             pos = np.asarray(z["position"], np.float32)
             ids = np.asarray(z["id"]).reshape(-1) if "id" in z.files else np.arange(pos.shape[0])
             raw.append((ids, pos))
+        elif i == 0:
+            return None                                        # no dataset at all: the caller's demo mode
         else:
-            return None
+            raise FileNotFoundError("frame %d of the sequence is missing: %s (frame 0 exists -- refusing to replace a "
+                                    "partly present dataset by synthetic particles)" % (i, path))
         nmax = max(nmax, int(raw[-1][0].max()) + 1, raw[-1][1].shape[0])
     p = []
     for ids, pos in raw:

@@ -44,8 +44,11 @@ def load_frames(config):
             z = np.load(npz)
             pos = np.asarray(z["position"], np.float32)[:, :2]
             den = np.asarray(z["density"], np.float32).reshape(pos.shape[0], -1)[:, :1]
+        elif i == 0:
+            return None                                        # no dataset at all: the caller's demo mode
         else:
-            return None
+            raise FileNotFoundError("frame %d of the sequence is missing: %s (frame 0 exists -- refusing to replace a "
+                                    "partly present dataset by synthetic particles)" % (i, path))
         px, py = pos[:, 0] / config.domain[1], pos[:, 1] / config.domain[0]
         p.append(np.stack([py, px], -1).astype(np.float32))
         r.append(den)

@@ -37,7 +37,10 @@ def load_frames(config):
             nmax = max(nmax, raw[-1][0].shape[0])
             continue
         if not os.path.exists(path):
-            return None
+            if i == 0:
+                return None                                    # no dataset at all: the caller's demo mode
+            raise FileNotFoundError("frame %d of the sequence is missing: %s (frame 0 exists -- refusing to replace a "
+                                    "partly present dataset by synthetic particles)" % (i, path))
         z = np.load(path)
         raw.append((np.asarray(z["position"], np.float32), np.asarray(z["density"], np.float32)))
         nmax = max(nmax, raw[-1][0].shape[0])

@@ -54,16 +54,24 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
                + fast, env={"NFS_DIST_BACKEND": "gloo"})
     assert two["n_gpus"] == 2 and two["config"]["views_per_rank"] == 4 and two["scaling"] == "strong"
     assert abs(two["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"])
-    # (b) ``python bench.py --gpus 2`` WITHOUT a launcher must become two ranks by itself; default sharding for N > 1
-    # is by frames (weak scaling), with the view-sharded number of the same box beside it
+    # (b) ``python bench.py --gpus 2`` WITHOUT a launcher must become two ranks by itself; the default for N > 1 is the
+    # BASELINE metric itself -- the same metric, workload and unit as the N = 1 line, views sharded (strong scaling) --
+    # with the frame-sharded sequence (weak scaling) of the same box beside it
     env = {"NFS_DIST_BACKEND": "gloo"}
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
-    seq2 = _run([sys.executable, "bench.py", "--gpus", "2"] + fast, env=env)
-    assert seq2["n_gpus"] == 2 and seq2["world_size_seen"] == 2 and seq2["scaling"] == "weak"
-    assert seq2["scaling_by"] == "frames" and seq2["config"]["frames"] == 2
+    v2 = _run([sys.executable, "bench.py", "--gpus", "2"] + args + ["--no-kernel-profile", "--no-sustained"], env=env)
+    assert v2["n_gpus"] == 2 and v2["world_size_seen"] == 2 and v2["scaling"] == "strong" and v2["scaling_by"] == "views"
+    assert v2["metric"] == one["metric"] and v2["unit"] == one["unit"]
+    assert v2["config"]["workload"] == one["config"]["workload"] and v2["config"]["views_per_rank"] == 4
+    assert abs(v2["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"])
+    assert v2["frames_weak"]["scaling"] == "weak" and v2["frames_weak"]["value"] > 0
+    # frames as the headline on request; the same two-frame sequence on one rank: identical trajectory (frame sharding +
+    # halo exchange are exact)
+    seq2 = _run([sys.executable, "bench.py", "--gpus", "2", "--scaling-by", "frames"] + fast, env=env)
+    assert seq2["scaling"] == "weak" and seq2["scaling_by"] == "frames" and seq2["config"]["frames"] == 2
     assert abs(seq2["views_strong"]["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"])
-    # the same two-frame sequence on one rank: identical trajectory (frame sharding + halo exchange are exact)
+    assert abs(seq2["final_loss"] - v2["frames_weak"]["final_loss"]) <= 1e-5 * abs(seq2["final_loss"])
     seq1 = _run([sys.executable, "bench.py", "--scaling-by", "frames", "--frames-per-rank", "2"] + fast)
     assert seq1["n_gpus"] == 1 and seq1["config"]["frames"] == 2
     assert abs(seq2["final_loss"] - seq1["final_loss"]) <= 1e-5 * abs(seq1["final_loss"])

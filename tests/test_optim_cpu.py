@@ -51,3 +51,29 @@ def test_lbfgs_history_is_bounded_and_skips_non_positive_curvature():
     for k in range(8):
         st.step(x, 2.0 * x.clone(), 0.3)                   # f = |x|^2: positive curvature
     assert len(st.S) == 3 and len(st.Y) == 3 and len(st.ro) == 3
+
+
+def test_lbfgs_guards_and_one_state_per_variable():
+    """a zero gradient on the first step (an empty or masked frame) must not divide by zero; a state must
+    not be fed another variable; frames of one Adam group get their own L-BFGS states"""
+    from neural_flow_style_amd.engine import LBFGSState, optimizer_slot
+    st = LBFGSState()
+    x = torch.ones(6)
+    st.step(x, torch.zeros(6), 0.5)                         # nothing moves, nothing is recorded
+    assert torch.equal(x, torch.ones(6)) and st.n == 0 and st.prev_g is None
+    st.step(x, 2.0 * x.clone(), 0.3)
+    assert st.n == 1 and not torch.equal(x, torch.ones(6))
+    import pytest
+    with pytest.raises(ValueError, match="one state per variable"):
+        st.step(torch.ones(4), torch.ones(4), 0.3)
+    # a direction that is not a descent direction moves nothing (torch.optim.LBFGS: gtd > -tolerance_change)
+    st = LBFGSState()
+    x = torch.ones(3)
+    st.step(x, torch.tensor([1.0, 0.0, 0.0]), 0.1)
+    st.H, st.S, st.Y, st.ro = -1.0, [], [], []              # force an ascent direction through a negative Hessian scale
+    before = x.clone()
+    st.prev_g = torch.tensor([1.0, 0.0, 0.0]); st.d = torch.zeros(3); st.t = 0.0
+    st.step(x, torch.tensor([1.0, 0.0, 0.0]), 0.1)
+    assert torch.equal(x, before)
+    assert optimizer_slot("adam", 7, 5) == 1 and optimizer_slot(None, 7, 5) == 1
+    assert optimizer_slot("lbfgs", 7, 5) != optimizer_slot("lbfgs", 8, 5)
