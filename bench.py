@@ -169,6 +169,10 @@ def work_of(name, a):
         D, H, W = a[5:8]
         # g_out 4 + gathered d 4 + vel/m/v read 36 + vel/m/v write 36 bytes per voxel
         return "B", 80.0 * D * H * W
+    if name == "nfs_advect_bwd_adam_fwd":
+        D, H, W = a[6:9]
+        # the same + the next iteration's forward sample written (4 bytes; its gathers hit the lines the adjoint just read)
+        return "B", 84.0 * D * H * W
     if name in ("nfs_smooth3d_relu_fwd",):
         D, H, W = a[2:5]
         return "B", 8.0 * D * H * W
@@ -674,12 +678,14 @@ def other_configs(device, base):
             pack = torch.empty(world_ * (cs + 5), G2, G2, device=device)
             g_chunk = torch.randn(cs + 4, G2, G2, device=device)
 
+            d_adv = ops.advect_fwd_slab(gs2.d0, vel_s, lo)
+
             def field_slab():
-                d_adv = ops.advect_fwd_slab(gs2.d0, vel_s, lo)
+                # (the forward advect of the next iteration is written by the Adam kernel: engine.GridStylizer._adv_target)
                 ops.smooth3d_relu_fwd(d_adv, 3.0)
                 torch.index_select(gpad, 0, idx, out=pack)
                 g_adv = ops.smooth3d_relu_bwd(d_s2[z0 - 2:z0 + cs + 2], g_chunk, 3.0)
-                ops.advect_bwd_adam_slab(gs2.d0, vel_s, g_adv[1:1 + (hi - lo)], m_s, v_s, lo, 1e-3)
+                ops.advect_bwd_adam_slab(gs2.d0, vel_s, g_adv[1:1 + (hi - lo)], m_s, v_s, lo, 1e-3, adv_next=d_adv)
             t_field = ev_time(field_slab, 20)
             slab_rows[str(world_)] = {"local_views": nv, "loss_chain_ms": t_loss, "field_slab_ms": t_field,
                                       "ms_per_step": t_loss + t_field}
@@ -1052,7 +1058,8 @@ def main():
         # accountings -- the kernels as built (the rotated volume is KEPT for the adjoint: written once, read once more)
         # and SURVEY 8(d)'s fully fused counts (rotate+render fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + 4VG^2)
         fam = [r for r in rows if r["kernel"] in ("nfs_rotate_render_fwd", "nfs_render_bwd", "nfs_rotate_bwd",
-                                                  "nfs_advect_fwd", "nfs_advect_bwd_adam", "nfs_advect_bwd")]
+                                                  "nfs_advect_fwd", "nfs_advect_bwd_adam", "nfs_advect_bwd",
+                                                  "nfs_advect_bwd_adam_fwd")]
         if fam:
             fms = sum(r["ms_per_step"] for r in fam)
             built = sum(r["achieved"] * r["ms_per_step"] for r in fam)        # GB/s * ms = MB

@@ -98,6 +98,15 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
                         int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
                         nfs_stream_t stream);
 
+/* ... and, in the same pass, the NEXT iteration's forward sample adv_next [D,H,W] = nfs_advect_fwd(d, UPDATED vel): advect
+ * (transform.py:557-569) reads the velocity of its own voxel only and the density it gathers from is constant, so the
+ * sample is formed while the new velocity is still in registers -- the forward advect launch of the next iteration
+ * (styler_3p.py:112-125 runs it at the top of every sess.run) and its 96 MB velocity read disappear from the steady-state
+ * step.  Bit-identical to calling nfs_advect_fwd on the updated velocity.  adv_next must not alias d or g_out. */
+int nfs_advect_bwd_adam_fwd(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                            int D, int H, int W, float lr_t, float beta1, float beta2, float eps,
+                            nfs_stream_t stream);
+
 /* Slab forms for the view-sharded (strong-scaling) run, where the replicated field work -- advect, smooth, their
  * adjoints, ApplyAdam -- is sharded over D-slabs between a reduce-scatter of the density-field gradient and an
  * all-gather of the smoothed density (engine.GridStylizer): d is the WHOLE [D,H,W] density (back-traced
@@ -108,6 +117,10 @@ int nfs_advect_fwd_slab(const float* d, const float* vel, float* out, int D, int
 int nfs_advect_bwd_adam_slab(const float* d, float* vel, const float* g_out, float* m, float* v,
                              int D, int H, int W, int z0, int nz, float lr_t, float beta1, float beta2, float eps,
                              nfs_stream_t stream);
+/* nfs_advect_bwd_adam_fwd on a slab: adv_next [nz,H,W] = the slab's planes of advect(d, updated vel) */
+int nfs_advect_bwd_adam_fwd_slab(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                                 int D, int H, int W, int z0, int nz, float lr_t, float beta1, float beta2,
+                                 float eps, nfs_stream_t stream);
 
 /* ---- histogram loss (styler_base.py:187-209 + util.histogram_match_tf, util.py:317-399) -------------
  * feat [B,HW,C] (a layer of the loss network, or d_img for hist_layer 'input'), templ [Bt,HWt,C] (the same layer of

@@ -59,6 +59,8 @@ SIGNATURES = {
     "nfs_advect_bwd_adam": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "nfs_advect_fwd_slab": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_advect_bwd_adam_slab": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P],
+    "nfs_advect_bwd_adam_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "nfs_advect_bwd_adam_fwd_slab": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P],
     "nfs_warp2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_warp2d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nfs_advect2d_fwd": [_P, _P, _P, _I, _I, _I, _P],

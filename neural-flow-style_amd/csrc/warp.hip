@@ -145,7 +145,11 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
 // clamping it to [0, n-1], base cell min(floor, n-2), weight in [0,1]; the four row-pairs of the stencil are
 // dword-aligned 8-byte loads.  D, H, W >= 2.  The first form (per-corner index clamps, two runtime integer
 // divisions per voxel) spent ~150 VALU instructions per voxel on a 20-byte-per-voxel stream.
-struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; };
+// adv_next (nullable, MODE 2): advect(d, UPDATED vel) of the same voxels -- the next iteration's forward sample, formed
+// while the new velocity is still in registers (advect reads the velocity of its own voxel only; the gathered density is
+// constant): the forward advect launch of the next iteration and its 96 MB velocity read disappear.  Same arithmetic
+// as MODE 0 on the stored velocity: bit-identical to running nfs_advect_fwd afterwards.
+struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; float* adv_next = nullptr; };
 
 // MODE 0: forward; 1: velocity gradient -> out; 2: velocity gradient consumed on the spot by the TF-Adam update of
 // the velocity itself (vel, m, v updated in place: every thread reads and writes only its own 4 voxels of them;
@@ -201,8 +205,10 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   const int zlast = zoff + D - 1;
   F2u p[4][4];
   float wz[4], wy[4], wx[4], mz[4], my[4], mx[4];
+  [[maybe_unused]] float fz[4], fh[4], fw[4];       // MODE 2 with adv_next: the voxel's own index, for the second sample
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (MODE == 2) { fz[j] = (float)z; fh[j] = (float)h; fw[j] = (float)w; }
     const float xz = fmaf(-vv[j].x, hz, (float)z), xy = fmaf(-vv[j].y, hy, (float)h),
                 xx = fmaf(-vv[j].z, hx, (float)w);
     const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
@@ -247,10 +253,9 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       const float dz = b1 - b0;
       // coordinate = index - vel * (n-1)/2  =>  d/dvel = -(n-1)/2 * d/dcoordinate (mz/my/mx carry the factor)
       const float gv[3] = {-gg[j] * dz * mz[j], -gg[j] * dy * my[j], -gg[j] * dx * mx[j]};
-      if (!ok[j]) continue;
       const int idx = first + 64 * j;
       if (MODE == 1) {
-        reinterpret_cast<F3u*>(out)[idx] = F3u{gv[0], gv[1], gv[2]};
+        if (ok[j]) reinterpret_cast<F3u*>(out)[idx] = F3u{gv[0], gv[1], gv[2]};
       } else {
         // TF ApplyAdam, same arithmetic as adam_kernel (field.hip); out == vel
         float xs[3] = {vv[j].x, vv[j].y, vv[j].z}, ms[3] = {mm[j].x, mm[j].y, mm[j].z},
@@ -261,9 +266,35 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
           us[c] = ad.b2 * us[c] + (1.f - ad.b2) * gv[c] * gv[c];
           xs[c] -= ad.lr_t * ms[c] / (sqrtf(us[c]) + ad.eps);
         }
-        reinterpret_cast<F3u*>(out)[idx] = F3u{xs[0], xs[1], xs[2]};
-        reinterpret_cast<F3u*>(ad.m)[idx] = F3u{ms[0], ms[1], ms[2]};
-        reinterpret_cast<F3u*>(ad.v)[idx] = F3u{us[0], us[1], us[2]};
+        vv[j] = F3u{xs[0], xs[1], xs[2]};
+        if (ok[j]) {
+          reinterpret_cast<F3u*>(out)[idx] = vv[j];
+          reinterpret_cast<F3u*>(ad.m)[idx] = F3u{ms[0], ms[1], ms[2]};
+          reinterpret_cast<F3u*>(ad.v)[idx] = F3u{us[0], us[1], us[2]};
+        }
+      }
+    }
+    if (MODE == 2 && ad.adv_next) {
+      // the next iteration's forward sample from the updated velocity (the same lines as the MODE 0 body above)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xz = fmaf(-vv[j].x, hz, fz[j]), xy = fmaf(-vv[j].y, hy, fh[j]), xx = fmaf(-vv[j].z, hx, fw[j]);
+        const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
+                    cx = __builtin_amdgcn_fmed3f(xx, 0.f, nx1);
+        const float bz = fminf(floorf(cz), nz1 - 1.f), by = fminf(floorf(cy), ny1 - 1.f), bx = fminf(floorf(cx), nx1 - 1.f);
+        wz[j] = cz - bz; wy[j] = cy - by; wx[j] = cx - bx;
+        const unsigned o = (unsigned)(int)bz * uHW + (unsigned)(int)by * uW + (unsigned)(int)bx;
+        p[j][0] = *reinterpret_cast<const F2u*>(d + o);
+        p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
+        p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
+        p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a00 = fmaf(wx[j], p[j][0].y - p[j][0].x, p[j][0].x), a01 = fmaf(wx[j], p[j][1].y - p[j][1].x, p[j][1].x);
+        const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
+        const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
+        if (ok[j]) ad.adv_next[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
       }
     }
   }
@@ -762,6 +793,20 @@ int nfs_advect_bwd_adam(const float* d, float* vel, const float* g_out, float* m
   return check_launch("nfs_advect_bwd_adam");
 }
 
+// ... and the NEXT iteration's forward advect of the updated velocity in the same pass (adv_next [D,H,W], see AdamFused)
+int nfs_advect_bwd_adam_fwd(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next, int D, int H,
+                            int W, float lr_t, float beta1, float beta2, float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v && adv_next, "nfs_advect_bwd_adam_fwd: null pointer");
+  NFS_REQUIRE(adv_next != d && adv_next != g_out, "nfs_advect_bwd_adam_fwd: adv_next must not alias d or g_out");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam_fwd: needs D, H, W >= 2 and D*H*W %% 4 == 0");
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next}, 0, D);
+  return check_launch("nfs_advect_bwd_adam_fwd");
+}
+
 // Slab forms (view-sharded runs shard the replicated field work over D-slabs, engine.GridStylizer): d is the whole
 // [D,H,W] density, vel / out / g_out / m / v hold the nz planes [z0, z0 + nz) only.  Same arithmetic per voxel as the
 // whole-volume entry points (the same kernel with a plane offset).
@@ -789,6 +834,21 @@ int nfs_advect_bwd_adam_slab(const float* d, float* vel, const float* g_out, flo
   hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out,
                      vel, nz, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps}, z0, D);
   return check_launch("nfs_advect_bwd_adam_slab");
+}
+
+int nfs_advect_bwd_adam_fwd_slab(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next, int D,
+                                 int H, int W, int z0, int nz, float lr_t, float beta1, float beta2, float eps,
+                                 nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v && adv_next, "nfs_advect_bwd_adam_fwd_slab: null pointer");
+  NFS_REQUIRE(adv_next != d && adv_next != g_out, "nfs_advect_bwd_adam_fwd_slab: adv_next must not alias d or g_out");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  NFS_REQUIRE(z0 >= 0 && nz >= 1 && z0 + nz <= D, "nfs_advect_bwd_adam_fwd_slab: slab outside the volume");
+  const int64_t n = (int64_t)nz * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && (int64_t)D * H * W < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam_fwd_slab: needs D, H, W >= 2 and nz*H*W %% 4 == 0");
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out,
+                     vel, nz, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next}, z0, D);
+  return check_launch("nfs_advect_bwd_adam_fwd_slab");
 }
 
 // one step of StylerBase._transport (styler_base.py:59-89) with the temporal filter's weighted accumulation fused in

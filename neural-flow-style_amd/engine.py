@@ -589,9 +589,10 @@ class TFAdamState(object):
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.adam_tf_step(x, self.m, self.v, g, float(lr_t), float(self.b1), float(self.b2), float(self.eps))
 
-    def step_through_advect(self, vel, d0, g_adv, lr):
+    def step_through_advect(self, vel, d0, g_adv, lr, adv_next=None):
         """the same update for the velocity variable of ``advect(d0, vel)`` given dL/d(advected density): the
-        velocity gradient is formed and consumed inside one kernel (never written to HBM)"""
+        velocity gradient is formed and consumed inside one kernel (never written to HBM).  ``adv_next`` [D,H,W]
+        (optional) receives advect(d0, updated vel) -- the next iteration's forward sample -- in the same pass"""
         if self.m is None or self.m.shape != vel.shape:
             self.m = torch.zeros_like(vel)
             self.v = torch.zeros_like(vel)
@@ -599,10 +600,10 @@ class TFAdamState(object):
         self.b2p = np.float32(self.b2p * self.b2)
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.advect_bwd_adam(d0, vel, g_adv, self.m, self.v, float(lr_t), float(self.b1), float(self.b2),
-                            float(self.eps))
+                            float(self.eps), adv_next=adv_next)
 
 
-    def step_through_advect_slab(self, vel_slab, d0, g_adv_slab, z0, lr):
+    def step_through_advect_slab(self, vel_slab, d0, g_adv_slab, z0, lr, adv_next=None):
         """``step_through_advect`` on the planes [z0, z0 + nz) only: the moments exist for these planes alone (the Adam
         state of a D-slab-sharded run is sharded with the variable)"""
         if self.m is None or self.m.shape != vel_slab.shape:
@@ -612,7 +613,7 @@ class TFAdamState(object):
         self.b2p = np.float32(self.b2p * self.b2)
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.advect_bwd_adam_slab(d0, vel_slab, g_adv_slab, self.m, self.v, z0, float(lr_t), float(self.b1),
-                                 float(self.b2), float(self.eps))
+                                 float(self.b2), float(self.eps), adv_next=adv_next)
 
 
 class LBFGSState(object):
@@ -729,6 +730,12 @@ class GridStylizer(object):
         self._graph_warm = 0
         self._pending = None
         self._owns_buffers = False
+        # advect(d0, var) of the NEXT iteration written by the Adam kernel of this one (ops.advect_bwd_adam(adv_next=...)):
+        # the buffer, and what it was computed from (tensor identities + torch version counters; any in-place torch op on
+        # the variable or the density, a bind() or a re-assignment makes it stale and the forward advect runs by itself)
+        self.fuse_advect = os.environ.get("NFS_FUSE_ADVECT", "1") != "0"
+        self._adv_buf = None
+        self._adv_src = None
         D, H, W = d0.shape
         if target == "v":
             self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
@@ -812,7 +819,7 @@ class GridStylizer(object):
         assert self._pending is None, "bind() is not available with the D-slab sharding (one frame per stylizer)"
         D, H, W = self.d0.shape
         if sl.z1 > sl.z0:
-            self.d_adv = ops.advect_fwd_slab(self.d0, self.var[sl.lo:sl.hi], sl.lo)
+            self.d_adv = self._advect_now()
             d_s_ext = ops.smooth3d_relu_fwd(self.d_adv, self.k)        # exact on the slab (cut planes are one further out)
             own = d_s_ext[sl.z0 - sl.lo: sl.z0 - sl.lo + (sl.z1 - sl.z0)]
             if sl.z1 - sl.z0 == sl.cs:
@@ -843,8 +850,11 @@ class GridStylizer(object):
             # chunk planes = global [z0 - 2, z0 + cs + 2); the same planes of the padded smoothed density
             g_adv = ops.smooth3d_relu_bwd(sl.ds_full[sl.z0:sl.z0 + sl.cs + 4], sl.recv[:sl.cs + 4], self.k)
             off = sl.lo - (sl.z0 - 2)
+            adv = self._adv_target()
             self.adam.step_through_advect_slab(self.var[sl.lo:sl.hi], self.d0, g_adv[off:off + (sl.hi - sl.lo)], sl.lo,
-                                               self.lr)
+                                               self.lr, adv_next=adv)
+            if adv is not None:
+                self._adv_mark()
         else:
             self.adam.b1p = np.float32(self.adam.b1p * self.adam.b1)      # (an idle rank keeps the step count)
             self.adam.b2p = np.float32(self.adam.b2p * self.adam.b2)
@@ -877,12 +887,47 @@ class GridStylizer(object):
             if var is not None:
                 self.var = var
 
+    # ---- the forward advect of iteration i + 1 rides in the Adam kernel of iteration i ---------------------------------------
+    def _adv_target(self):
+        """the buffer the fused Adam kernel writes the next forward sample into (None: fusion off / not applicable)"""
+        if not (self.fuse_advect and self.fuse_adam and self.target == "v"):
+            return None
+        sl = self.slab
+        shape = tuple(self.d0.shape) if sl is None else (sl.hi - sl.lo,) + tuple(self.d0.shape[1:])
+        if self._adv_buf is None or tuple(self._adv_buf.shape) != shape:
+            self._adv_buf = torch.empty(shape, dtype=torch.float32, device=self.d0.device)
+            self._adv_src = None
+        return self._adv_buf
+
+    def _adv_mark(self):
+        self._adv_src = (self.var, self.var._version, self.d0, self.d0._version)
+
+    def _adv_valid(self):
+        a = self._adv_src
+        return (a is not None and self._adv_buf is not None and a[0] is self.var and a[1] == self.var._version
+                and a[2] is self.d0 and a[3] == self.d0._version)
+
+    def _advect_now(self):
+        """d_adv = advect(d0, var) -- from the previous step's Adam kernel when it is still current, else computed here
+        (into the same buffer: a captured graph reads it by address)"""
+        sl = self.slab
+        buf = self._adv_target()
+        if buf is not None and self._adv_valid():
+            return buf
+        if sl is None:
+            out = ops.advect_fwd(self.d0.unsqueeze(-1), self.var, out=None if buf is None else buf.unsqueeze(-1)).squeeze(-1)
+        else:
+            out = ops.advect_fwd_slab(self.d0, self.var[sl.lo:sl.hi], sl.lo, out=buf)
+        if buf is not None:
+            self._adv_mark()
+        return out
+
     def forward_field(self):
         if self.slab is not None:
             return self._forward_field_slab()
         self._apply_binding()
         if self.target == "v":
-            self.d_adv = ops.advect_fwd(self.d0.unsqueeze(-1), self.var).squeeze(-1)
+            self.d_adv = self._advect_now()
         else:
             self.d_adv = self.var
         self.d_s = ops.smooth3d_relu_fwd(self.d_adv, self.k)
@@ -933,7 +978,12 @@ class GridStylizer(object):
         when any of that changes the graph is dropped and captured again.  The view matrices are copied into a
         static buffer."""
         body = self.field_gradient if with_field else (lambda r: self._loss_gradient(self.d_s, r))
-        key = self._capture_key(rot_local) + (with_field,)
+        if with_field and self.target == "v" and self._adv_target() is not None:
+            # the captured forward starts from the advected density in its fixed buffer: bring it up to date eagerly when
+            # the previous step's Adam kernel has not left it there (first step, a re-bound frame, a variable set by hand)
+            self._apply_binding()
+            self._advect_now()
+        key = self._capture_key(rot_local) + (with_field, self._adv_target() is not None)
         if self._graph is not None and key != self._graph_key:
             self._graph = None
             self._graph_warm = 0
@@ -1005,7 +1055,10 @@ class GridStylizer(object):
         D, H, W = self.d0.shape
         if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
-            self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr)
+            adv = self._adv_target()
+            self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr, adv_next=adv)
+            if adv is not None:
+                self._adv_mark()
         else:
             self.adam.step(self.var, self.variable_gradient(g_ds), self.lr)
         return total

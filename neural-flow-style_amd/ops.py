@@ -118,12 +118,18 @@ def advect_bwd(d, vel, g_out, need_d=True, need_vel=True, g_d_acc=None, g_vel=No
     return g_d_acc, g_vel
 
 
-def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
-    """velocity gradient of advect consumed on the spot by the TF-Adam update of vel (vel, m, v in place)"""
+def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None):
+    """velocity gradient of advect consumed on the spot by the TF-Adam update of vel (vel, m, v in place);
+    ``adv_next`` [D,H,W] (optional): advect(d, updated vel), the next iteration's forward sample, written in the same pass"""
     D, H, W, Cn = d.shape
     assert Cn == 1
-    _lib.call("nfs_advect_bwd_adam", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), D, H, W, float(lr_t),
-              float(beta1), float(beta2), float(eps), _stream())
+    if adv_next is None:
+        _lib.call("nfs_advect_bwd_adam", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), D, H, W, float(lr_t),
+                  float(beta1), float(beta2), float(eps), _stream())
+    else:
+        assert adv_next.is_contiguous() and adv_next.numel() == D * H * W
+        _lib.call("nfs_advect_bwd_adam_fwd", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), _ptr(adv_next), D, H, W,
+                  float(lr_t), float(beta1), float(beta2), float(eps), _stream())
 
 
 def advect_fwd_slab(d, vel_slab, z0, out=None):
@@ -136,13 +142,18 @@ def advect_fwd_slab(d, vel_slab, z0, out=None):
     return out
 
 
-def advect_bwd_adam_slab(d, vel_slab, g_slab, m_slab, v_slab, z0, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+def advect_bwd_adam_slab(d, vel_slab, g_slab, m_slab, v_slab, z0, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None):
     """advect_bwd_adam on the planes [z0, z0 + nz) only (vel_slab, m_slab, v_slab [nz,H,W,3] in place, g_slab [nz,H,W]);
-    d is the whole density [D,H,W]"""
+    d is the whole density [D,H,W]; ``adv_next`` [nz,H,W] (optional) as in advect_bwd_adam"""
     D, H, W = d.shape
     nz = vel_slab.shape[0]
-    _lib.call("nfs_advect_bwd_adam_slab", _ptr(d), _ptr(vel_slab), _ptr(g_slab), _ptr(m_slab), _ptr(v_slab), D, H, W,
-              int(z0), nz, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+    if adv_next is None:
+        _lib.call("nfs_advect_bwd_adam_slab", _ptr(d), _ptr(vel_slab), _ptr(g_slab), _ptr(m_slab), _ptr(v_slab), D, H, W,
+                  int(z0), nz, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+    else:
+        assert adv_next.is_contiguous() and adv_next.numel() == nz * H * W
+        _lib.call("nfs_advect_bwd_adam_fwd_slab", _ptr(d), _ptr(vel_slab), _ptr(g_slab), _ptr(m_slab), _ptr(v_slab),
+                  _ptr(adv_next), D, H, W, int(z0), nz, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
 
 
 def warp2d_fwd(imgs, coords):

@@ -143,6 +143,40 @@ def test_fused_advect_adam_equals_separate_kernels():
 
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_next_forward_advect_inside_the_adam_kernel_is_bit_identical(graph):
+    """The Adam kernel of iteration i also writes advect(d0, updated velocity), iteration i + 1's forward sample
+    (nfs_advect_bwd_adam_fwd): same trajectory, bit for bit, as running the forward advect by itself (NFS_FUSE_ADVECT=0
+    semantics); a variable changed by hand, a re-bound frame or a changed density make the stored sample stale."""
+    layers = ["conv1_1", "conv2_1"]
+    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, 2, layers)
+    rot = T.rot_to_device(mats, "cuda")
+    out = []
+    for fuse in (True, False):
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3, graph=graph)
+        gs.fuse_advect = fuse
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(4)]
+        assert (gs._adv_buf is not None and gs._adv_valid()) == fuse
+        if fuse:    # the stored sample IS the forward advect of the current variable
+            assert torch.equal(gs._adv_buf, ops_mod().advect_fwd(gs.d0.unsqueeze(-1), gs.var).squeeze(-1))
+        gs.var.mul_(0.5)                                            # by hand: the stored sample is stale now
+        assert not gs._adv_valid()
+        ls += [float(gs.step(rot)) for _ in range(2)]
+        gs.d0.mul_(0.9)                                             # the density it gathers from changed
+        assert not gs._adv_valid()
+        ls += [float(gs.step(rot)) for _ in range(2)]
+        out.append((ls, gs.var.clone(), gs.adam.m.clone(), gs.adam.v.clone(), gs.d_s.clone()))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert torch.equal(a, b)
+
+
+def ops_mod():
+    import neural_flow_style_amd.ops as o
+    return o
+
+
 def test_graph_replay_equals_eager_steps():
     """GridStylizer(graph=True): forward + adjoint replayed as one hipGraph (eager warm-up step, capture, replays)
     follows the eager trajectory; a different view tensor is copied into the captured buffer."""
