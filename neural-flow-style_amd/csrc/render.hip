@@ -623,6 +623,37 @@ __global__ void __launch_bounds__(256) maxnorm_input_kernel(const float* __restr
   }
 }
 
+// large groups, ONE launch: every one of the MN_NB blocks of a group first takes the maximum of the WHOLE group (n floats
+// from L2: 160 KB at 200 x 200 -- the maximum does not depend on the order it is taken in, so all blocks hold the same
+// value), then does its share of the pass.  Replaces -inf fill + atomic-max kernel + pass (three launches of ~5 us each on
+// the latency floor) by one; same arithmetic per pixel, bit-identical x and gmax.
+__global__ void __launch_bounds__(256) maxnorm_input_allmax_kernel(const float* __restrict__ img, float* __restrict__ gmax,
+                                                                   float* __restrict__ xo, int n) {
+  __shared__ float red[16];
+  const float* x = img + (int64_t)blockIdx.y * n;
+  float* o = xo + (int64_t)blockIdx.y * n * 3;
+  float m = -INFINITY;
+  const int n4 = n >> 2;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = x4[i];
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
+  }
+  m = block_max(m, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) gmax[blockIdx.y] = m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = __fmul_rn(x[i] / m, 255.f);        // (rounded like the stored intermediate of the two-step form)
+    o[3 * (int64_t)i] = __fsub_rn(v, kInputMean[0]);
+    o[3 * (int64_t)i + 1] = __fsub_rn(v, kInputMean[1]);
+    o[3 * (int64_t)i + 2] = __fsub_rn(v, kInputMean[2]);
+  }
+}
+
 // small groups (< 16384 pixels): one block per group does the maximum and the pass (no memset, no atomics)
 __global__ void __launch_bounds__(1024) maxnorm_input_small_kernel(const float* __restrict__ img, float* __restrict__ gmax,
                                                                    float* __restrict__ xo, int n) {
@@ -881,6 +912,11 @@ int nfs_maxnorm_input_fwd(const float* img, float* x, float* gmax, int G, int n,
   if (n < 16384) {
     hipLaunchKernelGGL(maxnorm_input_small_kernel, dim3(G), dim3(1024), 0, as_stream(stream), img, gmax, x, n);
     return check_launch("nfs_maxnorm_input_fwd");
+  }
+  static const bool three = [] { const char* e = getenv("NFS_MAXNORM_3K"); return e && atoi(e) != 0; }();
+  if (!three && (int64_t)n <= (1 << 20)) {        // (beyond 1 M pixels per group the redundant maxima stop being free)
+    hipLaunchKernelGGL(maxnorm_input_allmax_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, x, n);
+    return check_launch("nfs_maxnorm_input_fwd(one launch)");
   }
   hipLaunchKernelGGL(maxnorm_init_kernel, dim3((G + 63) / 64), dim3(64), 0, as_stream(stream), gmax, G);
   hipLaunchKernelGGL(maxnorm_max_kernel, dim3(MN_NB, G), dim3(256), 0, as_stream(stream), img, gmax, n);

@@ -1001,8 +1001,13 @@ class GridStylizer(object):
                 torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
             self._graph = g
             self._graph_key = key
+            self._graph_rot_src = (rot_local, rot_local._version)
         elif rot_local.data_ptr() != self._graph_rot.data_ptr():
-            self._graph_rot.copy_(rot_local)
+            # (the same tensor object, not modified in place since it was copied: nothing to copy -- a launch per step)
+            src = getattr(self, "_graph_rot_src", None)
+            if src is None or src[0] is not rot_local or src[1] != rot_local._version:
+                self._graph_rot.copy_(rot_local)
+                self._graph_rot_src = (rot_local, rot_local._version)
         self._graph.replay()
         return self._loss_slot, self.g_ds
 

@@ -90,7 +90,12 @@ def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True, g_max=None, overwrite=False
     """g_max: optional device scalar max|g_out| (render_bwd(..., want_max=True)): skips the pre-pass.
     overwrite (tiled adjoint, C == 1): g_d_acc is written, not accumulated into (no zero fill needed)"""
     V, D, H, W, Cn = g_out.shape
-    ws = workspace(g_out.device) if (tiled and Cn == 1) else None
+    if tiled and Cn == 1:
+        # the scratch word holds the pre-pass maximum: with g_max given it is not touched (inside a capture workspace() is a
+        # fresh zero-filled tensor, i.e. a fill launch in every replay: not needed here)
+        ws = _empty((64,), g_out) if (g_max is not None and torch.cuda.is_current_stream_capturing()) else workspace(g_out.device)
+    else:
+        ws = None
     if g_d_acc is None:
         overwrite = ws is not None                 # a fresh buffer: let the kernel write every voxel
         g_d_acc = _empty((D, H, W, Cn), g_out) if overwrite else _zeros((D, H, W, Cn), g_out)

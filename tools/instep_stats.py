@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-step per-kernel statistics from a rocprofv3 kernel trace of ``bench.py``: only the launches between the first
-advect launch of the first stylisation step and the end of the last step are counted (set-up work -- weight packing, the
+forward-smoothing launch of the first timed stylisation step and the end of the last step are counted (set-up work -- weight packing, the
 style-target pass at B = 1, the parity case -- is excluded), so that `avg_us` of the dominant kernel is the figure
 `roofline.avg_launch_us` must agree with.
 
@@ -20,8 +20,8 @@ def main():
         name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", ""))
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
-    # one advect forward launch opens every step (GridStylizer.forward_field)
-    starts = [i for i, r in enumerate(rows) if "advect1_kernel<0>" in r[2]]
+    # the forward smoothing launch opens every step (GridStylizer.forward_field; the forward advect rides in the previous step's Adam kernel since round 4)
+    starts = [i for i, r in enumerate(rows) if ("smooth3d_kernel<false>" in r[2])]
     if len(starts) < steps:
         raise SystemExit("found %d step starts, expected >= %d" % (len(starts), steps))
     first = starts[-steps]

@@ -7,7 +7,7 @@ import bench
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 gs, rot, base = bench.build_problem(200, 8, torch.device("cuda:0"), 0, 1)
-gs.use_graph = False
+gs.use_graph = (os.environ.get("ONE_VIEW_GRAPH", "0") == "1")
 rot = rot[:views].contiguous()
 for _ in range(n):
     gs.step(rot)
