@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnfs_hip.so")
+# NFS_LIB_PATH: load another build of the same library (measurement builds made with -DNFS_ABLATE; never the product)
+LIB_PATH = os.environ.get("NFS_LIB_PATH") or os.path.join(_HERE, "libnfs_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 
