@@ -522,18 +522,37 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
                                                                          float* __restrict__ g_d,
                                                                          const unsigned* __restrict__ gmax_bits,
                                                                          float bound_factor, int V, int D, int H,
-                                                                         int W, int tiles_y, int tiles_x, int overwrite) {
+                                                                         int W, int tiles_y, int tiles_x, int overwrite,
+                                                                         int order) {
   __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
   __shared__ ViewRows vrows[RT_VMAX];
   const int t = threadIdx.x;
-  // launch order: x-border tiles first, then z-border, then the interior (border tiles also collect the
-  // clamped out-of-volume samples and run longest; starting them first keeps them off the tail)
-  const int tiles_z = gridDim.x / (tiles_x * tiles_y);
-  const int by = blockIdx.x % tiles_y;
-  const int oz_ = (blockIdx.x / tiles_y) % tiles_z;
-  const int ox_ = blockIdx.x / (tiles_y * tiles_z);
-  const int bz = oz_ == 0 ? 0 : (oz_ == 1 ? tiles_z - 1 : oz_ - 1);
-  const int bx = ox_ == 0 ? 0 : (ox_ == 1 ? tiles_x - 1 : ox_ - 1);
+  // Which tile a block takes.  order 0 (round 1-3): x-border tiles first, then z-border, then the interior (border tiles
+  // also collect the clamped out-of-volume samples and run longest; starting them first keeps them off the tail), dealt
+  // round-robin to the XCDs by the hardware -- neighbouring tiles, whose catchments overlap by a third, then sit on
+  // different L2s and every XCD fetches its own copy of the shared rows (PMC: 608 MB fetched for 320 MB algorithmic).
+  // order 1 / 2 (NFS_RT_XCD; measured in round 4, tools/rot_xcd_ab.sh, NOT the default): every XCD owns a contiguous range
+  // of (z, y) tile columns (1: z-major, 2: y-major) with all their x tiles, x-border tiles first inside the XCD, so that
+  // shared catchment rows are L2 hits: FETCH_SIZE 340 -> 308 / 290 MB (raw counter) but 0.297 -> 0.308 ms -- the kernel is
+  // bound by its VALU + LDS-atomic stream, not by the fetch, and the round-robin deal balances the slow border tiles better.
+  int bz, by, bx;
+  if (order == 0) {
+    const int tiles_z = gridDim.x / (tiles_x * tiles_y);
+    by = blockIdx.x % tiles_y;
+    const int oz_ = (blockIdx.x / tiles_y) % tiles_z;
+    const int ox_ = blockIdx.x / (tiles_y * tiles_z);
+    bz = oz_ == 0 ? 0 : (oz_ == 1 ? tiles_z - 1 : oz_ - 1);
+    bx = ox_ == 0 ? 0 : (ox_ == 1 ? tiles_x - 1 : ox_ - 1);
+  } else {
+    const int tiles_z = (D + RT_TZ - 1) / RT_TZ;
+    const int cols = tiles_z * tiles_y, cpx = (cols + 7) / 8;
+    const int xcd = blockIdx.x % 8, i = blockIdx.x / 8;
+    const int c0 = xcd * cpx, nc = min(cpx, cols - c0);
+    if (nc <= 0 || i >= nc * tiles_x) return;
+    const int ox_ = i / nc, col = c0 + i % nc;
+    bx = ox_ == 0 ? 0 : (ox_ == 1 ? tiles_x - 1 : ox_ - 1);
+    if (order == 1) { bz = col / tiles_y; by = col % tiles_y; } else { by = col / tiles_z; bz = col % tiles_z; }
+  }
   const int z0 = bz * RT_TZ, y0 = by * RT_TY, x0 = bx * RT_TX;
   const int z1 = min(z0 + RT_TZ, D) - 1, y1 = min(y0 + RT_TY, H) - 1, x1 = min(x0 + RT_TX, W) - 1;  // inclusive
   for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
@@ -732,11 +751,13 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
     // clamped samples per face direction; 4*nmax per view is a safe bound on the summed weights
     const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
     const float bound_factor = 4.f * (float)nmax * (float)V + 8.f;
+    static const int order = [] { const char* e = getenv("NFS_RT_XCD"); return e ? atoi(e) : 0; }();
+    const int grid = order == 0 ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
     for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
       const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
-      hipLaunchKernelGGL(rotate_bwd_tiled_kernel, dim3(tz * ty * tx), dim3(RT_THREADS), 0, as_stream(stream),
+      hipLaunchKernelGGL(rotate_bwd_tiled_kernel, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                          g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
-                         ty, tx, (overwrite && v0 == 0) ? 1 : 0);
+                         ty, tx, (overwrite && v0 == 0) ? 1 : 0, order);
     }
     return check_launch("nfs_rotate_bwd(tiled)");
   }
