@@ -69,6 +69,40 @@ __device__ __forceinline__ int64_t cell_index(const SplatDev& s, const int* c) {
   return lin;
 }
 
+
+// The (2 nsize + 1)^nd neighbourhood of a particle with compile-time extents: the per-axis offsets r - n cell and their
+// squares are formed once (3 x SP values instead of 3 per cell), the loops unroll, no integer division (the generic
+// loops below spend ~120 instructions per cell on o / span, o % span with a run-time span).  f(i0, i1, i2, d2) with
+// i_k = n_k + NS in [0, SP); rr[k][i_k] = r_k - n_k cell.
+template <int ND, int NS>
+struct Hood {
+  static constexpr int SP = 2 * NS + 1;
+  float rr[3][SP];
+  __device__ __forceinline__ void init(const SplatDev& s, const Particle& P) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < SP; ++i) rr[k][i] = k < ND ? P.r[k] - (float)(i - NS) * s.cell : 0.f;
+  }
+  template <class F>
+  __device__ __forceinline__ void each(F&& f) const {
+#pragma unroll
+    for (int i0 = 0; i0 < SP; ++i0) {
+      const float q0 = rr[0][i0] * rr[0][i0];
+#pragma unroll
+      for (int i1 = 0; i1 < SP; ++i1) {
+        const float q01 = q0 + rr[1][i1] * rr[1][i1];
+        if (ND == 2) {
+          f(i0, i1, NS, q01);
+        } else {
+#pragma unroll
+          for (int i2 = 0; i2 < SP; ++i2) f(i0, i1, i2, q01 + rr[2][i2] * rr[2][i2]);
+        }
+      }
+    }
+  }
+};
+
 __global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* __restrict__ p,
                                                       const float* __restrict__ attr, const float* __restrict__ pd,
                                                       float* __restrict__ grid, float* __restrict__ wsum, int N,
@@ -109,34 +143,137 @@ __global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* _
 // The same scatter with the block's cells privatised in LDS.  Particles arrive in the order of the grid (Styler.run
 // sorts them once per sequence, by 8-cell bricks), so the own cells of a block's 256 particles sit in a small box
 // [lo, hi] per axis -- and stay in one while a Lagrangian run moves them by a few cells.  When the box, widened by
-// nsize, fits 48 KB the block accumulates into LDS (ds_add_f32: neighbouring particles share 18 of their 27 cells) and
+// nsize, fits the LDS accumulators the block accumulates there (neighbouring particles share 18 of their 27 cells) and
 // flushes each touched cell ONCE with a global atomic; otherwise (unsorted or very sparse particles: decided per block
 // from a min / max reduction of the cell coordinates) it falls back to the per-cell global atomics above.  Same
 // arithmetic per contribution.
-constexpr int SPL_LDS = 12288;     // floats of LDS accumulators
+//
+// Round 4: the LDS accumulators are 64-bit FIXED POINT, as in the rotate adjoint (warp.hip): on gfx950 ds_add_f32
+// sustains 0.33 lanes/clk/CU where ds_add_u64 runs at 9.4 (tools/lds_atomic_bench.hip) -- the 13.5 M float atomics of
+// 5e5 particles were 1/3 of this kernel.  Every block scales by its own power of two, chosen from the largest
+// |contribution| its particles can make (kernel maximum sigma x coefficient x largest |attribute|) times the
+// particles per block, so that no cell sum can overflow 2^62; > 40 bits stay below the largest contribution (more than
+// float accumulation keeps), and the integer sums do not depend on the order of the adds.
+constexpr int SPL_LDS = 8192;      // 64-bit LDS accumulators (64 KB: two blocks per CU)
 
-template <int SPL_PB>              // particles per block
+__device__ __forceinline__ unsigned long long splat_fix64(float c) {     // c = contribution * 2^(k - 32), |c| < 2^31
+  unsigned hi, lo;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi) : "v"(c));
+  const float fr = __builtin_amdgcn_fractf(c) * 4294967296.f;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(lo) : "v"(fr));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One particle per thread, 256 per block.  A block whose box does not fit (15 % of the blocks of the 5e5-particle set:
+// a block that straddles the end of a brick row, or sparse bricks far apart) sends its contributions to the grid with
+// global atomics.  Measured in round 4 and removed (tools/splat_phase_bench.py on an ablation build): peeling such a
+// block into groups that fit (first remaining particle's brick row, up to four bricks along the last axis; zero,
+// accumulate, flush, repeat) -- 171 us against 116: every extra pass costs its own box reduction, LDS clear and flush
+// (the flush runs at the global-atomic rate, ~85 G/s), more than the 29 us the scattered atomics of those blocks take.
+// Where the 116 us go: block skeleton (reductions, LDS clear, barriers) ~40, accumulation ~45 (neighbouring lanes hold
+// particles of the same cell: same-address LDS atomics serialise), flush ~35, fallback blocks ~29.
+template <int ND, int NS>          // (ND, NS) = (nd, nsize) known at compile time, or ND = 0: generic loops
 __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const float* __restrict__ p,
                                                           const float* __restrict__ attr, const float* __restrict__ pd,
                                                           float* __restrict__ grid, float* __restrict__ wsum, int N,
                                                           int C, int allow_lds) {
-  extern __shared__ float acc[];
-  __shared__ int red[6 * 4];
+  extern __shared__ unsigned long long acc[];
+  __shared__ int red[8 * 4];
   const int t = threadIdx.x;
-  const int64_t a0 = (int64_t)blockIdx.x * SPL_PB;
-  Particle P[SPL_PB / 256];
-  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-#pragma unroll
-  for (int j = 0; j < SPL_PB / 256; ++j) {
-    const int64_t a = a0 + t + 256 * j;
-    P[j].valid = false;
-    if (a < N) {
-      P[j] = load_particle(s, p, a);
-      if (P[j].valid)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], P[j].idx[k]); hi[k] = max(hi[k], P[j].idx[k]); }
+  const int64_t a = (int64_t)blockIdx.x * 256 + t;
+  Particle P;
+  P.valid = false;
+  float coef = 1.f, at[4] = {0.f, 0.f, 0.f, 0.f}, cmax = 0.f;
+  if (a < N) {
+    P = load_particle(s, p, a);
+    if (P.valid) {
+      if (s.mode == 0) coef = s.mass;
+      if (s.mode == 1) coef = s.mass / (pd ? pd[a] : s.rest_density);
+      float am = 1.f;
+      if (s.mode != 0) {
+        am = s.mode == 2 ? 1.f : 0.f;                   // (mode 2 also accumulates the bare weights)
+        for (int ch = 0; ch < C; ++ch) { at[ch] = attr[a * C + ch]; am = fmaxf(am, fabsf(at[ch])); }
+      }
+      cmax = fabsf(coef) * am;                          // largest |coefficient x attribute| of this particle
     }
   }
+  const int nch = s.mode == 0 ? 1 : (s.mode == 2 ? C + 1 : C);
+  const float h2 = s.h * s.h, inv_h = 1.f / s.h;
+  // one contribution of this thread's particle to cell c / LDS slot dst
+  auto weight = [&](float d2) {
+    // q = |r| / h as d2 * rsq(d2) * (1 / h): one v_rsq_f32 instead of a correctly rounded square root and a division
+    // (~20 instructions per cell; 1-2 ulp in q, far inside the parity tolerance)
+    return cubic_w(d2 > 0.f ? d2 * __frsqrt_rn(d2) * inv_h : 0.f, s.sigma);
+  };
+  auto to_global = [&](const int* c, float w) {
+    const int64_t ci = cell_index(s, c);
+    if (ci < 0) return;
+    if (s.mode == 0) {
+      atomicAdd(grid + ci, coef * w);
+    } else {
+      for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * at[ch]);
+      if (s.mode == 2) atomicAdd(wsum + ci, w);
+    }
+  };
+  // the whole neighbourhood of the particle through global atomics
+  auto all_global = [&]() {
+    if (ND > 0) {
+      constexpr int NDc = ND > 0 ? ND : 3, NSc = ND > 0 ? NS : 1;
+      Hood<NDc, NSc> hd;
+      hd.init(s, P);
+      hd.each([&](int i0, int i1, int i2, float d2) {
+        if (d2 > h2) return;
+        const float w = weight(d2);
+        if (w == 0.f) return;
+        const int c[3] = {P.idx[0] + i0 - NSc, P.idx[1] + i1 - NSc, NDc > 2 ? P.idx[2] + i2 - NSc : 0};
+        to_global(c, w);
+      });
+    } else {
+      const int span = 2 * s.nsize + 1;
+      const int total = s.nd == 2 ? span * span : span * span * span;
+      for (int o = 0; o < total; ++o) {
+        int n[3] = {0, 0, 0};
+        if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
+        else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
+        float d2 = 0.f;
+        int c[3] = {0, 0, 0};
+        for (int k = 0; k < s.nd; ++k) {
+          const float rr = P.r[k] - (float)n[k] * s.cell;
+          d2 += rr * rr;
+          c[k] = P.idx[k] + n[k];
+        }
+        const float w = cubic_w(sqrtf(d2) / s.h, s.sigma);
+        if (w != 0.f) to_global(c, w);
+      }
+    }
+  };
+  // block-wide maximum of cmax -> fixed-point scale 2^kexp: |any cell sum| <= 256 sigma cmax < 2^ebound stays below 2^62
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+  if ((t & 63) == 0) red[7 * 4 + (t >> 6)] = __float_as_int(cmax);
+  __syncthreads();
+  cmax = fmaxf(fmaxf(__int_as_float(red[28]), __int_as_float(red[29])), fmaxf(__int_as_float(red[30]), __int_as_float(red[31])));
+  const float bound = 256.f * s.sigma * cmax;
+  const bool scalable = bound > 0.f && bound < 3.0e38f;       // (inf / nan attributes: the float path reproduces them)
+  int kexp = 0;
+  float fs = 1.f, fs2 = 1.f;
+  if (scalable) {
+    int ebound;
+    frexpf(bound, &ebound);
+    kexp = 62 - ebound;
+    const int ks = kexp - 32, k1 = min(max(ks, -120), 120);
+    fs = ldexpf(1.f, k1);
+    fs2 = ldexpf(1.f, ks - k1);                               // (2^ks may exceed the float range: two factors)
+  }
+  if (!(allow_lds && scalable && ND > 0)) {                   // generic neighbourhoods / unscalable values: global atomics
+    if (P.valid) all_global();
+    return;
+  }
+  constexpr int NDc = ND > 0 ? ND : 3, NSc = ND > 0 ? NS : 1;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  if (P.valid)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = P.idx[k]; hi[k] = P.idx[k]; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -156,69 +293,52 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
     const int* r1 = red + (2 * k + 1) * 4;
     lo[k] = min(min(r0[0], r0[1]), min(r0[2], r0[3]));
     hi[k] = max(max(r1[0], r1[1]), max(r1[2], r1[3]));
-    if (k < s.nd) {
+    if (k < NDc) {
       any = any && hi[k] >= lo[k];
-      lo[k] = max(lo[k] - s.nsize, 0);
-      hi[k] = min(hi[k] + s.nsize, s.res[k] - 1);
+      lo[k] = max(lo[k] - NSc, 0);
+      hi[k] = min(hi[k] + NSc, s.res[k] - 1);
       ext[k] = hi[k] - lo[k] + 1;
       vol *= ext[k] > 0 ? ext[k] : 1;
     } else {
       lo[k] = 0; hi[k] = 0;
     }
   }
-  const int nch = s.mode == 0 ? 1 : (s.mode == 2 ? C + 1 : C);
-  const bool use_lds = allow_lds && any && vol * nch <= SPL_LDS;
+  if (!any) return;                                           // no live particle in the block
+  if (vol * nch > SPL_LDS) {
+    if (P.valid) all_global();
+    return;
+  }
   const int nvol = (int)vol;
-  if (use_lds) {
-    for (int i = t; i < nvol * nch; i += 256) acc[i] = 0.f;
-    __syncthreads();
-  }
-  const int span = 2 * s.nsize + 1;
-  const int total = s.nd == 2 ? span * span : span * span * span;
+  for (int i = t; i < nvol * nch; i += 256) acc[i] = 0ull;
+  __syncthreads();
+  if (P.valid) {
+    Hood<NDc, NSc> hd;
+    hd.init(s, P);
+    constexpr int SP = 2 * NSc + 1;
+    int off[3][SP];                  // address term of the cell along each axis, or -1 outside the grid
 #pragma unroll
-  for (int j = 0; j < SPL_PB / 256; ++j) {
-    if (!P[j].valid) continue;
-    const int64_t a = a0 + t + 256 * j;
-    float coef = 1.f;
-    if (s.mode == 0) coef = s.mass;
-    if (s.mode == 1) coef = s.mass / (pd ? pd[a] : s.rest_density);
-    for (int o = 0; o < total; ++o) {
-      int n[3] = {0, 0, 0};
-      if (s.nd == 2) { n[0] = o / span - s.nsize; n[1] = o % span - s.nsize; }
-      else { n[0] = o / (span * span) - s.nsize; n[1] = (o / span) % span - s.nsize; n[2] = o % span - s.nsize; }
-      float d2 = 0.f;
-      int c[3] = {0, 0, 0};
-      for (int k = 0; k < s.nd; ++k) {
-        const float rr = P[j].r[k] - (float)n[k] * s.cell;
-        d2 += rr * rr;
-        c[k] = P[j].idx[k] + n[k];
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < SP; ++i) {
+        const int c = P.idx[k] + i - NSc;
+        const bool in = k < NDc && c >= lo[k] && c <= hi[k];        // (the box is clipped to the grid)
+        const int stride = k == 0 ? ext[1] * ext[2] : (k == 1 ? ext[2] : 1);
+        off[k][i] = in ? (c - lo[k]) * stride : (k < NDc ? -1 : 0);
       }
-      const float w = cubic_w(sqrtf(d2) / s.h, s.sigma);
-      if (w == 0.f) continue;
-      if (use_lds) {
-        bool in = true;
-        for (int k = 0; k < s.nd; ++k) in = in && c[k] >= lo[k] && c[k] <= hi[k];   // (the box is clipped to the grid)
-        if (!in) continue;
-        float* dst = acc + (((c[0] - lo[0]) * ext[1] + (c[1] - lo[1])) * ext[2] + (c[2] - lo[2])) * nch;
-        if (s.mode == 0) {
-          atomicAdd(dst, coef * w);
-        } else {
-          for (int ch = 0; ch < C; ++ch) atomicAdd(dst + ch, coef * w * attr[a * C + ch]);
-          if (s.mode == 2) atomicAdd(dst + C, w);
-        }
-        continue;
-      }
-      const int64_t ci = cell_index(s, c);
-      if (ci < 0) continue;
+    hd.each([&](int i0, int i1, int i2, float d2) {
+      if (d2 > h2) return;
+      if ((off[0][i0] | off[1][i1] | off[2][i2]) < 0) return;
+      const float w = weight(d2);
+      if (w == 0.f) return;
+      unsigned long long* dst = acc + (off[0][i0] + off[1][i1] + off[2][i2]) * nch;
       if (s.mode == 0) {
-        atomicAdd(grid + ci, coef * w);
+        atomicAdd(dst, splat_fix64(coef * w * fs * fs2));
       } else {
-        for (int ch = 0; ch < C; ++ch) atomicAdd(grid + ci * C + ch, coef * w * attr[a * C + ch]);
-        if (s.mode == 2) atomicAdd(wsum + ci, w);
+        for (int ch = 0; ch < C; ++ch) atomicAdd(dst + ch, splat_fix64(coef * w * at[ch] * fs * fs2));
+        if (s.mode == 2) atomicAdd(dst + C, splat_fix64(w * fs * fs2));
       }
-    }
+    });
   }
-  if (!use_lds) return;
   __syncthreads();
   for (int i = t; i < nvol; i += 256) {
     int c[3];
@@ -226,18 +346,20 @@ __global__ void __launch_bounds__(256) p2g_fwd_lds_kernel(SplatDev s, const floa
     const int r = i / ext[2];
     c[1] = lo[1] + r % ext[1];
     c[0] = lo[0] + r / ext[1];
-    const float* src = acc + (int64_t)i * nch;
+    const unsigned long long* src = acc + (int64_t)i * nch;
     bool nz = false;
-    for (int ch = 0; ch < nch; ++ch) nz = nz || src[ch] != 0.f;
+    for (int ch = 0; ch < nch; ++ch) nz = nz || src[ch] != 0ull;
     if (!nz) continue;
     const int64_t cell = cell_index(s, c);
+#define NFS_SPL_F(q_) ((float)ldexp((double)(long long)(q_), -kexp))
     if (s.mode == 0) {
-      atomicAdd(grid + cell, src[0]);
+      atomicAdd(grid + cell, NFS_SPL_F(src[0]));
     } else {
       for (int ch = 0; ch < C; ++ch)
-        if (src[ch] != 0.f) atomicAdd(grid + cell * C + ch, src[ch]);
-      if (s.mode == 2 && src[C] != 0.f) atomicAdd(wsum + cell, src[C]);
+        if (src[ch] != 0ull) atomicAdd(grid + cell * C + ch, NFS_SPL_F(src[ch]));
+      if (s.mode == 2 && src[C] != 0ull) atomicAdd(wsum + cell, NFS_SPL_F(src[C]));
     }
+#undef NFS_SPL_F
   }
 }
 
@@ -300,6 +422,158 @@ __global__ void __launch_bounds__(256) p2g_bwd_kernel(SplatDev s, const float* _
   }
   if (g_p)
     for (int k = 0; k < s.nd; ++k) g_p[a * s.nd + k] = P.grad_ok[k] ? gp[k] * s.dom[k] : 0.f;
+  if (g_attr)
+    for (int ch = 0; ch < C; ++ch) g_attr[a * C + ch] = ga[ch];
+  if (g_pd) g_pd[a] = gpd;
+}
+
+// The adjoint with compile-time neighbourhoods and the block's box of the grid gradient staged in LDS: the 256 particles
+// of a block (grid order) read the same ~1000 cells 27 times between them -- one coalesced pass brings them in, the
+// gathers are LDS reads.  Same per-cell arithmetic and the same order of the sums as p2g_bwd_kernel (cells in the
+// order of the generic loop: axis 0 outermost), so the two agree bit for bit; a block whose box does not fit falls
+// back to global gathers.
+constexpr int SPB_LDS = 12288;     // floats of staged gradient (48 KB)
+
+template <int ND, int NS>
+__global__ void __launch_bounds__(256) p2g_bwd_box_kernel(SplatDev s, const float* __restrict__ p,
+                                                          const float* __restrict__ attr, const float* __restrict__ pd,
+                                                          const float* __restrict__ g_grid,
+                                                          const float* __restrict__ g_wsum, float* __restrict__ g_p,
+                                                          float* __restrict__ g_attr, float* __restrict__ g_pd, int N,
+                                                          int C) {
+  extern __shared__ float gbox[];
+  __shared__ int red[6 * 4];
+  const int t = threadIdx.x;
+  const int64_t a = (int64_t)blockIdx.x * 256 + t;
+  Particle P;
+  P.valid = false;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  if (a < N) {
+    P = load_particle(s, p, a);
+    if (P.valid)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lo[k] = P.idx[k]; hi[k] = P.idx[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[k] = min(lo[k], __shfl_xor(lo[k], o, 64));
+      hi[k] = max(hi[k], __shfl_xor(hi[k], o, 64));
+    }
+    if ((t & 63) == 0) { red[(2 * k) * 4 + (t >> 6)] = lo[k]; red[(2 * k + 1) * 4 + (t >> 6)] = hi[k]; }
+  }
+  __syncthreads();
+  int ext[3] = {1, 1, 1};
+  bool any = true;
+  int64_t vol = 1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int* r0 = red + (2 * k) * 4;
+    const int* r1 = red + (2 * k + 1) * 4;
+    lo[k] = min(min(r0[0], r0[1]), min(r0[2], r0[3]));
+    hi[k] = max(max(r1[0], r1[1]), max(r1[2], r1[3]));
+    if (k < ND) {
+      any = any && hi[k] >= lo[k];
+      lo[k] = max(lo[k] - NS, 0);
+      hi[k] = min(hi[k] + NS, s.res[k] - 1);
+      ext[k] = hi[k] - lo[k] + 1;
+      vol *= ext[k] > 0 ? ext[k] : 1;
+    } else {
+      lo[k] = 0; hi[k] = 0;
+    }
+  }
+  if (!any) {                                  // no live particle in the block: zero gradients
+    if (a < N) {
+      if (g_p) for (int k = 0; k < ND; ++k) g_p[a * ND + k] = 0.f;
+      if (g_attr) for (int ch = 0; ch < C; ++ch) g_attr[a * C + ch] = 0.f;
+      if (g_pd) g_pd[a] = 0.f;
+    }
+    return;
+  }
+  const int nch = s.mode == 2 ? C + 1 : C;     // (mode 0: C == 1)
+  const bool staged = vol * nch <= SPB_LDS;
+  const int nvol = (int)vol;
+  if (staged) {
+    for (int i = t; i < nvol; i += 256) {
+      int c[3];
+      c[2] = lo[2] + i % ext[2];
+      const int r = i / ext[2];
+      c[1] = lo[1] + r % ext[1];
+      c[0] = lo[0] + r / ext[1];
+      const int64_t cell = cell_index(s, c);
+      for (int ch = 0; ch < C; ++ch) gbox[i * nch + ch] = g_grid[cell * C + ch];
+      if (s.mode == 2) gbox[i * nch + C] = g_wsum[cell];
+    }
+    __syncthreads();
+  }
+  if (a >= N) return;
+  float gp[3] = {0.f, 0.f, 0.f};
+  float ga[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 4
+  float gpd = 0.f;
+  if (P.valid) {
+    const float pdv = (s.mode == 1) ? (pd ? pd[a] : s.rest_density) : 1.f;
+    float coef = 1.f;
+    if (s.mode == 0) coef = s.mass;
+    if (s.mode == 1) coef = s.mass / pdv;
+    float at[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s.mode != 0)
+      for (int ch = 0; ch < C; ++ch) at[ch] = attr[a * C + ch];
+    Hood<ND, NS> hd;
+    hd.init(s, P);
+    constexpr int SP = 2 * NS + 1;
+    int off[3][SP];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < SP; ++i) {
+        const int c = P.idx[k] + i - NS;
+        const bool in = k < ND && c >= lo[k] && c <= hi[k];
+        const int stride = k == 0 ? ext[1] * ext[2] : (k == 1 ? ext[2] : 1);
+        off[k][i] = in ? (c - lo[k]) * stride : (k < ND ? -1 : 0);
+      }
+    const float h2 = s.h * s.h, inv_h = 1.f / s.h;
+    hd.each([&](int i0, int i1, int i2, float d2) {
+      if (d2 > h2) return;
+      if ((off[0][i0] | off[1][i1] | off[2][i2]) < 0) return;
+      const float inv_d = d2 > 0.f ? __frsqrt_rn(d2) : 0.f;       // (as in the forward kernel: rsq instead of sqrt + two divisions)
+      const float dist = d2 * inv_d;
+      const float q = dist * inv_h;
+      if (q > 1.f) return;
+      const int li = off[0][i0] + off[1][i1] + off[2][i2];
+      float gv[5];
+      if (staged) {
+        for (int ch = 0; ch < nch; ++ch) gv[ch] = gbox[li * nch + ch];
+      } else {
+        const int c[3] = {P.idx[0] + i0 - NS, P.idx[1] + i1 - NS, P.idx[2] + i2 - NS};
+        const int64_t ci = cell_index(s, c);
+        for (int ch = 0; ch < C; ++ch) gv[ch] = g_grid[ci * C + ch];
+        if (s.mode == 2) gv[C] = g_wsum[ci];
+      }
+      const float w = cubic_w(q, s.sigma);
+      float gw;
+      if (s.mode == 0) {
+        gw = coef * gv[0];
+      } else {
+        float dot = 0.f;
+        for (int ch = 0; ch < C; ++ch) {
+          dot += at[ch] * gv[ch];
+          ga[ch] += coef * w * gv[ch];
+        }
+        gw = coef * dot;
+        if (s.mode == 1) gpd -= coef * w * dot / pdv;
+        if (s.mode == 2) gw += gv[C];
+      }
+      if (g_p && dist > 0.f) {  // safe sqrt: zero gradient at the cell centre
+        const float f = gw * cubic_dw(q, s.sigma) * (inv_d * inv_h);
+        gp[0] += f * hd.rr[0][i0];
+        if (ND > 1) gp[1] += f * hd.rr[1][i1];
+        if (ND > 2) gp[2] += f * hd.rr[2][i2];
+      }
+    });
+  }
+  if (g_p)
+    for (int k = 0; k < ND; ++k) g_p[a * ND + k] = P.grad_ok[k] ? gp[k] * s.dom[k] : 0.f;
   if (g_attr)
     for (int ch = 0; ch < C; ++ch) g_attr[a * C + ch] = ga[ch];
   if (g_pd) g_pd[a] = gpd;
@@ -443,8 +717,19 @@ int nfs_p2g_fwd(const float* p, const float* attr, const float* pd, float* grid,
   }
   static const int allow_lds = [] { const char* e = getenv("NFS_SPLAT_LDS"); return e ? atoi(e) : 1; }();
   // 256 particles per block: measured 0.156 ms against 0.184 (512) and 0.247 (1024) on the 5e5-particle blob set
-  hipLaunchKernelGGL(p2g_fwd_lds_kernel<256>, dim3(blocks_for(N, 256)), dim3(256), SPL_LDS * sizeof(float),
-                     as_stream(stream), s, p, attr, pd, grid, wsum, N, C, allow_lds);
+#define NFS_SPL_LAUNCH(ND_, NS_)                                                                                       \
+  hipLaunchKernelGGL((p2g_fwd_lds_kernel<ND_, NS_>), dim3(blocks_for(N, 256)), dim3(256),                         \
+                     SPL_LDS * sizeof(unsigned long long), as_stream(stream), s, p, attr, pd, grid, wsum, N, C, allow_lds)
+  // the neighbourhoods the drivers use as compile-time instances (test_smokegun / chocolate: 3-D nsize 1;
+  // test_dambreak2d: 2-D nsize 2..4), anything else through the generic loops
+  if (s.nd == 3 && s.nsize == 1) NFS_SPL_LAUNCH(3, 1);
+  else if (s.nd == 3 && s.nsize == 2) NFS_SPL_LAUNCH(3, 2);
+  else if (s.nd == 2 && s.nsize == 1) NFS_SPL_LAUNCH(2, 1);
+  else if (s.nd == 2 && s.nsize == 2) NFS_SPL_LAUNCH(2, 2);
+  else if (s.nd == 2 && s.nsize == 3) NFS_SPL_LAUNCH(2, 3);
+  else if (s.nd == 2 && s.nsize == 4) NFS_SPL_LAUNCH(2, 4);
+  else NFS_SPL_LAUNCH(0, 0);
+#undef NFS_SPL_LAUNCH
   return check_launch("nfs_p2g_fwd");
 }
 
@@ -457,8 +742,23 @@ int nfs_p2g_bwd(const float* p, const float* attr, const float* pd, const float*
   NFS_REQUIRE(s.mode == 0 || attr, "nfs_p2g_bwd: attr required for mode 1/2");
   NFS_REQUIRE(s.mode != 2 || g_wsum, "nfs_p2g_bwd: g_wsum required for mode 2");
   NFS_REQUIRE(s.mode != 0 || (!g_attr && !g_pd), "nfs_p2g_bwd: density mode has no attr/pd gradient");
-  hipLaunchKernelGGL(p2g_bwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, g_grid,
-                     g_wsum, g_p, g_attr, g_pd, N, C);
+  int64_t cells = 1;
+  for (int k = 0; k < s.nd; ++k) cells *= s.res[k];
+  static const int allow_box = [] { const char* e = getenv("NFS_SPLAT_LDS"); return e ? atoi(e) : 1; }();
+#define NFS_SPB_LAUNCH(ND_, NS_)                                                                                       \
+  hipLaunchKernelGGL((p2g_bwd_box_kernel<ND_, NS_>), dim3(blocks_for(N, 256)), dim3(256), SPB_LDS * sizeof(float),     \
+                     as_stream(stream), s, p, attr, pd, g_grid, g_wsum, g_p, g_attr, g_pd, N, C)
+  const bool box = allow_box && cells < ((int64_t)1 << 31);
+  if (box && s.nd == 3 && s.nsize == 1) NFS_SPB_LAUNCH(3, 1);
+  else if (box && s.nd == 3 && s.nsize == 2) NFS_SPB_LAUNCH(3, 2);
+  else if (box && s.nd == 2 && s.nsize == 1) NFS_SPB_LAUNCH(2, 1);
+  else if (box && s.nd == 2 && s.nsize == 2) NFS_SPB_LAUNCH(2, 2);
+  else if (box && s.nd == 2 && s.nsize == 3) NFS_SPB_LAUNCH(2, 3);
+  else if (box && s.nd == 2 && s.nsize == 4) NFS_SPB_LAUNCH(2, 4);
+  else
+    hipLaunchKernelGGL(p2g_bwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, g_grid,
+                       g_wsum, g_p, g_attr, g_pd, N, C);
+#undef NFS_SPB_LAUNCH
   return check_launch("nfs_p2g_bwd");
 }
 

@@ -423,15 +423,21 @@ class RenderStyleLoss(object):
         elif self.rotate:
             assert self.mode < 2, "the max / mean ray modes use the two-pass adjoint"
             ops.rotate_render_bwd(d, rot, rs, g_img, self.tau, self.mode, g_d_acc=g_d)
+        elif overwrite:
+            # one unrotated view: the render adjoint IS dL/dd -- written straight into g_d (no zero fill, no add pass)
+            ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.mode, g_d=g_d.unsqueeze(0))
         else:
             g_d.add_(ops.render_bwd(d.unsqueeze(0), rs, g_img, self.tau, self.mode)[0])
         return loss
 
     def writes_gradient(self, V):
         """True when loss_and_grad(..., overwrite=True) can write g_d without a zero fill: one view batch through the
-        tiled rotate adjoint, whose tiles partition the volume"""
+        tiled rotate adjoint, whose tiles partition the volume -- or the single unrotated view, whose render adjoint is
+        the gradient itself"""
+        if not self.rotate:
+            return True
         ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
-        return bool(self.rotate and self.two_pass_adjoint and min(ngroups, V) <= 1)
+        return bool(self.two_pass_adjoint and min(ngroups, V) <= 1)
 
     def loss_and_grad(self, d, rot, g_d, overwrite=False):
         """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
@@ -516,6 +522,10 @@ class GraphedLoss(object):
     def _eager(self, d, rot):
         if isinstance(self.loss, ImageStyleLoss):        # (d, d_gray) -> (losses, gradient)
             return self.loss.loss_and_grad(d, rot)
+        V = 1 if rot is None else int(rot.shape[0])
+        if hasattr(self.loss, "writes_gradient") and self.loss.writes_gradient(V):
+            g_d = torch.empty_like(d)
+            return self.loss.loss_and_grad(d, rot, g_d, overwrite=True), g_d
         g_d = torch.zeros_like(d)
         return self.loss.loss_and_grad(d, rot, g_d), g_d
 
@@ -553,6 +563,9 @@ class GraphedLoss(object):
             with torch.cuda.graph(g):
                 if isinstance(self.loss, ImageStyleLoss):
                     self._losses, self._gd = self.loss.loss_and_grad(self._d, self._rot)
+                elif hasattr(self.loss, "writes_gradient") and self.loss.writes_gradient(
+                        1 if self._rot is None else int(self._rot.shape[0])):
+                    self._losses = self.loss.loss_and_grad(self._d, self._rot, self._gd, overwrite=True)
                 else:
                     self._gd.zero_()
                     self._losses = self.loss.loss_and_grad(self._d, self._rot, self._gd)

@@ -110,9 +110,10 @@ class Styler(StylerBase):
                                    support=support, clip=self.clip, is_2d=False)
                 d_ = d_hat if d_ is None else d_ + d_hat
         else:
-            d_ = T.p2g(p_, self.domain, res, self.radius, self.rest_density, self.nsize, support=self.support,
+            # d / rest_density (styler_3p.py:96): the particle mass is linear in rest_density (transform.py:1348-1352), so
+            # the quotient is the splat with unit rest density -- no 32 MB scaling pass forward, none backward
+            d_ = T.p2g(p_, self.domain, res, self.radius, 1.0, self.nsize, support=self.support,
                        clip=self.clip, is_2d=False)
-            d_ = d_ / self.rest_density
             if self.w_pressure > 0:
                 pressure = torch.where(d_ > 0, d_ - 1, torch.zeros_like(d_))
                 extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
@@ -137,6 +138,9 @@ class Styler(StylerBase):
         if self._graph_loss and (self._graph_loss.force or nviews <= 2):
             losses, g_d = self._graph_loss(d3, rot)
             losses = losses.clone()
+        elif self.loss.writes_gradient(nviews):
+            g_d = torch.empty_like(d3)                       # (written, not accumulated into: no zero fill)
+            losses = self.loss.loss_and_grad(d3, rot, g_d, overwrite=True)
         else:
             g_d = torch.zeros_like(d3)
             losses = self.loss.loss_and_grad(d3, rot, g_d)
