@@ -205,10 +205,10 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   const int zlast = zoff + D - 1;
   F2u p[4][4];
   float wz[4], wy[4], wx[4], mz[4], my[4], mx[4];
-  [[maybe_unused]] float fz[4], fh[4], fw[4];       // MODE 2 with adv_next: the voxel's own index, for the second sample
+  [[maybe_unused]] const int w0 = w, h0 = h, z0 = z;   // MODE 2 with adv_next: the walk is repeated for the second sample
+  [[maybe_unused]] unsigned ob[4];                    // ... and the base cell of the first sample is remembered
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (MODE == 2) { fz[j] = (float)z; fh[j] = (float)h; fw[j] = (float)w; }
     const float xz = fmaf(-vv[j].x, hz, (float)z), xy = fmaf(-vv[j].y, hy, (float)h),
                 xx = fmaf(-vv[j].z, hx, (float)w);
     const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       mx[j] = (xx >= 0.f && xx < nx1) ? hx : 0.f;
     }
     const unsigned o = (unsigned)(int)bz * uHW + (unsigned)(int)by * uW + (unsigned)(int)bx;
+    if (MODE == 2) ob[j] = o;
     p[j][0] = *reinterpret_cast<const F2u*>(d + o);
     p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
     p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
@@ -275,19 +276,29 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       }
     }
     if (MODE == 2 && ad.adv_next) {
-      // the next iteration's forward sample from the updated velocity (the same lines as the MODE 0 body above)
+      // the next iteration's forward sample from the updated velocity (the same lines as the MODE 0 body above; the
+      // voxel indices are walked again rather than kept: twelve registers more cost the kernel a wave per SIMD)
+      w = w0; h = h0; z = z0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float xz = fmaf(-vv[j].x, hz, fz[j]), xy = fmaf(-vv[j].y, hy, fh[j]), xx = fmaf(-vv[j].z, hx, fw[j]);
+        const float xz = fmaf(-vv[j].x, hz, (float)z), xy = fmaf(-vv[j].y, hy, (float)h), xx = fmaf(-vv[j].z, hx, (float)w);
         const float cz = __builtin_amdgcn_fmed3f(xz, 0.f, nz1), cy = __builtin_amdgcn_fmed3f(xy, 0.f, ny1),
                     cx = __builtin_amdgcn_fmed3f(xx, 0.f, nx1);
         const float bz = fminf(floorf(cz), nz1 - 1.f), by = fminf(floorf(cy), ny1 - 1.f), bx = fminf(floorf(cx), nx1 - 1.f);
         wz[j] = cz - bz; wy[j] = cy - by; wx[j] = cx - bx;
         const unsigned o = (unsigned)(int)bz * uHW + (unsigned)(int)by * uW + (unsigned)(int)bx;
-        p[j][0] = *reinterpret_cast<const F2u*>(d + o);
-        p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
-        p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
-        p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
+        // One Adam step moves the back-traced point by a fraction of a cell: its base cell is almost always the one the
+        // adjoint just gathered, whose eight corners are still in registers -- only the weights change.  The second
+        // gather (a further memory round trip in every wave's life: 0.128 -> 0.166 ms when it was unconditional) is
+        // taken only by the lanes whose point crossed a cell face.
+        if (o != ob[j]) {
+          p[j][0] = *reinterpret_cast<const F2u*>(d + o);
+          p[j][1] = *reinterpret_cast<const F2u*>(d + o + uW);
+          p[j][2] = *reinterpret_cast<const F2u*>(d + o + uHW);
+          p[j][3] = *reinterpret_cast<const F2u*>(d + o + uHW + uW);
+        }
+        w += 64;
+        while (w >= W) { w -= W; if (++h == H) { h = 0; if (z < zlast) ++z; } }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
