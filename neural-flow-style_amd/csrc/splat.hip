@@ -148,9 +148,10 @@ __global__ void __launch_bounds__(256) p2g_fwd_kernel(SplatDev s, const float* _
 // from a min / max reduction of the cell coordinates) it falls back to the per-cell global atomics above.  Same
 // arithmetic per contribution.
 //
-// Round 4: the LDS accumulators are 64-bit FIXED POINT, as in the rotate adjoint (warp.hip): on gfx950 ds_add_f32
-// sustains 0.33 lanes/clk/CU where ds_add_u64 runs at 9.4 (tools/lds_atomic_bench.hip) -- the 13.5 M float atomics of
-// 5e5 particles were 1/3 of this kernel.  Every block scales by its own power of two, chosen from the largest
+// Round 4: the LDS accumulators are 64-bit FIXED POINT, as in the rotate adjoint (warp.hip; on gfx950 ds_add_f32
+// sustains 0.33 lanes/clk/CU where ds_add_u64 runs at 9.4, tools/lds_atomic_bench.hip -- here that alone did not change
+// the time, the index arithmetic was the bound; what it buys is sums that do not depend on the order of the adds).
+// Every block scales by its own power of two, chosen from the largest
 // |contribution| its particles can make (kernel maximum sigma x coefficient x largest |attribute|) times the
 // particles per block, so that no cell sum can overflow 2^62; > 40 bits stay below the largest contribution (more than
 // float accumulation keeps), and the integer sums do not depend on the order of the adds.
