@@ -90,14 +90,19 @@ class Styler(StylerBase):
         # the splat would fall back to scattered global atomics; it therefore sees every frame through that frame's
         # own grid order (a gather of the positions in, the scatter of their gradient out -- the splat does not care
         # about the order of its particles)
-        order = getattr(self, "_orders", {}).get((p.data_ptr(), p.shape[0]))
+        order = self._particle_order(p, p_)
+        inverse = None
         if order is not None:
-            p_ = p_[:, order]
+            inverse = self._order_inv.get((p.data_ptr(), p.shape[0]))
+            if inverse is None or inverse[0] is not order:
+                inverse = self._order_inv[(p.data_ptr(), p.shape[0])] = (order, T.inverse_permutation(order))
+            inverse = inverse[1]
+            p_ = T.permute_particles(p_, order, inverse)
         if "d" in self.target_field:
             r_opt = torch.clamp(var.unsqueeze(0), -1, 1)                    # "necessary!" (styler_3p.py:74)
             r_ = r.unsqueeze(0) + r_opt
             if order is not None:
-                r_ = r_[:, order]
+                r_ = T.permute_particles(r_, order, inverse)
             if getattr(self, "w_density", 0) > 0:
                 # density preservation on the clipped offsets (self.d[i], styler_3p.py:75; styler_base.py:217-223)
                 d_loss = r_opt[0].sum() ** 2
@@ -119,6 +124,28 @@ class Styler(StylerBase):
                 extra = (pressure ** 2).mean() * self.w_pressure           # styler_base.py:228-230
         d_out = _SmoothRelu.apply(d_, float(self.k)) if self.k > 0 else _SmoothRelu.apply(d_, 0.0)
         return p_all[0], d_out, extra
+
+    def _particle_order(self, p, p_now):
+        """the permutation the splat sees frame ``p`` through, or None (= the caller's order).  Frames beyond the first
+        get their own grid order at run start (``_orders``).  With the POSITIONS as the variable the particles drift away
+        from the order they were put in -- 0.4 cells per step at lr 0.002 on a 200^3 grid; after 100 steps the boxes of
+        consecutive particles no longer fit the splat's LDS accumulators and the forward splat runs at half speed
+        (tools/chocolate_iter_profile.py: 213 us against 116 in grid order) -- so the order of a frame is recomputed from
+        the CURRENT positions every ``reorder_every`` evaluations (default 10; 0 = never).  The splat does not care
+        about the order of its particles; autograd scatters the gradient back through the gather."""
+        orders = self.__dict__.setdefault("_orders", {})
+        self.__dict__.setdefault("_order_inv", {})
+        key = (p.data_ptr(), p.shape[0])
+        every = int(getattr(self, "reorder_every", 10) or 0)
+        if "p" not in self.target_field or every <= 0 or not getattr(self, "sort_particles", True) or p.shape[0] < 2:
+            return orders.get(key)
+        ages = self.__dict__.setdefault("_order_age", {})
+        age = ages.get(key, 0) + 1
+        if age >= every:
+            orders[key] = T.grid_order(p_now[0].detach(), self.resolution, stable=False)
+            age = 0
+        ages[key] = age
+        return orders.get(key)
 
     def _value_and_grad(self, p, r, var, res, rot, view_shard=True):
         """loss (per view, device) and d loss / d var for one frame.  ``view_shard``: the views are sharded over the
@@ -210,7 +237,7 @@ class Styler(StylerBase):
             inv[perm] = torch.arange(perm.numel(), device=self.device)
             p = [x[perm].contiguous() for x in p]
             r = [x[perm].contiguous() if x is not None else None for x in r]
-        self._orders = {}
+        self._orders, self._order_age, self._order_inv = {}, {}, {}
         if getattr(self, "sort_particles", True) and self.num_frames > 1:
             for x in p[1:]:                                  # (frame 0 is in its own order already)
                 if x.shape[0] > 1:
@@ -385,7 +412,7 @@ class Styler(StylerBase):
         result["d"] = np.array(d_sty)
         result["r"] = np.array(r_sty)
         result["opt"] = [(g if inv is None else g[inv]).cpu().numpy() for g in g_opt]   # build extension: the variables
-        self._orders = {}        # keyed by device address: the frame tensors die with this call, the addresses get re-used
+        self._orders, self._order_age, self._order_inv = {}, {}, {}   # keyed by device address: the frame tensors die with this call
         return result
 
     def loss_d_img(self, d_out):

@@ -277,7 +277,36 @@ def curl(s, is_2d=True):
     return torch.stack([_Curl.apply(s[b]) for b in range(s.shape[0])])
 
 
-def grid_order(p, resolution, brick=8):
+class _Permute(torch.autograd.Function):
+    """x[:, order] for a PERMUTATION ``order`` of axis 1, with the inverse permutation given: the adjoint of a gather
+    through a permutation is the gather through its inverse -- autograd's generic index backward (a sorted
+    scatter-add, 137 us for 5e5 x 3 floats) becomes one 8-us gather"""
+
+    @staticmethod
+    def forward(ctx, x, order, inverse):
+        ctx.save_for_backward(inverse)
+        return x.index_select(1, order)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inverse,) = ctx.saved_tensors
+        return g.index_select(1, inverse), None, None
+
+
+def permute_particles(x, order, inverse=None):
+    """x [1,N,k] seen through the permutation ``order`` (see grid_order); ``inverse`` = inverse_permutation(order)"""
+    if inverse is None:
+        inverse = inverse_permutation(order)
+    return _Permute.apply(x, order, inverse)
+
+
+def inverse_permutation(order):
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
+    return inv
+
+
+def grid_order(p, resolution, brick=8, stable=True):
     """Permutation that puts particles p [N,nd] (in [0,1], axis order = array order) in the order of the grid, brick by
     brick (``brick``^nd cells) and cell by cell inside a brick.  The splat accumulates a block of consecutive particles
     in LDS when their cells sit in a small box (csrc/splat.hip): bricks keep that box small in every direction, and
@@ -291,7 +320,9 @@ def grid_order(p, resolution, brick=8):
     for k in range(nd):
         bk = bk * nb[k] + cell[:, k] // brick
         ck = ck * brick + cell[:, k] % brick
-    return torch.argsort(bk * (brick ** nd) + ck, stable=True)
+    # stable: particles of one cell keep their relative order (what the run-start orders use: reproducible layouts);
+    # the periodic re-ordering of a drifting frame takes the radix sort (the stable merge sort is ~0.6 ms for 5e5 keys)
+    return torch.argsort(bk * (brick ** nd) + ck, stable=stable)
 
 
 class _P2G(torch.autograd.Function):
