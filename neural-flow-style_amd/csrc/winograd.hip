@@ -781,7 +781,8 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
 
   // epilogue: the tile through LDS (C layout: lane = column l & 15, rows 4 (l >> 4) + r), out as float4 rows; at most
   // five row tiles (80 rows) per pass, so that a tall tile does not need a tall buffer
-  constexpr int OS = BN + 4, EP = MT16 < 5 ? MT16 : 5, NPASS = (MT16 + EP - 1) / EP;
+  // (256-column tiles, NW16 = 4: two row tiles per pass keep the buffer at 33 KB, so that blocks still share a CU)
+  constexpr int OS = BN + 4, EPMAX = NW16 >= 4 ? 2 : 5, EP = MT16 < EPMAX ? MT16 : EPMAX, NPASS = (MT16 + EP - 1) / EP;
   float* otile = smem;
   float* Mc = a.M + (int64_t)comp * a.T * a.N;
   const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
@@ -1254,7 +1255,8 @@ static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
 template <int MT16, int NW16>
 static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16, BMP = (BM + 31) / 32 * 32;
-  const size_t oper = 2 * BMP * WG_LS, tile = 16 * (MT16 < 5 ? MT16 : 5) * (BN + 4);
+  constexpr int EPMAX = NW16 >= 4 ? 2 : 5;
+  const size_t oper = 2 * BMP * WG_LS, tile = 16 * (MT16 < EPMAX ? MT16 : EPMAX) * (BN + 4);
   const size_t lds = (oper > tile ? oper : tile) * sizeof(float);
   static std::once_flag attr_once;
   if (lds > 65536) std::call_once(attr_once, [&] {
@@ -1327,10 +1329,15 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   }
   if (variant == 2 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0) {
     a.mt = (int)((a.T + bm - 1) / bm);
-    if (bm == 80) { if (bn == 128) launch_gemm_rb16<5, 2>(a, s); else launch_gemm_rb16<5, 1>(a, s); }
-    else if (bm == 48) { if (bn == 128) launch_gemm_rb16<3, 2>(a, s); else launch_gemm_rb16<3, 1>(a, s); }
-    else if (bm == 112) { if (bn == 128) launch_gemm_rb16<7, 2>(a, s); else launch_gemm_rb16<7, 1>(a, s); }
-    else { if (bn == 128) launch_gemm_rb16<13, 2>(a, s); else launch_gemm_rb16<13, 1>(a, s); }
+    // (256-column tiles for the 80- / 48- / 112-row forms: four times the MFMA work per block between its prologue
+    // and its epilogue; a tuner candidate where N % 256 == 0)
+    if (bm == 80) { if (bn == 256) launch_gemm_rb16<5, 4>(a, s); else if (bn == 128) launch_gemm_rb16<5, 2>(a, s); else launch_gemm_rb16<5, 1>(a, s); }
+    else if (bm == 48) { if (bn == 256) launch_gemm_rb16<3, 4>(a, s); else if (bn == 128) launch_gemm_rb16<3, 2>(a, s); else launch_gemm_rb16<3, 1>(a, s); }
+    else if (bm == 112) { if (bn == 256) launch_gemm_rb16<7, 4>(a, s); else if (bn == 128) launch_gemm_rb16<7, 2>(a, s); else launch_gemm_rb16<7, 1>(a, s); }
+    else {
+      if (bn == 256) { bn = 128; a.nt = a.N / 128; }          // (no 256-column instance of the 208-row form: 208 accumulators)
+      if (bn == 128) launch_gemm_rb16<13, 2>(a, s); else launch_gemm_rb16<13, 1>(a, s);
+    }
     return;
   }
   if (variant == 1 && gemm_rb_applies(a)) {
@@ -1422,8 +1429,9 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
           for (int i = 0; i < 4; ++i) {                                  // row tiles that pad no worse than 1.2 x the best
             const int64_t p = rb16_rows_executed(a.T, kRb16Rows[i]);
             if (p * 10 > pad16 * 12) continue;
-            for (int cbn = 128; cbn >= 64; cbn -= 64)
-              if (a.N % cbn == 0) trial(kRb16Rows[i], cbn, 2);
+            static const bool bn256 = [] { const char* e = getenv("NFS_GEMM_BN256"); return !(e && atoi(e) == 0); }();
+            for (int cbn = bn256 ? 256 : 128; cbn >= 64; cbn /= 2)
+              if (a.N % cbn == 0 && !(cbn == 256 && kRb16Rows[i] == 208)) trial(kRb16Rows[i], cbn, 2);
           }
         } else {
           const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
