@@ -777,6 +777,48 @@ def other_configs(device, base):
     except Exception as e:  # pragma: no cover
         out.append({"config": "reference test_smokegun.py configuration (Inception-v1)", "error": repr(e)})
 
+    # BASELINE configs[2] through the reference's OWN loop: the driver's main() with its override block and the command line
+    # that selects VGG-19 and 8 rotated views -- particles ('d' field: a density offset per particle, two splat kernels),
+    # 200 x 300 x 200 grid, render resized x1.5 to 300 x 450, conv1_1..conv5_1, and the reference's SEQUENTIAL view mode:
+    # one TF-Adam step per view batch on the same variable, iterates averaged (styler_3p.py:326-352) -- inherently serial
+    # over the views, so one iteration = 8 loss evaluations + 8 Adam steps.  Wall time of Styler.run per iteration as a user
+    # of the driver sees it: two run lengths differenced (set-up and the final inference cancel).
+    try:
+        import contextlib, importlib, io as _io, tempfile
+        from config import get_config as _gcfg
+        drv = importlib.import_module("test_smokegun")
+        argv0, runs = sys.argv, []
+        for it in (4, 4, 12):                               # (the first run builds the lazy state: discarded)
+            sys.argv = ["test_smokegun.py", "--num_frames", "1", "--target_frame", "70", "--network", "vgg_19.ckpt",
+                        "--rotate", "true", "--n_views", "8", "--w_style", "1", "--synthetic_weights", "true",
+                        "--iter", str(it)]                  # (the driver's main() looks at sys.argv for the flags given)
+            try:
+                c3, _ = _gcfg()
+                tmp = tempfile.mkdtemp()
+                c3.log_dir, c3.data_dir = os.path.join(tmp, "log"), os.path.join(tmp, "nodata")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(_io.StringIO()):
+                    res = drv.main(c3)
+                torch.cuda.synchronize()
+                runs.append((it, time.perf_counter() - t0, sum(len(l) for l in res["l"])))
+            finally:
+                sys.argv = argv0
+        (i0, ta, n0), (i1, tb, n1) = runs[1:]
+        ms_iter = 1e3 * (tb - ta) / (i1 - i0)
+        out.append({"config": "BASELINE configs[2] through the reference's own driver and loop: test_smokegun.py --network "
+                              "vgg_19.ckpt --rotate true --n_views 8 (demo data: 50k particles, 'd' field, 200x300x200 grid, "
+                              "300x450 render, conv1_1..conv5_1), views_mode sequential (styler_3p.py:326-352: one Adam "
+                              "step per view, iterates averaged): Styler.run wall time per iteration",
+                    "value": 1e3 / ms_iter, "unit": "iters/s", "ms_per_step": ms_iter, "loss_evaluations_per_iteration": 8,
+                    "ms_per_loss_evaluation": ms_iter / 8.0,
+                    "note": "two run lengths (%d and %d iterations: %.2f s, %.2f s) differenced; the sequential mode is "
+                            "serial over the views by construction (each step starts from the previous view's update) -- "
+                            "replicas only on several GPUs (SURVEY 8(e)); the headline's views=sum batch of 8 is the form "
+                            "that shards" % (i0, i1, ta, tb)})
+    except Exception as e:  # pragma: no cover
+        out.append({"config": "configs[2] through the reference driver (sequential views)", "error": repr(e)})
+
     # the operators either side of the path, each at the size its caller uses -- time per call and the
     # fraction of 8 TB/s its ALGORITHMIC bytes make (compulsory reads + writes; gathers counted once per element read)
     try:

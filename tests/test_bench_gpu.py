@@ -44,7 +44,7 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
     assert 0 < one["render_advect_family"]["survey_fused"]["frac_hbm"] < one["render_advect_family"]["as_built"]["frac_hbm"]
     assert one["parity"]["grad_rel_l2"] < one["parity"]["tolerance"]
     assert "64^3" in one["metric"] and one["sustained"]["windows"] >= 3
-    assert len(one["other_configs"]) == 9 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
+    assert len(one["other_configs"]) == 10 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
     widened = one["other_configs"][-1]["ops"]                         # SURVEY 8(f) operators: one timed call each
     assert len(widened) == 10 and all(o["ms"] > 0 and 0 < o["frac_hbm"] < 1 for o in widened), widened
     fast = args + ["--no-kernel-profile", "--no-other-configs", "--no-sustained"]
