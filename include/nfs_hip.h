@@ -506,6 +506,14 @@ int nfs_p2g_bwd(const float* p, const float* attr, const float* pd, const float*
 /* out = wsum > eps ? xsum/wsum : xsum (transform.py:1701-1703); n cells x C channels */
 int nfs_p2g_wavg_finish(const float* xsum, const float* wsum, float* out, int64_t n, int C,
                         float eps, nfs_stream_t stream);
+/* nfs_p2g_wavg_finish_bwd + nfs_p2g_bwd (mode 2) in ONE launch (round 4): the adjoint of p2g_wavg (transform.py:1577-1704)
+ * from g_out [cells,C] = dL/d(finished average), the raw accumulators xsum [cells,C] / wsum [cells] of the forward and
+ * the particles: the gradients wrt the accumulators are formed per cell while a block stages its box of the grid, not
+ * in a five-array pass over the whole grid.  g_p [N,nd] / g_attr [N,C] overwritten (each nullable).  NFS_EINVAL for
+ * (nd, nsize) without a compile-time neighbourhood: use the two-step path then. */
+int nfs_p2g_wavg_bwd(const float* p, const float* attr, const float* xsum, const float* wsum, const float* g_out,
+                     float* g_p, float* g_attr, int N, int C, float eps, const nfs_splat_cfg* cfg_host,
+                     nfs_stream_t stream);
 int nfs_p2g_wavg_finish_bwd(const float* xsum, const float* wsum, const float* g_out,
                             float* g_xsum, float* g_wsum, int64_t n, int C, float eps,
                             nfs_stream_t stream);

@@ -132,6 +132,7 @@ SIGNATURES = {
     "nfs_p2g_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(SplatCfg), _P],
     "nfs_p2g_wavg_finish": [_P, _P, _P, _L, _I, _F, _P],
     "nfs_p2g_wavg_finish_bwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "nfs_p2g_wavg_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, C.POINTER(SplatCfg), _P],
     "nfs_g2p_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _P],
     "nfs_adam_tf_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P],
     "nfs_fill": [_P, _F, _L, _P],

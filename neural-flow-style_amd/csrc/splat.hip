@@ -435,13 +435,19 @@ __global__ void __launch_bounds__(256) p2g_bwd_kernel(SplatDev s, const float* _
 // back to global gathers.
 constexpr int SPB_LDS = 12288;     // floats of staged gradient (48 KB)
 
-template <int ND, int NS>
+// WAVG: mode 2 with the adjoint of nfs_p2g_wavg_finish folded in -- g_grid is then dL/d(out) of the finished average,
+// fin.xsum / fin.wsum the raw accumulators, and the gradients wrt the accumulators (g / w and -sum g x / w^2 where
+// w > eps, g and 0 elsewhere: wavg_finish_bwd_kernel's lines) are formed per cell while the box is staged, instead of
+// in a 5-array streaming pass over the whole grid (240 MB at 200 x 300 x 200).
+struct WavgFinish { const float* xsum; const float* wsum; float eps; };
+
+template <int ND, int NS, bool WAVG>
 __global__ void __launch_bounds__(256) p2g_bwd_box_kernel(SplatDev s, const float* __restrict__ p,
                                                           const float* __restrict__ attr, const float* __restrict__ pd,
                                                           const float* __restrict__ g_grid,
                                                           const float* __restrict__ g_wsum, float* __restrict__ g_p,
                                                           float* __restrict__ g_attr, float* __restrict__ g_pd, int N,
-                                                          int C) {
+                                                          int C, WavgFinish fin) {
   extern __shared__ float gbox[];
   __shared__ int red[6 * 4];
   const int t = threadIdx.x;
@@ -503,8 +509,23 @@ __global__ void __launch_bounds__(256) p2g_bwd_box_kernel(SplatDev s, const floa
       c[1] = lo[1] + r % ext[1];
       c[0] = lo[0] + r / ext[1];
       const int64_t cell = cell_index(s, c);
-      for (int ch = 0; ch < C; ++ch) gbox[i * nch + ch] = g_grid[cell * C + ch];
-      if (s.mode == 2) gbox[i * nch + C] = g_wsum[cell];
+      if (WAVG) {
+        const float w = fin.wsum[cell];
+        float gw = 0.f;
+        for (int ch = 0; ch < C; ++ch) {
+          const float g = g_grid[cell * C + ch];
+          if (w > fin.eps) {
+            gbox[i * nch + ch] = g / w;
+            gw -= g * fin.xsum[cell * C + ch] / (w * w);
+          } else {
+            gbox[i * nch + ch] = g;
+          }
+        }
+        gbox[i * nch + C] = gw;
+      } else {
+        for (int ch = 0; ch < C; ++ch) gbox[i * nch + ch] = g_grid[cell * C + ch];
+        if (s.mode == 2) gbox[i * nch + C] = g_wsum[cell];
+      }
     }
     __syncthreads();
   }
@@ -548,8 +569,23 @@ __global__ void __launch_bounds__(256) p2g_bwd_box_kernel(SplatDev s, const floa
       } else {
         const int c[3] = {P.idx[0] + i0 - NS, P.idx[1] + i1 - NS, P.idx[2] + i2 - NS};
         const int64_t ci = cell_index(s, c);
-        for (int ch = 0; ch < C; ++ch) gv[ch] = g_grid[ci * C + ch];
-        if (s.mode == 2) gv[C] = g_wsum[ci];
+        if (WAVG) {
+          const float ws_ = fin.wsum[ci];
+          float gws = 0.f;
+          for (int ch = 0; ch < C; ++ch) {
+            const float g = g_grid[ci * C + ch];
+            if (ws_ > fin.eps) {
+              gv[ch] = g / ws_;
+              gws -= g * fin.xsum[ci * C + ch] / (ws_ * ws_);
+            } else {
+              gv[ch] = g;
+            }
+          }
+          gv[C] = gws;
+        } else {
+          for (int ch = 0; ch < C; ++ch) gv[ch] = g_grid[ci * C + ch];
+          if (s.mode == 2) gv[C] = g_wsum[ci];
+        }
       }
       const float w = cubic_w(q, s.sigma);
       float gw;
@@ -695,6 +731,42 @@ __global__ void __launch_bounds__(256) g2p_kernel(G2PArgs a) {
   }
 }
 
+
+// p2g adjoint launch: compile-time neighbourhoods with the box staged in LDS where they exist, the generic gather otherwise;
+// fin != nullptr (mode 2): the adjoint of the weighted-average finish folded in (the generic kernel has no such form:
+// the caller falls back to the two-step path)
+static bool launch_p2g_bwd(const SplatDev& s, const float* p, const float* attr, const float* pd, const float* g_grid,
+                           const float* g_wsum, float* g_p, float* g_attr, float* g_pd, int N, int C,
+                           const WavgFinish* fin, hipStream_t stream) {
+  int64_t cells = 1;
+  for (int k = 0; k < s.nd; ++k) cells *= s.res[k];
+  static const int allow_box = [] { const char* e = getenv("NFS_SPLAT_LDS"); return e ? atoi(e) : 1; }();
+  const bool box = allow_box && cells < ((int64_t)1 << 31);
+  const WavgFinish f = fin ? *fin : WavgFinish{nullptr, nullptr, 0.f};
+#define NFS_SPB_LAUNCH(ND_, NS_)                                                                                       \
+  do {                                                                                                                 \
+    if (fin)                                                                                                           \
+      hipLaunchKernelGGL((p2g_bwd_box_kernel<ND_, NS_, true>), dim3(blocks_for(N, 256)), dim3(256),                    \
+                         SPB_LDS * sizeof(float), stream, s, p, attr, pd, g_grid, g_wsum, g_p, g_attr, g_pd, N, C, f); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((p2g_bwd_box_kernel<ND_, NS_, false>), dim3(blocks_for(N, 256)), dim3(256),                   \
+                         SPB_LDS * sizeof(float), stream, s, p, attr, pd, g_grid, g_wsum, g_p, g_attr, g_pd, N, C, f); \
+  } while (0)
+  if (box && s.nd == 3 && s.nsize == 1) NFS_SPB_LAUNCH(3, 1);
+  else if (box && s.nd == 3 && s.nsize == 2) NFS_SPB_LAUNCH(3, 2);
+  else if (box && s.nd == 2 && s.nsize == 1) NFS_SPB_LAUNCH(2, 1);
+  else if (box && s.nd == 2 && s.nsize == 2) NFS_SPB_LAUNCH(2, 2);
+  else if (box && s.nd == 2 && s.nsize == 3) NFS_SPB_LAUNCH(2, 3);
+  else if (box && s.nd == 2 && s.nsize == 4) NFS_SPB_LAUNCH(2, 4);
+  else {
+    if (fin) return false;
+    hipLaunchKernelGGL(p2g_bwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, stream, s, p, attr, pd, g_grid, g_wsum, g_p,
+                       g_attr, g_pd, N, C);
+  }
+#undef NFS_SPB_LAUNCH
+  return true;
+}
+
 }  // namespace nfs
 
 using namespace nfs;
@@ -743,24 +815,24 @@ int nfs_p2g_bwd(const float* p, const float* attr, const float* pd, const float*
   NFS_REQUIRE(s.mode == 0 || attr, "nfs_p2g_bwd: attr required for mode 1/2");
   NFS_REQUIRE(s.mode != 2 || g_wsum, "nfs_p2g_bwd: g_wsum required for mode 2");
   NFS_REQUIRE(s.mode != 0 || (!g_attr && !g_pd), "nfs_p2g_bwd: density mode has no attr/pd gradient");
-  int64_t cells = 1;
-  for (int k = 0; k < s.nd; ++k) cells *= s.res[k];
-  static const int allow_box = [] { const char* e = getenv("NFS_SPLAT_LDS"); return e ? atoi(e) : 1; }();
-#define NFS_SPB_LAUNCH(ND_, NS_)                                                                                       \
-  hipLaunchKernelGGL((p2g_bwd_box_kernel<ND_, NS_>), dim3(blocks_for(N, 256)), dim3(256), SPB_LDS * sizeof(float),     \
-                     as_stream(stream), s, p, attr, pd, g_grid, g_wsum, g_p, g_attr, g_pd, N, C)
-  const bool box = allow_box && cells < ((int64_t)1 << 31);
-  if (box && s.nd == 3 && s.nsize == 1) NFS_SPB_LAUNCH(3, 1);
-  else if (box && s.nd == 3 && s.nsize == 2) NFS_SPB_LAUNCH(3, 2);
-  else if (box && s.nd == 2 && s.nsize == 1) NFS_SPB_LAUNCH(2, 1);
-  else if (box && s.nd == 2 && s.nsize == 2) NFS_SPB_LAUNCH(2, 2);
-  else if (box && s.nd == 2 && s.nsize == 3) NFS_SPB_LAUNCH(2, 3);
-  else if (box && s.nd == 2 && s.nsize == 4) NFS_SPB_LAUNCH(2, 4);
-  else
-    hipLaunchKernelGGL(p2g_bwd_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, as_stream(stream), s, p, attr, pd, g_grid,
-                       g_wsum, g_p, g_attr, g_pd, N, C);
-#undef NFS_SPB_LAUNCH
+  (void)launch_p2g_bwd(s, p, attr, pd, g_grid, g_wsum, g_p, g_attr, g_pd, N, C, nullptr, as_stream(stream));
   return check_launch("nfs_p2g_bwd");
+}
+
+/* nfs_p2g_wavg_finish_bwd + nfs_p2g_bwd (mode 2) in one launch: g_out [cells,C] = dL/d(finished average); returns
+ * NFS_EINVAL for neighbourhoods without a compile-time instance (the caller then takes the two-step path) */
+int nfs_p2g_wavg_bwd(const float* p, const float* attr, const float* xsum, const float* wsum, const float* g_out,
+                     float* g_p, float* g_attr, int N, int C, float eps, const nfs_splat_cfg* cfg_host,
+                     nfs_stream_t stream) {
+  NFS_REQUIRE(p && attr && xsum && wsum && g_out && N > 0, "nfs_p2g_wavg_bwd: bad argument");
+  SplatDev s;
+  if (int e = make_dev_cfg(cfg_host, C, s)) return e;
+  NFS_REQUIRE(s.mode == 2, "nfs_p2g_wavg_bwd: mode 2 (weighted average) only");
+  const WavgFinish fin{xsum, wsum, eps};
+  NFS_REQUIRE(launch_p2g_bwd(s, p, attr, nullptr, g_out, nullptr, g_p, g_attr, nullptr, N, C, &fin, as_stream(stream)),
+              "nfs_p2g_wavg_bwd: no compile-time instance for nd %d, nsize %d (use nfs_p2g_wavg_finish_bwd + nfs_p2g_bwd)",
+              s.nd, s.nsize);
+  return check_launch("nfs_p2g_wavg_bwd");
 }
 
 int nfs_p2g_wavg_finish(const float* xsum, const float* wsum, float* out, int64_t n, int C, float eps,

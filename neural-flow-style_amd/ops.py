@@ -712,6 +712,20 @@ def p2g_bwd(p, cfg, g_grid, attr=None, pd=None, g_wsum=None, need_p=True, need_a
     return g_p, g_attr, g_pd
 
 
+def p2g_wavg_bwd(p, cfg, xsum, wsum, g_out, attr, eps=1e-6, need_p=True, need_attr=True):
+    """adjoint of the weighted-average splat in one launch (finish adjoint folded into the gather); None when the
+    neighbourhood has no compile-time instance (the caller takes p2g_wavg_finish_bwd + p2g_bwd)"""
+    if not ((cfg.nd == 3 and cfg.nsize in (1, 2)) or (cfg.nd == 2 and cfg.nsize in (1, 2, 3, 4))):
+        return None
+    N = p.shape[0]
+    Cn = attr.shape[-1]
+    g_p = _empty(p.shape, p) if need_p else None
+    g_attr = _empty(attr.shape, p) if need_attr else None
+    _lib.call("nfs_p2g_wavg_bwd", _ptr(p), _ptr(attr), _ptr(xsum), _ptr(wsum), _ptr(g_out), _ptr(g_p), _ptr(g_attr), N, Cn,
+              float(eps), C.byref(cfg), _stream())
+    return g_p, g_attr
+
+
 def p2g_wavg_finish(xsum, wsum, eps=1e-6):
     Cn = xsum.shape[-1]
     n = wsum.numel()

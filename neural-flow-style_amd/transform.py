@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -368,9 +370,16 @@ class _P2GWavg(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         p2, a, xs, ws = ctx.saved_tensors
-        g_xs, g_ws = ops.p2g_wavg_finish_bwd(xs, ws, g.contiguous()[0], ctx.eps)
-        gp, ga, _ = ops.p2g_bwd(p2, ctx.cfg, g_xs, attr=a, g_wsum=g_ws, need_p=ctx.needs_input_grad[0],
-                                need_attr=ctx.needs_input_grad[1])
+        fused = None
+        if os.environ.get("NFS_SPLAT_LDS", "1") != "0":
+            fused = ops.p2g_wavg_bwd(p2, ctx.cfg, xs, ws, g.contiguous()[0], a, ctx.eps,
+                                     need_p=ctx.needs_input_grad[0], need_attr=ctx.needs_input_grad[1])
+        if fused is not None:
+            gp, ga = fused
+        else:
+            g_xs, g_ws = ops.p2g_wavg_finish_bwd(xs, ws, g.contiguous()[0], ctx.eps)
+            gp, ga, _ = ops.p2g_bwd(p2, ctx.cfg, g_xs, attr=a, g_wsum=g_ws, need_p=ctx.needs_input_grad[0],
+                                    need_attr=ctx.needs_input_grad[1])
         return (None if gp is None else gp.unsqueeze(0), None if ga is None else ga.unsqueeze(0), None, None)
 
 
