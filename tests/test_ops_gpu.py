@@ -467,6 +467,9 @@ def test_p2g_cell_ordered_particles_accumulate_in_lds_and_agree_with_the_scatter
             xs, ws = ops.p2g_fwd(dev(pp), cfg, attr=dev(xx))
             g_xs, g_ws = ops.p2g_wavg_finish_bwd(xs, ws, dev(g.expand(G, G, G, 2).contiguous()))
             gp, ga, _ = ops.p2g_bwd(dev(pp), cfg, g_xs, attr=dev(xx), g_wsum=g_ws, need_p=True, need_attr=True)
+            # the same adjoint in ONE launch (finish adjoint formed while the box is staged): the same lines per cell
+            gp1, ga1 = ops.p2g_wavg_bwd(dev(pp), cfg, xs, ws, dev(g.expand(G, G, G, 2).contiguous()), dev(xx))
+            assert torch.equal(gp1, gp) and torch.equal(ga1, ga)
         back = np.empty(N, np.int64)
         back[perm] = np.arange(N)
         grads.append((gp.cpu()[back], None if ga is None else ga.cpu()[back]))

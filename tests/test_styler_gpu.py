@@ -464,3 +464,29 @@ def test_tv_and_content_divisors_do_not_depend_on_the_local_view_count():
     l_sh = [loss.loss_and_grad(d, rot[v:v + 1].contiguous(), g_sh) for v in range(V)]     # "rank v" holds view v only
     assert abs(float(sum(x.sum() for x in l_sh)) - float(l_all.sum())) < 1e-5 * abs(float(l_all.sum()))
     assert rel(g_sh.cpu(), g_all.cpu()) < 1e-5
+
+
+def test_permutation_gather_has_the_inverse_gather_as_adjoint_and_drifting_frames_are_reordered():
+    """transform._Permute (x[:, order] with the inverse permutation as its adjoint) equals autograd's index backward;
+    Styler._particle_order recomputes a frame's grid order from the CURRENT positions every ``reorder_every`` evaluations
+    when the positions are the variable, and leaves the caller's order alone otherwise"""
+    from neural_flow_style_amd import transform as T
+    from neural_flow_style_amd.styler_3p import Styler
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(1, 1000, 3, device="cuda", generator=g)
+    order = torch.randperm(1000, device="cuda", generator=g)
+    a = x.clone().requires_grad_(); b = x.clone().requires_grad_()
+    w = torch.rand(1, 1000, 3, device="cuda", generator=g)
+    (T.permute_particles(a, order) * w).sum().backward()
+    (b[:, order] * w).sum().backward()
+    assert torch.equal(T.permute_particles(a, order), b[:, order]) and torch.equal(a.grad, b.grad)
+    st = Styler.__new__(Styler)                      # (only the ordering logic: no network, no config)
+    st.target_field, st.sort_particles, st.resolution, st.reorder_every = "p", True, [16, 16, 16], 3
+    p = torch.rand(500, 3, device="cuda", generator=g)
+    seen = [st._particle_order(p, (p + 0.01 * k).unsqueeze(0)) for k in range(7)]
+    assert seen[0] is None and seen[1] is None                       # the caller's order until the third evaluation
+    assert seen[2] is not None and seen[3] is seen[2] and seen[5] is not seen[2]
+    assert torch.equal(seen[2], T.grid_order(p + 0.02, [16, 16, 16], stable=False))
+    st.target_field = "d"                                            # positions fixed: never re-ordered
+    st._orders, st._order_age = {}, {}
+    assert all(st._particle_order(p, p.unsqueeze(0)) is None for _ in range(5))
