@@ -54,14 +54,13 @@ class Styler(StylerBase):
         cache = self.__dict__.setdefault("_orders", {})
         key = (p.data_ptr(), p.shape[0])
         if key not in cache:
-            o = T.grid_order(p, self.resolution)
-            cache[key] = (o, T.inverse_permutation(o))
-        assert cache[key][0].numel() == p.shape[0]
+            cache[key] = T.grid_order(p, self.resolution)
+        assert cache[key].numel() == p.shape[0]
         return cache[key]
 
     def _density(self, p, res):
         o = self._order(p)
-        pp = p if o is None else p[o[0]]
+        pp = p if o is None else p[o]
         d = T.p2g(pp.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
                   support=self.support, clip=self.clip)
         return torch.clamp(d / self.rest_density, 0, 1)                      # [1,H,W,1]
@@ -69,9 +68,9 @@ class Styler(StylerBase):
     def _colour(self, p, r, var, res):
         c_ = torch.clamp(var.unsqueeze(0), 0, 1)
         o = self._order(p)
-        # (the colours through the permutation and back: the adjoint of a gather through a permutation is the gather
-        # through its inverse, transform._Permute)
-        pp, cc, rr = (p, c_, r) if o is None else (p[o[0]], T.permute_particles(c_, o[0], o[1]), r[o[0]])
+        # (the colours through the permutation and back: the adjoint of a gather through a permutation is a plain
+        # scatter, transform._Permute)
+        pp, cc, rr = (p, c_, r) if o is None else (p[o], T.permute_particles(c_, o), r[o])
         d = T.p2g(pp.unsqueeze(0), self.domain, res, self.radius, self.rest_density, self.nsize,
                   support=self.support, clip=self.clip, pc=cc, pd=rr.unsqueeze(0))
         return torch.clamp(d, 0, 1), c_[0]                                   # [1,H,W,3]

@@ -91,18 +91,13 @@ class Styler(StylerBase):
         # own grid order (a gather of the positions in, the scatter of their gradient out -- the splat does not care
         # about the order of its particles)
         order = self._particle_order(p, p_)
-        inverse = None
         if order is not None:
-            inverse = self._order_inv.get((p.data_ptr(), p.shape[0]))
-            if inverse is None or inverse[0] is not order:
-                inverse = self._order_inv[(p.data_ptr(), p.shape[0])] = (order, T.inverse_permutation(order))
-            inverse = inverse[1]
-            p_ = T.permute_particles(p_, order, inverse)
+            p_ = T.permute_particles(p_, order)
         if "d" in self.target_field:
             r_opt = torch.clamp(var.unsqueeze(0), -1, 1)                    # "necessary!" (styler_3p.py:74)
             r_ = r.unsqueeze(0) + r_opt
             if order is not None:
-                r_ = T.permute_particles(r_, order, inverse)
+                r_ = T.permute_particles(r_, order)
             if getattr(self, "w_density", 0) > 0:
                 # density preservation on the clipped offsets (self.d[i], styler_3p.py:75; styler_base.py:217-223)
                 d_loss = r_opt[0].sum() ** 2
@@ -134,7 +129,6 @@ class Styler(StylerBase):
         the CURRENT positions every ``reorder_every`` evaluations (default 10; 0 = never).  The splat does not care
         about the order of its particles; autograd scatters the gradient back through the gather."""
         orders = self.__dict__.setdefault("_orders", {})
-        self.__dict__.setdefault("_order_inv", {})
         key = (p.data_ptr(), p.shape[0])
         every = int(getattr(self, "reorder_every", 10) or 0)
         if "p" not in self.target_field or every <= 0 or not getattr(self, "sort_particles", True) or p.shape[0] < 2:
@@ -237,7 +231,7 @@ class Styler(StylerBase):
             inv[perm] = torch.arange(perm.numel(), device=self.device)
             p = [x[perm].contiguous() for x in p]
             r = [x[perm].contiguous() if x is not None else None for x in r]
-        self._orders, self._order_age, self._order_inv = {}, {}, {}
+        self._orders, self._order_age = {}, {}
         if getattr(self, "sort_particles", True) and self.num_frames > 1:
             for x in p[1:]:                                  # (frame 0 is in its own order already)
                 if x.shape[0] > 1:
@@ -412,7 +406,7 @@ class Styler(StylerBase):
         result["d"] = np.array(d_sty)
         result["r"] = np.array(r_sty)
         result["opt"] = [(g if inv is None else g[inv]).cpu().numpy() for g in g_opt]   # build extension: the variables
-        self._orders, self._order_age, self._order_inv = {}, {}, {}   # keyed by device address: the frame tensors die with this call
+        self._orders, self._order_age = {}, {}   # keyed by device address: the frame tensors die with this call
         return result
 
     def loss_d_img(self, d_out):

@@ -467,7 +467,7 @@ def test_tv_and_content_divisors_do_not_depend_on_the_local_view_count():
 
 
 def test_permutation_gather_has_the_inverse_gather_as_adjoint_and_drifting_frames_are_reordered():
-    """transform._Permute (x[:, order] with the inverse permutation as its adjoint) equals autograd's index backward;
+    """transform._Permute (x[:, order] with a plain scatter as its adjoint) equals autograd's index backward;
     Styler._particle_order recomputes a frame's grid order from the CURRENT positions every ``reorder_every`` evaluations
     when the positions are the variable, and leaves the caller's order alone otherwise"""
     from neural_flow_style_amd import transform as T
