@@ -6,8 +6,10 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      torch.distributed.run)
 
 One step at N = 1 = one stylisation iteration: advect -> smooth/clamp -> for all 8 views: rotate+render -> VGG-19
-conv1_1..conv5_1 -> Gram style loss -> full adjoint chain -> TF-Adam update of the 200^3 x 3 velocity field.  Inputs
-are synthetic (seed 123) and resident in HBM before the timed region.
+conv1_1..conv5_1 -> Gram style loss -> full adjoint chain -> TF-Adam update of the 200^3 x 3 velocity field.  (The
+advect of iteration i + 1 is formed inside the Adam kernel of iteration i -- the updated velocity is in registers
+there --, so every timed step still contains exactly one advect, one update and everything between them.)  Inputs are
+synthetic (seed 123) and resident in HBM before the timed region.
 
 N > 1 (``--scaling-by``):
   views (default)   the BASELINE metric: the 8 views of ONE frame sharded over the ranks (strong scaling); the exchange is
