@@ -7,7 +7,7 @@ import json
 import os
 
 import numpy as np
-from scipy.ndimage import gaussian_filter, map_coordinates
+from scipy.ndimage import gaussian_filter
 
 
 def denoise(img, sigma):
@@ -28,23 +28,54 @@ def crop_ratio(img, ratio):
     return img[oy:oy + hw[0], ox:ox + hw[1]]
 
 
+def _interp_matrix(n_in, n_out, order):
+    """[n_out, n_in] weights of skimage.transform.resize's 2-D path along one axis: output pixel i samples the input at
+    src = (i + 0.5) * n_in / n_out - 0.5 (resize's AffineTransform through the pixel CENTRES); order 0 nearest
+    (round), 1 linear, 3 Catmull-Rom cubic convolution -- the ``bicubic_interpolation`` of skimage's ``_warp_fast``
+    ("Interpolation using Catmull-Rom splines, based on the bicubic convolution algorithm" of Keys), taps
+    floor(src) - 1 ... floor(src) + 2; pixels outside the image read 0 (mode='constant', cval 0)"""
+    src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / float(n_out)) - 0.5
+    M = np.zeros((n_out, n_in), np.float64)
+    rows = np.arange(n_out)
+
+    def put(idx, w):
+        ok = (idx >= 0) & (idx < n_in)
+        np.add.at(M, (rows[ok], idx[ok]), w[ok])
+    if order == 0:
+        put(np.round(src).astype(np.int64), np.ones(n_out))
+    elif order == 1:
+        i0 = np.floor(src).astype(np.int64)
+        x = src - i0
+        put(i0, 1.0 - x); put(i0 + 1, x)
+    else:
+        i0 = np.floor(src).astype(np.int64)
+        x = src - i0
+        x2, x3 = x * x, x * x * x
+        put(i0 - 1, -0.5 * x3 + x2 - 0.5 * x)
+        put(i0, 1.5 * x3 - 2.5 * x2 + 1.0)
+        put(i0 + 1, -1.5 * x3 + 2.0 * x2 + 0.5 * x)
+        put(i0 + 2, 0.5 * x3 - 0.5 * x2)
+    return M
+
+
 def _resize_plane(a, size, order):
-    """bicubic (order 3) resize of one 2-D plane with anti-aliasing, following the published
-    algorithm of skimage.transform.resize (0.14.x): Gaussian pre-filter with
-    sigma = max(0, (scale-1)/2) per axis (mode 'constant'), then sampling at
-    src = (dst + 0.5) * scale - 0.5 with zero padding, result clipped to the input range.
-    scikit-image is not installed here; SciPy's spline interpolation stands in for its
-    cubic-convolution warp (host-side style-image preparation only -- parity unpinned)."""
+    """One 2-D plane through the published algorithm of skimage.transform.resize (0.14.x) as the reference calls it
+    (util.py:196-203: ``mode='constant', anti_aliasing=True``): Gaussian pre-filter with sigma = max(0, (scale - 1) / 2)
+    per axis (``ndi.gaussian_filter(..., mode='constant', cval=0)``), then the warp through the scale transform -- for a
+    2-D image that is skimage's ``_warp_fast``: separable cubic CONVOLUTION (Catmull-Rom) for order 3, not the B-spline
+    of ``ndi.map_coordinates`` (which skimage only uses for n-D volumes) --, zero outside the image, result clipped to
+    the input's range (``clip=True``).  scikit-image is not installed in this image, so this restatement is pinned by
+    its properties only (tests/test_util_resize_cpu.py): exact copy at equal size, partition of unity and linear
+    precision in the interior; "parity unpinned" against skimage 0.14.2 itself (host-side style-image preparation)."""
     a = np.asarray(a, np.float64)
+    lo, hi = a.min(), a.max()
     scale = [a.shape[k] / float(size[k]) for k in range(2)]
     sig = [max(0.0, (s - 1.0) / 2.0) for s in scale]
     if any(s > 0 for s in sig):
         a = gaussian_filter(a, sig, mode="constant", cval=0.0)
-    yy = (np.arange(size[0]) + 0.5) * scale[0] - 0.5
-    xx = (np.arange(size[1]) + 0.5) * scale[1] - 0.5
-    g = np.meshgrid(yy, xx, indexing="ij")
-    out = map_coordinates(a, g, order=order, mode="constant", cval=0.0, prefilter=order > 1)
-    return np.clip(out, a.min(), a.max())
+    order = 3 if order >= 2 else int(order)
+    out = _interp_matrix(a.shape[0], size[0], order) @ a @ _interp_matrix(a.shape[1], size[1], order).T
+    return np.clip(out, lo, hi)
 
 
 def resize(img, size=None, f=None, order=1):
