@@ -915,6 +915,13 @@ class GridStylizer(object):
     def _adv_mark(self):
         self._adv_src = (self.var, self.var._version, self.d0, self.d0._version)
 
+    def invalidate_forward(self):
+        """forget the stored forward advect.  In-place torch ops on ``var`` / ``d0`` (also through ``detach()`` views, which
+        share the version counter), ``bind()`` and re-assignment are noticed by themselves; a write that bypasses the
+        counter -- through ``tensor.data``, or by a kernel called on ``var.data_ptr()`` directly -- is not: call this
+        after one."""
+        self._adv_src = None
+
     def _adv_valid(self):
         a = self._adv_src
         return (a is not None and self._adv_buf is not None and a[0] is self.var and a[1] == self.var._version
