@@ -13,15 +13,16 @@ namespace nfs {
 // the 3x3 (y,x) neighbourhood of ONE new plane (9 loads, coalesced along x), reduces it to the
 // 2-D filtered value and combines the last three of those along z -- 9 loads per output instead
 // of 27 (the 2-D sums are reused by three consecutive z).  HBM traffic = one read + one write.
-// Tiled z-march.  A block (8 waves) owns SM_TY rows x txe (<= 64) columns of a z-chunk, one column per thread.
+// Tiled z-march.  A block (8 waves) owns TY = 8 or 16 rows x txe (<= 64) columns of a z-chunk, one column (two rows
+// of it at TY = 16) per thread.
 // Per plane it stages the tile plus a one-cell halo in LDS (zero outside the volume = SAME padding; for the
 // adjoint the staged value is g * (pre >= 0), the TF Maximum mask read from the sign bit of the forward output),
 // each thread forms the 3x3 in-plane sum from LDS and combines the last three plane sums along z in registers.
-// Global loads per output: (SM_TY+2)/SM_TY * (txe+2)/txe * (zc+2)/zc ~ 1.4 (x2 for the adjoint) instead of 9
+// Global loads per output: (TY+2)/TY * (txe+2)/txe * (zc+2)/zc ~ 1.3-1.4 (x2 for the adjoint) instead of 9
 // (18): the first version (one thread per column, 9 L1-cached loads per plane) was bound by vector-memory
 // instruction issue at 0.8-1.0 TB/s whatever the chunk length.  Planes are double-buffered in LDS and the
 // next plane's global loads are issued before the current plane is consumed: one barrier per plane.
-constexpr int SM_TY = 8, SM_TXMAX = 64, SM_THREADS = 512, SM_ZCHUNK = 25;
+constexpr int SM_TXMAX = 64, SM_THREADS = 512, SM_ZCHUNK = 25;
 #ifndef NFS_SM_PF
 #define NFS_SM_PF 2
 #endif
@@ -33,12 +34,24 @@ constexpr int SM_PF = NFS_SM_PF;                  // planes of register look-ahe
 // load or a store, so the compiler counts them (s_waitcnt vmcnt(n), not 0) and SM_PF planes really stay in flight.
 constexpr uint32_t SM_OOB = 0x80000000u;
 
-template <bool BWD>
+// RY = rows per thread: a block covers 8 * RY rows.  RY = 2 (round 4) halves the barriers and the halo rows per voxel:
+// 200^3 forward 21.1 -> 17.5 us back to back, ~27 -> ~24 us behind other kernels (tools/micro/field_variants.hip
+// "S2").  Its two staging slots per thread hold (16 + 2) x (txe + 2) elements, so the column tiles stop at 54.
+__device__ __forceinline__ float sm_tap(float wa, float wb, float a, float b, float c) {
+  return __fmaf_rn(wa, c, __fmaf_rn(wb, b, wa * a));
+}
+
+template <int RY> struct SmTile {
+  static constexpr int TY = 8 * RY, TXE_MAX = RY == 1 ? SM_TXMAX : 54;
+};
+
+template <bool BWD, int RY>
 __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ act, float* __restrict__ out,
                                                               int D, int H, int W, float k, int txe, int ntx, int nty, int nz) {
-  constexpr int TB = (SM_TY + 2) * (SM_TXMAX + 2);
-  __shared__ float tile[2][SM_TY + 2][SM_TXMAX + 2];
+  constexpr int TY = SmTile<RY>::TY, LW = SM_TXMAX + 2;
+  constexpr int TB = (TY + 2) * LW;
+  __shared__ float tile[2][TY + 2][LW];
   __shared__ float dump[TB + 1];                  // where the threads without a staging slot put their zeros
   const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
   // consecutive workgroups go round-robin to the 8 XCDs: give each XCD a contiguous range of tiles, so that x / y
@@ -47,9 +60,8 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
   const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lb >= (unsigned)(ntx * nty * nz)) return;
   const int bx = lb % ntx, by = (lb / ntx) % nty, bz = lb / (ntx * nty);
-  const int x0 = bx * txe, y0 = by * SM_TY, z0 = bz * SM_ZCHUNK, z1 = min(z0 + SM_ZCHUNK, D);
-  const int x = x0 + tx, y = y0 + ty;
-  const bool owner = tx < txe && x < W && y < H;
+  const int x0 = bx * txe, y0 = by * TY, z0 = bz * SM_ZCHUNK, z1 = min(z0 + SM_ZCHUNK, D);
+  const int x = x0 + tx;
   // 1-D weights [1,k,1]/(k+2); k <= 0 skips the conv (identity)
   const float inv = k > 0.f ? 1.f / (k + 2.f) : 1.f;
   const float wa = k > 0.f ? inv : 0.f, wb = k > 0.f ? k * inv : 1.f;
@@ -61,16 +73,23 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t act_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? act + base : in + base), 0, recs, 0x00020000);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out + base, 0, recs, 0x00020000);
-  // staging slots of this thread: elements t and t + 512 of the (SM_TY+2) x (txe+2) halo'd tile
-  const int cols = txe + 2, ne = (SM_TY + 2) * cols;
-  const int e0 = t, e1 = t + SM_THREADS;
-  const int r0 = e0 / cols, c0 = e0 - r0 * cols, r1 = e1 / cols, c1 = e1 - r1 * cols;
-  const int yy0 = y0 - 1 + r0, xx0 = x0 - 1 + c0, yy1 = y0 - 1 + r1, xx1 = x0 - 1 + c1;
-  const uint32_t o0 = (e0 < ne && yy0 >= 0 && yy0 < H && xx0 >= 0 && xx0 < W) ? (uint32_t)(yy0 * W + xx0) * 4u : SM_OOB;
-  const uint32_t o1 = (e1 < ne && yy1 >= 0 && yy1 < H && xx1 >= 0 && xx1 < W) ? (uint32_t)(yy1 * W + xx1) * 4u : SM_OOB;
-  float* const s0 = e0 < ne ? &tile[0][r0][c0] : dump;          // (+ TB for the second buffer: dump[TB])
-  float* const s1 = e1 < ne ? &tile[0][r1][c1] : dump;
-  const uint32_t oo = owner ? (uint32_t)(y * W + x) * 4u : SM_OOB;
+  // staging slots of this thread: elements t and t + 512 of the (TY+2) x (txe+2) halo'd tile
+  const int cols = txe + 2, ne = (TY + 2) * cols;
+  uint32_t so[2];
+  float* sp[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int e = t + SM_THREADS * s, r = e / cols, c = e - r * cols;
+    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    so[s] = (e < ne && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (uint32_t)(yy * W + xx) * 4u : SM_OOB;
+    sp[s] = e < ne ? &tile[0][r][c] : dump;                     // (+ TB for the second buffer: dump[TB])
+  }
+  uint32_t oo[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    const int y = y0 + ty + 8 * r;
+    oo[r] = (tx < txe && x < W && y < H) ? (uint32_t)(y * W + x) * 4u : SM_OOB;
+  }
   float v0, v1;
   // plane p_ of the volume -> (v0, v1); a plane outside the block's range reads as zeros
 #define NFS_SM_GLOAD(p_)                                                                               \
@@ -78,7 +97,7 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
     const int pz_ = (p_);                                                                              \
     const bool in_ = pz_ >= zb && pz_ < ze;                                                            \
     const uint32_t so_ = in_ ? (uint32_t)(pz_ - zb) * plane_b : 0u;                                    \
-    const uint32_t a0_ = in_ ? o0 : SM_OOB, a1_ = in_ ? o1 : SM_OOB;                                   \
+    const uint32_t a0_ = in_ ? so[0] : SM_OOB, a1_ = in_ ? so[1] : SM_OOB;                             \
     v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, a0_, so_, 0));        \
     v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, a1_, so_, 0));        \
     if (BWD) {                                     /* g_out * (pre >= 0): the sign bit of the forward output */ \
@@ -93,8 +112,8 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
   // 4 or 6 -- the stores of the same loop share the counter with the loads and the compiler keeps the waits near
   // vmcnt(2) whatever the ring depth; what is left is the per-plane barrier of eight waves)
   NFS_SM_GLOAD(z0 - 1)
-  s0[0] = v0;
-  s1[0] = v1;
+  sp[0][0] = v0;
+  sp[1][0] = v1;
   float rv0[SM_PF], rv1[SM_PF];
 #pragma unroll
   for (int u = 0; u < SM_PF; ++u) {
@@ -103,7 +122,9 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
     rv1[u] = v1;
   }
   __syncthreads();
-  float pm = 0.f, pc = 0.f;
+  float pm[RY], pc[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) pm[r] = pc[r] = 0.f;
   // iteration p consumes plane p (buffer (p - z0 + 1) & 1), stages plane p + 1 from the ring and fetches plane
   // p + 1 + SM_PF into the freed ring slot
   for (int pb = z0 - 1; pb <= z1; pb += SM_PF) {
@@ -112,28 +133,53 @@ __global__ void __launch_bounds__(SM_THREADS) smooth3d_kernel(const float* __res
       const int p = pb + u;
       if (p > z1) break;
       const int b = u & 1;
-      const float* t0 = &tile[b][ty][tx];
-      const float ra = wa * t0[0] + wb * t0[1] + wa * t0[2];
-      const float rb = wa * t0[SM_TXMAX + 2] + wb * t0[SM_TXMAX + 3] + wa * t0[SM_TXMAX + 4];
-      const float rc = wa * t0[2 * (SM_TXMAX + 2)] + wb * t0[2 * (SM_TXMAX + 2) + 1] + wa * t0[2 * (SM_TXMAX + 2) + 2];
-      const float pn = wa * ra + wb * rb + wa * rc;
-      s0[(b ^ 1) * TB] = rv0[u];                 // plane p + 1 (its buffer was last read in iteration p - 1)
-      s1[(b ^ 1) * TB] = rv1[u];
+      float pn[RY];
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const float* t0 = &tile[b][ty + 8 * r][tx];
+        // (explicit fmas: the 8- and 16-row instances must round alike, whatever the compiler would contract)
+        const float ra = sm_tap(wa, wb, t0[0], t0[1], t0[2]);
+        const float rb = sm_tap(wa, wb, t0[LW], t0[LW + 1], t0[LW + 2]);
+        const float rc = sm_tap(wa, wb, t0[2 * LW], t0[2 * LW + 1], t0[2 * LW + 2]);
+        pn[r] = sm_tap(wa, wb, ra, rb, rc);
+      }
+      sp[0][(b ^ 1) * TB] = rv0[u];              // plane p + 1 (its buffer was last read in iteration p - 1)
+      sp[1][(b ^ 1) * TB] = rv1[u];
       NFS_SM_GLOAD(p + 1 + SM_PF)
       rv0[u] = v0;
       rv1[u] = v1;
-      float r = wa * pm + wb * pc + wa * pn;     // output plane p - 1
-      // forward: max(pre,0) with the sign bit carrying (pre < 0) for the TF Maximum gradient
-      if (!BWD) r = (r >= 0.f) ? fabsf(r) : (r < 0.f ? -0.0f : r);
       const bool wr = p >= z0 + 1;               // (p - 1 is a plane of this chunk: inside [zb, ze))
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), out_rsrc, wr ? oo : SM_OOB,
-                                            wr ? (uint32_t)(p - 1 - zb) * plane_b : 0u, 0);
-      pm = pc;
-      pc = pn;
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        float o = sm_tap(wa, wb, pm[r], pc[r], pn[r]);    // output plane p - 1
+        // forward: max(pre,0) with the sign bit carrying (pre < 0) for the TF Maximum gradient
+        if (!BWD) o = (o >= 0.f) ? fabsf(o) : (o < 0.f ? -0.0f : o);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), out_rsrc, wr ? oo[r] : SM_OOB,
+                                              wr ? (uint32_t)(p - 1 - zb) * plane_b : 0u, 0);
+        pm[r] = pc[r];
+        pc[r] = pn[r];
+      }
       __syncthreads();
     }
   }
 #undef NFS_SM_GLOAD
+}
+
+// 16-row tiles once they still give every CU a block; 8-row tiles for small volumes (NFS_SM_ROWS=8 / 16 forces one)
+template <bool BWD>
+static void launch_smooth3d(const float* in, const float* act, float* out, int D, int H, int W, float k, hipStream_t st) {
+  static const int forced = [] { const char* e = getenv("NFS_SM_ROWS"); return e ? atoi(e) : 0; }();
+  const int nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
+  auto go = [&](auto ry) {
+    constexpr int RY = decltype(ry)::value;
+    const int ntx = (W + SmTile<RY>::TXE_MAX - 1) / SmTile<RY>::TXE_MAX, txe = (W + ntx - 1) / ntx;   // balanced column tiles
+    const int nty = (H + SmTile<RY>::TY - 1) / SmTile<RY>::TY;
+    hipLaunchKernelGGL((smooth3d_kernel<BWD, RY>), dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, st, in, act,
+                       out, D, H, W, k, txe, ntx, nty, nz);
+  };
+  const int blocks16 = ((W + 53) / 54) * ((H + 15) / 16) * nz;
+  if (forced == 16 || (forced != 8 && blocks16 >= 256)) go(std::integral_constant<int, 2>{});
+  else go(std::integral_constant<int, 1>{});
 }
 
 // ---- A10 -----------------------------------------------------------------------------
@@ -331,10 +377,7 @@ int nfs_smooth3d_relu_fwd(const float* d, float* out, int D, int H, int W, float
   NFS_REQUIRE(d && out, "nfs_smooth3d_relu_fwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_fwd: non-positive dimension");
   NFS_REQUIRE((int64_t)H * W * 4 * (SM_ZCHUNK + 2) < ((int64_t)1 << 31), "nfs_smooth3d_relu_fwd: a z-chunk of planes must stay below 2 GB (32-bit buffer offsets)");
-  const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;   // balanced column tiles
-  const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
-  hipLaunchKernelGGL(smooth3d_kernel<false>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
-                     d, (const float*)nullptr, out, D, H, W, k, txe, ntx, nty, nz);
+  launch_smooth3d<false>(d, nullptr, out, D, H, W, k, as_stream(stream));
   return check_launch("nfs_smooth3d_relu_fwd");
 }
 
@@ -343,10 +386,7 @@ int nfs_smooth3d_relu_bwd(const float* out, const float* g_out, float* g_d, int 
   NFS_REQUIRE(out && g_out && g_d, "nfs_smooth3d_relu_bwd: null pointer");
   NFS_REQUIRE(D > 0 && H > 0 && W > 0, "nfs_smooth3d_relu_bwd: non-positive dimension");
   NFS_REQUIRE((int64_t)H * W * 4 * (SM_ZCHUNK + 2) < ((int64_t)1 << 31), "nfs_smooth3d_relu_bwd: a z-chunk of planes must stay below 2 GB (32-bit buffer offsets)");
-  const int ntx = (W + SM_TXMAX - 1) / SM_TXMAX, txe = (W + ntx - 1) / ntx;
-  const int nty = (H + SM_TY - 1) / SM_TY, nz = (D + SM_ZCHUNK - 1) / SM_ZCHUNK;
-  hipLaunchKernelGGL(smooth3d_kernel<true>, dim3((ntx * nty * nz + 7) / 8 * 8), dim3(SM_THREADS), 0, as_stream(stream),
-                     g_out, out, g_d, D, H, W, k, txe, ntx, nty, nz);
+  launch_smooth3d<true>(g_out, out, g_d, D, H, W, k, as_stream(stream));
   return check_launch("nfs_smooth3d_relu_bwd");
 }
 

@@ -285,6 +285,88 @@ __global__ void __launch_bounds__(512) advect_smooth_kernel(const float* __restr
   }
 }
 
+
+// ---- S2: smooth + clamp alone in the fused kernel's geometry (16 rows x txe columns per block, two outputs and two staging
+// slots per thread, PF planes of register look-ahead): does halving the barriers per voxel help the marching stencil? -------
+template <int PF>
+__global__ void __launch_bounds__(512) smooth2_kernel(const float* __restrict__ in, float* __restrict__ out, int D, int H,
+                                                      int W, float k, int txe, int ntx, int nty, int nz, int zchunk) {
+  constexpr int TYI = 16, TXM = 64, TB = (TYI + 2) * (TXM + 2);
+  __shared__ float tile[2][TYI + 2][TXM + 2];
+  __shared__ float dump[TB + 2];
+  const int t = threadIdx.x, tx = t & 63, wv = t >> 6;
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lb >= (unsigned)(ntx * nty * nz)) return;
+  const int bx = lb % ntx, by = (lb / ntx) % nty, bz = lb / (ntx * nty);
+  const int x0 = bx * txe, y0 = by * TYI, z0 = bz * zchunk, z1 = min(z0 + zchunk, D);
+  const float inv = k > 0.f ? 1.f / (k + 2.f) : 1.f;
+  const float wa = k > 0.f ? inv : 0.f, wb = k > 0.f ? k * inv : 1.f;
+  const int cols = txe + 2, ne = (TYI + 2) * cols;
+  const unsigned uHW = (unsigned)(H * W);
+  uint32_t so[2];
+  float* sp[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int e = t + 512 * s, r = e / cols, c = e - r * cols;
+    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    so[s] = (e < ne && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (uint32_t)(yy * W + xx) * 4u : OOB;
+    sp[s] = e < ne ? &tile[0][r][c] : dump + s;
+  }
+  const __amdgpu_buffer_rsrc_t i_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (uint32_t)((size_t)D * H * W * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)((size_t)D * H * W * 4), 0x00020000);
+  auto gload = [&](int pz, float* v) {
+    const bool in_ = pz >= 0 && pz < D;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(i_rsrc, in_ ? so[s] : OOB, in_ ? (uint32_t)pz * uHW * 4u : 0u, 0));
+  };
+  const int pf = z0 - 1;
+  float rv[PF][2], v0[2];
+  gload(pf, v0);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) gload(pf + 1 + u, rv[u]);
+  sp[0][0] = v0[0]; sp[1][0] = v0[1];
+  __syncthreads();
+  float pm[2] = {0.f, 0.f}, pc[2] = {0.f, 0.f};
+  const int oy0 = y0 + wv, oy1 = y0 + wv + 8, ox = x0 + tx;
+  const bool own0 = tx < txe && ox < W && oy0 < H, own1 = tx < txe && ox < W && oy1 < H;
+  const uint32_t oo0 = own0 ? (uint32_t)(oy0 * W + ox) * 4u : OOB, oo1 = own1 ? (uint32_t)(oy1 * W + ox) * 4u : OOB;
+  constexpr int LC = PF % 2 ? 2 * PF : PF;
+  for (int pb = pf; pb <= z1; pb += LC) {
+#pragma unroll
+    for (int u = 0; u < LC; ++u) {
+      const int p = pb + u;
+      if (p > z1) break;
+      const int b = u & 1;
+      float pn[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float* t0 = &tile[b][wv + 8 * r][tx];
+        const float ra = wa * t0[0] + wb * t0[1] + wa * t0[2];
+        const float rb = wa * t0[TXM + 2] + wb * t0[TXM + 3] + wa * t0[TXM + 4];
+        const float rcc = wa * t0[2 * (TXM + 2)] + wb * t0[2 * (TXM + 2) + 1] + wa * t0[2 * (TXM + 2) + 2];
+        pn[r] = wa * ra + wb * rb + wa * rcc;
+      }
+      const int rs = u % PF;
+      sp[0][(b ^ 1) * TB] = rv[rs][0];
+      sp[1][(b ^ 1) * TB] = rv[rs][1];
+      gload(p + 1 + PF, rv[rs]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float o = wa * pm[r] + wb * pc[r] + wa * pn[r];
+        o = (o >= 0.f) ? fabsf(o) : (o < 0.f ? -0.0f : o);
+        const bool wr = p >= z0 + 1;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), o_rsrc, wr ? (r ? oo1 : oo0) : OOB,
+                                              wr ? (uint32_t)(p - 1) * uHW * 4u : 0u, 0);
+        pm[r] = pc[r];
+        pc[r] = pn[r];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 static float time_it(hipStream_t s, int reps, const std::function<void()>& f) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -381,6 +463,17 @@ int main(int argc, char** argv) {
   // fused advect + smooth
   smooth_ref_kernel<<<(n + 255) / 256, 256, 0, s>>>(o1, o3, G, G, G, 3.f);
   CK(hipDeviceSynchronize());
+  for (int zc : {25, 13}) {
+    const int txe = G <= 62 ? G : (G + ((G + 53) / 54) - 1) / ((G + 53) / 54);
+    const int ntx = (G + txe - 1) / txe, nty = (G + 15) / 16, nz = (G + zc - 1) / zc;
+    const unsigned grid = (ntx * nty * nz + 7) / 8 * 8;
+    char name[128];
+#define RUNS(PF_)                                                                                              \
+    us = time_it(s, R, [&] { smooth2_kernel<PF_><<<grid, 512, 0, s>>>(o1, o2, G, G, G, 3.f, txe, ntx, nty, nz, zc); }); \
+    snprintf(name, sizeof name, "S2 smooth alone, 16-row tiles, zc=%d PF=%d (%u blocks)", zc, PF_, grid);           \
+    report(name, us, 64.0 * n / 8e6, max_diff(o3, o2, n));
+    RUNS(1) RUNS(2) RUNS(4)
+  }
   for (int zc : {25, 20, 13, 10}) {
     const int txe = G <= 62 ? G : (G + ((G + 53) / 54) - 1) / ((G + 53) / 54);
     const int ntx = (G + txe - 1) / txe, nty = (G + 15) / 16, nz = (G + zc - 1) / zc;
