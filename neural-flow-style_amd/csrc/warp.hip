@@ -457,75 +457,82 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
 }
 
-// catchment of one (tile, view).  Kept out of line: its double-precision temporaries must not raise the
-// register count of the hot loop.
-__device__ __attribute__((noinline)) void rotate_tile_catchment(const float* r, int D, int H, int W, int z0, int y0,
+// catchment of one (tile, view).  One lane per view runs this while the other 1023 threads of the block wait, so its
+// latency is a fixed cost of every block (measured in round 4, tools/render_family_by_views.py: the kernel took
+// 42 us + 30 us per view at 200^3 -- the first version of this function, 21 double-precision divisions and 148 bytes of
+// scratch under the kernel's 64-register cap, was most of the 42).  Now: double precision where it sets the floats the
+// sample loop reads (A, c, 1 / A[a][2]: bit-identical to before), one reciprocal of the determinant for the lattice box
+// (a bound, padded by 0.05 cells), every array fully unrolled and the outputs stored as soon as they are final: inlined
+// it fits the 64 registers without scratch (out of line the ABI's callee-saved registers alone cost 16 scratch round
+// trips).  200^3: 71.8 -> 62.6 us at one view, 278.7 -> 271.5 at eight, bit-identical; with the sample loop compiled out
+// the kernel (zero fill of the accumulators, this function, write-back) takes 16.7 us, of which this function 1.3.
+__device__ __forceinline__ void rotate_tile_catchment(const float* r, int D, int H, int W, int z0, int y0,
                                                                  int x0, int z1, int y1, int x1, ViewRows* out) {
   const int n[3] = {D, H, W};
   const int tlo[3] = {z0, y0, x0}, thi[3] = {z1, y1, x1};
+  float rr[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rr[i] = r[i];
+  double sb[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) sb[b] = n[b] > 1 ? 2.0 / (n[b] - 1) : 0.0;
   // cmin/cmax: the range the (unclamped) sample coordinate of axis a takes over the whole output lattice;
   // a border tile also catches the samples clamped onto it, so its catchment extends to that range
-  double A[3][3], c[3], xl[3], xh[3];
+  double A[3][3], mid[3], half[3];
+#pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double ha = 0.5 * (n[a] - 1);
     double rs = 0.0, mn = 0.0, mx = 0.0;
+#pragma unroll
     for (int b = 0; b < 3; ++b) {
-      const double sb = n[b] > 1 ? 2.0 / (n[b] - 1) : 0.0;
-      A[a][b] = (double)r[a * 3 + b] * sb * ha;
-      rs += (double)r[a * 3 + b];
+      A[a][b] = (double)rr[a * 3 + b] * sb[b] * ha;
+      rs += (double)rr[a * 3 + b];
       mn += fmin(A[a][b] * (n[b] - 1), 0.0);
       mx += fmax(A[a][b] * (n[b] - 1), 0.0);
     }
-    c[a] = (1.0 - rs) * ha;
+    const double c = (1.0 - rs) * ha;
     // base cell floor(u) in [tlo-1, thi]  <=>  u in [tlo-1, thi+1); 0.05-cell pad covers the float evaluation
-    xl[a] = (tlo[a] == 0) ? fmin(c[a] + mn - 0.5, -1.05) : tlo[a] - 1.05;
-    xh[a] = (thi[a] == n[a] - 1) ? fmax(c[a] + mx + 0.5, n[a] + 0.05) : thi[a] + 1.05;
+    const double xl = (tlo[a] == 0) ? fmin(c + mn - 0.5, -1.05) : tlo[a] - 1.05;
+    const double xh = (thi[a] == n[a] - 1) ? fmax(c + mx + 0.5, n[a] + 0.05) : thi[a] + 1.05;
+    mid[a] = 0.5 * (xl + xh) - c;
+    half[a] = 0.5 * (xh - xl);
+    out->a0[a] = (float)A[a][0];
+    out->a1[a] = (float)A[a][1];
+    out->s[a] = (float)A[a][2];
+    out->inv_s[a] = fabs(A[a][2]) > 1e-6 ? (float)(1.0 / A[a][2]) : 0.f;
+    out->c[a] = (float)c;
+    out->lo[a] = (float)xl;
+    out->hi[a] = (float)xh;
   }
-  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) -
-                     A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  const double k00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], k01 = A[0][2] * A[2][1] - A[0][1] * A[2][2],
+               k02 = A[0][1] * A[1][2] - A[0][2] * A[1][1];
+  const double det = A[0][0] * k00 + A[1][0] * k01 + A[2][0] * k02;
   int lo[3] = {0, 0, 0}, hi[3] = {D - 1, H - 1, W - 1};
   if (fabs(det) > 1e-9) {
-    double inv[3][3];
-    inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
-    inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
-    inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
-    inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
-    inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
-    inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
-    inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
-    inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
-    inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
-    // box centre / half widths in voxel space -> centre / half extents in lattice space
-    double oc[3] = {0, 0, 0}, oe[3] = {0, 0, 0};
-    for (int a = 0; a < 3; ++a) {
-      const double mid = 0.5 * (xl[a] + xh[a]) - c[a], half = 0.5 * (xh[a] - xl[a]);
-      for (int b = 0; b < 3; ++b) {
-        oc[b] += inv[b][a] * mid;
-        oe[b] += fabs(inv[b][a]) * half;
-      }
-    }
+    const double rd = 1.0 / det;
+    // row b of the inverse = cofactors / det; box centre / half widths in voxel space -> centre / half extents in
+    // lattice space (the reciprocal instead of nine divisions moves the box by ~1e-13 cells: it is a padded bound)
+    double iv[3][3];
+    iv[0][0] = k00; iv[0][1] = k01; iv[0][2] = k02;
+    iv[1][0] = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    iv[1][1] = A[0][0] * A[2][2] - A[0][2] * A[2][0];
+    iv[1][2] = A[0][2] * A[1][0] - A[0][0] * A[1][2];
+    iv[2][0] = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    iv[2][1] = A[0][1] * A[2][0] - A[0][0] * A[2][1];
+    iv[2][2] = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+#pragma unroll
     for (int b = 0; b < 3; ++b) {
-      lo[b] = (int)fmin(fmax(floor(oc[b] - oe[b]), 0.0), (double)n[b]);
-      hi[b] = (int)fmax(fmin(ceil(oc[b] + oe[b]), (double)(n[b] - 1)), -1.0);
+      const double oc = (iv[b][0] * mid[0] + iv[b][1] * mid[1] + iv[b][2] * mid[2]) * rd;
+      const double oe = (fabs(iv[b][0]) * half[0] + fabs(iv[b][1]) * half[1] + fabs(iv[b][2]) * half[2]) * fabs(rd) + 1e-9;
+      lo[b] = (int)fmin(fmax(floor(oc - oe), 0.0), (double)n[b]);
+      hi[b] = (int)fmax(fmin(ceil(oc + oe), (double)(n[b] - 1)), -1.0);
     }
-  }
-  ViewRows vr;
-  for (int a = 0; a < 3; ++a) {
-    vr.a0[a] = (float)A[a][0];
-    vr.a1[a] = (float)A[a][1];
-    vr.s[a] = (float)A[a][2];
-    vr.inv_s[a] = fabs(A[a][2]) > 1e-6 ? (float)(1.0 / A[a][2]) : 0.f;
-    vr.c[a] = (float)c[a];
-    vr.lo[a] = (float)xl[a];
-    vr.hi[a] = (float)xh[a];
   }
   const int ez = max(hi[0] - lo[0] + 1, 0), ey = max(hi[1] - lo[1] + 1, 0);
-  vr.z_lo = lo[0]; vr.y_lo = lo[1]; vr.x_lo = lo[2]; vr.x_hi = hi[2];
-  vr.ey = ey;
-  vr.rows = hi[2] >= lo[2] ? ez * ey : 0;
-  vr.my = ey > 1 ? (unsigned)(((1ull << 32) + ey - 1) / ey) : 0u;
-  *out = vr;
+  out->z_lo = lo[0]; out->y_lo = lo[1]; out->x_lo = lo[2]; out->x_hi = hi[2];
+  out->ey = ey;
+  out->rows = hi[2] >= lo[2] ? ez * ey : 0;
+  out->my = ey > 1 ? 0xFFFFFFFFu / (unsigned)ey + 1u : 0u;     // ceil(2^32 / ey), ey >= 2
 }
 
 __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,

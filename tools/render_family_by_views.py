@@ -1,0 +1,33 @@
+"""The render family (rotate+render forward, render adjoint, rotate adjoint) at 200^3 for 1, 2, 4, 8 views, each kernel
+alone and back to back: microseconds per launch and per view -- how much of the one-view chain is the family's own
+small-launch inefficiency."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import neural_flow_style_amd.ops as ops
+from neural_flow_style_amd import synthetic as S, transform as T
+
+G = 200
+d = torch.tensor(S.blob_density(G, np.random.RandomState(0)), device="cuda")
+mats = S.uniform_views(8)
+
+
+def timeit(f, reps=20):
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps): f()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best * 1e3
+
+
+for V in (1, 2, 4, 8):
+    rot = T.rot_to_device(mats[:V], "cuda")
+    g = torch.randn(V, G, G, G, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+    acc = torch.zeros(G, G, G, 1, device="cuda")
+    gmax = g.abs().max().reshape(1)
+    t_rb = timeit(lambda: ops.rotate_bwd(g, rot, g_d_acc=acc, g_max=gmax))
+    print("V=%d rotate_bwd %7.1f us  %6.1f us/view" % (V, t_rb, t_rb / V))
