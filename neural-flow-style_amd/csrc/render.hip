@@ -782,10 +782,13 @@ int nfs_render_fwd(const float* d, float* img, float* raysum, int V, int D, int 
 // segment's starting prefix / weighted sum (the transmittance factorises: exp(-tau (total - p0 - local)) =
 // exp(tau p0) * exp(-tau (total - local))), a second walk writes the gradient.  The volume is read twice, so this
 // form is only used while it stays cache-resident (<= 64 MB).
-__global__ void __launch_bounds__(256) render_bwd_seg_kernel(const float* d, const float* __restrict__ raysum,
-                                                             const float* __restrict__ g_img, float* g_d, int V, int D,
-                                                             int HW, float tau, unsigned* __restrict__ gmax_bits) {
-  __shared__ float seg_S[RR_SEG][64], seg_R[RR_SEG][64], red[16];
+extern "C++" {
+template <int NSEG>
+__global__ void __launch_bounds__(64 * NSEG) render_bwd_seg_kernel(const float* d, const float* __restrict__ raysum,
+                                                                   const float* __restrict__ g_img, float* g_d, int V,
+                                                                   int D, int HW, float tau,
+                                                                   unsigned* __restrict__ gmax_bits) {
+  __shared__ float seg_S[NSEG][64], seg_R[NSEG][64], red[16];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int64_t total_rays = (int64_t)V * HW;
   const int64_t gid_raw = (int64_t)blockIdx.x * 64 + lane;
@@ -796,8 +799,8 @@ __global__ void __launch_bounds__(256) render_bwd_seg_kernel(const float* d, con
   const int64_t base = (int64_t)v * D * HW + px;
   const float total = raysum[gid], g = g_img[gid];
   const float ntau = -tau * 1.44269504088896341f;
-  const int L = (D + RR_SEG - 1) / RR_SEG;
-  const int zlo = seg * L, zhi = min(zlo + L, D);                 // segment 0 starts at z = 0 (prefix order)
+  const int L = (D + NSEG - 1) / NSEG;
+  const int zlo = min(seg * L, D), zhi = min(zlo + L, D);         // segment 0 starts at z = 0 (prefix order)
   float S = 0.f, R = 0.f;
 #pragma unroll 4
   for (int z = zlo; z < zhi; ++z) {
@@ -829,6 +832,7 @@ __global__ void __launch_bounds__(256) render_bwd_seg_kernel(const float* d, con
     if (threadIdx.x == 0 && amax > 0.f) atomicMax(gmax_bits, __float_as_uint(fminf(amax, 3.0e38f)));
   }
 }
+}  // extern "C++"
 
 int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, float* g_d, int V, int D, int H, int W,
                    float tau, int liquid, float* gmax_out, nfs_stream_t stream) {
@@ -842,8 +846,23 @@ int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, floa
   static const bool no_seg = getenv("NFS_RB_NOSEG") != nullptr;   // timing comparisons only
   NFS_REQUIRE(liquid >= 0 && liquid <= 3, "nfs_render_bwd: mode must be 0 (transmittance), 1 (liquid), 2 (max) or 3 (mean)");
   if (!liquid && !no_seg && D >= 4 * RR_SEG && (int64_t)V * D * H * W <= ((int64_t)16 << 20)) {
-    hipLaunchKernelGGL(render_bwd_seg_kernel, dim3(blocks_for(n, 64)), dim3(256), 0, as_stream(stream), d, raysum,
-                       g_img, g_d, V, D, H * W, tau, reinterpret_cast<unsigned*>(gmax_out));
+    // segments per ray: 4, or 8 while the 64-ray blocks are few (200^2 rays: one view 32.5 -> 24.7 us, two views
+    // 45.0 -> 41.2 us; 16 segments 25.4 / 39.7; tools/render_family_by_views.py, NFS_RB_SEG forces a count)
+    static const int seg_env = getenv("NFS_RB_SEG") ? atoi(getenv("NFS_RB_SEG")) : 0;
+    const int64_t blocks = blocks_for(n, 64);
+    int nseg = blocks >= 2048 ? 4 : 8;
+    if (seg_env == 4 || seg_env == 8 || seg_env == 16) nseg = seg_env;
+    while (nseg > 4 && D < 4 * nseg) nseg /= 2;
+    unsigned* gm = reinterpret_cast<unsigned*>(gmax_out);
+    if (nseg == 16)
+      hipLaunchKernelGGL(render_bwd_seg_kernel<16>, dim3(blocks), dim3(1024), 0, as_stream(stream), d, raysum, g_img, g_d,
+                         V, D, H * W, tau, gm);
+    else if (nseg == 8)
+      hipLaunchKernelGGL(render_bwd_seg_kernel<8>, dim3(blocks), dim3(512), 0, as_stream(stream), d, raysum, g_img, g_d,
+                         V, D, H * W, tau, gm);
+    else
+      hipLaunchKernelGGL(render_bwd_seg_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), d, raysum, g_img, g_d,
+                         V, D, H * W, tau, gm);
     return check_launch("nfs_render_bwd(segmented)");
   }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, raysum, g_img, g_d,

@@ -30,4 +30,12 @@ for V in (1, 2, 4, 8):
     acc = torch.zeros(G, G, G, 1, device="cuda")
     gmax = g.abs().max().reshape(1)
     t_rb = timeit(lambda: ops.rotate_bwd(g, rot, g_d_acc=acc, g_max=gmax))
-    print("V=%d rotate_bwd %7.1f us  %6.1f us/view" % (V, t_rb, t_rb / V))
+    d_rot = torch.empty(V, G, G, G, device="cuda")
+    img = torch.empty(V, G, G, device="cuda"); rs = torch.empty(V, G, G, device="cuda")
+    t_rr = timeit(lambda: ops.rotate_render_fwd(d, rot, 0.01, 0, img=img, raysum=rs, d_rot=d_rot))
+    g_img = torch.randn(V, G, G, device="cuda")
+    keep = d_rot.clone()
+    gd = torch.empty_like(d_rot)
+    t_re = timeit(lambda: ops.render_bwd(keep, rs, g_img, 0.01, 0, g_d=gd, want_max=True))
+    print("V=%d rotate_bwd %7.1f us (%5.1f /view)  rotate_render_fwd %6.1f us (%5.1f /view)  render_bwd %6.1f us (%5.1f /view)"
+          % (V, t_rb, t_rb / V, t_rr, t_rr / V, t_re, t_re / V))
