@@ -1443,6 +1443,10 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         g_tile_cache[key] = std::make_tuple(bm, bn, variant);
+        static const bool log = getenv("NFS_GEMM_TUNE_LOG") != nullptr;
+        if (log)
+          fprintf(stderr, "gemm tuner: Z=%d T=%lld K=%d N=%d mask=%d -> %d x %d (variant %d), %.1f us / launch\n", Z,
+                  (long long)a.T, a.K, a.N, a.mask ? 1 : 0, bm, bn, variant, 500.f * best);
         return;                                                       // the result is already in place
       }
     }
