@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the timed steps: everything from the (steps)-th last forward-smoothing launch (first kernel of a step)
-starts = [i for i, r in enumerate(rows) if ("smooth3d_kernel<false>" in r["Kernel_Name"])]
+starts = [i for i, r in enumerate(rows) if ("smooth3d_kernel<false" in r["Kernel_Name"])]
 first = starts[-steps]
 rows = rows[first:]
 t0 = int(rows[0]["Start_Timestamp"])

@@ -21,7 +21,7 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
     # the forward smoothing launch opens every step (GridStylizer.forward_field; the forward advect rides in the previous step's Adam kernel since round 4)
-    starts = [i for i, r in enumerate(rows) if ("smooth3d_kernel<false>" in r[2])]
+    starts = [i for i, r in enumerate(rows) if ("smooth3d_kernel<false" in r[2])]
     if len(starts) < steps:
         raise SystemExit("found %d step starts, expected >= %d" % (len(starts), steps))
     first = starts[-steps]

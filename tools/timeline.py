@@ -5,7 +5,7 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "smooth3d_kernel<false>" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "smooth3d_kernel<false" in r["Kernel_Name"]]
 a, b = starts[-k - 1], starts[-k]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
