@@ -134,6 +134,29 @@ def test_smooth3d_relu(ops, k, shape):
     assert rel(gd_h, gd[0, ..., 0]) < TOL
 
 
+def test_smooth3d_relu_sixteen_row_tiles(ops):
+    """from 256 blocks on the kernel runs two rows per thread (16-row tiles, column tiles <= 54): a ragged volume large
+    enough to take that instance (4 x 9 x 8 blocks; edge tiles in every direction) against the oracle, and bit for bit
+    against the same planes computed as part of a thin slab that still takes the 8-row instance"""
+    torch.manual_seed(5)
+    shape = (190, 139, 213)
+    d = torch.randn(1, *shape, 1)
+    d[0, :2] = 0.0
+    d = d.requires_grad_()
+    ref = O.smooth3d_relu(d, 3.0)
+    out = ops.smooth3d_relu_fwd(dev(d[0, ..., 0]), 3.0)
+    assert rel(out, ref[0, ..., 0]) < TOL
+    g = torch.randn_like(ref)
+    (gd,) = torch.autograd.grad(ref, d, g)
+    gd_h = ops.smooth3d_relu_bwd(out, dev(g[0, ..., 0]), 3.0)
+    assert rel(gd_h, gd[0, ..., 0]) < TOL
+    # planes 40 .. 59 as the interior of a 22-plane slab (2 z-chunks x 3 x 9 blocks < 256: the 8-row instance)
+    slab = ops.smooth3d_relu_fwd(dev(d[0, 39:61, :, :, 0].detach().contiguous()), 3.0)
+    assert torch.equal(slab[1:-1], out[40:60])
+    gslab = ops.smooth3d_relu_bwd(out[38:62].contiguous(), dev(g[0, 38:62, :, :, 0].contiguous()), 3.0)
+    assert torch.equal(gslab[1:-1], gd_h[39:61])
+
+
 @pytest.mark.parametrize("liquid", [False, True])
 def test_render_and_maxnorm(ops, liquid):
     torch.manual_seed(4)
