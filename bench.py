@@ -155,6 +155,17 @@ def work_of(name, a):
     if name == "nfs_render_bwd":
         V, D, H, W = a[4:8]
         return "B", 8.0 * V * D * H * W + 4.0 * V * H * W
+    if name == "nfs_rotate_render_fwd_coef":
+        V, D, H, W = a[6:10]
+        # read d once per view + write the kept u volume + img / ray sums / the three per-segment planes
+        return "B", 8.0 * V * D * H * W + (8.0 + 48.0) * V * H * W
+    if name == "nfs_render_ray_coef":
+        V, H, W = a[4:7]
+        return "B", (4.0 + 48.0 + 32.0) * V * H * W
+    if name == "nfs_rotate_bwd_coef":
+        V, D, H, W = a[4:8]
+        # read u once + the (A, B) planes + write g_d (the adjoint reads no render-adjoint volume any more)
+        return "B", 4.0 * V * D * H * W + 32.0 * V * H * W + 4.0 * D * H * W
     if name == "nfs_rotate_bwd":
         V, D, H, W, C = a[3:8]
         return "B", 4.0 * V * D * H * W * C + 8.0 * D * H * W * C
@@ -1102,6 +1113,7 @@ def main():
         # accountings -- the kernels as built (the rotated volume is KEPT for the adjoint: written once, read once more)
         # and SURVEY 8(d)'s fully fused counts (rotate+render fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + 4VG^2)
         fam = [r for r in rows if r["kernel"] in ("nfs_rotate_render_fwd", "nfs_render_bwd", "nfs_rotate_bwd",
+                                                  "nfs_rotate_render_fwd_coef", "nfs_render_ray_coef", "nfs_rotate_bwd_coef",
                                                   "nfs_advect_fwd", "nfs_advect_bwd_adam", "nfs_advect_bwd",
                                                   "nfs_advect_bwd_adam_fwd")]
         if fam:
@@ -1113,7 +1125,10 @@ def main():
             out["render_advect_family"] = {
                 "kernels": [r["kernel"] for r in fam], "ms_per_step": fms,
                 "as_built": {"bytes_per_step": built * 1e6, "frac_hbm": built / fms / HBM_PEAK_GBS,
-                             "note": "rotated volume kept: fwd 8VG^3, render adjoint 8VG^3, rotate adjoint 4VG^3 + 8G^3"},
+                             "note": "as the kernels move them: with the u / coefficient form of the adjoint (round 4) the "
+                                     "forward writes a kept volume (8VG^3) and the rotate adjoint reads it once (4VG^3 + "
+                                     "4G^3) -- the render-adjoint pass (8VG^3) is gone; with NFS_RENDER_COEF=0: fwd 8VG^3, "
+                                     "render adjoint 8VG^3, rotate adjoint 4VG^3 + 8G^3"},
                 "survey_fused": {"bytes_per_step": fused, "frac_hbm": fused / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "note": "SURVEY 8(d) fully fused rotate+render (fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + "
                                          "4VG^2) + the advect kernels as built, over the same measured time"}}

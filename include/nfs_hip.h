@@ -250,6 +250,28 @@ int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum,
                           int V, int D, int H, int W, float tau, int liquid,
                           nfs_stream_t stream);
 
+/* The same adjoint (transform.py:611-628 + styler_3p.py:147-158, transmittance mode) without a pass over the rotated
+ * volume: the image gradient of a sample is affine in a per-sample quantity the forward march already holds,
+ *     dI/ds_z = T_z - tau * sum_{z' <= z} s_z' T_z' = E u_z - tau (I - F),
+ * u_z = t_z + tau * i_z (t_z: the transmittance factor inside the sample's depth segment, i_z: the segment's image sum
+ * before the sample), E / F per (ray, depth segment).  nfs_rotate_render_fwd_coef writes u [V,D,H,W] instead of the
+ * samples and seg [3][V][nseg][H][W] (segment ray sum, segment image sum, max |u|); nfs_render_ray_coef turns seg and
+ * the image gradient g_img [V,H,W] into ab [V][nseg][H][W][2] = (A, B) with sample gradient = A u - B, and writes
+ * bounds [nfs_render_ray_coef_bounds(V,H,W)]: every launch block's bound on max |sample gradient| (their maximum sets the
+ * adjoint's fixed-point scale; no zero-initialised scalar, no atomics); nfs_rotate_bwd_coef is nfs_rotate_bwd (tiled
+ * form, overwrite as there) reading u, ab and the bounds.  nfs_render_coef_layout: NFS_OK and (nseg, seg_len) when the shape is supported (D >= 16,
+ * H, W >= 2, V*D*H*W < 2^30), else NFS_EINVAL -- the caller then takes nfs_rotate_render_fwd(d_rot) + nfs_render_bwd +
+ * nfs_rotate_bwd.  Results agree with that path to float32 rounding. */
+int nfs_render_coef_layout(int V, int D, int H, int W, int* nseg, int* seg_len);
+int nfs_rotate_render_fwd_coef(const float* d, const float* rot, float* img, float* raysum, float* u_rot, float* seg,
+                               int V, int D, int H, int W, float tau, nfs_stream_t stream);
+int nfs_render_ray_coef_bounds(int V, int H, int W);
+int nfs_render_ray_coef(const float* g_img, const float* seg, float* ab, float* bounds,
+                        int V, int H, int W, float tau, nfs_stream_t stream);
+int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, float* g_d_acc,
+                        int V, int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds,
+                        int overwrite, nfs_stream_t stream);
+
 /* d /= reduce_max(d) (styler_3p.py:158): G groups of n contiguous floats, one max per
  * group (v_batch views form one group; v_batch=1 => per view).  gmax [G] is written by
  * fwd and read by bwd; the max gradient is split equally among ties like TF's.  bwd `workspace`

@@ -78,6 +78,11 @@ SIGNATURES = {
     "nfs_render_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_render_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "nfs_rotate_render_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "nfs_render_coef_layout": [_I, _I, _I, _I, _P, _P],
+    "nfs_rotate_render_fwd_coef": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "nfs_render_ray_coef": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "nfs_render_ray_coef_bounds": [_I, _I, _I],
+    "nfs_rotate_bwd_coef": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_maxnorm_fwd": [_P, _P, _P, _I, _I, _P],
     "nfs_maxnorm_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],

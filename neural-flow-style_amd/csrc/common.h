@@ -65,6 +65,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < nw; ++i) r += red[i];
   return r;
 }
+// Zero fill as a KERNEL.  A hipMemsetAsync in front of a kernel that accumulates into the same words (atomicMax / atomicAdd)
+// is a memset node in a captured hipGraph, and in replays that node did not reliably complete before a SHORT following
+// kernel issued its atomics (round 4: an all-zero gradient in one replay of four; the long kernels that used to follow
+// such memsets hid it).  Kernel nodes of one captured stream do run in order.
+template <int UNUSED = 0>                             // (a template: one definition across the translation units)
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ x, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 0u;
+}
+static inline void zero_words(void* p, long long n_words, hipStream_t s) {
+  hipLaunchKernelGGL(zero_words_kernel<0>, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<unsigned*>(p), n_words);
+}
+
 __device__ __forceinline__ float block_max(float v, float* red) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   v = wave_max(v);

@@ -430,10 +430,7 @@ int nfs_loss_net_input_bwd(const float* g_x, float* g_img, int B, int H, int W, 
   NFS_REQUIRE(B > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "nfs_loss_net_input_bwd: non-positive dimension");
   NFS_REQUIRE(Cin == 1 || Cin == 3, "nfs_loss_net_input_bwd: Cin must be 1 or 3");
   if (H2 != H || W2 != W) {
-    if (hipMemsetAsync(g_img, 0, sizeof(float) * (size_t)B * H * W * Cin, as_stream(stream)) != hipSuccess) {
-      set_error("nfs_loss_net_input_bwd: memset failed");
-      return NFS_ELAUNCH;
-    }
+    zero_words(g_img, (long long)B * H * W * Cin, as_stream(stream));     // (a kernel, not a memset node: common.h)
   }
   const int64_t n = (int64_t)B * H2 * W2;
   hipLaunchKernelGGL(loss_net_input_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g_x, g_img,

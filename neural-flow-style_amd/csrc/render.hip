@@ -249,14 +249,23 @@ __device__ __forceinline__ float lean_blend(const LeanCoord& c, F2u p00, F2u p01
 // the ray four ways quadruples the loads in flight (one view per GPU: 0.074 -> 0.041 ms).  Segments combine exactly:
 //   I = sum_s exp(-tau * P_s) * I_s,   P_s = sum of the ray sums of the segments farther than s,
 // because the transmittance of a sample is exp(-tau (P_s + local suffix sum)).
+//
+// UOUT (transmittance mode, round 4): instead of the samples, d_rot receives per sample
+//   u = t + tau * i,   t = exp(-tau * local suffix sum incl. the sample),  i = the segment's image sum BEFORE the sample,
+// and seg_out the per-(view, segment, ray) triple (segment ray sum, segment image sum, max |u|).  With
+// E_s = exp(-tau P_s) and F_s = sum over the farther segments of E_s' I_s', the image gradient of a sample is
+//   dI/ds = T - tau * sum_{z' <= z} s T = E_s u - tau (I - F_s):
+// affine in u with per-(ray, segment) coefficients (render_ray_coef_kernel), so the rotate adjoint forms it from u on
+// the fly and the render-adjoint pass over the rotated volume (K4a) is not needed.
 constexpr int RR_SEG = 4;
-template <bool REUSE>
+template <bool REUSE, bool UOUT = false>
 __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const float* __restrict__ d,
                                                                     const float* __restrict__ rot,
                                                                     float* __restrict__ img,
                                                                     float* __restrict__ raysum,
                                                                     float* __restrict__ d_rot, int V, int D, int H,
-                                                                    int W, float tau, int liquid, int lxb, int band) {
+                                                                    int W, float tau, int liquid, int lxb, int band,
+                                                                    float* __restrict__ seg_out = nullptr) {
   __shared__ float seg_sum[RR_SEG][64], seg_I[RR_SEG][64];
   const int HW = H * W;
   // a wave is one segment: telling the compiler so keeps the depth index and the plane offsets in scalar registers
@@ -315,6 +324,7 @@ __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const flo
   const int zhi = D - 1 - seg * L, zlo = max(zhi - L + 1, 0);     // segment 0 is the far end
   float* drow = d_rot ? d_rot + (int64_t)v * D * HW + px : nullptr;
   float acc = 0.f, I = 0.f;
+  [[maybe_unused]] float umax = 0.f;
   int z = zhi;
   // REUSE path: buffer addressing (32-bit byte offsets; the launcher checks the sizes) so that the +W / +HW
   // neighbours and the output plane cost scalar offsets instead of 64-bit vector adds
@@ -367,22 +377,33 @@ __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const flo
         sv[u] = lean_blend(c[u], l0[u], l1[u], u0[u], u1[u]);
       }
       pbase = pb;
-      if (d_rot && live) {
+      // what the kept volume receives: the samples (stored before the serial transmittance chain), or (UOUT) u
+      auto keep = [&](const float* ov) {
+        if (d_rot && live) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {  // plane offset is wave-uniform: it rides in the scalar offset of the store
-          if (lxb && lxb < 5)           // half-line pieces: let the L2 merge them with the neighbouring tile's
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv[u]), rot_rsrc, rot_vo,
-                                                  (unsigned)(z - u) * n.HW * 4u, 0);
-          else
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv[u]), rot_rsrc, rot_vo,
-                                                  (unsigned)(z - u) * n.HW * 4u, 2 /* nt */);
+          for (int u = 0; u < NB; ++u) {  // plane offset is wave-uniform: it rides in the scalar offset of the store
+            if (lxb && lxb < 5)           // half-line pieces: let the L2 merge them with the neighbouring tile's
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[u]), rot_rsrc, rot_vo,
+                                                    (unsigned)(z - u) * n.HW * 4u, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[u]), rot_rsrc, rot_vo,
+                                                    (unsigned)(z - u) * n.HW * 4u, 2 /* nt */);
+          }
         }
-      }
+      };
+      if constexpr (!UOUT) keep(sv);
+      [[maybe_unused]] float uu[NB];
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         acc += sv[u];
-        I = fmaf(sv[u], __builtin_amdgcn_exp2f(acc * ntau), I);
+        const float t = __builtin_amdgcn_exp2f(acc * ntau);
+        if constexpr (UOUT) {
+          uu[u] = fmaf(tau, I, t);
+          umax = fmaxf(umax, fabsf(uu[u]));
+        }
+        I = fmaf(sv[u], t, I);
       }
+      if constexpr (UOUT) keep(uu);
       continue;
     } else {
 #pragma unroll
@@ -390,17 +411,35 @@ __global__ void __launch_bounds__(256, 4) rotate_render_fwd_seg_kernel(const flo
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      // rotated volume kept for the adjoint: streaming store, must not evict the volume from L2
-      if (drow && live) __builtin_nontemporal_store(sv[u], drow + (int64_t)(z - u) * HW);
       acc += sv[u];
-      I = fmaf(sv[u], __builtin_amdgcn_exp2f(acc * ntau), I);
+      const float t = __builtin_amdgcn_exp2f(acc * ntau);
+      float o = sv[u];
+      if (UOUT) {
+        o = fmaf(tau, I, t);
+        umax = fmaxf(umax, fabsf(o));
+      }
+      // rotated volume kept for the adjoint: streaming store, must not evict the volume from L2
+      if (drow && live) __builtin_nontemporal_store(o, drow + (int64_t)(z - u) * HW);
+      I = fmaf(sv[u], t, I);
     }
   }
   for (; z >= zlo; --z) {
     const float sone = lean_sample(d, n, q, (float)z);
-    if (drow && live) __builtin_nontemporal_store(sone, drow + (int64_t)z * HW);
     acc += sone;
-    I = fmaf(sone, __builtin_amdgcn_exp2f(acc * ntau), I);
+    const float t = __builtin_amdgcn_exp2f(acc * ntau);
+    float o = sone;
+    if (UOUT) {
+      o = fmaf(tau, I, t);
+      umax = fmaxf(umax, fabsf(o));
+    }
+    if (drow && live) __builtin_nontemporal_store(o, drow + (int64_t)z * HW);
+    I = fmaf(sone, t, I);
+  }
+  if (UOUT && live) {                                             // [3][V][RR_SEG][HW]
+    const int64_t plane = (int64_t)V * RR_SEG * HW, at = ((int64_t)v * RR_SEG + seg) * HW + px;
+    seg_out[at] = acc;
+    seg_out[plane + at] = I;
+    seg_out[2 * plane + at] = umax;
   }
   seg_sum[seg][lane] = acc;
   seg_I[seg][lane] = I;
@@ -759,6 +798,46 @@ __global__ void __launch_bounds__(1024) maxnorm_bwd_kernel(const float* __restri
   }
 }
 
+// per (view, depth segment, ray): the coefficients of dI/ds = A u - B for the rotate adjoint's COEF form, from the UOUT
+// forward's per-segment sums (seg: [3][V][RR_SEG][HW] = segment ray sum, segment image sum, max |u|) and the image
+// gradient g [V][HW].  E_s = exp(-tau P_s) (P_s: ray sums of the farther segments), F_s = sum_{s' < s} E_s' I_s',
+// I = F_{RR_SEG}:  A_s = g E_s,  B_s = g tau (I - F_s).  max over everything of |A_s| umax_s + |B_s| bounds every
+// sample gradient of the batch: the rotate adjoint's fixed-point scale.  Every block writes ITS maximum to
+// bounds[blockIdx.x] and the consumer takes the maximum of them: no zero-initialised word, no atomics (a 4-byte
+// memset node in front of an atomicMax did not reliably precede it in hipGraph replays).
+__global__ void __launch_bounds__(256) render_ray_coef_kernel(const float* __restrict__ g_img,
+                                                              const float* __restrict__ seg, float2* __restrict__ ab,
+                                                              int V, int HW, float tau, float* __restrict__ bounds) {
+  __shared__ float red[16];
+  const int64_t total = (int64_t)V * HW, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float bound = 0.f;
+  if (gid < total) {
+    const int v = (int)(gid / HW), px = (int)(gid - (int64_t)v * HW);
+    const int64_t plane = (int64_t)V * RR_SEG * HW, at0 = (int64_t)v * RR_SEG * HW + px;
+    const float ntau = -tau * 1.44269504088896341f, g = g_img[gid];
+    float S[RR_SEG], Is[RR_SEG], um[RR_SEG], E[RR_SEG], F[RR_SEG];
+    float P = 0.f, Itot = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < RR_SEG; ++s2) {          // same order of sums as the forward's own combination
+      S[s2] = seg[at0 + (int64_t)s2 * HW];
+      Is[s2] = seg[plane + at0 + (int64_t)s2 * HW];
+      um[s2] = seg[2 * plane + at0 + (int64_t)s2 * HW];
+      E[s2] = __builtin_amdgcn_exp2f(P * ntau);
+      F[s2] = Itot;
+      Itot = fmaf(E[s2], Is[s2], Itot);
+      P += S[s2];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < RR_SEG; ++s2) {
+      const float A = g * E[s2], B = g * tau * (Itot - F[s2]);
+      ab[at0 + (int64_t)s2 * HW] = make_float2(A, B);
+      bound = fmaxf(bound, fmaf(fabsf(A), um[s2], fabsf(B)));
+    }
+  }
+  bound = block_max(bound, red);
+  if (threadIdx.x == 0) bounds[blockIdx.x] = bound > 0.f ? fminf(bound, 3.0e38f) : 0.f;   // (NaN -> 0: no finite scale)
+}
+
 }  // namespace nfs
 
 using namespace nfs;
@@ -839,10 +918,7 @@ int nfs_render_bwd(const float* d, const float* raysum, const float* g_img, floa
   NFS_REQUIRE(d && raysum && g_img && g_d, "nfs_render_bwd: null pointer");
   NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_render_bwd: non-positive dimension");
   const int64_t n = (int64_t)V * H * W;
-  if (gmax_out && hipMemsetAsync(gmax_out, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
-    set_error("nfs_render_bwd: memset failed");
-    return NFS_ELAUNCH;
-  }
+  if (gmax_out) zero_words(gmax_out, 1, as_stream(stream));               // (a kernel, not a memset node: common.h)
   static const bool no_seg = getenv("NFS_RB_NOSEG") != nullptr;   // timing comparisons only
   NFS_REQUIRE(liquid >= 0 && liquid <= 3, "nfs_render_bwd: mode must be 0 (transmittance), 1 (liquid), 2 (max) or 3 (mean)");
   if (!liquid && !no_seg && D >= 4 * RR_SEG && (int64_t)V * D * H * W <= ((int64_t)16 << 20)) {
@@ -899,6 +975,49 @@ int nfs_rotate_render_fwd(const float* d, const float* rot, float* img, float* r
     hipLaunchKernelGGL(rotate_render_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), d, rot,
                        img, raysum, d_rot, V, D, H, W, tau, liquid);
   return check_launch("nfs_rotate_render_fwd");
+}
+
+// does the segmented forward (and with it the u / coefficient form of the adjoint) take this shape?  nseg / seg_len: the
+// depth segments of a ray, far end first (segment of plane z = (D - 1 - z) / seg_len)
+int nfs_render_coef_layout(int V, int D, int H, int W, int* nseg, int* seg_len) {
+  NFS_REQUIRE(V > 0 && D > 0 && H > 0 && W > 0, "nfs_render_coef_layout: non-positive dimension");
+  if (nseg) *nseg = RR_SEG;
+  if (seg_len) *seg_len = (D + RR_SEG - 1) / RR_SEG;
+  const bool ok = W >= 2 && H >= 2 && D >= 4 * RR_SEG && (int64_t)D * H * W < (1ll << 31) &&
+                  (int64_t)V * D * H * W < (1ll << 30);
+  if (!ok) {
+    set_error("nfs_render_coef_layout: shape outside the segmented forward (needs D >= 16, H, W >= 2, V*D*H*W < 2^30)");
+    return NFS_EINVAL;
+  }
+  return NFS_OK;
+}
+
+int nfs_rotate_render_fwd_coef(const float* d, const float* rot, float* img, float* raysum, float* u_rot, float* seg,
+                               int V, int D, int H, int W, float tau, nfs_stream_t stream) {
+  NFS_REQUIRE(d && rot && img && u_rot && seg, "nfs_rotate_render_fwd_coef: null pointer");
+  if (int e = nfs_render_coef_layout(V, D, H, W, nullptr, nullptr)) return e;
+  const int lxb = W >= 16 && H >= 4 ? 4 : 0;
+  int64_t waves = blocks_for((int64_t)V * H * W, 64);
+  const int64_t tiles_v = (int64_t)((W + (1 << lxb) - 1) >> lxb) * ((H + (64 >> lxb) - 1) / (64 >> lxb));
+  if (lxb) waves = (int64_t)V * ((tiles_v + 7) / 8) * 8;
+  hipLaunchKernelGGL((rotate_render_fwd_seg_kernel<true, true>), dim3((waves + 7) / 8 * 8), dim3(256), 0,
+                     as_stream(stream), d, rot, img, raysum, u_rot, V, D, H, W, tau, 0, lxb, lxb ? 1 : 0, seg);
+  return check_launch("nfs_rotate_render_fwd_coef");
+}
+
+int nfs_render_ray_coef_bounds(int V, int H, int W) {
+  if (V <= 0 || H <= 0 || W <= 0) return 0;
+  return (int)blocks_for((int64_t)V * H * W, 256);
+}
+
+int nfs_render_ray_coef(const float* g_img, const float* seg, float* ab, float* bounds, int V, int H, int W, float tau,
+                        nfs_stream_t stream) {
+  NFS_REQUIRE(g_img && seg && ab && bounds, "nfs_render_ray_coef: null pointer");
+  NFS_REQUIRE(V > 0 && H > 0 && W > 0, "nfs_render_ray_coef: non-positive dimension");
+  const int64_t n = (int64_t)V * H * W;
+  hipLaunchKernelGGL(render_ray_coef_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g_img, seg,
+                     reinterpret_cast<float2*>(ab), V, H * W, tau, bounds);
+  return check_launch("nfs_render_ray_coef");
 }
 
 int nfs_rotate_render_bwd(const float* d, const float* rot, const float* raysum, const float* g_img, float* g_d_acc,

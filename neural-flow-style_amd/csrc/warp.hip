@@ -535,15 +535,21 @@ __device__ __forceinline__ void rotate_tile_catchment(const float* r, int D, int
   out->my = ey > 1 ? 0xFFFFFFFFu / (unsigned)ey + 1u : 0u;     // ceil(2^32 / ey), ey >= 2
 }
 
+// COEF: g_out holds, per sample, the render's u (nfs_rotate_render_fwd with u_rot) and `ab` the per-(view, depth
+// segment, ray) pair (A, B) of nfs_render_ray_coef: the sample's gradient is A u - B, formed here instead of by a
+// render-adjoint pass over the whole rotated volume (K4a: 512 MB of traffic and a launch at eight views)
+template <bool COEF>
 __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const float* __restrict__ g_out,
                                                                          const float* __restrict__ rot,
                                                                          float* __restrict__ g_d,
                                                                          const unsigned* __restrict__ gmax_bits,
                                                                          float bound_factor, int V, int D, int H,
                                                                          int W, int tiles_y, int tiles_x, int overwrite,
-                                                                         int order) {
+                                                                         int order, const float2* __restrict__ ab,
+                                                                         int nseg, int seg_len, int nbounds) {
   __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
   __shared__ ViewRows vrows[RT_VMAX];
+  [[maybe_unused]] __shared__ float gred[RT_THREADS / 64];
   const int t = threadIdx.x;
   // Which tile a block takes.  order 0 (round 1-3): x-border tiles first, then z-border, then the interior (border tiles
   // also collect the clamped out-of-volume samples and run longest; starting them first keeps them off the tail), dealt
@@ -575,7 +581,20 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   const int z1 = min(z0 + RT_TZ, D) - 1, y1 = min(y0 + RT_TY, H) - 1, x1 = min(x0 + RT_TX, W) - 1;  // inclusive
   for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
   // fixed-point scale 2^k: |any voxel sum| <= bound_factor * max|g_out| must stay below 2^62
-  const float gmax = __uint_as_float(*gmax_bits);
+  float gmax;
+  if (COEF) {                                     // the maximum of the coefficient kernel's per-block bounds
+    const float* bounds = reinterpret_cast<const float*>(gmax_bits);
+    float m = 0.f;
+    for (int i = t; i < nbounds; i += RT_THREADS) m = fmaxf(m, bounds[i]);
+    m = wave_max(m);
+    if ((t & 63) == 0) gred[t >> 6] = m;
+    __syncthreads();
+    gmax = gred[0];
+#pragma unroll
+    for (int i = 1; i < RT_THREADS / 64; ++i) gmax = fmaxf(gmax, gred[i]);
+  } else {
+    gmax = __uint_as_float(*gmax_bits);
+  }
   if (!(gmax > 0.f)) {                            // all-zero gradient: nothing to add
     if (overwrite)
       for (int i = t; i < RT_TZ * RT_TY * RT_TX; i += RT_THREADS) {
@@ -627,13 +646,34 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
       }
       const int xa = (int)ceilf(ta), xb = (int)floorf(tb);
       if (xb < xa) continue;
-      const float sz = vr.s[0], sy = vr.s[1], sx = vr.s[2];
+      float sz = vr.s[0], sy = vr.s[1], sx = vr.s[2];
+      // COEF: settle the three LDS reads HERE -- left to the compiler, their first use inside the sample loop puts an
+      // s_waitcnt lgkmcnt(0) into every iteration, which also waits for the previous sample's eight LDS atomics.
+      // Measured on one box (8 views of 200^3): COEF 324 -> 311 us with it, the plain instance 271 -> 278: that one keeps
+      // the compiler's waits.
+      if constexpr (COEF) asm volatile("" : "+v"(sz), "+v"(sy), "+v"(sx));
       const float* grow = gv + ((int64_t)oz * H + oy) * W;
+      // (COEF: the ray of a sample is its (oy, ox); its depth segment, far end first, is wave-uniform per row)
+      [[maybe_unused]] const float2* abrow =
+          COEF ? ab + (((int64_t)v * nseg + (D - 1 - oz) / seg_len) * H + oy) * W : nullptr;
+      // the next sample's operands are loaded one iteration ahead and stay RAW until they are used (forming A u - B at
+      // load time would put a full wait behind every load)
       int ox = xa + gl;
-      float g = ox <= xb ? grow[ox] : 0.f;
+      float g = 0.f;
+      [[maybe_unused]] float2 cab = make_float2(0.f, 0.f);
+      if (ox <= xb) {
+        g = grow[ox];
+        if (COEF) cab = abrow[ox];
+      }
       while (ox <= xb) {
         const int oxn = ox + RT_GROUP;
-        const float gn = oxn <= xb ? grow[oxn] : 0.f;
+        float gn = 0.f;
+        [[maybe_unused]] float2 cabn = make_float2(0.f, 0.f);
+        if (oxn <= xb) {                       // (one exec-mask block around both loads)
+          gn = grow[oxn];
+          if (COEF) cabn = abrow[oxn];
+        }
+        if (COEF) g = fmaf(cab.x, g, -cab.y);
         if (g != 0.f) {
           // lean stencil (same form as the ray march): the sample's voxel coordinate is affine in ox; border
           // replication = clamp the coordinate; base cell floor(c), weights (1-w, w).  A sample clamped onto the far
@@ -687,6 +727,7 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
           }
         }
         g = gn;
+        if (COEF) cab = cabn;
         ox = oxn;
       }
     }
@@ -757,10 +798,7 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
     const unsigned* gmax_bits = reinterpret_cast<const unsigned*>(g_max);
     if (!gmax_bits) {                       // no max |g_out| supplied: streaming pre-pass
       unsigned* wb = reinterpret_cast<unsigned*>(workspace);
-      if (hipMemsetAsync(wb, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) {
-        set_error("nfs_rotate_bwd: memset failed");
-        return NFS_ELAUNCH;
-      }
+      zero_words(wb, 1, as_stream(stream));                              // (a kernel, not a memset node: common.h)
       const int64_t n = (int64_t)V * D * H * W;
       hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g_out, n, wb);
       gmax_bits = wb;
@@ -773,9 +811,9 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
     const int grid = order == 0 ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
     for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
       const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
-      hipLaunchKernelGGL(rotate_bwd_tiled_kernel, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
+      hipLaunchKernelGGL(rotate_bwd_tiled_kernel<false>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                          g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
-                         ty, tx, (overwrite && v0 == 0) ? 1 : 0, order);
+                         ty, tx, (overwrite && v0 == 0) ? 1 : 0, order, (const float2*)nullptr, 1, D, 0);
     }
     return check_launch("nfs_rotate_bwd(tiled)");
   }
@@ -785,6 +823,30 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
   hipLaunchKernelGGL(warp_bwd_kernel<COORD_ROTATE>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a,
                      g_out, g_d_acc, (float*)nullptr);
   return check_launch("nfs_rotate_bwd");
+}
+
+// the tiled adjoint on the render's u volume and per-(view, segment, ray) coefficients: sample gradient = A u - B
+// (nfs_rotate_render_fwd_coef / nfs_render_ray_coef); bounds [nbounds]: per-block bounds on max |sample gradient|, whose
+// maximum sets the fixed-point scale
+int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H, int W,
+                        int nseg, int seg_len, const float* bounds, int nbounds, int overwrite, nfs_stream_t stream) {
+  NFS_REQUIRE(u_rot && ab && rot && g_d_acc && bounds, "nfs_rotate_bwd_coef: null pointer");
+  NFS_REQUIRE(nbounds > 0, "nfs_rotate_bwd_coef: no bounds");
+  if (int e = check_dims(V, D, H, W, 1)) return e;
+  NFS_REQUIRE(nseg > 0 && seg_len > 0 && (int64_t)nseg * seg_len >= D, "nfs_rotate_bwd_coef: the segments do not cover D");
+  const int tz = (D + RT_TZ - 1) / RT_TZ, ty = (H + RT_TY - 1) / RT_TY, tx = (W + RT_TX - 1) / RT_TX;
+  const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
+  const float bound_factor = 4.f * (float)nmax * (float)V + 8.f;
+  static const int order = [] { const char* e = getenv("NFS_RT_XCD"); return e ? atoi(e) : 0; }();
+  const int grid = order == 0 ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
+  for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
+    const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
+    hipLaunchKernelGGL(rotate_bwd_tiled_kernel<true>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
+                       u_rot + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, reinterpret_cast<const unsigned*>(bounds),
+                       bound_factor, vn, D, H, W, ty, tx, (overwrite && v0 == 0) ? 1 : 0, order,
+                       reinterpret_cast<const float2*>(ab) + (int64_t)v0 * nseg * H * W, nseg, seg_len, nbounds);
+  }
+  return check_launch("nfs_rotate_bwd_coef");
 }
 
 int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, int W, int C, nfs_stream_t stream) {

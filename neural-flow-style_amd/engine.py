@@ -221,8 +221,15 @@ class RenderStyleLoss(object):
         return self.style_grams
 
     # -- forward only (rendered image, used for the final inference) ------------------------
+    def _coef_form(self, V, shape):
+        """transmittance rendering of a shape the segmented forward takes: the adjoint runs without the render-adjoint
+        pass over the rotated volume (K4a; ``NFS_RENDER_COEF=0`` keeps that pass)"""
+        return (self.mode == 0 and os.environ.get("NFS_RENDER_COEF", "1") != "0"
+                and ops.render_coef_layout(V, *shape) is not None)
+
     def render(self, d, rot, keep_rotated=False, normalise=True):
         self.d_rot = None
+        self._seg = None
         if self.rotate:
             if keep_rotated:
                 self.d_rot = torch.empty((rot.shape[0],) + tuple(d.shape), dtype=torch.float32, device=d.device)
@@ -231,6 +238,9 @@ class RenderStyleLoss(object):
                 img, rs = ops.render_fwd(self.d_rot, self.tau, self.mode)
                 if not keep_rotated:
                     self.d_rot = None
+            elif keep_rotated and self._coef_form(rot.shape[0], d.shape):
+                # the kept volume holds u, not the samples: the rotate adjoint forms the sample gradient from it
+                img, rs, _, self._seg = ops.rotate_render_fwd_coef(d, rot, self.tau, u_rot=self.d_rot)
             else:
                 img, rs = ops.rotate_render_fwd(d, rot, self.tau, self.mode, d_rot=self.d_rot)
         else:
@@ -390,8 +400,8 @@ class RenderStyleLoss(object):
         fused_in = (not self.liquid and (H2, W2) == (H, W) and not (self.w_tv > 0 or hist_in)
                     and os.environ.get("NFS_FUSE_INPUT", "1") != "0")
         img, rs, norm, gmax = self.render(d, rot, keep_rotated=self.two_pass_adjoint, normalise=not fused_in)
-        d_rot = self.d_rot
-        self.d_rot = None
+        d_rot, seg = self.d_rot, self._seg
+        self.d_rot = self._seg = None
         V = img.shape[0]
         if fused_in:
             dimg = None
@@ -415,7 +425,11 @@ class RenderStyleLoss(object):
         else:
             g_norm = ops.loss_net_input_bwd(g_x, H, W, 1).reshape(V, H, W)
             g_img = g_norm if self.liquid else ops.maxnorm_bwd(img, gmax, g_norm)
-        if self.rotate and d_rot is not None:
+        if self.rotate and d_rot is not None and seg is not None:
+            # u form: per-(ray, segment) coefficients from the image gradient, then the rotate adjoint alone
+            ab, bounds = ops.render_ray_coef(g_img, seg, self.tau)
+            ops.rotate_bwd_coef(d_rot, ab, rot, bounds, g_d_acc=g_d, overwrite=overwrite)
+        elif self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
             g_rot, g_max = ops.render_bwd(d_rot, rs, g_img, self.tau, self.mode, g_d=d_rot, want_max=True)
@@ -665,25 +679,26 @@ class LBFGSState(object):
         else:
             y = g - self.prev_g
             s_ = self.d * self.t
-            ys = float((y * s_).sum())
+            ys = float(y.dot(s_))                          # (dot products, as torch.optim.LBFGS forms them: a sum of
+            # products in another order can land on the other side of the 1e-10 curvature test)
             if ys > 1e-10:
                 if len(self.S) == self.history:
                     self.S.pop(0); self.Y.pop(0); self.ro.pop(0)
                 self.S.append(s_); self.Y.append(y); self.ro.append(1.0 / ys)
-                self.H = ys / float((y * y).sum())
+                self.H = ys / float(y.dot(y))
             q = g.neg()
             al = [0.0] * len(self.S)
             for i in range(len(self.S) - 1, -1, -1):
-                al[i] = float((self.S[i] * q).sum()) * self.ro[i]
+                al[i] = float(self.S[i].dot(q)) * self.ro[i]
                 q.add_(self.Y[i], alpha=-al[i])
             d = q.mul(self.H)
             for i in range(len(self.S)):
-                be = float((self.Y[i] * d).sum()) * self.ro[i]
+                be = float(self.Y[i].dot(d)) * self.ro[i]
                 d.add_(self.S[i], alpha=al[i] - be)
         self.prev_g = g.clone()
         self.t = min(1.0, 1.0 / float(g.abs().sum())) * float(lr) if self.n == 1 else float(lr)
         self.d = d
-        if float((g * d).sum()) > -self.tol_c:
+        if float(g.dot(d)) > -self.tol_c:
             self.t = 0.0                 # (no move; the pair of the next call is then s = 0: y.s = 0, not kept)
             return
         x.reshape(-1).add_(d, alpha=self.t)

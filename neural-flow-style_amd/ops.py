@@ -325,6 +325,65 @@ def rotate_render_fwd(d, rot, tau, liquid=False, img=None, raysum=None, d_rot=No
     return img, raysum
 
 
+_coef_layouts = {}
+
+
+def render_coef_layout(V, D, H, W):
+    """(nseg, seg_len) of the u / coefficient form of the rotate + render adjoint (transmittance mode), or None when the
+    shape is outside the segmented forward kernel -- the caller then keeps the rotated samples and runs render_bwd"""
+    key = (int(V), int(D), int(H), int(W))
+    if key not in _coef_layouts:
+        import ctypes
+        nseg, seg_len = ctypes.c_int(0), ctypes.c_int(0)
+        rc = _lib.lib().nfs_render_coef_layout(key[0], key[1], key[2], key[3], ctypes.byref(nseg), ctypes.byref(seg_len))
+        _coef_layouts[key] = (nseg.value, seg_len.value) if rc == 0 else None
+    return _coef_layouts[key]
+
+
+def rotate_render_fwd_coef(d, rot, tau, img=None, raysum=None, u_rot=None, seg=None):
+    """d [D,H,W], rot [V,3,3] -> (img [V,H,W], raysum [V,H,W], u_rot [V,D,H,W], seg [3,V,nseg,H,W]): the forward of
+    rotate_render_fwd (transmittance) that keeps u = t + tau i per sample instead of the sample (see nfs_hip.h)"""
+    D, H, W = d.shape
+    V = rot.shape[0]
+    nseg, _ = render_coef_layout(V, D, H, W)
+    if img is None:
+        img = _empty((V, H, W), d)
+    if raysum is None:
+        raysum = _empty((V, H, W), d)
+    if u_rot is None:
+        u_rot = _empty((V, D, H, W), d)
+    if seg is None:
+        seg = _empty((3, V, nseg, H, W), d)
+    _lib.call("nfs_rotate_render_fwd_coef", _ptr(d), _ptr(rot), _ptr(img), _ptr(raysum), _ptr(u_rot), _ptr(seg), V, D, H, W,
+              float(tau), _stream())
+    return img, raysum, u_rot, seg
+
+
+def render_ray_coef(g_img, seg, tau, ab=None, bounds=None):
+    """image gradient g_img [V,H,W] + the forward's seg -> (ab [V,nseg,H,W,2], bounds [nblocks]: per-block bounds on
+    max |sample gradient|, reduced by the consumer)"""
+    V, H, W = g_img.shape
+    nseg = seg.shape[2]
+    if ab is None:
+        ab = _empty((V, nseg, H, W, 2), g_img)
+    if bounds is None:
+        bounds = _empty((_lib.lib().nfs_render_ray_coef_bounds(V, H, W),), g_img)
+    _lib.call("nfs_render_ray_coef", _ptr(g_img), _ptr(seg), _ptr(ab), _ptr(bounds), V, H, W, float(tau), _stream())
+    return ab, bounds
+
+
+def rotate_bwd_coef(u_rot, ab, rot, bounds, g_d_acc=None, overwrite=False):
+    """the tiled rotate adjoint with the sample gradient A u - B formed on the fly; g_d_acc [D,H,W] (+=, or written)"""
+    V, D, H, W = u_rot.shape
+    nseg, seg_len = render_coef_layout(V, D, H, W)
+    if g_d_acc is None:
+        overwrite = True
+        g_d_acc = _empty((D, H, W), u_rot)
+    _lib.call("nfs_rotate_bwd_coef", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
+              _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _stream())
+    return g_d_acc
+
+
 def rotate_render_bwd(d, rot, raysum, g_img, tau, liquid=False, g_d_acc=None):
     D, H, W = d.shape
     V = rot.shape[0]

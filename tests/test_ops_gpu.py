@@ -134,6 +134,43 @@ def test_smooth3d_relu(ops, k, shape):
     assert rel(gd_h, gd[0, ..., 0]) < TOL
 
 
+@pytest.mark.parametrize("shape,V,big", [((40, 37, 50), 3, False), ((64, 20, 33), 1, True), ((17, 16, 16), 2, False),
+                                         ((33, 5, 9), 4, True)])
+def test_rotate_render_adjoint_coefficient_form(ops, shape, V, big):
+    """the u / coefficient form of the rotate + render adjoint (no render-adjoint pass over the rotated volume) against
+    the oracle and against the two-pass form: same image and ray sums bit for bit, gradient to float32 rounding"""
+    torch.manual_seed(11)
+    D, H, W = shape
+    tau = 0.07
+    d = torch.rand(1, D, H, W, 1).requires_grad_()
+    R = rots(V + 1, 7, big)[1:]                         # (no identity view)
+    rot = dev(R)
+    assert ops.render_coef_layout(V, D, H, W) is not None
+    dd = dev(d[0, ..., 0])
+    img, rs, u_rot, seg = ops.rotate_render_fwd_coef(dd, rot, tau)
+    d_rot = torch.empty(V, D, H, W, device="cuda")
+    img2, rs2 = ops.rotate_render_fwd(dd, rot, tau, 0, d_rot=d_rot)
+    assert torch.equal(img, img2) and torch.equal(rs, rs2)
+    g_img = torch.randn(V, H, W, device="cuda")
+    g_img[0, :2] = 0.0                                   # rays without gradient: skipped samples
+    ab, gmax = ops.render_ray_coef(g_img, seg, tau)
+    g_new = ops.rotate_bwd_coef(u_rot, ab, rot, gmax)
+    g_rot, gm2 = ops.render_bwd(d_rot, rs2, g_img, tau, 0, want_max=True)
+    assert float(gmax.max()) >= float(gm2) * (1 - 1e-6)  # (per-block bounds) a bound on every sample gradient
+    g_old = ops.rotate_bwd(g_rot.unsqueeze(-1), rot, g_max=gm2)[..., 0]
+    assert rel(g_new, g_old.cpu()) < 2e-6
+    acc = torch.ones(D, H, W, device="cuda")             # accumulate form
+    ops.rotate_bwd_coef(u_rot, ab, rot, gmax, g_d_acc=acc)
+    assert rel(acc - 1.0, g_old.cpu()) < 1e-5
+    # oracle: autograd through rotate + the un-normalised transmittance integral
+    img_o = O.render_unnormalised(O.rotate(d, R), tau)
+    assert rel(img, img_o[..., 0]) < TOL
+    (g_o,) = torch.autograd.grad(img_o, d, g_img.cpu().unsqueeze(-1))
+    assert rel(g_new, g_o[0, ..., 0]) < TOL
+    # a shape the segmented forward does not take: the caller is told to keep the two-pass form
+    assert ops.render_coef_layout(1, 8, 8, 8) is None
+
+
 def test_smooth3d_relu_sixteen_row_tiles(ops):
     """from 256 blocks on the kernel runs two rows per thread (16-row tiles, column tiles <= 54): a ragged volume large
     enough to take that instance (4 x 9 x 8 blocks; edge tiles in every direction) against the oracle, and bit for bit

@@ -39,3 +39,10 @@ for V in (1, 2, 4, 8):
     t_re = timeit(lambda: ops.render_bwd(keep, rs, g_img, 0.01, 0, g_d=gd, want_max=True))
     print("V=%d rotate_bwd %7.1f us (%5.1f /view)  rotate_render_fwd %6.1f us (%5.1f /view)  render_bwd %6.1f us (%5.1f /view)"
           % (V, t_rb, t_rb / V, t_rr, t_rr / V, t_re, t_re / V))
+    if ops.render_coef_layout(V, G, G, G) is not None:          # the u / coefficient form of the adjoint
+        _, _, u_rot, seg = ops.rotate_render_fwd_coef(d, rot, 0.01, img=img, raysum=rs, u_rot=d_rot)
+        t_fc = timeit(lambda: ops.rotate_render_fwd_coef(d, rot, 0.01, img=img, raysum=rs, u_rot=d_rot, seg=seg))
+        ab, gm = ops.render_ray_coef(g_img, seg, 0.01)
+        t_co = timeit(lambda: ops.render_ray_coef(g_img, seg, 0.01, ab=ab, bounds=gm))
+        t_bc = timeit(lambda: ops.rotate_bwd_coef(u_rot, ab, rot, gm, g_d_acc=acc[..., 0]))
+        print("     coefficient form: forward %6.1f us  ray coefficients %5.1f us  rotate adjoint %6.1f us" % (t_fc, t_co, t_bc))
