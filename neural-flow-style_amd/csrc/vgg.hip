@@ -321,7 +321,19 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_fwd_kernel(const float* __
   __shared__ float patch[(C3F_TH + 2) * C3F_PW * 3 + 4];
   __shared__ __attribute__((aligned(16))) float otile[C3F_TH * C3F_TW * C3F_OS];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, i = lane & 31, h = lane >> 5;
-  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  float bfr[14][2];                                  // the lane's 28 weights: gathered once, used for every tile it walks
+#pragma unroll
+  for (int s2 = 0; s2 < 14; ++s2) {
+    const int k = 2 * s2 + h;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bfr[s2][nt] = k < 27 ? w[k * 64 + nt * 32 + i] : 0.f;
+  }
+  float bv2[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bv2[nt] = bias ? bias[nt * 32 + i] : 0.f;
+  const int ntiles_all = B * tiles_x * tiles_y;
+  for (int tile_id = blockIdx.x; tile_id < ntiles_all; tile_id += gridDim.x) {
+  const int tx = tile_id % tiles_x, ty = (tile_id / tiles_x) % tiles_y, b = tile_id / (tiles_x * tiles_y);
   const int y0 = ty * C3F_TH, x0 = tx * C3F_TW;
   for (int e = t; e < (C3F_TH + 2) * C3F_PW * 3; e += 256) {
     const int r = e / (C3F_PW * 3), rem = e - r * (C3F_PW * 3);
@@ -330,13 +342,6 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_fwd_kernel(const float* __
     float v = 0.f;
     if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) v = x[(((int64_t)b * H + gy_) * W + gx_) * 3 + ci];
     patch[e] = v;
-  }
-  float bfr[14][2];
-#pragma unroll
-  for (int s2 = 0; s2 < 14; ++s2) {
-    const int k = 2 * s2 + h;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bfr[s2][nt] = k < 27 ? w[k * 64 + nt * 32 + i] : 0.f;
   }
   __syncthreads();
   const int m = wid * 32 + i;                       // pixel of this lane's A row
@@ -356,7 +361,7 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_fwd_kernel(const float* __
   }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    const float bv = bias ? bias[nt * 32 + i] : 0.f;
+    const float bv = bv2[nt];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -372,6 +377,8 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_fwd_kernel(const float* __
     if (gy_ < H && gx_ < W)
       *reinterpret_cast<float4*>(y + (((int64_t)b * H + gy_) * W + gx_) * 64 + 4 * q) =
           *reinterpret_cast<const float4*>(otile + row * C3F_OS + 4 * q);
+  }
+  __syncthreads();                                    // patch and otile are rewritten by the next tile
   }
 }
 
@@ -425,14 +432,18 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_dgrad_kernel(const float* 
                                                                    int tiles_x, int tiles_y) {
   __shared__ float Tt[C3D_M * C3D_TS];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, i = lane & 31, h = lane >> 5;
-  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
-  const int y0 = ty * C3D_TH, x0 = tx * C3D_TW;
   // B operand: column n = i (tap = n / 3, ci = n % 3; columns 27..31 are zero), rows k = 8j + 4h + u
   float bw[8][4];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int u = 0; u < 4; ++u) bw[j][u] = i < 27 ? wd[((i / 3) * 64 + 8 * j + 4 * h + u) * 3 + i % 3] : 0.f;
+  // a block walks several pixel tiles with the 32 weight registers it gathered once (they were two thirds of a one-tile
+  // block's vector-memory instructions)
+  const int ntiles_all = B * tiles_x * tiles_y;
+  for (int tile_id = blockIdx.x; tile_id < ntiles_all; tile_id += gridDim.x) {
+  const int tx = tile_id % tiles_x, ty = (tile_id / tiles_x) % tiles_y, b = tile_id / (tiles_x * tiles_y);
+  const int y0 = ty * C3D_TH, x0 = tx * C3D_TW;
   // M tiles of 32 halo'd pixels: waves 0,1 take two, waves 2,3 one (6 tiles = 192 >= 180 rows)
   const int ntile = wid < 2 ? 2 : 1, tile0 = wid < 2 ? 2 * wid : 2 + wid;
   for (int mt = 0; mt < ntile; ++mt) {
@@ -475,6 +486,8 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_dgrad_kernel(const float* 
       float* o = gx + (((int64_t)b * H + py) * W + px) * 3;
       o[0] = o0; o[1] = o1; o[2] = o2;
     }
+  }
+  __syncthreads();                                               // Tt is rewritten by the next tile
   }
 }
 
@@ -725,7 +738,9 @@ int nfs_conv3x3_fwd(const float* x, const float* packed_fwd, const float* bias, 
   static const bool old_c3 = getenv("NFS_C3_OLD") != nullptr;        // timing comparisons only
   if (Ci == 3 && Co == 64 && !old_c3) {
     const int tiles_x = (W + C3F_TW - 1) / C3F_TW, tiles_y = (H + C3F_TH - 1) / C3F_TH;
-    hipLaunchKernelGGL(conv3x3_c3co64_fwd_kernel, dim3((unsigned)((int64_t)B * tiles_x * tiles_y)), dim3(256), 0,
+    static const int per_cu = [] { const char* e = getenv("NFS_C3F_BLOCKS"); return e ? atoi(e) : 4; }();   // (27.1 us with 0, 25.2 with 4)
+    const int64_t ntiles = (int64_t)B * tiles_x * tiles_y, cap = 256 * (int64_t)per_cu;
+    hipLaunchKernelGGL(conv3x3_c3co64_fwd_kernel, dim3((unsigned)(per_cu > 0 && ntiles > cap ? cap : ntiles)), dim3(256), 0,
                        as_stream(stream), x, packed_fwd, bias, y, B, H, W, relu, tiles_x, tiles_y);
     return check_launch("nfs_conv3x3_fwd(c3, Co=64, MFMA)");
   }
@@ -752,8 +767,12 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
     static const bool old_c3 = getenv("NFS_C3_OLD") != nullptr;      // timing comparisons only
     if (Co == 64 && !old_c3) {
       const int tiles_x = (W + C3D_TW - 1) / C3D_TW, tiles_y = (H + C3D_TH - 1) / C3D_TH;
-      hipLaunchKernelGGL(conv3x3_c3co64_dgrad_kernel, dim3((unsigned)((int64_t)B * tiles_x * tiles_y)), dim3(256), 0,
-                         as_stream(stream), gy, packed_dgrad, gx, B, H, W, tiles_x, tiles_y);
+      // blocks per CU of the tile-walking form (0: one block per tile, as before round 4).  8 x 200 x 200: 44.3 us with 0,
+      // 38.6 / 38.2 / 38.8 / 40.5 / 41.1 with 2 / 3 / 4 / 6 / 8 (tools/conv11_bench.py)
+      static const int per_cu = [] { const char* e = getenv("NFS_C3D_BLOCKS"); return e ? atoi(e) : 3; }();
+      const int64_t ntiles = (int64_t)B * tiles_x * tiles_y, cap = 256 * (int64_t)per_cu;
+      hipLaunchKernelGGL(conv3x3_c3co64_dgrad_kernel, dim3((unsigned)(per_cu > 0 && ntiles > cap ? cap : ntiles)),
+                         dim3(256), 0, as_stream(stream), gy, packed_dgrad, gx, B, H, W, tiles_x, tiles_y);
       return check_launch("nfs_conv3x3_dgrad(c3, Co=64, MFMA)");
     }
     const int64_t n = (int64_t)B * H * W;
