@@ -425,7 +425,10 @@ __global__ void __launch_bounds__(256) conv3x3_c3_fwd_kernel(const float* __rest
 // for 4 consecutive k-steps: lane (i, h) of step 4j+u multiplies channel 8j + 4h + u), the 64 x 27 weights sit
 // in 32 registers per lane.  The VALU version (one thread per pixel, 144 float4 loads at a 256-byte lane stride)
 // took 118 us for an 82 MB input.
-constexpr int C3D_TH = 8, C3D_TW = 16, C3D_PH = C3D_TH + 2, C3D_PW = C3D_TW + 2, C3D_M = 192, C3D_TS = 33;
+// (round 4: 14 x 14 pixel tiles -- their 16 x 16 halo'd pixels are exactly 8 M tiles, two per wave; the 8 x 16 tiles before
+// had 6, i.e. two waves with twice the MFMA chain of the others, and a halo of 1.5 x instead of 1.31 x.  The kernel is
+// bound by its 32-deep dependent MFMA chains, not by HBM: 2.0 GFLOP executed for 8 x 200 x 200)
+constexpr int C3D_TH = 14, C3D_TW = 14, C3D_PH = C3D_TH + 2, C3D_PW = C3D_TW + 2, C3D_M = 256, C3D_TS = 33;
 __global__ void __launch_bounds__(256) conv3x3_c3co64_dgrad_kernel(const float* __restrict__ gy,
                                                                    const float* __restrict__ wd,   // [9][64][3]
                                                                    float* __restrict__ gx, int B, int H, int W,
@@ -444,12 +447,15 @@ __global__ void __launch_bounds__(256) conv3x3_c3co64_dgrad_kernel(const float* 
   for (int tile_id = blockIdx.x; tile_id < ntiles_all; tile_id += gridDim.x) {
   const int tx = tile_id % tiles_x, ty = (tile_id / tiles_x) % tiles_y, b = tile_id / (tiles_x * tiles_y);
   const int y0 = ty * C3D_TH, x0 = tx * C3D_TW;
-  // M tiles of 32 halo'd pixels: waves 0,1 take two, waves 2,3 one (6 tiles = 192 >= 180 rows)
-  const int ntile = wid < 2 ? 2 : 1, tile0 = wid < 2 ? 2 * wid : 2 + wid;
+  // M tiles of 32 halo'd pixels: two per wave (8 tiles = the 256 rows of the 16 x 16 halo'd tile)
+  constexpr int ntile = C3D_PH * C3D_PW / 128;
+  static_assert(ntile * 128 == C3D_M && C3D_PH * C3D_PW == C3D_M, "the halo'd tile must fill whole M tiles");
+  const int tile0 = ntile * wid;
   for (int mt = 0; mt < ntile; ++mt) {
+    // (both M tiles' loads up front and their MFMA chains interleaved was measured: 36.5 us against 34.1 for this form)
     const int q = (tile0 + mt) * 32 + i;                         // halo'd pixel index of this lane's A row
     const int qy = y0 - 1 + q / C3D_PW, qx = x0 - 1 + q % C3D_PW;
-    const bool ok = q < C3D_PH * C3D_PW && qy >= 0 && qy < H && qx >= 0 && qx < W;
+    const bool ok = qy >= 0 && qy < H && qx >= 0 && qx < W;
     const float* gp = gy + (((int64_t)b * H + (ok ? qy : 0)) * W + (ok ? qx : 0)) * 64 + 4 * h;
     float4 av[8];
 #pragma unroll
@@ -767,9 +773,10 @@ int nfs_conv3x3_dgrad(const float* gy, const float* packed_dgrad, const float* x
     static const bool old_c3 = getenv("NFS_C3_OLD") != nullptr;      // timing comparisons only
     if (Co == 64 && !old_c3) {
       const int tiles_x = (W + C3D_TW - 1) / C3D_TW, tiles_y = (H + C3D_TH - 1) / C3D_TH;
-      // blocks per CU of the tile-walking form (0: one block per tile, as before round 4).  8 x 200 x 200: 44.3 us with 0,
-      // 38.6 / 38.2 / 38.8 / 40.5 / 41.1 with 2 / 3 / 4 / 6 / 8 (tools/conv11_bench.py)
-      static const int per_cu = [] { const char* e = getenv("NFS_C3D_BLOCKS"); return e ? atoi(e) : 3; }();
+      // blocks per CU of the tile-walking form (0: one block per tile, as before round 4).  8 x 200 x 200, 8 x 16 tiles:
+      // 44.3 us with 0, 38.6 / 38.2 / 38.8 / 40.5 / 41.1 with 2 / 3 / 4 / 6 / 8; 14 x 14 tiles: 38.5 with 0, 34.1 / 36.5 /
+      // 36.9 with 2 / 3 / 4 (tools/conv11_bench.py)
+      static const int per_cu = [] { const char* e = getenv("NFS_C3D_BLOCKS"); return e ? atoi(e) : 2; }();
       const int64_t ntiles = (int64_t)B * tiles_x * tiles_y, cap = 256 * (int64_t)per_cu;
       hipLaunchKernelGGL(conv3x3_c3co64_dgrad_kernel, dim3((unsigned)(per_cu > 0 && ntiles > cap ? cap : ntiles)),
                          dim3(256), 0, as_stream(stream), gy, packed_dgrad, gx, B, H, W, tiles_x, tiles_y);
