@@ -283,7 +283,7 @@ class RenderStyleLoss(object):
         return (name != self.top and name != self.content_layer and os.environ.get("NFS_NO_DEFER_MASK") is None
                 and self.net.masks_addend_of(name, F.shape))
 
-    def _vgg_loss_grad(self, x):
+    def _vgg_loss_grad(self, x, total_out=None):
         """x [B,h,w,3] (mean-subtracted) -> (dL/dx, per-image losses [B] of the style / content / histogram terms).
 
         Default: the Gram work of ALL style layers runs after the forward pass as three launches (tile pairs of every
@@ -312,6 +312,9 @@ class RenderStyleLoss(object):
                                                  [w * self.w_style for w in self.w_layers], masks,
                                                  channels=[_channels(acts, n, F) for n, F in zip(self.layers, Fs)])
             sg.update(zip(self.layers, dFs))
+            if total_out is not None:                # (sums_total(): no other loss term) the total straight from the
+                torch.sum(parts.view(-1), dim=0, keepdim=True, out=total_out)     # per-block partial sums: one launch
+                return self.net.backward(acts, sg, self.top, unmasked=unmasked), None
             loss = parts.sum(0)
             self._content_job(acts, sg, loss)
             self._hist_job(acts, sg, loss)
@@ -389,7 +392,7 @@ class RenderStyleLoss(object):
             _add_logical(sg, self.content_layer, acts[self.content_layer], g)
 
     # -- the hot step -----------------------------------------------------------------------
-    def _chain(self, d, rot, g_d, overwrite=False):
+    def _chain(self, d, rot, g_d, overwrite=False, total_out=None):
         """render -> loss net -> Gram losses -> full adjoint for the views ``rot`` on the CURRENT stream;
         g_d [D,H,W] += dL/dd (= with ``overwrite``, two-pass rotate adjoint only); returns the per-view losses"""
         D, H, W = d.shape
@@ -408,7 +411,7 @@ class RenderStyleLoss(object):
             x, gmax = ops.maxnorm_input_fwd(img, max(V // self.v_batch, 1))
         else:
             dimg, x = ops.loss_net_input_fwd(norm.unsqueeze(-1), H2, W2, want_d_img=self.w_tv > 0 or hist_in)
-        g_x, loss = self._vgg_loss_grad(x)
+        g_x, loss = self._vgg_loss_grad(x, total_out=total_out)
         if hist_in:
             self._hist_input(dimg, loss, g_x)
         if self.w_tv > 0:
@@ -453,7 +456,16 @@ class RenderStyleLoss(object):
         ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
         return bool(self.two_pass_adjoint and min(ngroups, V) <= 1)
 
-    def loss_and_grad(self, d, rot, g_d, overwrite=False):
+    def sums_total(self, V):
+        """True when loss_and_grad(..., total_out=slot) can write the TOTAL loss of the view batch into ``slot`` itself (and
+        return None instead of the per-view losses): the grouped Gram chain is the only loss term and the batch is one
+        chain -- the total is then one reduction of the kernels' partial sums instead of a per-view reduction here and a
+        second one over the views at the caller"""
+        ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
+        return bool(self.gram_grouped and self.layers and not self.w_tv and not self.hist_layers
+                    and not self.content_layer and min(ngroups, V) <= 1)
+
+    def loss_and_grad(self, d, rot, g_d, overwrite=False, total_out=None):
         """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
         Returns loss per view [V] (device tensor).
 
@@ -465,8 +477,10 @@ class RenderStyleLoss(object):
         ngroups = self.view_groups if (V >= 4 and self.rotate and self.v_batch == 1) else 1
         ngroups = min(ngroups, V)
         if ngroups <= 1:
-            return self._chain(d, rot, g_d, overwrite=overwrite and self.writes_gradient(V))
+            return self._chain(d, rot, g_d, overwrite=overwrite and self.writes_gradient(V),
+                               total_out=total_out if (total_out is not None and self.sums_total(V)) else None)
         assert not overwrite, "overwrite needs a single view batch (see writes_gradient)"
+        assert total_out is None, "total_out needs a single view batch (see sums_total)"
         nst = min(self.vgg_streams, ngroups)
         main = torch.cuda.current_stream(d.device)
         if len(self._streams) < nst:
@@ -968,16 +982,22 @@ class GridStylizer(object):
         self.d_s = ops.smooth3d_relu_fwd(self.d_adv, self.k)
         return self.d_s
 
-    def field_gradient(self, rot_local):
-        """forward + adjoint down to the smoothed density: (loss_per_view, dL/d d_s of the LOCAL views)"""
-        return self._loss_gradient(self.forward_field(), rot_local)
+    def field_gradient(self, rot_local, total=False):
+        """forward + adjoint down to the smoothed density: (loss_per_view, dL/d d_s of the LOCAL views); ``total``: see
+        _loss_gradient"""
+        return self._loss_gradient(self.forward_field(), rot_local, total=total)
 
-    def _loss_gradient(self, d_s, rot_local):
+    def _loss_gradient(self, d_s, rot_local, total=False):
+        """total: let the loss write the summed loss of the local views into the loss slot where it can (then None is
+        returned instead of the per-view losses)"""
         V = rot_local.shape[0]
         fresh = hasattr(self.loss, "writes_gradient") and self.loss.writes_gradient(V)
         if not fresh:
             self.g_ds.zero_()
-        losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds, **({"overwrite": True} if fresh else {}))
+        kw = {"overwrite": True} if fresh else {}
+        if total and hasattr(self.loss, "sums_total") and self.loss.sums_total(V):
+            kw["total_out"] = self._loss_slot
+        losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds, **kw)
         return losses, self.g_ds
 
     def variable_gradient(self, g_ds):
@@ -1012,7 +1032,12 @@ class GridStylizer(object):
         (style / content targets, loss hyper-parameters, the addresses of d0 and the variable, the number of views):
         when any of that changes the graph is dropped and captured again.  The view matrices are copied into a
         static buffer."""
-        body = self.field_gradient if with_field else (lambda r: self._loss_gradient(self.d_s, r))
+        body = ((lambda r: self.field_gradient(r, total=True)) if with_field
+                else (lambda r: self._loss_gradient(self.d_s, r, total=True)))
+
+        def to_slot(losses):              # (None: the loss chain has written the total into the slot itself)
+            if losses is not None:
+                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # one kernel: reduce straight into the slot
         if with_field and self.target == "v" and self._adv_target() is not None:
             # the captured forward starts from the advected density in its fixed buffer: bring it up to date eagerly when
             # the previous step's Adam kernel has not left it there (first step, a re-bound frame, a variable set by hand)
@@ -1026,14 +1051,14 @@ class GridStylizer(object):
             if self._graph_warm < 1:
                 self._graph_warm += 1
                 losses, g_ds = body(rot_local)
-                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
+                to_slot(losses)
                 return self._loss_slot, g_ds
             self._graph_rot = rot_local.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 losses, _ = body(self._graph_rot)
-                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
+                to_slot(losses)
             self._graph = g
             self._graph_key = key
             self._graph_rot_src = (rot_local, rot_local._version)
@@ -1079,19 +1104,26 @@ class GridStylizer(object):
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)
         elif self.pg is None:
-            losses, g_ds = self.field_gradient(rot_local)
-            total = None
-            total_new = losses.sum()                                         # (one kernel, a fresh tensor: no slot, no copy)
+            losses, g_ds = self.field_gradient(rot_local, total=True)
+            total = self._loss_slot if losses is None else None
+            total_new = None if losses is None else losses.sum()             # (one kernel, a fresh tensor: no slot, no copy)
         else:
-            losses, g_ds = self.field_gradient(rot_local)
-            torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)     # (one kernel: reduce straight into the slot)
+            losses, g_ds = self.field_gradient(rot_local, total=True)
+            if losses is not None:
+                torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)  # (one kernel: reduce straight into the slot)
             total = self._loss_slot
         if self.pg is not None:
             # The one exchange step (RCCL over xGMI): ONE all-reduce of gradient + loss.  The reduction is placed on
             # the 4*G^3-byte density gradient, not on the 12*G^3-byte velocity gradient: everything below it is
             # linear and replicated, so reducing early moves 3x fewer bytes over the links.
             parallel.all_reduce_sum_([self._gbuf], group=self.pg)
-        total = total[0].clone() if total is not None else total_new
+        # single rank: the returned scalar is a VIEW of the loss slot -- valid until the next step() (a copy here is a launch
+        # of its own after the graph replay: 5 us + a 9-us gap in the 1-ms one-view step); read it (float()) or clone it
+        # before stepping again.  Multi-rank: a copy (the slot lives in the all-reduce buffer).
+        if total is not None:
+            total = total[0] if self.pg is None else total[0].clone()
+        else:
+            total = total_new
         D, H, W = self.d0.shape
         if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
