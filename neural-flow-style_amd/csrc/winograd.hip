@@ -280,11 +280,12 @@ __global__ void __launch_bounds__(256) winograd_input4_kernel(const float* __res
   }
 }
 
-template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
+template <int MODE, int NSPLIT = 1>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
 __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
                                                                int B, int H, int W, int N, int TH, int TW, int relu,
                                                                float* __restrict__ ypool, uint32_t* __restrict__ bits) {
+  // NSPLIT: M holds the products in NSPLIT K parts, 36 * T * N floats apart (winograd_ksplit), summed here
   // ReLU bit cache (layout as in winograd_input4_kernel): MODE 0 WRITES the mask of its own output (read back by the
   // pooled data gradient of this layer), MODE 1 READS the mask of x_in instead of aux0 (both nullable)
   const int N2 = N >> 1;
@@ -315,7 +316,14 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
   for (int s = 0; s < 6; ++s) {
     float2 m[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 6 + s) * comp_stride);
+    for (int r = 0; r < 6; ++r) {
+      m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 6 + s) * comp_stride);
+#pragma unroll
+      for (int p = 1; p < NSPLIT; ++p) {
+        const float2 q = *reinterpret_cast<const float2*>(mi + ((int64_t)p * 36 + r * 6 + s) * comp_stride);
+        m[r].x += q.x; m[r].y += q.y;
+      }
+    }
     wg4_at(m, t[s]);
   }
   float2 bias = make_float2(0.f, 0.f);
@@ -699,14 +707,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // One block's work on MT16 live row tiles starting at row m0 (a block of a taller grid tile whose last rows lie beyond T
 // runs the instance for the row tiles that exist: no MFMA, LDS read or staging load is spent on rows of padding).
 template <int MT16, int NW16>
-__device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, float* smem, int comp, int64_t m0, int n0) {
+__device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, float* smem, int comp, int64_t m0, int n0,
+                                                         int split = 0) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16;
   constexpr int BMP = (BM + 31) / 32 * 32;            // staged rows (a multiple of the 32 rows one pass of the block moves)
   constexpr int AJ = BMP / 32;
   float* As = smem;                                   // [2][BMP][36]
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int nchunks = a.K / WG_KC;
+  const int nchunks = a.K / WG_KC / a.ksplit, c0 = split * nchunks;     // this block's share of the K chunks
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -730,11 +739,11 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
   const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
   float4 av[AJ], bq[NW16][2];
 #pragma unroll
-  for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], 0);
+  for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], (uint32_t)c0 * (WG_KC * 4));
 #pragma unroll
   for (int nt = 0; nt < NW16; ++nt)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + g * gst);
+    for (int g = 0; g < 2; ++g) bq[nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * c0 + g) * gst);
 
   const int afrag = (lane & 15) * WG_LS + 4 * (lane >> 4);     // + 16 mt rows, + 16 g floats
 
@@ -753,7 +762,7 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
       for (int j = 0; j < AJ; ++j) *reinterpret_cast<float4*>(ad + 32 * j * WG_LS) = av[j];
     }
     __syncthreads();                                   // buffer (c&1) visible; buffer (c+1)&1 was last read in iteration c-1
-    const int cn = c + 1 < nchunks ? c + 1 : c;        // (the last iteration re-fetches its own chunk: no branch)
+    const int cn = c0 + (c + 1 < nchunks ? c + 1 : c); // (the last iteration re-fetches its own chunk: no branch)
 #pragma unroll
     for (int j = 0; j < AJ; ++j) av[j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4));
     __builtin_amdgcn_sched_barrier(0);
@@ -784,7 +793,7 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
   // (256-column tiles, NW16 = 4: two row tiles per pass keep the buffer at 33 KB, so that blocks still share a CU)
   constexpr int OS = BN + 4, EPMAX = NW16 >= 4 ? 2 : 5, EP = MT16 < EPMAX ? MT16 : EPMAX, NPASS = (MT16 + EP - 1) / EP;
   float* otile = smem;
-  float* Mc = a.M + (int64_t)comp * a.T * a.N;
+  float* Mc = a.M + ((int64_t)split * a.Z + comp) * a.T * a.N;
   const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
   constexpr int Q = BN / 4;
 #pragma unroll
@@ -823,21 +832,24 @@ template <int MT16, int NW16>
 __device__ __forceinline__ void winograd_gemm_rb16_tile(const WgGemmArgs& a, float* smem, int block, int nblocks) {
   const int per_xcd = nblocks / WG_XCDS;
   const int logical = (block % WG_XCDS) * per_xcd + block / WG_XCDS;   // XCD-aware order, see above
-  if (logical >= a.mt * a.nt * a.Z) return;
-  const int comp = logical / (a.mt * a.nt);
-  const int rem = logical - comp * (a.mt * a.nt);
+  const int per_split = a.mt * a.nt * a.Z;
+  if (logical >= per_split * a.ksplit) return;
+  const int split = logical / per_split;                 // (the K parts of a tile sit a whole grid apart: different CUs)
+  const int lg = logical - split * per_split;
+  const int comp = lg / (a.mt * a.nt);
+  const int rem = lg - comp * (a.mt * a.nt);
   const int64_t m0 = (int64_t)(rem % a.mt) * (16 * MT16);
   const int n0 = (rem / a.mt) * (64 * NW16);
   if constexpr (MT16 <= 5) {
     const int64_t left = (a.T - m0 + 15) / 16;
     const int live = left < MT16 ? (int)left : MT16;
-    if (live == MT16) winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0);
-    else if (live == 1) winograd_gemm_rb16_block<1, NW16>(a, smem, comp, m0, n0);
-    else if (MT16 > 2 && live == 2) winograd_gemm_rb16_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem, comp, m0, n0);
-    else if (MT16 > 3 && live == 3) winograd_gemm_rb16_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem, comp, m0, n0);
-    else if (MT16 > 4 && live == 4) winograd_gemm_rb16_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem, comp, m0, n0);
+    if (live == MT16) winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0, split);
+    else if (live == 1) winograd_gemm_rb16_block<1, NW16>(a, smem, comp, m0, n0, split);
+    else if (MT16 > 2 && live == 2) winograd_gemm_rb16_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem, comp, m0, n0, split);
+    else if (MT16 > 3 && live == 3) winograd_gemm_rb16_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem, comp, m0, n0, split);
+    else if (MT16 > 4 && live == 4) winograd_gemm_rb16_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem, comp, m0, n0, split);
   } else {
-    winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0);
+    winograd_gemm_rb16_block<MT16, NW16>(a, smem, comp, m0, n0, split);
   }
 }
 
@@ -1262,7 +1274,7 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
   if (lds > 65536) std::call_once(attr_once, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16_kernel<MT16, NW16>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-  const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  const int total = a.mt * a.nt * a.Z * a.ksplit, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
   if (timed) (void)hipEventRecord(rec.e0, s);
@@ -1376,7 +1388,16 @@ struct GemmKey {
 static std::map<GemmKey, std::tuple<int, int, int>> g_tile_cache;   // (BM, BN, kernel variant: 0 LDS-B, 1 register-B)
 static std::mutex g_tile_mu;
 
-static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
+int winograd_ksplit(int64_t T, int K) {
+  static const int forced = [] { const char* e = getenv("NFS_GEMM_KSPLIT"); return e ? atoi(e) : 0; }();
+  static const int tmax = [] { const char* e = getenv("NFS_GEMM_KSPLIT_T"); return e ? atoi(e) : 64; }();
+  static const int kmin = [] { const char* e = getenv("NFS_GEMM_KSPLIT_K"); return e ? atoi(e) : 512; }();
+  int ks = forced > 0 ? (forced > 2 ? 2 : forced) : (T <= tmax && K >= kmin ? 2 : 1);    // (the output transforms sum 1 or 2)
+  while (ks > 1 && (K / WG_KC) % ks) ks >>= 1;
+  return ks < 1 ? 1 : ks;
+}
+
+static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   static const bool tune = [] {
     const char* e = getenv("NFS_GEMM_TUNE");
     return !(e && atoi(e) == 0) && !getenv("NFS_GEMM_BM") && !getenv("NFS_GEMM_BN");
@@ -1396,6 +1417,9 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   static const bool bm_forced = getenv("NFS_GEMM_BM") != nullptr;
   const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
                       pad16 * 100 <= pad32 * rows16_pct;
+  // K parts (winograd_ksplit: by shape alone) only on the 16-row register-B form of a plain product (no mask / scale in
+  // the epilogue: those apply to the complete sum)
+  a.ksplit = (rows16 && !a.mask && !a.alpha_dev && a.alpha == 1.f && !a.symb) ? winograd_ksplit(a.T, a.K) : 1;
   if (rows16 && !tune) { variant = 2; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }
   if (force_rb == 2) {
     static const int fbm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 80; }();
@@ -1449,16 +1473,18 @@ static void launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
         g_tile_cache[key] = std::make_tuple(bm, bn, variant);
         static const bool log = getenv("NFS_GEMM_TUNE_LOG") != nullptr;
         if (log)
-          fprintf(stderr, "gemm tuner: Z=%d T=%lld K=%d N=%d mask=%d -> %d x %d (variant %d), %.1f us / launch\n", Z,
-                  (long long)a.T, a.K, a.N, a.mask ? 1 : 0, bm, bn, variant, 500.f * best);
-        return;                                                       // the result is already in place
+          fprintf(stderr, "gemm tuner: Z=%d T=%lld K=%d N=%d mask=%d ksplit=%d -> %d x %d (variant %d), %.1f us / launch\n",
+                  Z, (long long)a.T, a.K, a.N, a.mask ? 1 : 0, a.ksplit, bm, bn, variant, 500.f * best);
+        return a.ksplit;                                              // the result is already in place
       }
     }
   }
+  if (variant != 2) a.ksplit = 1;                                     // (only the rb16 kernels know about K parts)
   launch_gemm_tile(a, Z, bm, bn, s, variant);
+  return a.ksplit;
 }
 
-void winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s) { launch_batched_gemm(a, Z, cus, s); }
+int winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s) { return launch_batched_gemm(a, Z, cus, s); }
 
 // dF[b] = alpha_b * F[b] @ D[b] (D symmetric, so row n of D serves as column n), optional (F > 0) mask
 int gram_bwd_gemm(const float* F, const float* Dm, float* dF, int B, int HW, int C, float alpha, const float* alpha_dev,
@@ -1532,7 +1558,9 @@ int winograd_path(int B, int H, int W, int K, int N) {
 int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
   const int m = winograd_tile();
   const int64_t T = (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
-  const int64_t f4 = (m + 2) * (m + 2) * T * ((int64_t)K + N), f5 = m == 4 ? winograd5_workspace_floats(B, H, W, K, N) : 0;
+  // (M once per K part of the GEMM: winograd_ksplit)
+  const int64_t f4 = (m + 2) * (m + 2) * T * ((int64_t)K + (int64_t)N * winograd_ksplit(T, K)),
+                f5 = m == 4 ? winograd5_workspace_floats(B, H, W, K, N) : 0;
   return f4 > f5 ? f4 : f5;
 }
 
@@ -1604,15 +1632,26 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
     a.Uq = U + (int64_t)90 * K * N;
     a.Uq16 = U + (int64_t)126 * K * N;
   }
-  launch_batched_gemm(a, comps, cus, s);
+  const int nsplit = launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {
     const unsigned ob = blocks_for(T * (N / 2), 256);
-    if (mode == 0)
-      hipLaunchKernelGGL(winograd_output4_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+    uint32_t* ib = aux0 ? in_bits : nullptr;                              // a mask only where the caller asks for one
+    if (nsplit != 1 && nsplit != 2) {
+      set_error("winograd_conv: unsupported number of K parts");
+      return NFS_EINVAL;
+    }
+    if (mode == 0 && nsplit == 1)
+      hipLaunchKernelGGL((winograd_output4_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                          ypool, out_bits);
+    else if (mode == 0)
+      hipLaunchKernelGGL((winograd_output4_kernel<0, 2>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                         ypool, out_bits);
+    else if (nsplit == 1)
+      hipLaunchKernelGGL((winograd_output4_kernel<1, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                         (float*)nullptr, ib);
     else
-      hipLaunchKernelGGL(winograd_output4_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                         (float*)nullptr, aux0 ? in_bits : nullptr);       // a mask only where the caller asks for one
+      hipLaunchKernelGGL((winograd_output4_kernel<1, 2>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                         (float*)nullptr, ib);
   } else {
     const unsigned ob = blocks_for(T * (N / 4), 256);
     if (mode == 0)

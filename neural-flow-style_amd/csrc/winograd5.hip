@@ -147,11 +147,13 @@ __global__ void __launch_bounds__(256) winograd5_input_kernel(const float* __res
 }
 
 // output transform + layer epilogue: one thread = one 5 x 5 output tile x 1 channel
-template <int MODE>  // 0: y = relu?(Y + bias); 1: y = (Y [+ addend if relu]) * (x_in > 0) [+ addend if !relu]
+template <int MODE, int NSPLIT = 1>  // 0: y = relu?(Y + bias); 1: y = (Y [+ addend if relu]) * (x_in > 0) [+ addend if !relu]
 __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
                                                                const float* __restrict__ aux1, float* __restrict__ y,
                                                                int B, int H, int W, int N, int TH, int TW, int relu,
                                                                const uint32_t* __restrict__ bits) {
+  // NSPLIT: M holds the products in NSPLIT K parts, 49 * T * N floats apart (winograd_ksplit), summed here (a template
+  // parameter: as a run-time loop the 49 loads of a column no longer went out together -- +12 us on a 6-us kernel)
   const int64_t T = (int64_t)B * TH * TW;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= T * N) return;
@@ -178,7 +180,11 @@ __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __re
   for (int s = 0; s < 7; ++s) {
     float m[7];
 #pragma unroll
-    for (int r = 0; r < 7; ++r) m[r] = mi[(int64_t)(r * 7 + s) * comp_stride];
+    for (int r = 0; r < 7; ++r) {
+      m[r] = mi[(int64_t)(r * 7 + s) * comp_stride];
+#pragma unroll
+      for (int p = 1; p < NSPLIT; ++p) m[r] += mi[((int64_t)p * 49 + r * 7 + s) * comp_stride];
+    }
     w5_at(m, t[s]);
   }
   const float bias = (MODE == 0 && aux0) ? aux0[c] : 0.f;
@@ -232,7 +238,8 @@ int64_t winograd5_packed_floats(int Ci, int Co) { return winograd5_channels(Ci, 
 
 int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N) {
   if (!winograd5_takes(H, W, K, N)) return 0;
-  return (int64_t)49 * B * ((H + 4) / 5) * ((W + 4) / 5) * ((int64_t)K + N);
+  const int64_t T = (int64_t)B * ((H + 4) / 5) * ((W + 4) / 5);
+  return (int64_t)49 * T * ((int64_t)K + (int64_t)N * winograd_ksplit(T, K));     // (M once per K part of the GEMM)
 }
 
 // up5: [49][K/32][N][32] followed by the 16x16x4 fragment order of the same
@@ -259,14 +266,23 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
                      mode == 0 ? in_bits : nullptr);
   WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   a.Uq16 = U5 + (int64_t)49 * K * N;
-  winograd_launch_batched_gemm(a, 49, cus, s);
+  const int nsplit = winograd_launch_batched_gemm(a, 49, cus, s);
   const unsigned ob = blocks_for(T * N, 256);
-  if (mode == 0)
-    hipLaunchKernelGGL(winograd5_output_kernel<0>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+  if (nsplit != 1 && nsplit != 2) {
+    set_error("winograd5_conv: unsupported number of K parts");
+    return NFS_EINVAL;
+  }
+  const uint32_t* ib = aux0 ? in_bits : nullptr;
+  if (mode == 0 && nsplit == 1)
+    hipLaunchKernelGGL((winograd5_output_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                        (const uint32_t*)nullptr);
+  else if (mode == 0)
+    hipLaunchKernelGGL((winograd5_output_kernel<0, 2>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
+                       (const uint32_t*)nullptr);
+  else if (nsplit == 1)
+    hipLaunchKernelGGL((winograd5_output_kernel<1, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu, ib);
   else
-    hipLaunchKernelGGL(winograd5_output_kernel<1>, dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                       aux0 ? in_bits : nullptr);
+    hipLaunchKernelGGL((winograd5_output_kernel<1, 2>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu, ib);
   return check_launch("winograd5_conv");
 }
 

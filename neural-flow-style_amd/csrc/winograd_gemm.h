@@ -24,10 +24,17 @@ struct WgGemmArgs {
   int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
+  int ksplit = 1;            // rb16: the K range in `ksplit` parts, part p of a tile written to M + p * Z*T*N (summed by the
+                             // output transform): fills the chip when T is a few dozen rows (one view per GPU)
 };
 
 // picks kernel family (by shape) and tile (measured per shape at first use) and launches; defined in winograd.hip
-void winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s);
+// returns the number of K parts the result was written in (1 unless winograd_ksplit() says otherwise AND the 16-row
+// register-B kernel took the launch): the caller's output transform sums M + p * Z*T*N over the parts
+int winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_t s);
+// K parts by shape alone (never by a measurement: the parts change the order of a tile's sums): 2 when a launch has at
+// most 64 rows and K >= 512 (conv4_x / conv5_1 at one view: 392 blocks of 16 chunks -> 784 of 8), else 1
+int winograd_ksplit(int64_t T, int K);
 // filters U [Z][K/32][N][32] -> the 16x16x4 fragment order [Z][N/16][K/16][64][4] (total = Z*K*N elements)
 void winograd_pack_frag16(const float* up, float* uq, int K, int N, int64_t total, hipStream_t s);
 
