@@ -363,6 +363,7 @@ def test_winograd_f5_error_budget(ops, B, H, W, Ci, Co):
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128),
                                           (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
                                           (4, 64, 64, 128, 128),
+                                          (1, 24, 24, 512, 512),      # 36 tiles, K = 512: the GEMM runs in two K parts
                                           # ragged single-kernel instances: odd sides floor in the pool (a window exists
                                           # when its lower right pixel does), the pooled gradient is zero beyond them
                                           (2, 30, 45, 64, 64), (4, 61, 66, 128, 128), (2, 150, 225, 128, 128)])
