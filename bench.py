@@ -501,11 +501,11 @@ def other_configs(device, base):
         gs.var.copy_(torch.tensor(vel))
         rot = T.rot_to_device(S.uniform_views(1), device)
         for _ in range(5):
-            gs.step(rot)
+            gs.step(rot, loss_view=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(100):
-            gs.step(rot)
+            gs.step(rot, loss_view=True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 100
         out.append({"config": "configs[1] smokegun 100^3 single-frame, 1 view, conv1_1..conv5_1", "value": 1.0 / dt,
@@ -660,11 +660,11 @@ def other_configs(device, base):
             gs2.var.copy_(torch.tensor(base["vel"]))
             rot2 = T.rot_to_device(base["mats"][:nv], device)
             for _ in range(4):
-                gs2.step(rot2)
+                gs2.step(rot2, loss_view=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(30):
-                gs2.step(rot2)
+                gs2.step(rot2, loss_view=True)
             torch.cuda.synchronize()
             rows[str(nv)] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / 30, "hipgraph": bool(gs2.use_graph)}
             del gs2, loss2
@@ -956,7 +956,7 @@ def main():
                   "vgg_weights": "synthetic He-normal seed 123 (no checkpoint offline)"}
 
     def views_step():
-        return gs.step(rot_local)
+        return gs.step(rot_local, loss_view=True)
 
     def settle(step, n=5):
         """untimed set-up steps before the W warm-up steps: lazy state (packed filters, tile tuner), and -- at one or
@@ -1000,8 +1000,13 @@ def main():
         out["config"] = dict(cfg_common, workload="smokegun %d^3 single-frame, %d rotated views, VGG-19 conv1_1..conv5_1 "
                              "Gram style loss, grid velocity variable through advect + TF-Adam (BASELINE configs[2])"
                              % (G, V), views_per_rank=V // world,
-                             parallelism="views sharded over %d rank(s), ONE all-reduce(sum) of the %d MB density-field "
-                                         "gradient + loss per iteration" % (world, 4 * G ** 3 // 2 ** 20))
+                             parallelism="views sharded over %d rank(s), ONE all-reduce's worth of link traffic for the "
+                                         "%d MB density-field gradient + loss per iteration" % (world, 4 * G ** 3 // 2 ** 20),
+                             field_work=("D-slab sharded: reduce-scatter of the gradient over slabs of %d planes (two-plane "
+                                         "halos in the chunks) -> slab-local smooth adjoint, advect adjoint + Adam, advect, "
+                                         "smooth -> all-gather of the smoothed density" % gs.slab.cs)
+                             if gs.slab is not None else
+                             ("replicated on every rank behind one all-reduce(sum)" if world > 1 else "one rank"))
         step_fn, units = views_step, 1
         if world > 1 and not args.no_other_configs:
             # the same box, the other sharding: a sequence with one frame per rank (weak scaling)
@@ -1057,7 +1062,7 @@ def main():
         # the library on the stream the kernel is launched on
         L.nfs_gemm_timer(1)
         for _ in range(psteps):
-            gs.step(rot_local)
+            gs.step(rot_local, loss_view=True)
         torch.cuda.synchronize()
         g_ms, g_fl, g_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
         L.nfs_gemm_timer_read(ctypes.byref(g_ms), ctypes.byref(g_fl), ctypes.byref(g_n))
@@ -1070,7 +1075,7 @@ def main():
         gs.loss.gram_side_stream = False
         _lib.PROFILE = {}
         for _ in range(psteps):
-            gs.step(rot_local)
+            gs.step(rot_local, loss_view=True)
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
         gs.loss.gram_side_stream = side

@@ -558,6 +558,15 @@ int nfs_adam_tf_step(float* x, float* m, float* v, const float* g, int64_t n,
 int nfs_fill(float* x, float value, int64_t n, nfs_stream_t stream);
 int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream); /* y += a*x */
 
+/* ---- (e) multi-GPU: send buffer of the D-slab reduce-scatter ----------------------------------
+ * The reference has no collective; the view-sharded step exchanges the density-field gradient as a
+ * reduce-scatter over D-slabs whose chunks OVERLAP by a two-plane halo either side (engine.GridStylizer._slab_setup).
+ * gpad [D+5][plane]: planes [2, D+2) = the local gradient, planes 0,1,D+2,D+3 zero, plane D+4 carries the local loss in
+ * its first word.  pack [world][cs+5][plane]: chunk k = planes [k*cs, k*cs+cs+4) of gpad (zero where that runs past
+ * plane D+3: the short / empty slabs of a ragged split) followed by plane D+4.  plane % 4 == 0, 16-byte aligned
+ * pointers.  One copy kernel (4*(world*(cs+5))*plane bytes written) in place of a gather by an index table. */
+int nfs_slab_pack(const float* gpad, float* pack, int D, int64_t plane, int world, int cs, nfs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,17 @@ class NfsLibraryError(RuntimeError):
     pass
 
 
+NFS_EINVAL, NFS_ELAUNCH = -1, -2            # include/nfs_hip.h
+
+
+class NfsError(RuntimeError):
+    """an entry point returned non-zero: ``code`` is its NFS_E* value, the message carries nfs_last_error()"""
+
+    def __init__(self, name, code, msg):
+        RuntimeError.__init__(self, "%s failed (%d): %s" % (name, code, msg))
+        self.name, self.code = name, int(code)
+
+
 class SplatCfg(C.Structure):
     _fields_ = [("nd", C.c_int), ("res", C.c_int * 3), ("domain", C.c_float * 3),
                 ("radius", C.c_float), ("support", C.c_float), ("rest_density", C.c_float),
@@ -142,6 +153,7 @@ SIGNATURES = {
     "nfs_adam_tf_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P],
     "nfs_fill": [_P, _F, _L, _P],
     "nfs_axpy": [_P, _P, _F, _L, _P],
+    "nfs_slab_pack": [_P, _P, _I, _L, _I, _I, _P],
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,
@@ -209,5 +221,5 @@ def call(name, *args):
     else:
         rc = getattr(L, name)(*args)
     if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (name, rc, L.nfs_last_error().decode()))
+        raise NfsError(name, rc, L.nfs_last_error().decode())
     return rc

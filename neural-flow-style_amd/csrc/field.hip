@@ -223,6 +223,18 @@ __global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ y, const 
   if (i < n) y[i] += a * x[i];
 }
 
+// send buffer of the D-slab reduce-scatter (nfs_hip.h: nfs_slab_pack): blockIdx.y = destination plane, 16 bytes a lane
+__global__ void __launch_bounds__(256) slab_pack_kernel(const float4* __restrict__ gpad, float4* __restrict__ pack, int D,
+                                                        int64_t plane4, int cs) {
+  const int dp = blockIdx.y, k = dp / (cs + 5), j = dp - k * (cs + 5);
+  const int sp = j == cs + 4 ? D + 4 : k * cs + j;            // source plane of gpad; >= D + 4 here: past the volume
+  const bool zero = j != cs + 4 && sp >= D + 4;
+  const float4* __restrict__ src = gpad + (int64_t)sp * plane4;
+  float4* __restrict__ dst = pack + (int64_t)dp * plane4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane4; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : src[i];
+}
+
 // ---- A5 ------------------------------------------------------------------------------
 __constant__ float kVggMean[3] = {0.485f * 255.f, 0.456f * 255.f, 0.406f * 255.f};  // vgg.py:18-20
 
@@ -411,6 +423,19 @@ int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream) 
   NFS_REQUIRE(x && y && n > 0, "nfs_axpy: bad argument");
   hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), y, x, a, n);
   return check_launch("nfs_axpy");
+}
+
+int nfs_slab_pack(const float* gpad, float* pack, int D, int64_t plane, int world, int cs, nfs_stream_t stream) {
+  NFS_REQUIRE(gpad && pack, "nfs_slab_pack: null pointer");
+  NFS_REQUIRE(D > 0 && plane > 0 && world > 0 && cs > 0, "nfs_slab_pack: non-positive dimension");
+  NFS_REQUIRE(plane % 4 == 0 && ((uintptr_t)gpad & 15) == 0 && ((uintptr_t)pack & 15) == 0,
+              "nfs_slab_pack: plane size must be a multiple of 4 floats and the buffers 16-byte aligned");
+  NFS_REQUIRE((int64_t)world * (cs + 5) <= 65535, "nfs_slab_pack: more than 65535 packed planes");
+  const int64_t plane4 = plane / 4;
+  const unsigned bx = (unsigned)((plane4 + 255) / 256 < 64 ? (plane4 + 255) / 256 : 64);
+  hipLaunchKernelGGL(slab_pack_kernel, dim3(bx, (unsigned)(world * (cs + 5))), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(gpad), reinterpret_cast<float4*>(pack), D, plane4, cs);
+  return check_launch("nfs_slab_pack");
 }
 
 int nfs_loss_net_input_fwd(const float* img, float* d_img, float* x, int B, int H, int W, int Cin, int H2, int W2,

@@ -827,13 +827,7 @@ class GridStylizer(object):
         self._gpad = torch.zeros(D + 5, H, W, dtype=torch.float32, device=dev)
         self.g_ds = self._gpad[2:D + 2]
         self._loss_slot = self._gpad[D + 4].view(-1)[:1]
-        idx = []
-        for k in range(world):
-            for j in range(cs + 4):
-                z = k * cs - 2 + j
-                idx.append(z + 2 if -2 <= z < D + 2 else 0)               # (plane 0 is a zero plane)
-            idx.append(D + 4)
-        sl.idx = torch.tensor(idx, dtype=torch.int64, device=dev)
+        sl.idx = torch.tensor(parallel.slab_pack_index(D, world), dtype=torch.int64, device=dev)    # (NFS_SLAB_PACK=torch)
         sl.pack = torch.empty(world, cs + 5, H, W, dtype=torch.float32, device=dev)
         sl.recv = torch.empty(cs + 5, H, W, dtype=torch.float32, device=dev)
         # padded smoothed density: planes [2, 2 + world * cs) are gathered, d_s = planes [2, 2 + D)
@@ -885,7 +879,10 @@ class GridStylizer(object):
         else:
             losses, _ = self.field_gradient(rot_local)
             torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)
-        torch.index_select(self._gpad, 0, sl.idx, out=sl.pack.view(-1, H, W))
+        if os.environ.get("NFS_SLAB_PACK") == "torch":                  # (the gather by index table the copy kernel replaced)
+            torch.index_select(self._gpad, 0, sl.idx, out=sl.pack.view(-1, H, W))
+        else:
+            ops.slab_pack(self._gpad, sl.pack, D, sl.world, sl.cs)
         parallel.reduce_scatter_sum(sl.recv, sl.pack, group=self.pg)
         total = sl.recv[sl.cs + 4].view(-1)[0].clone()
         if sl.z1 > sl.z0:
@@ -932,7 +929,7 @@ class GridStylizer(object):
     # ---- the forward advect of iteration i + 1 rides in the Adam kernel of iteration i ---------------------------------------
     def _adv_target(self):
         """the buffer the fused Adam kernel writes the next forward sample into (None: fusion off / not applicable)"""
-        if not (self.fuse_advect and self.fuse_adam and self.target == "v"):
+        if not (self.fuse_advect and self._fused_step_ok()):
             return None
         sl = self.slab
         shape = tuple(self.d0.shape) if sl is None else (sl.hi - sl.lo,) + tuple(self.d0.shape[1:])
@@ -940,6 +937,13 @@ class GridStylizer(object):
             self._adv_buf = torch.empty(shape, dtype=torch.float32, device=self.d0.device)
             self._adv_src = None
         return self._adv_buf
+
+    def _fused_step_ok(self):
+        """may step() consume the advect adjoint inside the Adam kernel (``nfs_advect_bwd_adam*``: volumes of at least two
+        cells a side whose cell count is a multiple of 4)?  The stored forward advect exists only then: any other shape
+        updates the variable through ``TFAdamState.step``, which writes no next forward sample."""
+        D, H, W = self.d0.shape
+        return self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0
 
     def _adv_mark(self):
         self._adv_src = (self.var, self.var._version, self.d0, self.d0._version)
@@ -1084,7 +1088,11 @@ class GridStylizer(object):
         self.graph_trial = (t_issue, t_wall)
         return t_issue > 0.85 * t_wall
 
-    def step(self, rot_local):
+    def step(self, rot_local, loss_view=False):
+        """one iteration: loss + gradient of the local views, the exchange, the update; returns the summed loss (a 0-d
+        device tensor of its own).  ``loss_view=True`` (single rank): return a VIEW of the loss slot instead -- no copy
+        launch behind the step (5 us + a 9-us gap of the 1-ms one-view step) -- valid only until the next step()
+        overwrites it: read it (``float()``) or clone it before stepping again"""
         if self.use_graph is None:
             nv = max(int(rot_local.shape[0]), 1)
             if self.d0.numel() * nv <= (2 << 20):    # small volumes, few views: the host needs longer than the GPU
@@ -1117,15 +1125,11 @@ class GridStylizer(object):
             # the 4*G^3-byte density gradient, not on the 12*G^3-byte velocity gradient: everything below it is
             # linear and replicated, so reducing early moves 3x fewer bytes over the links.
             parallel.all_reduce_sum_([self._gbuf], group=self.pg)
-        # single rank: the returned scalar is a VIEW of the loss slot -- valid until the next step() (a copy here is a launch
-        # of its own after the graph replay: 5 us + a 9-us gap in the 1-ms one-view step); read it (float()) or clone it
-        # before stepping again.  Multi-rank: a copy (the slot lives in the all-reduce buffer).
         if total is not None:
-            total = total[0] if self.pg is None else total[0].clone()
+            total = total[0] if (loss_view and self.pg is None) else total[0].clone()
         else:
             total = total_new
-        D, H, W = self.d0.shape
-        if self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0:
+        if self._fused_step_ok():
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
             adv = self._adv_target()
             self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr, adv_next=adv)
@@ -1133,6 +1137,7 @@ class GridStylizer(object):
                 self._adv_mark()
         else:
             self.adam.step(self.var, self.variable_gradient(g_ds), self.lr)
+            self._adv_src = None          # (the variable moved and nothing wrote advect(d0, var) for it)
         return total
 
 

@@ -135,6 +135,7 @@ def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8,
         assert adv_next.is_contiguous() and adv_next.numel() == D * H * W
         _lib.call("nfs_advect_bwd_adam_fwd", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), _ptr(adv_next), D, H, W,
                   float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+    _written(vel, m, v, adv_next)
 
 
 def advect_fwd_slab(d, vel_slab, z0, out=None):
@@ -159,6 +160,7 @@ def advect_bwd_adam_slab(d, vel_slab, g_slab, m_slab, v_slab, z0, lr_t, beta1=0.
         assert adv_next.is_contiguous() and adv_next.numel() == nz * H * W
         _lib.call("nfs_advect_bwd_adam_fwd_slab", _ptr(d), _ptr(vel_slab), _ptr(g_slab), _ptr(m_slab), _ptr(v_slab),
                   _ptr(adv_next), D, H, W, int(z0), nz, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+    _written(vel_slab, m_slab, v_slab, adv_next)
 
 
 def warp2d_fwd(imgs, coords):
@@ -780,8 +782,15 @@ def p2g_wavg_bwd(p, cfg, xsum, wsum, g_out, attr, eps=1e-6, need_p=True, need_at
     Cn = attr.shape[-1]
     g_p = _empty(p.shape, p) if need_p else None
     g_attr = _empty(attr.shape, p) if need_attr else None
-    _lib.call("nfs_p2g_wavg_bwd", _ptr(p), _ptr(attr), _ptr(xsum), _ptr(wsum), _ptr(g_out), _ptr(g_p), _ptr(g_attr), N, Cn,
-              float(eps), C.byref(cfg), _stream())
+    try:
+        _lib.call("nfs_p2g_wavg_bwd", _ptr(p), _ptr(attr), _ptr(xsum), _ptr(wsum), _ptr(g_out), _ptr(g_p), _ptr(g_attr), N,
+                  Cn, float(eps), C.byref(cfg), _stream())
+    except _lib.NfsError as e:
+        # the library's own predicate (launch_p2g_bwd: cells < 2^31, its reading of NFS_SPLAT_LDS) is the authority: an
+        # argument it refuses (nothing was launched) sends the caller down the two-launch adjoint
+        if e.code != _lib.NFS_EINVAL:
+            raise
+        return None
     return g_p, g_attr
 
 
@@ -804,9 +813,27 @@ def p2g_wavg_finish_bwd(xsum, wsum, g_out, eps=1e-6):
 
 # ---- A10 ----------------------------------------------------------------------------
 
+def _written(*tensors):
+    """the kernels write through raw pointers: tell torch's version counters (views share them), so that anything keyed on
+    ``tensor._version`` -- the stylizer's stored forward advect, autograd's saved-tensor checks -- sees the write"""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def adam_tf_step(x, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
     _lib.call("nfs_adam_tf_step", _ptr(x), _ptr(m), _ptr(v), _ptr(g), x.numel(), float(lr_t), float(beta1),
               float(beta2), float(eps), _stream())
+    _written(x, m, v)
+
+
+def slab_pack(gpad, pack, D, world, cs):
+    """send buffer of the D-slab reduce-scatter: pack [world, cs+5, H, W] <- overlapping plane ranges of gpad [D+5, H, W]
+    (nfs_hip.h: nfs_slab_pack)"""
+    assert gpad.is_contiguous() and pack.is_contiguous() and gpad.shape[0] == D + 5
+    assert tuple(pack.shape) == (world, cs + 5) + tuple(gpad.shape[1:])
+    _lib.call("nfs_slab_pack", _ptr(gpad), _ptr(pack), int(D), int(gpad[0].numel()), int(world), int(cs), _stream())
+    return pack
 
 
 def fill(x, value):

@@ -57,6 +57,21 @@ def slab_plan(D, world):
     return cs, [(min(r * cs, D), min((r + 1) * cs, D)) for r in range(world)]
 
 
+def slab_pack_index(D, world):
+    """plane indices that build the send buffer of the D-slab reduce-scatter from the padded gradient volume
+    gpad [D + 5] (planes [2, D + 2) = the gradient, 0, 1, D + 2, D + 3 zero, D + 4 the loss plane): chunk k = planes
+    [k cs - 2, k cs + cs + 2) of the volume (zero outside it) + the loss plane.  The definition ``nfs_slab_pack``
+    implements as one copy kernel (tests hold the kernel to ``gpad.index_select(0, this)``)."""
+    cs, _ = slab_plan(D, world)
+    idx = []
+    for k in range(world):
+        for j in range(cs + 4):
+            z = k * cs - 2 + j
+            idx.append(z + 2 if -2 <= z < D + 2 else 0)                   # (plane 0 is a zero plane)
+        idx.append(D + 4)
+    return idx
+
+
 def replicas_identical(t, group=None, atol=0.0):
     """debug check: max |t - t_rank0| over ranks is <= atol"""
     if not (dist.is_available() and dist.is_initialized()):

@@ -127,7 +127,10 @@ class Styler(StylerBase):
         consecutive particles no longer fit the splat's LDS accumulators and the forward splat runs at half speed
         (tools/chocolate_iter_profile.py: 213 us against 116 in grid order) -- so the order of a frame is recomputed from
         the CURRENT positions every ``reorder_every`` evaluations (default 10; 0 = never).  The splat does not care
-        about the order of its particles; autograd scatters the gradient back through the gather."""
+        about the order of its particles; autograd scatters the gradient back through the gather.  The sort is STABLE
+        (32-bit keys: the radix path either way), so two runs, or two ranks of a view-sharded run, that hold the same
+        positions build the same layout and feed identically rounded sums to the blocks that fall back to float
+        atomics."""
         orders = self.__dict__.setdefault("_orders", {})
         key = (p.data_ptr(), p.shape[0])
         every = int(getattr(self, "reorder_every", 10) or 0)
@@ -136,7 +139,7 @@ class Styler(StylerBase):
         ages = self.__dict__.setdefault("_order_age", {})
         age = ages.get(key, 0) + 1
         if age >= every:
-            orders[key] = T.grid_order(p_now[0].detach(), self.resolution, stable=False)
+            orders[key] = T.grid_order(p_now[0].detach(), self.resolution, stable=True)
             age = 0
         ages[key] = age
         return orders.get(key)

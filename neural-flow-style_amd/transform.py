@@ -317,8 +317,7 @@ def grid_order(p, resolution, brick=8, stable=True):
     key = bk * (brick ** nd) + ck
     if int(np.prod(nb)) * brick ** nd < 2 ** 31:
         key = key.to(torch.int32)       # (32-bit keys take the radix sort: ~10x faster than the 64-bit merge sort at 5e5 keys)
-    # stable: particles of one cell keep their relative order (what the run-start orders use: reproducible layouts);
-    # the periodic re-ordering of a drifting frame does not need it
+    # stable: particles of one cell keep their relative order (reproducible layouts: run to run and rank to rank)
     return torch.argsort(key, stable=stable)
 
 

@@ -68,12 +68,15 @@ def _resize_plane(a, size, order):
     its properties only (tests/test_util_resize_cpu.py): exact copy at equal size, partition of unity and linear
     precision in the interior; "parity unpinned" against skimage 0.14.2 itself (host-side style-image preparation)."""
     a = np.asarray(a, np.float64)
-    lo, hi = a.min(), a.max()
+    if int(order) not in (0, 1, 3):
+        raise ValueError("resize order %r: 0 (nearest), 1 (bilinear) or 3 (bicubic, what the reference passes, "
+                         "styler_base.py:257-260) -- skimage's order 2 / 4 / 5 warps are not restated" % (order,))
+    order = int(order)
     scale = [a.shape[k] / float(size[k]) for k in range(2)]
     sig = [max(0.0, (s - 1.0) / 2.0) for s in scale]
     if any(s > 0 for s in sig):
         a = gaussian_filter(a, sig, mode="constant", cval=0.0)
-    order = 3 if order >= 2 else int(order)
+    lo, hi = a.min(), a.max()             # (skimage warps and clips the FILTERED image: the range after the pre-filter)
     out = _interp_matrix(a.shape[0], size[0], order) @ a @ _interp_matrix(a.shape[1], size[1], order).T
     return np.clip(out, lo, hi)
 

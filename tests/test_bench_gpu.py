@@ -77,6 +77,24 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
     assert abs(seq2["final_loss"] - seq1["final_loss"]) <= 1e-5 * abs(seq1["final_loss"])
 
 
+def test_bench_gpus_4_and_8_over_gloo():
+    """the rank counts of a SCALE run, functionally: ``bench.py --gpus 8`` (one view per rank, slabs of 64 / 8 planes)
+    and ``--gpus 4`` (two views per rank) as the driver launches them, the ranks sharing the one GPU over gloo.  Same
+    metric / workload as the one-rank line, the world size the ranks saw, and the trajectory of the one-rank run."""
+    args = ["--steps", "3", "--warmup", "1", "--grid", "64", "--no-cpu-baseline", "--no-kernel-profile",
+            "--no-other-configs", "--no-sustained", "--no-split-limb"]
+    one = _run([sys.executable, "bench.py"] + args)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    for n in (8, 4):
+        r = _run([sys.executable, "bench.py", "--gpus", str(n)] + args, env={"NFS_DIST_BACKEND": "gloo"})
+        assert r["n_gpus"] == n and r["world_size_seen"] == n and r["collective_backend"] == "gloo"
+        assert r["config"]["views_per_rank"] == 8 // n and r["scaling"] == "strong"
+        assert r["metric"] == one["metric"] and r["config"]["workload"] == one["config"]["workload"]
+        assert abs(r["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"]), (n, r["final_loss"])
+        assert r["config"]["field_work"].startswith("D-slab sharded"), r["config"]
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1"], cwd=ROOT, capture_output=True,

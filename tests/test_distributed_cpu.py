@@ -198,11 +198,11 @@ def test_halo_exchange_of_frame_updates_world3():
     assert seen == set(range(F))
 
 
-def _slab_worker(rank, world, port, q):
+def _slab_worker(rank, world, port, q, D=11):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from neural_flow_style_amd import parallel
-    D, H, W = 11, 3, 4
+    H, W = 3, 4
     cs, plan = parallel.slab_plan(D, world)
     z0, z1 = plan[rank]
     # every rank's local "gradient" (a function of rank and voxel), packed as engine.GridStylizer packs it: chunk k =
@@ -211,9 +211,7 @@ def _slab_worker(rank, world, port, q):
     gpad = torch.zeros(D + 5, H, W)
     gpad[2:D + 2] = g
     gpad[D + 4].view(-1)[0] = 10.0 + rank
-    idx = []
-    for k in range(world):
-        idx += [(k * cs - 2 + j + 2 if -2 <= k * cs - 2 + j < D + 2 else 0) for j in range(cs + 4)] + [D + 4]
+    idx = parallel.slab_pack_index(D, world)
     pack = gpad.index_select(0, torch.tensor(idx)).view(world, cs + 5, H, W).contiguous()
     recv = torch.empty(cs + 5, H, W)
     parallel.reduce_scatter_sum(recv, pack)
@@ -227,33 +225,69 @@ def _slab_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _slab_exchange_case(world, D):
+    from neural_flow_style_amd import parallel
+    H, W = 3, 4
+    cs, plan = parallel.slab_plan(D, world)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q, D)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = np.arange(D * H * W, dtype=np.float32).reshape(D, H, W) * (world * (world + 1) / 2.0)   # ranks 1 + ... + world
+    padded = np.zeros((D + 4, H, W), np.float32)
+    padded[2:D + 2] = total
+    for rank, recv, full in got:
+        z0 = rank * cs                       # (chunk origin; an idle rank's plan entry is clipped to (D, D))
+        want = np.zeros((cs + 4, H, W), np.float32)
+        hi = min(z0 + cs + 4, D + 4)
+        if hi > z0:
+            want[:hi - z0] = padded[z0:hi]
+        np.testing.assert_array_equal(recv[:cs + 4], want)
+        assert recv[cs + 4].reshape(-1)[0] == 10.0 * world + world * (world - 1) / 2.0      # sum of (10 + rank)
+        np.testing.assert_array_equal(full, total)
+
+
 def test_slab_reduce_scatter_with_overlapping_chunks_and_all_gather_world3():
     """the exchange of the D-slab sharded step (engine.GridStylizer._step_slab) on a ragged split (11 planes over 3
     ranks: 4 + 4 + 3): every rank receives the SUM over ranks of its slab with a two-plane halo (zero beyond the volume)
     and the summed loss; the all-gather of the slabs rebuilds the whole volume"""
     from neural_flow_style_amd import parallel
-    world, D, H, W = 3, 11, 3, 4
-    cs, plan = parallel.slab_plan(D, world)
+    cs, plan = parallel.slab_plan(11, 3)
     assert cs == 4 and plan == [(0, 4), (4, 8), (8, 11)]
     assert parallel.slab_plan(200, 8) == (25, [(25 * r, 25 * r + 25) for r in range(8)])
     assert parallel.slab_plan(5, 8)[1][5:] == [(5, 5)] * 3                      # idle ranks: empty slabs
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-    total = np.arange(D * H * W, dtype=np.float32).reshape(D, H, W) * 6.0        # ranks 1 + 2 + 3
-    padded = np.zeros((D + 4, H, W), np.float32)
-    padded[2:D + 2] = total
-    for rank, recv, full in got:
-        z0 = plan[rank][0]
-        want = np.zeros((cs + 4, H, W), np.float32)
-        hi = min(z0 + cs + 4, D + 4)
-        want[:hi - z0] = padded[z0:hi]
-        np.testing.assert_array_equal(recv[:cs + 4], want)
-        assert recv[cs + 4].reshape(-1)[0] == 33.0                               # 10 + 11 + 12
-        np.testing.assert_array_equal(full, total)
+    _slab_exchange_case(3, 11)
+
+
+def test_slab_exchange_world8_ragged_split_with_an_idle_rank():
+    """the world size a SCALE run uses, on a depth that does not divide: 27 planes over 8 ranks = 6 slabs of 4, one of 3
+    and an EMPTY one (rank 7 owns no plane: it still sends its chunks and receives zeros)"""
+    from neural_flow_style_amd import parallel
+    cs, plan = parallel.slab_plan(27, 8)
+    assert cs == 4 and plan[6] == (24, 27) and plan[7] == (27, 27)
+    _slab_exchange_case(8, 27)
+
+
+def test_slab_exchange_world4_and_world8_at_the_headline_split():
+    """200 planes over 4 and 8 ranks divide evenly (50 / 25 planes): the plan, and the index table of the send buffer --
+    every plane of the gradient appears in its owner's chunk at offset 2, the halo planes in the neighbours' chunks, the
+    loss plane closes every chunk"""
+    from neural_flow_style_amd import parallel
+    for world in (4, 8):
+        D = 200
+        cs, plan = parallel.slab_plan(D, world)
+        assert cs * world == D and plan == [(cs * r, cs * r + cs) for r in range(world)]
+        idx = np.asarray(parallel.slab_pack_index(D, world)).reshape(world, cs + 5)
+        for r in range(world):
+            assert idx[r, cs + 4] == D + 4
+            np.testing.assert_array_equal(idx[r, 2:cs + 2], np.arange(r * cs, r * cs + cs) + 2)     # the slab itself
+            lo = [z + 2 for z in (r * cs - 2, r * cs - 1)]              # (planes 0, 1 of gpad are zero planes)
+            hi = [z + 2 if z < D + 2 else 0 for z in (r * cs + cs, r * cs + cs + 1)]
+            assert list(idx[r, :2]) == lo and list(idx[r, cs + 2:cs + 4]) == hi
+    _slab_exchange_case(4, 10)

@@ -177,6 +177,51 @@ def ops_mod():
     return o
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_stored_forward_advect_never_goes_stale_on_shapes_the_fused_kernel_refuses(graph):
+    """9 x 10 x 11 cells (990: not a multiple of 4) cannot take the fused advect-adjoint + Adam kernel: step() updates the
+    velocity through TFAdamState.step, which writes no next forward sample -- so none may be kept (round-4 advisor find:
+    the stylizer kept advect(d0, OLD velocity) and optimised against a frozen density from step 2 on).  Same trajectory
+    with the switch on and off; an external raw-pointer Adam step on gs.var is seen through the version counter."""
+    import neural_flow_style_amd.vgg as vgg
+    import neural_flow_style_amd.engine as eng
+    import neural_flow_style_amd.transform as T
+    D, H, W = 9, 10, 11
+    rng = np.random.RandomState(3)
+    d0 = np.clip(rng.rand(D, H, W).astype(np.float32) - 0.4, 0, 1)
+    vel0 = (rng.randn(D, H, W, 3) * 0.05).astype(np.float32)
+    layers = ["conv1_1", "conv2_1"]
+    net = vgg.VGG(vgg.synthetic_weights(123, upto="conv2_1"), "cuda")
+    loss = eng.RenderStyleLoss(net, layers, [1.0, 1.0], 1.0, transmit=0.05)
+    loss.set_style_image(style_image(H, W, rng))
+    rot = T.rot_to_device(uniform_views(2), "cuda")
+    out = []
+    for fuse in (True, False):
+        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=5e-3, graph=graph)
+        gs.fuse_advect = fuse
+        assert not gs._fused_step_ok() and gs._adv_target() is None
+        gs.var.copy_(torch.tensor(vel0))
+        ls = [float(gs.step(rot)) for _ in range(4)]
+        assert not gs._adv_valid()
+        out.append((ls, gs.var.clone(), gs.d_s.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert len(set(out[0][0])) == 4                                 # the density the loss sees does move
+    # a fusable shape, updated from OUTSIDE through the raw-pointer Adam kernel: the stored sample is dropped
+    d0c, vel0c, mats, lossc, cfg, w_or, sfe, T, eng = _setup(24, 2, layers)
+    gs = eng.GridStylizer(lossc, torch.tensor(d0c).cuda(), k=3, target="v", lr=1e-3, graph=graph)
+    gs.var.copy_(torch.tensor(vel0c))
+    rotc = T.rot_to_device(mats, "cuda")
+    for _ in range(3):
+        gs.step(rotc)
+    assert gs._adv_valid()
+    _, g = gs.gradient(rotc)
+    eng.TFAdamState().step(gs.var, g.contiguous(), 1e-2)
+    assert not gs._adv_valid()
+    d_ref = ops_mod().smooth3d_relu_fwd(ops_mod().advect_fwd(gs.d0.unsqueeze(-1), gs.var).squeeze(-1), 3.0)
+    assert torch.equal(gs.forward_field(), d_ref)                   # the forward follows the externally updated variable
+    assert np.isfinite(float(gs.step(rotc))) and gs._adv_valid()
+
+
 def test_graph_replay_equals_eager_steps():
     """GridStylizer(graph=True): forward + adjoint replayed as one hipGraph (eager warm-up step, capture, replays)
     follows the eager trajectory; a different view tensor is copied into the captured buffer."""
@@ -490,7 +535,7 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 if world > 1:
     dist.init_process_group("gloo")
-D, V = %(D)d, 6
+D, V = %(D)d, %(V)d
 rng = np.random.RandomState(5)
 d0 = S.blob_density(D, rng); vel = S.curl_velocity(D, rng, max_cells=1.0); simg = S.style_image(D, D, rng)
 net = vgg.VGG(vgg.synthetic_weights(123, upto="conv3_1"), dev)
@@ -510,19 +555,21 @@ if world > 1:
 """
 
 
-@pytest.mark.parametrize("D,world,graph", [(24, 2, False), (28, 3, False), (24, 2, True)])
+@pytest.mark.parametrize("D,world,graph", [(24, 2, False), (28, 3, False), (24, 2, True), (24, 4, False), (24, 8, True),
+                                           (28, 8, False)])
 def test_slab_sharded_field_work_reproduces_the_single_rank_trajectory(tmp_path, D, world, graph):
     """views sharded over ranks (sharing the GPU over gloo) with the field work sharded over D-slabs: reduce-scatter of
     the packed gradient chunks (two-plane halos, the loss in an extra plane) -> slab-local smooth adjoint, advect adjoint
     + ApplyAdam, advect, smooth -> all-gather of the smoothed density.  Even (24 / 2) and ragged (28 / 3: slabs of 10,
     10, 8 planes) splits, with and without the hipGraph of the loss chain, against the one-rank run and against the
-    replicated all-reduce form of the same ranks"""
+    replicated all-reduce form of the same ranks.  World 4 and 8 on eight views are the rank counts of a SCALE run (two
+    views / one view per rank; 24 / 8 = slabs of 3 planes; 28 / 8 = seven slabs of 4 and an IDLE eighth rank)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "rank.py"
-    script.write_text(_SLAB_SCRIPT % {"root": root, "D": D, "graph": graph})
+    script.write_text(_SLAB_SCRIPT % {"root": root, "D": D, "graph": graph, "V": 8 if world in (4, 8) else 6})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NFS_SLAB_SHARD"):
         env.pop(k, None)

@@ -1001,3 +1001,21 @@ def test_style_mask_kernels():
     g = rng.randn(2, 8, 6, 16).astype(np.float32)
     got = ops.style_mask_bwd(torch.tensor(g).cuda(), m.cuda().contiguous(), torch.tensor(F_).cuda()).cpu()
     assert rel(got, torch.tensor(g) * m * (torch.tensor(F_) > 0)) < 1e-6
+
+
+@pytest.mark.parametrize("D,H,W,world", [(11, 3, 4, 3), (27, 6, 6, 8), (24, 8, 8, 8), (40, 10, 10, 4), (5, 4, 4, 8),
+                                         (200, 20, 20, 8)])
+def test_slab_pack_is_the_index_table_gather(D, H, W, world):
+    """send buffer of the D-slab reduce-scatter (nfs_slab_pack): overlapping plane ranges of the padded gradient volume,
+    zero past it (ragged / empty slabs), the loss plane behind every chunk -- bit for bit the gather through
+    parallel.slab_pack_index that it replaced"""
+    from neural_flow_style_amd import ops, parallel
+    cs, _ = parallel.slab_plan(D, world)
+    rng = np.random.RandomState(D + world)
+    gpad = torch.zeros(D + 5, H, W, device="cuda")
+    gpad[2:D + 2] = torch.tensor(rng.randn(D, H, W).astype(np.float32)).cuda()
+    gpad[D + 4].view(-1)[0] = 7.25
+    pack = torch.full((world, cs + 5, H, W), float("nan"), device="cuda")
+    ops.slab_pack(gpad, pack, D, world, cs)
+    idx = torch.tensor(parallel.slab_pack_index(D, world), device="cuda")
+    assert torch.equal(pack.view(-1, H, W), gpad.index_select(0, idx))

@@ -8,11 +8,11 @@ for V, graph in ((1, False), (2, False), (4, False), (8, False), (1, True), (8, 
     gs, rot, data = bench.build_problem(200, V, torch.device("cuda", 0), 0, 1)
     gs.use_graph = graph
     for _ in range(3):
-        gs.step(rot)
+        gs.step(rot, loss_view=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(20):
-        gs.step(rot)
+        gs.step(rot, loss_view=True)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()

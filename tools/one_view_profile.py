@@ -10,5 +10,5 @@ gs, rot, base = bench.build_problem(200, 8, torch.device("cuda:0"), 0, 1)
 gs.use_graph = (os.environ.get("ONE_VIEW_GRAPH", "0") == "1")
 rot = rot[:views].contiguous()
 for _ in range(n):
-    gs.step(rot)
+    gs.step(rot, loss_view=True)
 torch.cuda.synchronize()
