@@ -52,13 +52,6 @@ int nfs_gemm_timer(int enable);
  *      float32, each product is carried to within 2^-26 (float32-equivalent accuracy, 2.67x the MFMA rate).
  * NFS_GEMM_MODE presets it. */
 int nfs_gemm_mode(int mode);
-/* Few-row form of the Winograd GEMMs of a 3x3 convolution (process-wide; returns the previous setting; any value other
- * than 0 / 1 only queries).  A launch of at most 64 Winograd tiles (the deep VGG layers at one or two views per GPU,
- * vgg.py:89-108 on a 25 x 25 or 12 x 12 image) is bound by streaming the 49 (36) transformed filter planes; with 1 (the
- * default) such launches transform the 3x3 filters in registers from the direct-form pack instead (5.4 x fewer filter
- * bytes), with 0 they take the packed-filter GEMM like every other launch.  Same products up to float32 rounding.
- * NFS_WG_FEWROW=0 presets 0. */
-int nfs_conv3x3_fewrow(int mode);
 int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
 
 /* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------

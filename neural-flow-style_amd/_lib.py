@@ -61,7 +61,6 @@ SIGNATURES = {
     "nfs_device_cus": [],
     "nfs_gemm_timer": [_I],
     "nfs_gemm_mode": [_I],
-    "nfs_conv3x3_fewrow": [_I],
     "nfs_gemm_timer_read": [_P, _P, _P],
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -43,8 +43,7 @@ int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N);
 int winograd5_pack(const float* w_hwio, float* up5, int Ci, int Co, int kind, hipStream_t s);
 int64_t winograd5_bits_words(int B, int H, int W, int C);
 int winograd5_conv(const float* x, const float* U5, const float* aux0, const float* aux1, float* y, float* ws, int B,
-                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits,
-                   const float* wp);
+                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -132,7 +131,16 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 }
 
 // ---- F(4x4, 3x3): weights U_k = (G g G^T)[k], k = 0..35, packed [36][K/32][N][32] ----------------------
-// G (6 x 3) and wg4_g: winograd_math.h (shared with the few-row GEMM, which applies it in registers)
+// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+__device__ __forceinline__ void wg4_g(const float g0, const float g1, const float g2, float* u) {
+  u[0] = 0.25f * g0;
+  u[1] = (-1.f / 6.f) * (g0 + g1 + g2);
+  u[2] = (-1.f / 6.f) * (g0 - g1 + g2);
+  u[3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  u[4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  u[5] = g2;
+}
+
 __global__ void __launch_bounds__(256) winograd_pack4_kernel(const float* __restrict__ w, float* __restrict__ up,
                                                              int Ci, int Co, int kind) {
   const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
@@ -657,6 +665,7 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb_kernel(WgGemmArgs a) {
 
   // epilogue: transpose the tile through LDS, leave as float4 rows -- one half (the rows of waves wm = 0, then wm = 1)
   // at a time, so that the tile buffer is no larger than the operand buffers and more blocks fit a CU
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (inline-asm MFMAs: the last one retires before an accumulator is read)
   constexpr int OS = BN + 4, HR = BM / 2;
   float* otile = smem;
   float* Mc = a.M + (int64_t)comp * a.T * a.N;
@@ -784,6 +793,10 @@ __device__ __forceinline__ void winograd_gemm_rb16_block(const WgGemmArgs& a, fl
   // five row tiles (80 rows) per pass, so that a tall tile does not need a tall buffer
   // (256-column tiles, NW16 = 4: two row tiles per pass keep the buffer at 33 KB, so that blocks still share a CU)
   constexpr int OS = BN + 4, EPMAX = NW16 >= 4 ? 2 : 5, EP = MT16 < EPMAX ? MT16 : EPMAX, NPASS = (MT16 + EP - 1) / EP;
+  // The inline-asm MFMAs are opaque to the compiler's hazard recogniser: nothing may read an accumulator until the last
+  // MFMA has retired (8 passes).  The barrier below used to be reached behind the loop's outstanding loads; a kernel
+  // with nothing outstanding (a round-5 experiment with one row tile) read stale sums.
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   float* otile = smem;
   float* Mc = a.M + ((int64_t)split * a.Z + comp) * a.T * a.N;
   const float alpha = a.alpha * (a.alpha_dev ? a.alpha_dev[comp] : 1.f);
@@ -1551,7 +1564,7 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
   const int m = winograd_tile();
   const int64_t T = (int64_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
   // (M once per K part of the GEMM: winograd_ksplit)
-  const int64_t f4 = (m + 2) * (m + 2) * T * ((int64_t)K + (int64_t)N * winograd_mparts(T, K, N, (m + 2) * (m + 2))),
+  const int64_t f4 = (m + 2) * (m + 2) * T * ((int64_t)K + (int64_t)N * winograd_ksplit(T, K)),
                 f5 = m == 4 ? winograd5_workspace_floats(B, H, W, K, N) : 0;
   return f4 > f5 ? f4 : f5;
 }
@@ -1601,7 +1614,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   // layout, sized by nfs_conv3x3_relu_bits_words for exactly the layers that come here)
   if (m == 4 && !pooled_grad && !ypool && !out_bits && y && winograd5_takes(H, W, K, N))
     return winograd5_conv(x, U + (int64_t)162 * K * N + winograd_fused_packed_floats(K, N), aux0, aux1, y, ws, B, H, W, K, N,
-                          mode, relu, cus, s, in_bits, U - (int64_t)9 * K * N);
+                          mode, relu, cus, s, in_bits);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
@@ -1624,23 +1637,15 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
     a.Uq = U + (int64_t)90 * K * N;
     a.Uq16 = U + (int64_t)126 * K * N;
   }
-  // a few dozen rows: the filter transform inside the GEMM, from the direct-form pack in front of U (winograd_fewrow.hip)
-  int nsplit = (m == 4 && g_gemm_mode == 0) ? winograd_fewrow_gemm(V, U - (int64_t)9 * K * N, M, T, K, N, comps, s) : 0;
-  if (nsplit == 0) nsplit = launch_batched_gemm(a, comps, cus, s);
+  const int nsplit = launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {
     const unsigned ob = blocks_for(T * (N / 2), 256);
     uint32_t* ib = aux0 ? in_bits : nullptr;                              // a mask only where the caller asks for one
-    if (nsplit != 1 && nsplit != 2 && nsplit != 4) {
+    if (nsplit != 1 && nsplit != 2) {
       set_error("winograd_conv: unsupported number of K parts");
       return NFS_EINVAL;
     }
-    if (nsplit == 4 && mode == 0)
-      hipLaunchKernelGGL((winograd_output4_kernel<0, 4>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                         ypool, out_bits);
-    else if (nsplit == 4)
-      hipLaunchKernelGGL((winograd_output4_kernel<1, 4>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                         (float*)nullptr, ib);
-    else if (mode == 0 && nsplit == 1)
+    if (mode == 0 && nsplit == 1)
       hipLaunchKernelGGL((winograd_output4_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                          ypool, out_bits);
     else if (mode == 0)

@@ -20,11 +20,20 @@
 // gradient's output transform (same tiling, one 8-byte load per thread) instead of x_in.
 #include "common.h"
 #include "winograd_gemm.h"
-#include "winograd_math.h"
 
 namespace nfs {
 
-// G (7 x 3) and w5_g: winograd_math.h (shared with the few-row GEMM, which applies it in registers)
+// G (7 x 3) = {-1/2,0,0} {-1/3,-1/3,-1/3} {1/9,-1/9,1/9} {1/36,1/18,1/9} {-1/60,1/30,-1/15} {32/45,16/45,8/45} {0,0,1}
+__device__ __forceinline__ void w5_g(const float g0, const float g1, const float g2, float* u) {
+  u[0] = -0.5f * g0;
+  u[1] = (-1.f / 3.f) * (g0 + g1 + g2);
+  u[2] = (1.f / 9.f) * (g0 - g1 + g2);
+  u[3] = (1.f / 36.f) * g0 + (1.f / 18.f) * g1 + (1.f / 9.f) * g2;
+  u[4] = (-1.f / 60.f) * g0 + (1.f / 30.f) * g1 - (1.f / 15.f) * g2;
+  u[5] = (32.f / 45.f) * g0 + (16.f / 45.f) * g1 + (8.f / 45.f) * g2;
+  u[6] = g2;
+}
+
 // U_z[ci][co] = (G g G^T)[z], z = 7 r + q, packed [49][K/32][N][32] (the layout of winograd_pack4_kernel); kind as there
 __global__ void __launch_bounds__(256) winograd5_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Ci,
                                                              int Co, int kind) {
@@ -230,7 +239,7 @@ int64_t winograd5_packed_floats(int Ci, int Co) { return winograd5_channels(Ci, 
 int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N) {
   if (!winograd5_takes(H, W, K, N)) return 0;
   const int64_t T = (int64_t)B * ((H + 4) / 5) * ((W + 4) / 5);
-  return (int64_t)49 * T * ((int64_t)K + (int64_t)N * winograd_mparts(T, K, N, 49));     // (M once per K part of the GEMM)
+  return (int64_t)49 * T * ((int64_t)K + (int64_t)N * winograd_ksplit(T, K));     // (M once per K part of the GEMM)
 }
 
 // up5: [49][K/32][N][32] followed by the 16x16x4 fragment order of the same
@@ -246,8 +255,7 @@ int winograd5_pack(const float* w_hwio, float* up5, int Ci, int Co, int kind, hi
 int64_t winograd5_bits_words(int B, int H, int W, int C) { return (int64_t)B * ((H + 4) / 5) * ((W + 4) / 5) * C; }
 
 int winograd5_conv(const float* x, const float* U5, const float* aux0, const float* aux1, float* y, float* ws, int B,
-                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits,
-                   const float* wp) {
+                   int H, int W, int K, int N, int mode, int relu, int cus, hipStream_t s, uint32_t* in_bits) {
   const int TH = (H + 4) / 5, TW = (W + 4) / 5;
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
@@ -258,22 +266,14 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
                      mode == 0 ? in_bits : nullptr);
   WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   a.Uq16 = U5 + (int64_t)49 * K * N;
-  // a few dozen rows (one or two views per GPU): the filter transform inside the GEMM (winograd_fewrow.hip), else the
-  // packed transformed filters
-  int nsplit = wp ? winograd_fewrow_gemm(V, wp, M, T, K, N, 49, s) : 0;
-  if (nsplit == 0) nsplit = winograd_launch_batched_gemm(a, 49, cus, s);
+  const int nsplit = winograd_launch_batched_gemm(a, 49, cus, s);
   const unsigned ob = blocks_for(T * N, 256);
-  if (nsplit != 1 && nsplit != 2 && nsplit != 4) {
+  if (nsplit != 1 && nsplit != 2) {
     set_error("winograd5_conv: unsupported number of K parts");
     return NFS_EINVAL;
   }
   const uint32_t* ib = aux0 ? in_bits : nullptr;
-  if (nsplit == 4 && mode == 0)
-    hipLaunchKernelGGL((winograd5_output_kernel<0, 4>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
-                       (const uint32_t*)nullptr);
-  else if (nsplit == 4)
-    hipLaunchKernelGGL((winograd5_output_kernel<1, 4>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu, ib);
-  else if (mode == 0 && nsplit == 1)
+  if (mode == 0 && nsplit == 1)
     hipLaunchKernelGGL((winograd5_output_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                        (const uint32_t*)nullptr);
   else if (mode == 0)

@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
     NFS_TICK(3)
   }
 
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (inline-asm MFMAs: the last one retires before an accumulator is read)
   // ---- output transform + layer epilogue, all in-lane: tiles 4 g + {0..3} of the run (as two pairs), channel n0 ----
   // (!RAG: H and W are multiples of 4, every pixel of a live tile is inside the image.  Staging the tile through
   // LDS to store 256-byte rows instead of these 64-byte pieces was measured: no gain, one more barrier.)

@@ -35,16 +35,6 @@ int winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_
 // K parts by shape alone (never by a measurement: the parts change the order of a tile's sums): 2 when a launch has at
 // most 64 rows and K >= 512 (conv4_x / conv5_1 at one view: 392 blocks of 16 chunks -> 784 of 8), else 1
 int winograd_ksplit(int64_t T, int K);
-// few-row launches (winograd_fewrow.hip): the filter transform in registers from the direct-form pack wp [K/32][9][N][32].
-// winograd_fewrow_parts: 0 = not taken, else the number of K parts (1 / 2 / 4), by shape alone; winograd_fewrow_gemm
-// returns the same number after launching.  winograd_mparts: K parts of M a convolution's workspace must hold.
-int winograd_fewrow_parts(int64_t T, int K, int N, int Z);
-int winograd_fewrow_parts_of_shape(int64_t T, int K, int N, int Z);          // ... whether the path is switched on or not
-int winograd_fewrow_gemm(const float* V, const float* wp, float* M, int64_t T, int K, int N, int Z, hipStream_t s);
-inline int winograd_mparts(int64_t T, int K, int N, int Z) {
-  const int f = winograd_fewrow_parts_of_shape(T, K, N, Z), k = winograd_ksplit(T, K);
-  return f > k ? f : k;
-}
 // filters U [Z][K/32][N][32] -> the 16x16x4 fragment order [Z][N/16][K/16][64][4] (total = Z*K*N elements)
 void winograd_pack_frag16(const float* up, float* uq, int K, int N, int64_t total, hipStream_t s);
 

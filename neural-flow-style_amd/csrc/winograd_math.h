@@ -45,28 +45,4 @@ __device__ __forceinline__ void wg4_bt1(const float* d, float* o) {
   o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
 
-// ---- filter transforms G (applied twice: U = G g G^T) ---------------------------------------------------------------
-// F(4x4, 3x3)
-// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
-__device__ __forceinline__ void wg4_g(const float g0, const float g1, const float g2, float* u) {
-  u[0] = 0.25f * g0;
-  u[1] = (-1.f / 6.f) * (g0 + g1 + g2);
-  u[2] = (-1.f / 6.f) * (g0 - g1 + g2);
-  u[3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-  u[4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-  u[5] = g2;
-}
-
-// F(5x5, 3x3): interpolation points 0, +-1, +-2, 1/2, inf
-// G (7 x 3) = {-1/2,0,0} {-1/3,-1/3,-1/3} {1/9,-1/9,1/9} {1/36,1/18,1/9} {-1/60,1/30,-1/15} {32/45,16/45,8/45} {0,0,1}
-__device__ __forceinline__ void w5_g(const float g0, const float g1, const float g2, float* u) {
-  u[0] = -0.5f * g0;
-  u[1] = (-1.f / 3.f) * (g0 + g1 + g2);
-  u[2] = (1.f / 9.f) * (g0 - g1 + g2);
-  u[3] = (1.f / 36.f) * g0 + (1.f / 18.f) * g1 + (1.f / 9.f) * g2;
-  u[4] = (-1.f / 60.f) * g0 + (1.f / 30.f) * g1 - (1.f / 15.f) * g2;
-  u[5] = (32.f / 45.f) * g0 + (16.f / 45.f) * g1 + (8.f / 45.f) * g2;
-  u[6] = g2;
-}
-
 }  // namespace nfs

@@ -76,10 +76,6 @@ class RenderStyleLoss(object):
         # all style layers' Gram work as three launches after the forward pass (default) / per layer (side stream)
         self.gram_grouped = os.environ.get("NFS_GRAM_GROUP", "1") != "0"
         self.gram_side_stream = os.environ.get("NFS_GRAM_STREAM", "1") != "0"
-        # grouped Gram work of the lower style layers on a side stream under the deeper layers' forward pass, at up to
-        # this many views per call (_gram_split; 0 = never)
-        self.gram_split_views = int(os.environ.get("NFS_GRAM_SPLIT", "2"))
-        self._top_parts = {}
         self._side = None
         self.vgg_streams = int(os.environ.get("NFS_VGG_STREAMS", "1"))
         self.view_groups = int(os.environ.get("NFS_VIEW_GROUPS", "1"))
@@ -303,14 +299,9 @@ class RenderStyleLoss(object):
             self._content_job(acts, sg, loss)
             self._hist_job(acts, sg, loss)
             return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
-        split_key = tuple(x.shape)
-        if self.gram_grouped and self._gram_split(x.shape[0]) and split_key in self._top_parts:
-            return self._vgg_loss_grad_split(x, total_out, self._top_parts[split_key])
         if self.gram_grouped:
             acts = self.net.forward(x, self.top, keep=self._keep())
             Fs = [acts[n] for n in self.layers]
-            if self._gram_split(x.shape[0]):             # (the next call of this shape takes the split form)
-                self._top_parts[split_key] = ops.gram_style_group_parts([acts[self.top]])
             masks = []
             for n, F in zip(self.layers, Fs):
                 d = self._defers_mask(n, F)
@@ -368,67 +359,6 @@ class RenderStyleLoss(object):
         self._content_job(acts, sg, loss)
         self._hist_job(acts, sg, loss)
         return self.net.backward(acts, sg, self.top, unmasked=unmasked), loss
-
-    def _gram_split(self, B):
-        """one or two views per call: the loss chain is a string of latency-bound launches that leave most of the chip
-        idle, and the Gram work of the LOWER style layers (tile pairs, reduction + style loss, gradient GEMMs: ~50 us of
-        a one-view chain between the forward and the backward pass) does not depend on the layers above them -- it runs
-        on a side stream while the deeper layers' forward pass runs on the main one; only the top layer's Gram work stays
-        between the two passes.  Same kernels on the same operands (the grouped launch treats its layers independently):
-        identical gradients; the loss is summed from the same partial sums in another order.  NFS_GRAM_SPLIT=0: off."""
-        return (B <= self.gram_split_views and len(self.layers) >= 2 and self.layers[-1] == self.top
-                and type(self.net).__name__ == "VGG" and not self.content_layer and not self.hist_layers)
-
-    def _vgg_loss_grad_split(self, x, total_out, P_top):
-        lower, top = self.layers[:-1], self.layers[-1]
-        sg, unmasked, seen, st = {}, set(), {}, {}
-        main = torch.cuda.current_stream(x.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=x.device)
-        side = self._side
-
-        def group(names, Fs, parts_out):
-            masks = []
-            for n, F in zip(names, Fs):
-                d = self._defers_mask(n, F)
-                if d:
-                    unmasked.add(n)
-                masks.append(_post_relu(n) and not d)
-            ws = [self.w_layers[self.layers.index(n)] * self.w_style for n in names]
-            _, dFs, _ = ops.gram_style_group(Fs, [self.style_grams[n] for n in names], ws, masks, parts_out=parts_out)
-            sg.update(zip(names, dFs))
-
-        def on_layer(name, F):
-            if name in lower:
-                seen[name] = F
-            if name != lower[-1]:
-                return
-            Fs = [seen[n] for n in lower]
-            P_lo = ops.gram_style_group_parts(Fs)
-            parts = torch.empty(P_lo + P_top, x.shape[0], dtype=torch.float32, device=F.device)
-            st["P_lo"], st["parts"] = P_lo, parts
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)                          # (style targets and the activations come from the main stream)
-            capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:                            # a captured step owns its buffers: nothing to tell the allocator
-                for F_ in Fs:
-                    F_.record_stream(side)
-                parts.record_stream(side)
-            with torch.cuda.stream(side):
-                group(lower, Fs, parts[:P_lo])
-            if not capturing:
-                for n in lower:
-                    sg[n].record_stream(main)
-
-        acts = self.net.forward(x, self.top, on_layer=on_layer, keep=self._keep())
-        parts, P_lo = st["parts"], st["P_lo"]
-        group([top], [acts[top]], parts[P_lo:])
-        main.wait_stream(side)
-        if total_out is not None:
-            torch.sum(parts.view(-1), dim=0, keepdim=True, out=total_out)
-            return self.net.backward(acts, sg, self.top, unmasked=unmasked), None
-        return self.net.backward(acts, sg, self.top, unmasked=unmasked), parts.sum(0)
 
     def _batch_views(self, V):
         """views per loss-net batch of the reference graph: v_batch (RenderStyleLoss: a property of the run, not of

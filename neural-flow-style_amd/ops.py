@@ -458,13 +458,6 @@ def loss_net_input_bwd(g_x, H, W, Cin):
 
 # ---- A6 -----------------------------------------------------------------------------
 
-def conv3x3_fewrow(mode=None):
-    """few-row form of a convolution's Winograd GEMMs (launches of at most 64 tiles transform the filters in registers
-    instead of streaming the 49 / 36 packed planes; nfs_hip.h: nfs_conv3x3_fewrow): 1 on (default), 0 off.  Returns the
-    previous setting; ``None`` only queries."""
-    return int(_lib.lib().nfs_conv3x3_fewrow(-1 if mode is None else int(mode)))
-
-
 def gemm_mode(mode=None):
     """Arithmetic of the batched Winograd GEMMs (process-wide): 0 = float32-input MFMA (default), 1 = split-limb form
     (float32 operands as three exact bf16 limbs, six limb products on the bf16 MFMA, float32 accumulation: float32-
@@ -614,29 +607,15 @@ def style_loss_fwd(G, Gs, weight, loss_acc, Dmat=None):
     return Dmat
 
 
-def gram_style_group_parts(Fs):
-    """rows P of the loss_parts [P, B] array ``gram_style_group`` fills for these activations"""
-    import ctypes
-    arr = (_lib.GramLayer * len(Fs))()
-    B = Fs[0].shape[0]
-    for y, F in zip(arr, Fs):
-        y.B, y.Bs, y.C = B, 1, F.shape[-1]
-        y.HW = F.numel() // (B * F.shape[-1])
-        y.F = y.Gs = y.Dmat = _ptr(F)             # (the plan only asks that they are set; nothing is read or written)
-    return int(_lib.lib().nfs_gram_style_group_parts(ctypes.cast(arr, ctypes.c_void_p), len(Fs)))
-
-
-def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False, channels=None, parts_out=None):
+def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False, channels=None):
     """Gram matrix, style loss and Gram gradient of SEVERAL style layers in three launches (the loop of
     styler_base.py:152-185): ``Fs`` list of [B,h,w,C] activations, ``Gss`` their style Grams [Bs,C,C] (scaled by
     1/(2 h w C) like G), ``weights`` w_layer * w_style, ``relu_masks`` whether dF carries the layer's ReLU mask.
     Returns (loss_parts [P,B] -- the style loss of image b is loss_parts[:, b].sum(), every entry written, no atomics --,
-    list of dF, list of G or None).  ``parts_out`` [P,B] (contiguous, P = gram_style_group_parts(Fs)): write the parts
-    there (several groups of one loss can then be summed in one reduction)."""
+    list of dF, list of G or None)."""
     import ctypes
     n = len(Fs)
-    if n > 8:
-        assert parts_out is None                                          # the descriptor table of one launch holds 8 layers
+    if n > 8:                                          # the descriptor table of one launch holds 8 layers
         a = gram_style_group(Fs[:8], Gss[:8], weights[:8], relu_masks[:8], want_G, channels and channels[:8])
         b = gram_style_group(Fs[8:], Gss[8:], weights[8:], relu_masks[8:], want_G, channels and channels[8:])
         return torch.cat([a[0], b[0]]), a[1] + b[1], (a[2] + b[2] if want_G else None)
@@ -662,9 +641,7 @@ def gram_style_group(Fs, Gss, weights, relu_masks, want_G=False, channels=None, 
     if P < 0 or nws < 0:
         raise ValueError("gram_style_group: 1..8 layers of one batch size with C a multiple of 64")
     ws = conv_workspace(Fs[0].device, max(nws, 1))      # shared scratch (calls on one stream are ordered)
-    if parts_out is not None:
-        assert parts_out.is_contiguous() and tuple(parts_out.shape) == (P, B)
-    parts = _empty((P, B), Fs[0]) if parts_out is None else parts_out
+    parts = _empty((P, B), Fs[0])
     _lib.call("nfs_gram_style_group_fwd", ap, n, _ptr(parts), _ptr(ws), ws.numel(), _stream())
     _lib.call("nfs_gram_group_bwd", ap, n, _stream())
     return parts, [k[1] for k in keep], ([k[2] for k in keep] if want_G else None)

@@ -75,6 +75,16 @@ class Styler(StylerBase):
                   support=self.support, clip=self.clip, pc=cc, pd=rr.unsqueeze(0))
         return torch.clamp(d, 0, 1), c_[0]                                   # [1,H,W,3]
 
+    def _colour_ordered(self, frame, var, res):
+        """``_colour`` on a frame already brought into its grid order (``frame`` = (order, positions [1,N,2], densities
+        [1,N,1], mask): what run() prepares once per octave); only the colours go through the permutation per step"""
+        o, pp, rr, _ = frame
+        c_ = torch.clamp(var.unsqueeze(0), 0, 1)
+        cc = c_ if o is None else T.permute_particles(c_, o)
+        d = T.p2g(pp, self.domain, res, self.radius, self.rest_density, self.nsize, support=self.support, clip=self.clip,
+                  pc=cc, pd=rr)
+        return torch.clamp(d, 0, 1)                                          # [1,H,W,3]
+
     def render_test(self, params):
         res = list(self.resolution)
         out = []
@@ -119,6 +129,18 @@ class Styler(StylerBase):
             if self.content_img is not None:                     # styler_2p.py:209-211
                 self.loss.set_content_image(self._content_feature(self.content_img, res), top_k=self._content_top_k())
             lr = self.lr[octave] if isinstance(self.lr, list) else self.lr
+            # what an iteration does not change is formed once per octave: every frame in its grid order (a gather of
+            # positions and densities per step otherwise) and its density mask (a splat + two scalings per step)
+            frames = []
+            for t in range(self.num_frames):
+                o = self._order(p[t])
+                pp, rr = (p[t], r[t]) if o is None else (p[t][o], r[t][o])
+                with torch.no_grad():
+                    frames.append((o, pp.unsqueeze(0), rr.unsqueeze(0), self._density(p[t], res)))
+            nb = self.num_frames // max(self.batch_size, 1)
+            # the per-step losses stay on the device until the octave is done: reading one back per step is a host
+            # synchronisation per step, and the whole iteration is ~0.3 ms of kernels
+            loss_dev = torch.zeros(self.iter * max(nb, 1), dtype=torch.float32, device=self.device)
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames
                 B = self.batch_size
@@ -131,9 +153,9 @@ class Styler(StylerBase):
                     opt_id = engine.optimizer_slot(getattr(self, "optimizer", "adam"), t, self.frames_per_opt)
                     if opt_id not in opt_:
                         opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
-                    d = torch.cat([self._colour(p[t + i], r[t + i], vars_[i], res)[0] for i in range(B)], 0)
-                    with torch.no_grad():
-                        d_gray = torch.cat([self._density(p[t + i], res) for i in range(B)], 0)
+                    imgs = [self._colour_ordered(frames[t + i], vars_[i], res) for i in range(B)]
+                    d = imgs[0] if B == 1 else torch.cat(imgs, 0)
+                    d_gray = frames[t][3] if B == 1 else torch.cat([frames[t + i][3] for i in range(B)], 0)
                     if self._graph_loss is None:
                         # the loss chain of one colour image is ~40 small launches: hipGraph replay where a measured
                         # trial finds the host cannot keep up with it (engine.GraphedLoss; NFS_GRAPH=0 / 1 forces)
@@ -142,13 +164,17 @@ class Styler(StylerBase):
                                             engine.GraphedLoss(self.loss) if env is None else False)
                     if self._graph_loss:
                         losses, g_d = self._graph_loss(d.detach().contiguous(), d_gray)
-                        losses = losses.clone()
                     else:
                         losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
+                    k = step * nb + t // B
+                    torch.sum(losses, dim=0, keepdim=True, out=loss_dev[k:k + 1])    # (before the next call overwrites them)
                     d.backward(g_d)
-                    x = torch.stack([v.detach() for v in vars_])                    # [B,N,3]
-                    opt_[opt_id].step(x, torch.stack([v.grad for v in vars_]).contiguous(), lr)
-                    loss_history_o.append(float(losses.sum()))
+                    if B == 1:                                                       # (views: nothing to stack)
+                        x, gx = vars_[0].detach().unsqueeze(0), vars_[0].grad.unsqueeze(0)
+                    else:
+                        x = torch.stack([v.detach() for v in vars_])                # [B,N,3]
+                        gx = torch.stack([v.grad for v in vars_])
+                    opt_[opt_id].step(x, gx.contiguous(), lr)
                     for i in range(B):
                         g_tmp[t + i] = torch.nan_to_num(x[i]) - g_opt[t + i]
                     if step == self.iter - 1 and octave < self.octave_n - 1:
@@ -160,6 +186,7 @@ class Styler(StylerBase):
                     g_tmp = [self._dev(s) for s in stack]
                 for t in range(self.num_frames):
                     g_opt[t] = g_opt[t] + g_tmp[t]
+            loss_history_o = [float(v) for v in loss_dev.cpu().numpy()]
             loss_history.append(loss_history_o)
             if octave < self.octave_n - 1:
                 d_intm.append(np.concatenate(d_intm_o, axis=0))

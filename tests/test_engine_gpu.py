@@ -222,30 +222,6 @@ def test_stored_forward_advect_never_goes_stale_on_shapes_the_fused_kernel_refus
     assert np.isfinite(float(gs.step(rotc))) and gs._adv_valid()
 
 
-@pytest.mark.parametrize("V,graph", [(1, False), (2, False), (1, True)])
-def test_lower_style_layers_gram_work_on_a_side_stream_is_the_same_gradient(V, graph):
-    """one or two views per call: the grouped Gram work of the style layers below the top one runs on a side stream
-    under the deeper layers' forward pass (RenderStyleLoss._gram_split).  Same kernels on the same operands: the
-    gradient is bit-identical to the one-group form, the loss the same partial sums in another order; the first call of
-    a shape takes the one-group form (it learns the top layer's plan), later ones the split form -- also as a captured
-    graph"""
-    layers = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
-    d0, vel0, mats, loss, cfg, w_or, sfe, T, eng = _setup(24, V, layers)
-    rot = T.rot_to_device(mats, "cuda")
-    out = []
-    for split in (2, 0):
-        loss.gram_split_views = split
-        loss._top_parts.clear()
-        gs = eng.GridStylizer(loss, torch.tensor(d0).cuda(), k=3, target="v", lr=1e-3, graph=graph)
-        gs.var.copy_(torch.tensor(vel0))
-        ls = [float(gs.step(rot)) for _ in range(5)]
-        assert bool(loss._top_parts) == bool(split)
-        out.append((ls, gs.var.clone(), gs.g_ds.clone()))
-    loss.gram_split_views = 2
-    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
-    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
-
-
 def test_graph_replay_equals_eager_steps():
     """GridStylizer(graph=True): forward + adjoint replayed as one hipGraph (eager warm-up step, capture, replays)
     follows the eager trajectory; a different view tensor is copied into the captured buffer."""

@@ -360,48 +360,6 @@ def test_winograd_f5_error_budget(ops, B, H, W, Ci, Co):
     assert rel(ops.conv3x3_dgrad(dev(gy), wd, Ci), gx) < 2e-5
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 25, 25, 512, 512),     # F(5x5), 25 tiles: two row tiles, two K parts
-                                          (1, 25, 25, 256, 512), (1, 25, 25, 512, 256),    # conv4_1 and its gradient: 4 parts
-                                          (2, 25, 25, 512, 512),     # 50 tiles: four row tiles (two views per GPU)
-                                          (1, 25, 25, 256, 256),     # configs[1]: conv3_x at 100^3
-                                          (1, 12, 12, 512, 512),     # F(4x4), 9 tiles: one row tile, four K parts
-                                          (1, 6, 6, 512, 512), (3, 6, 6, 512, 512),        # 4 / 12 tiles
-                                          (1, 13, 9, 128, 192), (1, 32, 32, 128, 256)])    # ragged image; 64 tiles
-def test_few_row_gemm_with_the_filter_transform_in_registers(ops, B, H, W, Ci, Co):
-    """launches of at most 64 Winograd tiles (one or two views per GPU, BASELINE configs[1]) run their 49 / 36 products
-    with the filter transform G g G^T done in registers from the direct-form pack (winograd_fewrow.hip): against the
-    packed-filter GEMM of the same library (same values up to float32 rounding of sums taken in another grouping) and
-    against a float64 convolution at the F(5x5) budget; forward with bias + ReLU, data gradient plain and with mask +
-    addend"""
-    rng = np.random.RandomState(31)
-    x = torch.tensor(np.maximum(rng.randn(B, H, W, Ci), 0) * 3.0, dtype=torch.float32)
-    w = (rng.randn(3, 3, Ci, Co) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
-    b = (rng.randn(Co) * 0.3).astype(np.float32)
-    gy = torch.tensor(rng.randn(B, H, W, Co), dtype=torch.float32)
-    xin = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
-    add = torch.tensor(rng.randn(B, H, W, Ci), dtype=torch.float32)
-    wf, wd = ops.conv3x3_pack(dev(torch.tensor(w)), 0), ops.conv3x3_pack(dev(torch.tensor(w)), 1)
-    got = {}
-    prev = ops.conv3x3_fewrow(1)
-    try:
-        for mode in (1, 0):
-            ops.conv3x3_fewrow(mode)
-            got[mode] = (ops.conv3x3_fwd(dev(x), wf, dev(torch.tensor(b)), Co, relu=True).clone(),
-                         ops.conv3x3_dgrad(dev(gy), wd, Ci).clone(),
-                         ops.conv3x3_dgrad(dev(gy), wd, Ci, x_in=dev(xin), addend=dev(add)).clone())
-    finally:
-        ops.conv3x3_fewrow(prev)
-    for a_, b_ in zip(got[1], got[0]):
-        assert rel(a_, b_) < 3e-6
-    assert not all(torch.equal(a_, b_) for a_, b_ in zip(got[1], got[0]))     # (the few-row kernel did take the launches)
-    x64 = x.double().requires_grad_()
-    w64 = torch.tensor(w).double().permute(3, 2, 0, 1)
-    pre = torch.nn.functional.conv2d(x64.permute(0, 3, 1, 2), w64, torch.tensor(b).double(), padding=1).permute(0, 2, 3, 1)
-    (gx,) = torch.autograd.grad(pre, x64, gy.double())
-    assert rel(got[1][0], torch.relu(pre).detach()) < 2e-5 and rel(got[1][1], gx) < 2e-5
-    assert rel(got[1][2], gx * (xin.double() > 0) + add.double()) < 2e-5
-
-
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 13, 11, 64, 64), (1, 25, 25, 128, 128), (2, 8, 12, 64, 128),
                                           (3, 20, 28, 64, 64), (2, 12, 16, 128, 128), (5, 8, 8, 128, 64),
                                           (4, 64, 64, 128, 128),

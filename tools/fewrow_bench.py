@@ -1,6 +1,7 @@
 """the deep VGG layers at the row counts of a one- / two-view step and of BASELINE configs[1] (100^3, one view): forward and
-data gradient per layer with the few-row GEMM (filter transform in registers, winograd_fewrow.hip) on and off.
-    python tools/fewrow_bench.py"""
+data gradient per layer, warm and behind a cache-polluting fill (what a layer sees inside the step: its filters come from
+HBM).  The measured floor of the three-kernel path at these row counts (round 5: a GEMM with every operand in flight at
+once ran at exactly these times -- the launches stream their transformed filters at the HBM rate already)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +21,7 @@ def timed(fn, reps=50):
 
 
 cold = torch.empty(192 << 20, dtype=torch.float32, device="cuda")          # 768 MB: evicts L2 + Infinity Cache between calls
-rows = []
+t_fill = timed(lambda: cold.zero_())
 for B, H, Ci, Co, name in [(1, 50, 256, 256, "conv3_2 @200^2 x1 (100 tiles: not few-row)"),
                            (1, 25, 256, 512, "conv4_1 @200^2 x1"), (1, 25, 512, 512, "conv4_2 @200^2 x1"),
                            (2, 25, 512, 512, "conv4_2 @200^2 x2"), (1, 12, 512, 512, "conv5_1 @200^2 x1"),
@@ -29,15 +30,8 @@ for B, H, Ci, Co, name in [(1, 50, 256, 256, "conv3_2 @200^2 x1 (100 tiles: not 
     x = torch.relu(torch.randn(B, H, H, Ci, device="cuda")); w = torch.randn(3, 3, Ci, Co, device="cuda") * 0.05
     b = torch.zeros(Co, device="cuda"); wf = ops.conv3x3_pack(w, 0); wd = ops.conv3x3_pack(w, 1)
     out = torch.empty(B, H, H, Co, device="cuda"); gy = torch.randn(B, H, H, Co, device="cuda")
-    r = [name]
-    for mode in (0, 1):
-        ops.conv3x3_fewrow(mode)
-        tf = timed(lambda: ops.conv3x3_fwd(x, wf, b, Co, True, out=out))
-        tb = timed(lambda: ops.conv3x3_dgrad(gy, wd, Ci))
-        # the same behind a cache-polluting fill (what a layer sees inside the step: its filters come from HBM)
-        tfc = timed(lambda: (cold.zero_(), ops.conv3x3_fwd(x, wf, b, Co, True, out=out))) - timed(lambda: cold.zero_())
-        r += [tf, tb, tfc]
-    rows.append(r)
-    print("%-44s  packed: fwd %6.1f us dgrad %6.1f us (cold fwd %6.1f)   few-row: fwd %6.1f us dgrad %6.1f us (cold fwd %6.1f)"
-          % tuple(r), flush=True)
-ops.conv3x3_fewrow(1)
+    tf = timed(lambda: ops.conv3x3_fwd(x, wf, b, Co, True, out=out))
+    tb = timed(lambda: ops.conv3x3_dgrad(gy, wd, Ci))
+    tfc = timed(lambda: (cold.zero_(), ops.conv3x3_fwd(x, wf, b, Co, True, out=out))) - t_fill
+    tbc = timed(lambda: (cold.zero_(), ops.conv3x3_dgrad(gy, wd, Ci))) - t_fill
+    print("%-44s  warm: fwd %6.1f us dgrad %6.1f us   cold: fwd %6.1f us dgrad %6.1f us" % (name, tf, tb, tfc, tbc), flush=True)
