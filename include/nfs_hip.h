@@ -46,13 +46,21 @@ int nfs_device_cus(void);
 int nfs_gemm_timer(int enable);
 
 /* Arithmetic of the batched Winograd GEMMs (process-wide; returns the previous mode; any other value only queries):
- *   0  float32-input MFMA (v_mfma_f32_32x32x2_f32), the default;
- *   1  split-limb form: every float32 operand is written exactly as three bf16 limbs and the six leading limb
- *      products run on v_mfma_f32_32x32x16_bf16 with float32 accumulation -- inputs, outputs and accumulation stay
- *      float32, each product is carried to within 2^-26 (float32-equivalent accuracy, 2.67x the MFMA rate).
- * NFS_GEMM_MODE presets it. */
+ *   1  split-limb form (the default): every float32 operand is written exactly as three bf16 limbs (round to nearest
+ *      at each level) and the six leading limb products run on v_mfma_f32_16x16x32_bf16 with float32 accumulation --
+ *      inputs, outputs and accumulation stay float32, each product is carried to within 2^-26 (float32-equivalent
+ *      accuracy: measured against float64 it is no worse than mode 0 at every tested shape and at the 200^3 headline
+ *      size, tests/test_ops_gpu.py::test_split_limb_gemm_is_float32_accurate, bench.py parity.full_size), at 2.67x the
+ *      matrix-pipe rate of the f32-input MFMA.  A (transformed activations) is split while a block stages it into LDS,
+ *      B (the packed float32 filters: 4 bytes per element from HBM) in registers by the wave that loaded it;
+ *   0  float32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2).
+ * The Gram gradient (mask / scale / symmetric operand) runs on the f32-input MFMA in both modes.
+ * NFS_GEMM_MODE=0 presets 0. */
 int nfs_gemm_mode(int mode);
 int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
+/* the same for one kind of launch only (split_limb != 0: the bf16-MFMA split-limb launches; 0: the f32-input ones);
+ * records of the other kind stay for a later read */
+int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches);
 
 /* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------
  * imgs [B,X,Y,Z,C], coords [B,3,X,Y,Z] normalised [-1,1] (axis order = array order),

@@ -62,6 +62,7 @@ SIGNATURES = {
     "nfs_gemm_timer": [_I],
     "nfs_gemm_mode": [_I],
     "nfs_gemm_timer_read": [_P, _P, _P],
+    "nfs_gemm_timer_read_kind": [_I, _P, _P, _P],
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

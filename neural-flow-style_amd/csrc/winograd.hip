@@ -880,6 +880,195 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_group_kernel(WgGroupAr
   winograd_gemm_rb16_tile<MT16, NW16>(G.g[p], smem, (int)blockIdx.x - G.ustart[p], G.ustart[p + 1] - G.ustart[p]);
 }
 
+// ---- the 16-row register-B form in split-limb arithmetic ("rb16s") ------------------------------------------------------
+// The same tiling as winograd_gemm_rb16_kernel on v_mfma_f32_16x16x32_bf16: every float32 operand is written exactly as
+// three bf16 limbs (round-to-nearest at each level, see the split-limb notes further down) and the six leading limb
+// products of a 16 x 16 x 32 block take 6 x 16 cycles where the f32-input MFMA needs 8 x 32 (2.67 x).  Where the limbs
+// are made is what the round-2 kernel (winograd_gemm_split_kernel, both operands through LDS, filters as limb planes
+// from memory: 6 bytes per element) got wrong for these shapes:
+//   * B stays the float32 fragment pack of the rb16 kernel (4 bytes per element from HBM -- the deep layers stream
+//     51 MB of filters per launch and are within 2 x of that bound at the bf16 rate) and is split IN REGISTERS by the
+//     wave that loaded it: 8 NW16 values per lane and chunk, amortised over the wave's MT16 row tiles;
+//   * A is split ONCE per block while it is staged (each thread splits the float4 it moves) into three LDS planes laid
+//     out in fragment order, so that a lane's 8 k values of a limb are one ds_read_b128.
+// The k index a lane position stands for is the rb16 pack's: position j of lane group q is k = 16 (j / 4) + 4 q + j % 4
+// of the 32-deep chunk, for A and B alike (the MFMA pairs positions, whatever k they are called).
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+constexpr int WS_RB = 80;            // bytes per LDS row of one limb plane: 32 bf16 + 16 pad (conflict-free b128 reads)
+
+typedef float rb16s_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rb16s_b2 __attribute__((ext_vector_type(2)));
+// two floats -> their hi / mid / lo limbs, each pair packed in one dword (one v_cvt_pk_bf16_f32 per level)
+__device__ __forceinline__ void rb16s_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const rb16s_f2 x = {x0, x1};
+  const rb16s_b2 bh = __builtin_convertvector(x, rb16s_b2);
+  const rb16s_f2 r1 = x - __builtin_convertvector(bh, rb16s_f2);
+  const rb16s_b2 bm = __builtin_convertvector(r1, rb16s_b2);
+  const rb16s_f2 r2 = r1 - __builtin_convertvector(bm, rb16s_f2);
+  const rb16s_b2 bl = __builtin_convertvector(r2, rb16s_b2);
+  h = __builtin_bit_cast(unsigned, bh);
+  m = __builtin_bit_cast(unsigned, bm);
+  l = __builtin_bit_cast(unsigned, bl);
+}
+// 8 floats (two float4 of the fragment pack) -> the three limb fragments
+__device__ __forceinline__ void rb16s_split8(const float4& a, const float4& b, bf16x8s& H, bf16x8s& M, bf16x8s& L) {
+  uint4 hv, mv, lv;
+  rb16s_split2(a.x, a.y, hv.x, mv.x, lv.x); rb16s_split2(a.z, a.w, hv.y, mv.y, lv.y);
+  rb16s_split2(b.x, b.y, hv.z, mv.z, lv.z); rb16s_split2(b.z, b.w, hv.w, mv.w, lv.w);
+  H = __builtin_bit_cast(bf16x8s, hv); M = __builtin_bit_cast(bf16x8s, mv); L = __builtin_bit_cast(bf16x8s, lv);
+}
+
+template <int MT16, int NW16>
+__device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, unsigned char* smem, int comp, int64_t m0,
+                                                          int n0, int split) {
+  constexpr int BM = 16 * MT16, BN = 64 * NW16;
+  constexpr int BMP = (BM + 31) / 32 * 32, AJ = BMP / 32;
+  constexpr int PLANE = BMP * WS_RB, BUF = 3 * PLANE;          // bytes: [2][3 limbs][BMP rows][80]
+  constexpr int G = MT16 <= 5 ? MT16 : (MT16 == 7 ? 4 : 5);   // row tiles whose A fragments are live together
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nchunks = a.K / WG_KC / a.ksplit, c0 = split * nchunks;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Uq16 + (int64_t)comp * a.K * a.N), 0, (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
+  // A staging: thread t moves float4 #(t & 7) (k = 4 (t & 7) ...) of rows (t >> 3) + 32 j; in fragment order those four
+  // values are positions 8 q + 4 half .. + 3 with q = (t & 3), half = (t >> 2) & 1: 8 bytes at 16 q + 8 half
+  const int q4 = 4 * (t & 7), r0 = t >> 3;
+  const int a_st = r0 * WS_RB + 16 * (t & 3) + 8 * ((t >> 2) & 1);
+  uint32_t ao[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int r = r0 + 32 * j;
+    const int64_t m = m0 + r;
+    ao[j] = (r < BM && m < a.T) ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
+  }
+  const uint32_t bo = (uint32_t)lane * 16u;
+  const uint32_t kgs = (uint32_t)(a.K / 16) * 1024u;
+  const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
+  // Two register sets, two chunks in flight per wave: at the split-limb rate a chunk's MFMAs take ~0.4 us, a round trip
+  // to HBM 1-2 us, and the accumulators leave room for two blocks per CU only -- with one chunk ahead (the rb16 kernel's
+  // distance) every chunk waited for its operands (measured: 40 us where the MFMAs need 12)
+  float4 av[2][AJ], bq[2][NW16][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int cc = c0 + (st < nchunks ? st : nchunks - 1);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) av[st][j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cc * (WG_KC * 4));
+#pragma unroll
+    for (int nt = 0; nt < NW16; ++nt)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) bq[st][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cc + g) * 1024u);
+  }
+
+  const int afrag = (lane & 15) * WS_RB + 16 * (lane >> 4);     // + 16 mt rows, + plane
+  f32x4 acc[MT16][NW16];
+#pragma unroll
+  for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NW16; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define NFS_RB16S_STEP(ST, C)                                                                                      \
+  {                                                                                                                \
+    unsigned char* Ac = smem + ((C) & 1) * BUF;                                                                    \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                               \
+      uint2 hv, mv, lv;                                                                                            \
+      rb16s_split2(av[ST][j].x, av[ST][j].y, hv.x, mv.x, lv.x);                                                    \
+      rb16s_split2(av[ST][j].z, av[ST][j].w, hv.y, mv.y, lv.y);                                                    \
+      unsigned char* d_ = Ac + a_st + 32 * j * WS_RB;                                                              \
+      *reinterpret_cast<uint2*>(d_) = hv;                                                                          \
+      *reinterpret_cast<uint2*>(d_ + PLANE) = mv;                                                                  \
+      *reinterpret_cast<uint2*>(d_ + 2 * PLANE) = lv;                                                              \
+    }                                                                                                              \
+    __syncthreads();       /* buffer (C & 1) visible; the other one was last read in the step before */            \
+    const int cn = c0 + ((C) + 2 < nchunks ? (C) + 2 : nchunks - 1);     /* (past the end: a harmless re-fetch) */  \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) av[ST][j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4));   \
+    bf16x8s bf[NW16][3];                                                                                           \
+    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
+      rb16s_split8(bq[ST][nt][0], bq[ST][nt][1], bf[nt][0], bf[nt][1], bf[nt][2]);                                 \
+    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                \
+        bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);                       \
+    _Pragma("unroll") for (int mg = 0; mg < MT16; mg += G) {                                                       \
+      bf16x8s af[G][3];                                                                                            \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
+        if (mg + gi < MT16)                                                                                        \
+          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                            \
+            af[gi][p] = *reinterpret_cast<const bf16x8s*>(Ac + p * PLANE + afrag + 16 * (mg + gi) * WS_RB);        \
+      /* limb product outermost (smallest terms first: hi lo, lo hi, mid mid | hi mid, mid hi | hi hi), tiles      \
+         inner: consecutive MFMAs go to different accumulators */                                                  \
+      _Pragma("unroll") for (int lp = 0; lp < 6; ++lp) {                                                           \
+        const int pa = lp == 0 ? 0 : lp == 1 ? 2 : lp == 2 ? 1 : lp == 3 ? 0 : lp == 4 ? 1 : 0;                    \
+        const int pb = lp == 0 ? 2 : lp == 1 ? 0 : lp == 2 ? 1 : lp == 3 ? 1 : lp == 4 ? 0 : 0;                    \
+        _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                        \
+          _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                         \
+            if (mg + gi < MT16)                                                                                    \
+              acc[mg + gi][nt] =                                                                                   \
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi][pa], bf[nt][pb], acc[mg + gi][nt], 0, 0, 0);      \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c += 2) {
+    NFS_RB16S_STEP(0, c)
+    if (c + 1 < nchunks) NFS_RB16S_STEP(1, c + 1)
+  }
+#undef NFS_RB16S_STEP
+
+  // epilogue: as winograd_gemm_rb16_block (same C layout)
+  constexpr int OS = BN + 4, EPMAX = NW16 >= 4 ? 2 : 5, EP = MT16 < EPMAX ? MT16 : EPMAX, NPASS = (MT16 + EP - 1) / EP;
+  float* otile = reinterpret_cast<float*>(smem);
+  float* Mc = a.M + ((int64_t)split * a.Z + comp) * a.T * a.N;
+  constexpr int Q = BN / 4;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT16; ++mt)
+      if (mt / EP == pass)
+#pragma unroll
+        for (int nt = 0; nt < NW16; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            otile[(16 * (mt % EP) + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
+    __syncthreads();
+    const int rows = 16 * ((pass + 1) * EP <= MT16 ? EP : MT16 - pass * EP);
+    for (int f = t; f < rows * Q; f += 256) {
+      const int row = f / Q, q = f - row * Q;
+      const int64_t m = m0 + 16 * EP * pass + row;
+      if (m >= a.T) continue;
+      *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+    }
+  }
+}
+
+template <int MT16, int NW16>
+__global__ void __launch_bounds__(256) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+  const int nblocks = (int)gridDim.x, block = (int)blockIdx.x;
+  const int per_xcd = nblocks / WG_XCDS;
+  const int logical = (block % WG_XCDS) * per_xcd + block / WG_XCDS;   // XCD-aware order, as the rb16 kernel
+  const int per_split = a.mt * a.nt * a.Z;
+  if (logical >= per_split * a.ksplit) return;
+  const int split = logical / per_split;
+  const int lg = logical - split * per_split;
+  const int comp = lg / (a.mt * a.nt);
+  const int rem = lg - comp * (a.mt * a.nt);
+  const int64_t m0 = (int64_t)(rem % a.mt) * (16 * MT16);
+  const int n0 = (rem / a.mt) * (64 * NW16);
+  if constexpr (MT16 <= 5) {
+    const int64_t left = (a.T - m0 + 15) / 16;
+    const int live = left < MT16 ? (int)left : MT16;
+    if (live == MT16) winograd_gemm_rb16s_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
+    else if (live == 1) winograd_gemm_rb16s_block<1, NW16>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 2 && live == 2) winograd_gemm_rb16s_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 3 && live == 3) winograd_gemm_rb16s_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 4 && live == 4) winograd_gemm_rb16s_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem_s, comp, m0, n0, split);
+  } else {
+    winograd_gemm_rb16s_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
+  }
+}
+
 // U [Z][K/32][N][32] -> Uq16 [Z][N/16][K/16][64][4]
 __global__ void __launch_bounds__(256) winograd_pack_frag16_kernel(const float* __restrict__ up, float* __restrict__ uq,
                                                                    int K, int N, int64_t total) {
@@ -1171,7 +1360,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 
 // ---- host side -----------------------------------------------------------------------------------------------
 // ---- optional per-launch event timing of the GEMM kernel (nfs_gemm_timer) ---------------------------------
-struct GemmTimerRec { hipEvent_t e0, e1; double flops; };
+struct GemmTimerRec { hipEvent_t e0, e1; double flops; int split = 0; };   // split: a split-limb (bf16 MFMA) launch
 static std::atomic<bool> g_timer_on{false};
 static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
@@ -1227,7 +1416,7 @@ static void pick_gemm_tile(int64_t T, int N, int Z, int cus, int* bm_out, int* b
 
 // 0: float32-input MFMA (v_mfma_f32_32x32x2_f32); 1: split-limb form on the bf16 MFMA (float32-equivalent, see
 // winograd_gemm_split_kernel).  Process-wide setting (nfs_gemm_mode); NFS_GEMM_MODE presets it.
-static std::atomic<int> g_gemm_mode{[] { const char* e = getenv("NFS_GEMM_MODE"); return e ? atoi(e) : 0; }()};
+static std::atomic<int> g_gemm_mode{[] { const char* e = getenv("NFS_GEMM_MODE"); return e ? (atoi(e) == 0 ? 0 : 1) : 1; }()};
 
 template <int BM, int BN, int NBUF>
 static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
@@ -1243,6 +1432,7 @@ static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
   if (timed) (void)hipEventRecord(rec.e0, s);
   hipLaunchKernelGGL((winograd_gemm_split_kernel<BM, BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
+    rec.split = 1;
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
@@ -1285,6 +1475,29 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
   if (timed) (void)hipEventRecord(rec.e0, s);
   hipLaunchKernelGGL((winograd_gemm_rb16_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    g_timer_recs.push_back(rec);
+  }
+}
+
+template <int MT16, int NW16>
+static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
+  constexpr int BM = 16 * MT16, BN = 64 * NW16, BMP = (BM + 31) / 32 * 32;
+  constexpr int EPMAX = NW16 >= 4 ? 2 : 5;
+  const size_t oper = (size_t)2 * 3 * BMP * WS_RB, tile = (size_t)16 * (MT16 < EPMAX ? MT16 : EPMAX) * (BN + 4) * sizeof(float);
+  const size_t lds = oper > tile ? oper : tile;
+  static std::once_flag attr_once;
+  if (lds > 65536) std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16s_kernel<MT16, NW16>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+  const int total = a.mt * a.nt * a.Z * a.ksplit, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
+  GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
+  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+  if (timed) (void)hipEventRecord(rec.e0, s);
+  hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
+  if (timed) {
+    rec.split = 1;
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
@@ -1337,11 +1550,22 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   static const int dbg = getenv("NFS_GEMM_DBG") ? atoi(getenv("NFS_GEMM_DBG")) : 0;
   a.dbg = dbg;
 #endif
-  if (g_gemm_mode == 1 && a.Ub && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.K % 64 == 0) {
+  if (variant != 3 && g_gemm_mode == 1 && a.Ub && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.K % 64 == 0) {
     if (bm == 128 && bn == 128) launch_gemm_split<128, 128, 1>(a, s);
     else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
     else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
     else launch_gemm_split<64, 64, 1>(a, s);
+    return;
+  }
+  if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0 && !a.mask && !a.alpha_dev &&
+      a.alpha == 1.f && !a.symb) {
+    // the 16-row register-B form in split-limb arithmetic (mode 1): 64- or 128-column tiles
+    a.mt = (int)((a.T + bm - 1) / bm);
+    if (bn > 128 && bm == 208) { bn = 128; a.nt = a.N / 128; }
+    if (bm == 80) { if (bn == 256) launch_gemm_rb16s<5, 4>(a, s); else if (bn == 128) launch_gemm_rb16s<5, 2>(a, s); else launch_gemm_rb16s<5, 1>(a, s); }
+    else if (bm == 48) { if (bn == 256) launch_gemm_rb16s<3, 4>(a, s); else if (bn == 128) launch_gemm_rb16s<3, 2>(a, s); else launch_gemm_rb16s<3, 1>(a, s); }
+    else if (bm == 112) { if (bn == 256) launch_gemm_rb16s<7, 4>(a, s); else if (bn == 128) launch_gemm_rb16s<7, 2>(a, s); else launch_gemm_rb16s<7, 1>(a, s); }
+    else { if (bn == 128) launch_gemm_rb16s<13, 2>(a, s); else launch_gemm_rb16s<13, 1>(a, s); }
     return;
   }
   if (variant == 2 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0) {
@@ -1420,20 +1644,26 @@ static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   int bm16 = 80;
   const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = rb16_best_rows(a.T, &bm16);
   static const bool bm_forced = getenv("NFS_GEMM_BM") != nullptr;
-  const bool rows16 = g_gemm_mode == 0 && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
+  // mode 1: a plain product takes the split-limb instance of the 16-row form (variant 3; NFS_GEMM_SPLIT16=0: the
+  // round-2 kernel on 64-row tiles instead); the Gram gradient (mask / scale / symmetric B) stays on the f32-input MFMA
+  static const bool split16 = [] { const char* e = getenv("NFS_GEMM_SPLIT16"); return !(e && atoi(e) == 0); }();
+  const bool plain = !a.mask && !a.alpha_dev && a.alpha == 1.f && !a.symb;
+  const int mode = g_gemm_mode;
+  const int v16 = (mode == 1 && plain) ? 3 : 2;
+  const bool rows16 = (mode == 0 || !plain || split16) && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
                       pad16 * 100 <= pad32 * rows16_pct;
   // K parts (winograd_ksplit: by shape alone) only on the 16-row register-B form of a plain product (no mask / scale in
   // the epilogue: those apply to the complete sum)
   a.ksplit = (rows16 && !a.mask && !a.alpha_dev && a.alpha == 1.f && !a.symb) ? winograd_ksplit(a.T, a.K) : 1;
-  if (rows16 && !tune) { variant = 2; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }
+  if (rows16 && !tune) { variant = v16; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }
   if (force_rb == 2) {
     static const int fbm = [] { const char* e = getenv("NFS_GEMM_BM"); return e ? atoi(e) : 80; }();
     static const int fbn = [] { const char* e = getenv("NFS_GEMM_BN"); return e ? atoi(e) : 128; }();
     if (rb16_rows_ok(fbm) && a.N % fbn == 0 && gemm_rb16_applies(a)) { bm = fbm; bn = fbn; } else variant = 0;
   }
   if (tune) {
-    const GemmKey key{a.T, a.K, a.N, Z, g_gemm_mode * 2 + (a.mask ? 1 : 0)};
-    if (rows16) { variant = 2; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
+    const GemmKey key{a.T, a.K, a.N, Z, mode * 2 + (a.mask ? 1 : 0)};
+    if (rows16) { variant = v16; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
     std::unique_lock<std::mutex> lk(g_tile_mu);
     auto it = g_tile_cache.find(key);
     if (it != g_tile_cache.end()) {
@@ -1464,7 +1694,7 @@ static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
             if (p * 10 > pad16 * 12) continue;
             static const bool bn256 = [] { const char* e = getenv("NFS_GEMM_BN256"); return !(e && atoi(e) == 0); }();
             for (int cbn = bn256 ? 256 : 128; cbn >= 64; cbn /= 2)
-              if (a.N % cbn == 0 && !(cbn == 256 && kRb16Rows[i] == 208)) trial(kRb16Rows[i], cbn, 2);
+              if (a.N % cbn == 0 && !(cbn == 256 && kRb16Rows[i] == 208)) trial(kRb16Rows[i], cbn, v16);
           }
         } else {
           const int cand[4][2] = {{64, 64}, {64, 128}, {128, 64}, {128, 128}};
@@ -1484,7 +1714,7 @@ static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
       }
     }
   }
-  if (variant != 2) a.ksplit = 1;                                     // (only the rb16 kernels know about K parts)
+  if (variant != 2 && variant != 3) a.ksplit = 1;                     // (only the rb16 kernels know about K parts)
   launch_gemm_tile(a, Z, bm, bn, s, variant);
   return a.ksplit;
 }
@@ -1687,25 +1917,38 @@ int nfs_gemm_timer(int enable) {
   return NFS_OK;
 }
 
-int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches) {
-  NFS_REQUIRE(ms_total && flops_total && launches, "nfs_gemm_timer_read: null pointer");
+// which: 0 every record, 1 only the split-limb launches, 2 only the f32-input launches; the records read are removed
+static int gemm_timer_read(double* ms_total, double* flops_total, long long* launches, int which, const char* who) {
+  if (!ms_total || !flops_total || !launches) { nfs::set_error("%s: null pointer", who); return NFS_EINVAL; }
   if (hipDeviceSynchronize() != hipSuccess) {
-    nfs::set_error("nfs_gemm_timer_read: device synchronise failed");
+    nfs::set_error("%s: device synchronise failed", who);
     return NFS_ELAUNCH;
   }
   std::lock_guard<std::mutex> lk(nfs::g_timer_mu);
   double ms = 0.0, fl = 0.0;
+  long long n = 0;
+  std::vector<nfs::GemmTimerRec> keep;
   for (auto& r : nfs::g_timer_recs) {
+    if ((which == 1 && !r.split) || (which == 2 && r.split)) { keep.push_back(r); continue; }
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; }
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
+    ++n;
   }
   *ms_total = ms;
   *flops_total = fl;
-  *launches = (long long)nfs::g_timer_recs.size();
-  nfs::g_timer_recs.clear();
+  *launches = n;
+  nfs::g_timer_recs.swap(keep);
   return NFS_OK;
+}
+
+int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches) {
+  return gemm_timer_read(ms_total, flops_total, launches, 0, "nfs_gemm_timer_read");
+}
+
+int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches) {
+  return gemm_timer_read(ms_total, flops_total, launches, split_limb ? 1 : 2, "nfs_gemm_timer_read_kind");
 }
 }
 

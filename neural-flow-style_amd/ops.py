@@ -459,9 +459,9 @@ def loss_net_input_bwd(g_x, H, W, Cin):
 # ---- A6 -----------------------------------------------------------------------------
 
 def gemm_mode(mode=None):
-    """Arithmetic of the batched Winograd GEMMs (process-wide): 0 = float32-input MFMA (default), 1 = split-limb form
-    (float32 operands as three exact bf16 limbs, six limb products on the bf16 MFMA, float32 accumulation: float32-
-    equivalent accuracy at 2.67x the matrix-pipe rate).  Returns the previous mode; ``None`` only queries."""
+    """Arithmetic of the batched Winograd GEMMs (process-wide): 1 = split-limb form, the default (float32 operands as
+    three exact bf16 limbs, six limb products on the bf16 MFMA, float32 accumulation: float32-equivalent accuracy at 2.67x
+    the matrix-pipe rate), 0 = float32-input MFMA.  Returns the previous mode; ``None`` only queries."""
     return int(_lib.lib().nfs_gemm_mode(-1 if mode is None else int(mode)))
 
 

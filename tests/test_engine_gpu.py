@@ -582,8 +582,12 @@ def test_slab_sharded_field_work_reproduces_the_single_rank_trajectory(tmp_path,
     a, b, c = np.load(one), np.load(slab), np.load(repl)
     np.testing.assert_allclose(b["l"], a["l"], rtol=2e-6)
     np.testing.assert_allclose(c["l"], a["l"], rtol=2e-6)
+    # (two ranks: one order of a + b.  From three on the collectives may add the ranks in another order than the one
+    # rank adds its views: rounding noise of 1e-11 in a voxel whose gradient is of the order of Adam's epsilon moves that
+    # voxel's update by 1e-6 -- the bound admits that, not a wrong plane)
+    tol = 2e-6 if world == 2 else 1e-4
     for other in (b, c):
-        assert np.abs(other["var"] - a["var"]).max() <= 2e-6 * np.abs(a["var"]).max()
+        assert np.abs(other["var"] - a["var"]).max() <= tol * np.abs(a["var"]).max()
         assert np.abs(other["d_s"] - a["d_s"]).max() <= 1e-6
     # the two multi-rank forms apply the same kernels to the same sums: with two ranks (a + b has one order) identical
     # variables; with three the collectives may add the ranks in different orders

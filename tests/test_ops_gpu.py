@@ -750,14 +750,22 @@ def test_pooled_layer_without_full_resolution_output(ops, shape):
         ops.conv3x3_dgrad_pool(gp, None, wd, Ci, x_in=x, relu_bits=None, hw=(H, W))
 
 
-def test_split_limb_gemm_is_float32_accurate():
+@pytest.mark.parametrize("B,H,W,Ci,Co,floor", [
+    (2, 24, 20, 64, 128, 5e-4),        # 64-row tiles of the round-2 kernel (K = 64: no 16-row instance applies? it does: rb16s)
+    (8, 25, 25, 512, 512, 5e-3),       # conv4_2 at 8 views: F(5x5), 200 rows (the 208-row / 112-row split-limb tiles)
+    (2, 25, 25, 256, 512, 5e-3),       # 50 rows, K != N
+    (1, 50, 50, 256, 256, 5e-3),       # conv3_2 at one view: 100 rows
+    (8, 12, 12, 512, 512, 5e-4),       # conv5_1 at 8 views: F(4x4), 72 rows (80-row tile, 5 live)
+    (1, 12, 12, 512, 512, 5e-4),       # 9 rows, two K parts
+    (3, 28, 28, 256, 256, 5e-4)])      # F(4x4), 147 rows
+def test_split_limb_gemm_is_float32_accurate(B, H, W, Ci, Co, floor):
     """The split-limb GEMM mode (nfs_gemm_mode(1): every float32 operand written exactly as three bf16 limbs, six limb
     products on the bf16 MFMA, float32 accumulation) against a float64 convolution, next to the float32-input MFMA
     (mode 0) on the same inputs: same accuracy class -- each product is carried to 2^-26, below float32's rounding unit.
-    Inputs span 10 orders of magnitude per tensor (the limb split must be exact at every scale)."""
+    Inputs span 10 orders of magnitude per tensor (the limb split must be exact at every scale).  The shapes cover the
+    16-row register-B instance (rb16s: F(5x5) and F(4x4) deep layers, ragged last row tiles, K parts)."""
     from neural_flow_style_amd import ops
     rng = np.random.RandomState(12)
-    B, H, W, Ci, Co = 2, 24, 20, 64, 128
     x = (rng.randn(B, H, W, Ci) * np.exp(rng.uniform(-11, 11, (B, H, W, Ci)))).astype(np.float32)
     x = np.maximum(x, 0)
     w = (rng.randn(3, 3, Ci, Co) * 0.05 * np.exp(rng.uniform(-3, 3, (3, 3, Ci, Co)))).astype(np.float32)
@@ -780,9 +788,10 @@ def test_split_limb_gemm_is_float32_accurate():
     finally:
         ops.gemm_mode(prev)
     # the error floor here is Winograd's, not the GEMM's: F(4x4)'s transforms mix pixels whose magnitudes differ by
-    # orders of magnitude in this input (measured 1.1e-4 for the float32-input MFMA); the point is that the split-limb
-    # arithmetic lands on the SAME floor
-    assert errs[0] < 5e-4 and errs[1] < 5e-4, errs
+    # orders of magnitude in this input (measured 1.1e-4 for the float32-input MFMA; F(5x5)'s larger constants put it
+    # higher); the point is that the split-limb arithmetic lands on the SAME floor
+    print("split-limb accuracy %s: f32-input MFMA %.3g, split-limb %.3g" % ((B, H, W, Ci, Co), errs[0], errs[1]))
+    assert errs[0] < floor and errs[1] < floor, errs
     assert errs[1] < 1.5 * errs[0] + 1e-7, errs
 
 

@@ -1,11 +1,13 @@
 """Kernel timeline of ONE step from a rocprofv3 kernel trace: start offset, duration and the idle gap before every launch
-(the step = from the last-but-one forward-smoothing launch to the next one).
-    python tools/timeline.py <kernel_trace.csv> [step_from_end=2]"""
+(the step = from the last-but-one forward-smoothing launch to the next one; any other kernel-name fragment marks the
+first launch of a step of another loop, e.g. p2g_fwd for the particle stylers).
+    python tools/timeline.py <kernel_trace.csv> [step_from_end=2] [first-kernel-of-a-step=smooth3d_kernel<false]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "smooth3d_kernel<false" in r["Kernel_Name"]]
+mark = sys.argv[3] if len(sys.argv) > 3 else "smooth3d_kernel<false"
+starts = [i for i, r in enumerate(rows) if mark in r["Kernel_Name"]]
 a, b = starts[-k - 1], starts[-k]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
