@@ -49,6 +49,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0   # v_mfma_f32_16x16x32_bf16 / 32x32x16 dense peak (MI355X_MICROARCH.md; never the sparse figure)
+DTYPE_SPLIT = "f32 (3xbf16 split-limb MFMA, f32 accumulate)"
 STYLE_LAYERS = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
 
 
@@ -357,18 +359,32 @@ def cpu_baseline(data, G, V, n_views, gs=None, device=None, full=False):
            "per_view_spread": (max(sec["views"]) - min(sec["views"])) / per_view}
     parity = None
     if gs is not None:
+        from neural_flow_style_amd import ops
         from neural_flow_style_amd import transform as T
-        rows = []
-        gs.var.copy_(torch.tensor(data["vel"]))        # the timed steps moved the variable: back to the oracle's input
-        for v, lo, go in zip(sample, losses, g_vel):
-            lh, gh = gs.gradient(T.rot_to_device(data["mats"][v:v + 1], device))     # (gs.var = the initial velocity, below)
-            gh = gh.double().cpu()
-            rows.append({"view": v, "grad_rel_l2": float((gh - go.double()).norm() / go.double().norm()),
-                         "loss_rel": abs(float(lh.double().sum()) - lo) / abs(lo)})
-        parity = {"grad_rel_l2": max(r["grad_rel_l2"] for r in rows), "loss_rel": max(r["loss_rel"] for r in rows),
-                  "case": "%d^3, 1 view, conv1_1..conv5_1: dL/d velocity field [%d,%d,%d,3] of the HIP path vs the CPU "
-                          "oracle, views %s of the benchmark's lattice (worst view reported)" % (G, G, G, G, sample),
-                  "per_view": rows, "tolerance": 1e-3}
+
+        def against_oracle():
+            rows = []
+            gs.var.copy_(torch.tensor(data["vel"]))    # the timed steps moved the variable: back to the oracle's input
+            for v, lo, go in zip(sample, losses, g_vel):
+                lh, gh = gs.gradient(T.rot_to_device(data["mats"][v:v + 1], device))
+                gh = gh.double().cpu()
+                rows.append({"view": v, "grad_rel_l2": float((gh - go.double()).norm() / go.double().norm()),
+                             "loss_rel": abs(float(lh.double().sum()) - lo) / abs(lo)})
+            return {"grad_rel_l2": max(r["grad_rel_l2"] for r in rows), "loss_rel": max(r["loss_rel"] for r in rows),
+                    "case": "%d^3, 1 view, conv1_1..conv5_1: dL/d velocity field [%d,%d,%d,3] of the HIP path vs the CPU "
+                            "oracle, views %s of the benchmark's lattice (worst view reported)" % (G, G, G, G, sample),
+                    "per_view": rows, "tolerance": 1e-3}
+        mode0 = ops.gemm_mode(None)
+        parity = against_oracle()
+        parity["gemm_mode"] = mode0
+        if mode0 == 1:
+            # the same comparison with the Winograd GEMMs on the f32-input MFMA: the split-limb arithmetic is the default
+            # BECAUSE it is no further from the float64-checked oracle than this
+            ops.gemm_mode(0)
+            try:
+                parity["f32_mfma"] = {k: v for k, v in against_oracle().items() if k in ("grad_rel_l2", "loss_rel", "per_view")}
+            finally:
+                ops.gemm_mode(mode0)
     return out, parity
 
 
@@ -949,8 +965,19 @@ def main():
     else:
         _, _, base = build_problem(G, V, device, 0, 1)
 
+    from neural_flow_style_amd import ops as _ops
+    gemm_mode0 = _ops.gemm_mode(None)          # the library's arithmetic for the Winograd GEMMs (1: split-limb, the default)
     out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic", "unit": "iters/s", "scaling_by": mode,
+           "dtype": DTYPE_SPLIT if gemm_mode0 == 1 else "f32", "data": "synthetic", "unit": "iters/s", "scaling_by": mode,
+           "gemm_arithmetic": (
+               "inputs, outputs, accumulators and every stored tensor are float32.  The batched Winograd GEMMs of the deep "
+               "VGG layers write each float32 operand exactly as three bf16 limbs (round to nearest at each level: 3 x 8 "
+               "significand bits = float32's 24) and run the six leading limb products on v_mfma_f32_16x16x32_bf16 with "
+               "float32 accumulation: each product is carried to 2^-26, below float32's own rounding unit.  Measured "
+               "against the float64 oracle the step's gradient is no worse than with the f32-input MFMA (parity.full_size "
+               "vs parity.full_size_f32_mfma; tests/test_ops_gpu.py::test_split_limb_gemm_is_float32_accurate).  "
+               "NFS_GEMM_MODE=0 runs the same GEMMs on v_mfma_f32_16x16x4_f32: `f32_mfma_gemm` below."
+               if gemm_mode0 == 1 else "float32-input MFMA (NFS_GEMM_MODE=0)"),
            "metric": "stylization iters/sec on %d^3 smoke grid, %d views" % (G, V)}
     cfg_common = {"grid": G, "views": V, "image": [G, G], "style_layers": STYLE_LAYERS,
                   "vgg_weights": "synthetic He-normal seed 123 (no checkpoint offline)"}
@@ -1032,23 +1059,22 @@ def main():
     if not args.no_sustained:
         out["sustained"] = dict(sustained(step_fn, barrier, units, device, world), unit=out["unit"])
 
-    # ---- the same workload with the Winograd GEMMs in split-limb arithmetic (float32-equivalent, see nfs_gemm_mode) -----
+    # ---- the same workload with the Winograd GEMMs in the OTHER arithmetic (see nfs_gemm_mode) ---------------------------
     if gs is not None and mode == "views" and not args.no_split_limb:
         from neural_flow_style_amd import ops
-        prev = ops.gemm_mode(1)
+        other = 1 - gemm_mode0
+        prev = ops.gemm_mode(other)
         try:
             gs.use_graph = False
             dts, lasts = time_steps(views_step, barrier, max(args.warmup, 2), args.steps, device, world)
-            out["split_limb_gemm"] = {
+            out["f32_mfma_gemm" if other == 0 else "split_limb_gemm"] = {
                 "value": args.steps / dts, "unit": "iters/s", "ms_per_step": 1e3 * dts / args.steps,
-                "final_loss": float(lasts),
-                "note": "NOT the headline: same step with nfs_gemm_mode(1) -- every float32 GEMM operand written exactly "
-                        "as three bf16 limbs, the six leading limb products on v_mfma_f32_32x32x16_bf16, float32 "
-                        "accumulation; inputs/outputs/accumulators float32, per-product error <= 2^-26 (parity tests: "
-                        "same error against float64 as the float32-input MFMA).  The headline `value` uses the "
-                        "float32-input MFMA -- which, since the narrow layers run in one kernel and the deep ones on "
-                        "F(5x5) tiles and register-B kernels (neither has a split-limb form), is no longer the slower of "
-                        "the two."}
+                "final_loss": float(lasts), "dtype": "f32" if other == 0 else DTYPE_SPLIT,
+                "note": "NOT the headline: the same step with nfs_gemm_mode(%d) -- " % other +
+                        ("every Winograd GEMM on the float32-input MFMA (v_mfma_f32_16x16x4_f32, dense peak %.1f TFLOP/s): "
+                         "the arithmetic of rounds 1-4's headline" % MFMA_F32_PEAK_TF if other == 0 else
+                         "every float32 GEMM operand written exactly as three bf16 limbs, the six leading limb products "
+                         "on v_mfma_f32_16x16x32_bf16, float32 accumulation")}
         finally:
             ops.gemm_mode(prev)
 
@@ -1064,8 +1090,10 @@ def main():
         for _ in range(psteps):
             gs.step(rot_local, loss_view=True)
         torch.cuda.synchronize()
+        s_ms, s_fl, s_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        L.nfs_gemm_timer_read_kind(1, ctypes.byref(s_ms), ctypes.byref(s_fl), ctypes.byref(s_n))    # split-limb launches
         g_ms, g_fl, g_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-        L.nfs_gemm_timer_read(ctypes.byref(g_ms), ctypes.byref(g_fl), ctypes.byref(g_n))
+        L.nfs_gemm_timer_read(ctypes.byref(g_ms), ctypes.byref(g_fl), ctypes.byref(g_n))             # the f32-input rest
         L.nfs_gemm_timer(0)
         # pass 2 -- event pairs around every C-ABI call; clean per-family timings need a single stream (an event pair
         # on one stream also counts the other stream's kernels sharing the chip)
@@ -1087,8 +1115,40 @@ def main():
         fl = sum(r["achieved"] * r["ms_per_step"] for r in conv)              # executed TF/s * ms
         fa = sum(r.get("algorithmic_tflops", 0.0) * r["ms_per_step"] for r in conv)   # direct-conv TF/s * ms
         n_launch = sum(r["launches_per_step"] for r in conv)
-        tf = g_fl.value / (g_ms.value * 1e-3) / 1e12
-        out["roofline"] = {
+        tf = g_fl.value / (g_ms.value * 1e-3) / 1e12 if g_ms.value > 0 else 0.0
+        f32_roof = {
+            "kernel": "nfs::winograd_gemm_rb16_kernel / winograd_gemm_rb16_group_kernel on v_mfma_f32_16x16x4_f32"
+                      + (": the Gram gradients of the five style layers (one grouped launch; mask / scale / symmetric "
+                         "operand: f32-input MFMA in both arithmetic modes)" if s_n.value else ""),
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+            "launches_per_step": g_n.value / psteps, "ms_per_step": g_ms.value / psteps,
+            "avg_launch_us": 1e3 * g_ms.value / max(g_n.value, 1)}
+        if s_n.value:
+            # the dominant kernel in the default arithmetic: executed bf16-MFMA flops = 6 limb products per float32 product
+            tfe = s_fl.value / (s_ms.value * 1e-3) / 1e12
+            out["roofline"] = {
+                "kernel": "nfs::winograd_gemm_rb16s_kernel: the 49 Winograd F(5x5,3x3) / 36 F(4x4,3x3) products of every conv "
+                          "layer from conv3_1 on (forward and data gradient) as batched GEMMs in split-limb arithmetic on "
+                          "v_mfma_f32_16x16x32_bf16 (A split into three bf16 limb planes while staged into LDS, B = the "
+                          "float32 fragment pack, split in registers; six limb products per 16 x 16 x 32 block): %d "
+                          "launches/step, %.2f ms/step = the largest share of the step"
+                          % (s_n.value // psteps, s_ms.value / psteps),
+                "bound": "mfma", "achieved": 6.0 * tfe, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": 6.0 * tfe / MFMA_BF16_PEAK_TF, "f32_equivalent_tflops": tfe,
+                "traffic": pmc_traffic("winograd_gemm_rb16s"),
+                "flops_per_launch": 6.0 * s_fl.value / max(s_n.value, 1),
+                "f32_equivalent_flops_per_launch": s_fl.value / max(s_n.value, 1),
+                "avg_launch_us": 1e3 * s_ms.value / max(s_n.value, 1), "event_pair_overhead_us": None,
+                "ms_per_step": s_ms.value / psteps,
+                "configuration": "headline, %d local views, one stream" % rot_local.shape[0],
+                "note": "achieved = EXECUTED bf16 MFMA flops (6 limb products x 2*Z*T*K*N per launch) / summed launch "
+                        "durations, HIP events on the launch stream around every launch (nfs_gemm_timer) in the headline "
+                        "configuration; peak = the dense bf16 MFMA rate.  f32_equivalent_tflops = 2*Z*T*K*N / time, the "
+                        "figure comparable with rounds 1-4 (f32-input MFMA, peak %.1f)" % MFMA_F32_PEAK_TF,
+                "f32_input_launches": f32_roof}
+        else:
+            out["roofline"] = {}
+        _roof_f32 = {
             "kernel": "nfs::winograd_gemm_rb16_kernel (+ its grouped form winograd_gemm_rb16_group_kernel: the five Gram "
                       "gradients in one launch): batched f32-MFMA GEMM on v_mfma_f32_16x16x4_f32, filters from L2 "
                       "straight into registers -- the 49 Winograd F(5x5,3x3) or 36 F(4x4,3x3) products of every conv layer "
@@ -1113,7 +1173,14 @@ def main():
                             "note": "frac = executed MFMA flops (Winograd products incl. tile padding, "
                                     "nfs_conv3x3_executed_flops) / ABI-call time / f32 MFMA peak; algorithmic_tflops = "
                                     "the direct-conv flops 2*B*H*W*9*Ci*Co of the same calls over the same time, for "
-                                    "reference (Winograd executes 2.25-4.6x fewer multiplies: not a roofline figure)"}}
+                                    "reference (Winograd executes 2.25-4.6x fewer multiplies: not a roofline figure; in the "
+                                    "split-limb arithmetic the deep layers' products run on the bf16 pipe, so this fraction "
+                                    "of the f32-input peak is an f32-EQUIVALENT rate, not a pipe utilisation)"}}
+        if s_n.value:
+            out["roofline"]["event_pair_overhead_us"] = ov_us
+            out["roofline"]["conv_family"] = _roof_f32["conv_family"]
+        else:
+            out["roofline"] = _roof_f32
         # render + advect family against the HBM roofline (north_star's >= 40 % target): measured kernels, two byte
         # accountings -- the kernels as built (the rotated volume is KEPT for the adjoint: written once, read once more)
         # and SURVEY 8(d)'s fully fused counts (rotate+render fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + 4VG^2)
@@ -1151,7 +1218,10 @@ def main():
             cb, fsp = cpu_baseline(base, G, V, args.cpu_views, gs=gs, device=device, full=args.cpu_baseline_full)
             out["cpu_baseline"] = cb
             if fsp is not None:
+                f32p = fsp.pop("f32_mfma", None)
                 out.setdefault("parity", {})["full_size"] = fsp
+                if f32p is not None:
+                    out["parity"]["full_size_f32_mfma"] = f32p
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -37,8 +37,13 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
               "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "parity", "sustained", "other_configs",
               "scaling_by"):
         assert k in one, k
-    assert one["n_gpus"] == 1 and one["dtype"] == "f32" and one["scaling"] == "strong" and one["vs_baseline"] is None
-    assert one["roofline"]["bound"] == "mfma" and 0 < one["roofline"]["frac"] < 1.0
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["vs_baseline"] is None
+    # float32 everywhere; the deep layers' GEMMs in float32-equivalent split-limb arithmetic on the bf16 MFMA by default,
+    # the same step on the f32-input MFMA beside it
+    assert one["dtype"] == "f32 (3xbf16 split-limb MFMA, f32 accumulate)" and one["f32_mfma_gemm"]["dtype"] == "f32"
+    assert 0 < one["f32_mfma_gemm"]["value"] and "split_limb_gemm" not in one
+    assert one["roofline"]["bound"] == "mfma" and 0 < one["roofline"]["frac"] < 1.0 and one["roofline"]["peak"] == 2500.0
+    assert 0 < one["roofline"]["f32_input_launches"]["frac"] < 1.0 and one["roofline"]["f32_input_launches"]["peak"] == 157.3
     assert "frac_net" not in one["roofline"] and 0 < one["roofline"]["conv_family"]["frac"] < 1.0
     assert all(r.get("frac", 0.0) < 1.0 for r in one["kernels"])          # executed flops / bytes: never above the peak
     assert 0 < one["render_advect_family"]["survey_fused"]["frac_hbm"] < one["render_advect_family"]["as_built"]["frac_hbm"]
