@@ -894,6 +894,15 @@ __global__ void __launch_bounds__(256) winograd_gemm_rb16_group_kernel(WgGroupAr
 // The k index a lane position stands for is the rb16 pack's: position j of lane group q is k = 16 (j / 4) + 4 q + j % 4
 // of the 32-deep chunk, for A and B alike (the MFMA pairs positions, whatever k they are called).
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+#ifndef NFS_RB16S_PF
+#define NFS_RB16S_PF 2
+#endif
+// timing-only ablations of the rb16s kernel (tools/variant_sweep.sh -DNFS_RB16S_ABL=<mask>; WRONG RESULTS by construction,
+// never in the product build): 1 no MFMAs, 2 no limb split of B, 4 no limb split / LDS staging of A, 8 no operand loads
+// after the prologue, 16 no epilogue stores
+#ifndef NFS_RB16S_ABL
+#define NFS_RB16S_ABL 0
+#endif
 constexpr int WS_RB = 80;            // bytes per LDS row of one limb plane: 32 bf16 + 16 pad (conflict-free b128 reads)
 
 typedef float rb16s_f2 __attribute__((ext_vector_type(2)));
@@ -949,9 +958,10 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   // Two register sets, two chunks in flight per wave: at the split-limb rate a chunk's MFMAs take ~0.4 us, a round trip
   // to HBM 1-2 us, and the accumulators leave room for two blocks per CU only -- with one chunk ahead (the rb16 kernel's
   // distance) every chunk waited for its operands (measured: 40 us where the MFMAs need 12)
-  float4 av[2][AJ], bq[2][NW16][2];
+  constexpr int PF = NFS_RB16S_PF;                // register sets = chunks in flight per wave
+  float4 av[PF][AJ], bq[PF][NW16][2];
 #pragma unroll
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < PF; ++st) {
     const int cc = c0 + (st < nchunks ? st : nchunks - 1);
 #pragma unroll
     for (int j = 0; j < AJ; ++j) av[st][j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cc * (WG_KC * 4));
@@ -971,24 +981,35 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
 #define NFS_RB16S_STEP(ST, C)                                                                                      \
   {                                                                                                                \
     unsigned char* Ac = smem + ((C) & 1) * BUF;                                                                    \
-    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                               \
+    if (!(NFS_RB16S_ABL & 4)) _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                     \
       uint2 hv, mv, lv;                                                                                            \
-      rb16s_split2(av[ST][j].x, av[ST][j].y, hv.x, mv.x, lv.x);                                                    \
-      rb16s_split2(av[ST][j].z, av[ST][j].w, hv.y, mv.y, lv.y);                                                    \
+      if (NFS_RB16S_ABL & 32) {                                                                                    \
+        hv = make_uint2(__float_as_uint(av[ST][j].x), __float_as_uint(av[ST][j].y));                               \
+        mv = make_uint2(__float_as_uint(av[ST][j].z), __float_as_uint(av[ST][j].w)); lv = hv;                      \
+      } else {                                                                                                     \
+        rb16s_split2(av[ST][j].x, av[ST][j].y, hv.x, mv.x, lv.x);                                                  \
+        rb16s_split2(av[ST][j].z, av[ST][j].w, hv.y, mv.y, lv.y);                                                  \
+      }                                                                                                            \
       unsigned char* d_ = Ac + a_st + 32 * j * WS_RB;                                                              \
       *reinterpret_cast<uint2*>(d_) = hv;                                                                          \
       *reinterpret_cast<uint2*>(d_ + PLANE) = mv;                                                                  \
       *reinterpret_cast<uint2*>(d_ + 2 * PLANE) = lv;                                                              \
     }                                                                                                              \
     __syncthreads();       /* buffer (C & 1) visible; the other one was last read in the step before */            \
-    const int cn = c0 + ((C) + 2 < nchunks ? (C) + 2 : nchunks - 1);     /* (past the end: a harmless re-fetch) */  \
-    _Pragma("unroll") for (int j = 0; j < AJ; ++j) av[ST][j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4));   \
+    const int cn = c0 + ((C) + PF < nchunks ? (C) + PF : nchunks - 1);   /* (past the end: a harmless re-fetch) */  \
+    if (!(NFS_RB16S_ABL & 8))                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) av[ST][j] = wg_ld4(a_rsrc, ao[j], (uint32_t)cn * (WG_KC * 4)); \
     bf16x8s bf[NW16][3];                                                                                           \
-    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
-      rb16s_split8(bq[ST][nt][0], bq[ST][nt][1], bf[nt][0], bf[nt][1], bf[nt][2]);                                 \
-    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
-      _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                \
-        bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);                       \
+    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt) {                                                          \
+      if (NFS_RB16S_ABL & 2) {                                                                                     \
+        bf[nt][0] = __builtin_bit_cast(bf16x8s, bq[ST][nt][0]); bf[nt][1] = __builtin_bit_cast(bf16x8s, bq[ST][nt][1]); \
+        bf[nt][2] = bf[nt][0];                                                                                     \
+      } else rb16s_split8(bq[ST][nt][0], bq[ST][nt][1], bf[nt][0], bf[nt][1], bf[nt][2]);                          \
+    }                                                                                                              \
+    if (!(NFS_RB16S_ABL & 8))                                                                                      \
+      _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                          \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                              \
+          bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);                     \
     _Pragma("unroll") for (int mg = 0; mg < MT16; mg += G) {                                                       \
       bf16x8s af[G][3];                                                                                            \
       _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
@@ -1002,16 +1023,18 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
         const int pb = lp == 0 ? 2 : lp == 1 ? 0 : lp == 2 ? 1 : lp == 3 ? 1 : lp == 4 ? 0 : 0;                    \
         _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                        \
           _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                         \
-            if (mg + gi < MT16)                                                                                    \
+            if (mg + gi < MT16 && !(NFS_RB16S_ABL & 1))                                                            \
               acc[mg + gi][nt] =                                                                                   \
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi][pa], bf[nt][pb], acc[mg + gi][nt], 0, 0, 0);      \
       }                                                                                                            \
     }                                                                                                              \
   }
 #pragma unroll 1
-  for (int c = 0; c < nchunks; c += 2) {
+  for (int c = 0; c < nchunks; c += PF) {
     NFS_RB16S_STEP(0, c)
     if (c + 1 < nchunks) NFS_RB16S_STEP(1, c + 1)
+    if (PF > 2 && c + 2 < nchunks) NFS_RB16S_STEP(PF > 2 ? 2 : 0, c + 2)
+    if (PF > 3 && c + 3 < nchunks) NFS_RB16S_STEP(PF > 3 ? 3 : 0, c + 3)
   }
 #undef NFS_RB16S_STEP
 
@@ -1037,7 +1060,8 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
       const int row = f / Q, q = f - row * Q;
       const int64_t m = m0 + 16 * EP * pass + row;
       if (m >= a.T) continue;
-      *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+      const float4 ov = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
+      if (!(NFS_RB16S_ABL & 16) || ov.x == 12345.678f) *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = ov;
     }
   }
 }

@@ -588,7 +588,7 @@ def test_slab_sharded_field_work_reproduces_the_single_rank_trajectory(tmp_path,
     tol = 2e-6 if world == 2 else 1e-4
     for other in (b, c):
         assert np.abs(other["var"] - a["var"]).max() <= tol * np.abs(a["var"]).max()
-        assert np.abs(other["d_s"] - a["d_s"]).max() <= 1e-6
+        assert np.abs(other["d_s"] - a["d_s"]).max() <= (1e-6 if world == 2 else 1e-5)
     # the two multi-rank forms apply the same kernels to the same sums: with two ranks (a + b has one order) identical
     # variables; with three the collectives may add the ranks in different orders
     if world == 2:
