@@ -210,6 +210,17 @@ int nfs_curl_bwd(const float* g_out, float* g_s, int D, int H, int W, int nd, nf
 int nfs_lap_down(const float* x, const float* k, float* out, int D, int H, int W, int C, int nd, nfs_stream_t stream);
 int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend, float* out,
                int D, int H, int W, int C, int nd, nfs_stream_t stream);
+/* nfs_lap_up with the RMS normalisation of pyramid levels (normalize_std, 86-90) riding in it -- a level of the 200^3 x 3
+ *   pyramid is 96 MB, and a normalisation pass of its own reads it twice and writes it once:
+ *   out_part (nullable) [nfs_lap_up_rms_parts()]: per-block sums of out^2, written in the same pass (the level's RMS);
+ *   addend_part (nullable) [addend_nparts] + addend_n + eps: the addend enters as addend / max(sqrt(sum / addend_n), eps),
+ *   the sum formed by every block from the partial sums in a fixed order (deterministic).
+ * nfs_lap_up_rms_parts: the number of partial sums (blocks) for an output volume, 0 where only nfs_lap_up applies
+ *   (2-D, other channel counts, volumes under 2^21 cells). */
+int nfs_lap_up_rms_parts(int D, int H, int W, int C, int nd);
+int nfs_lap_up_rms(const float* lo, const float* k, float scale, const float* addend, const float* addend_part,
+                   int addend_nparts, int64_t addend_n, float eps, float* out, float* out_part, int D, int H, int W, int C,
+                   int nd, nfs_stream_t stream);
 int nfs_normalize_mean(const float* x, float* out, int64_t n, int use_abs, float eps, float* workspace, int ws_floats,
                        nfs_stream_t stream);
 

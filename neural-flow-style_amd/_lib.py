@@ -83,6 +83,8 @@ SIGNATURES = {
     "nfs_curl_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "nfs_lap_down": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_lap_up": [_P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nfs_lap_up_rms_parts": [_I, _I, _I, _I, _I],
+    "nfs_lap_up_rms": [_P, _P, _F, _P, _P, _I, _L, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_normalize_mean": [_P, _P, _L, _I, _F, _P, _I, _P],
     "nfs_transport_step": [_P, _P, _F, _F, _P, _F, _P, _I, _I, _I, _I, _P],
     "nfs_smooth3d_relu_fwd": [_P, _P, _I, _I, _I, _F, _P],

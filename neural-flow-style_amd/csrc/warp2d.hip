@@ -432,12 +432,33 @@ __global__ void __launch_bounds__(256) lap_up_kernel(const float* __restrict__ l
 // (zeros outside the coarse volume: an out-of-range tap adds k * 0; equal to the gather form to rounding).
 constexpr int LU_CZ = 4, LU_CY = 4, LU_CX = 16;
 template <int C>
+// addend_part (nullable): the addend enters as addend / max(rms(addend), eps), its sum of squares given as addend_nparts
+// partial sums (every block forms the total itself, in a fixed order); out_part (nullable): this block's sum of out^2
+// goes to out_part[blockIdx.x] (fixed order inside the block) -- the RMS normalisation of a pyramid level rides in the
+// kernels that produce and consume the level instead of two passes of its own over it
 __global__ void __launch_bounds__(256) lap_up3_cell_kernel(const float* __restrict__ lo, const float* __restrict__ k,
                                                            const float* __restrict__ addend, float* __restrict__ out,
-                                                           int D, int H, int W, float scale, int nbx, int nby) {
+                                                           int D, int H, int W, float scale, int nbx, int nby,
+                                                           const float* __restrict__ addend_part = nullptr,
+                                                           int addend_nparts = 0, double addend_n = 1.0, float eps = 0.f,
+                                                           float* __restrict__ out_part = nullptr) {
   constexpr int IZ = LU_CZ + 2, IY = LU_CY + 2, IX = LU_CX + 2, ROW = IX * C;
   __shared__ float tile[IZ * IY * ROW];
   __shared__ float ks[125];
+  __shared__ double tot[256];
+  __shared__ float red[16];
+  float amul = 1.f;
+  if (addend_part) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < addend_nparts; i += 256) t += (double)addend_part[i];
+    tot[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) tot[threadIdx.x] += tot[threadIdx.x + w];
+      __syncthreads();
+    }
+    amul = 1.f / fmaxf(sqrtf((float)(tot[0] / addend_n)), eps);
+  }
   const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
   const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
@@ -454,7 +475,10 @@ __global__ void __launch_bounds__(256) lap_up3_cell_kernel(const float* __restri
   __syncthreads();
   const int ix = threadIdx.x % LU_CX, iy = (threadIdx.x / LU_CX) % LU_CY, iz = threadIdx.x / (LU_CX * LU_CY);
   const int ze = 2 * (mz0 + iz) - pz, ye = 2 * (my0 + iy) - py, xe = 2 * (mx0 + ix) - px;
-  if (ze >= D || ye >= H || xe >= W) return;
+  const bool active = !(ze >= D || ye >= H || xe >= W);
+  if (!active && !out_part) return;
+  float sq = 0.f;
+  if (active) {
   // coarse neighbourhood, cq[jz][jy][jx][c] = coarse voxel (m - j) per axis
   float cq[3][3][3][C];
 #pragma unroll
@@ -486,10 +510,16 @@ __global__ void __launch_bounds__(256) lap_up3_cell_kernel(const float* __restri
               for (int tx = 0; tx < 3 - ex; ++tx)
                 s += ks[((ez + 2 * tz) * 5 + ey + 2 * ty) * 5 + ex + 2 * tx] * cq[tz][ty][tx][c];
           s *= scale;
-          if (addend) s += addend[gid + c];
+          if (addend) s += amul * addend[gid + c];
           out[gid + c] = s;
+          sq += s * s;
         }
       }
+  }
+  if (out_part) {
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) out_part[blockIdx.x] = sq;
+  }
 }
 
 // normalize_std / mean-abs normalisation: partial sums (fixed block order => deterministic) then scale
@@ -571,13 +601,45 @@ int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend
     // cells m = (p >> 1) ... floor((n - 1 + p) / 2) per axis
     const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
     const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
-    if (C == 1) hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby);
-    else hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby);
+    if (C == 1) hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby, (const float*)nullptr, 0, 1.0, 0.f, (float*)nullptr);
+    else hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby, (const float*)nullptr, 0, 1.0, 0.f, (float*)nullptr);
     return check_launch("nfs_lap_up");
   }
   hipLaunchKernelGGL(lap_up_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W,
                      C, nd, scale);
   return check_launch("nfs_lap_up");
+}
+
+// blocks (= partial sums) of the cell kernel for an output volume; 0 where nfs_lap_up takes another kernel
+static int lap_up_cell_blocks(int D, int H, int W, int C, int nd, int* nbx_, int* nby_) {
+  if (!(nd == 3 && (C == 1 || C == 3) && (int64_t)D * H * W >= ((int64_t)1 << 21))) return 0;
+  const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
+  const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
+  const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
+  if (nbx_) *nbx_ = nbx;
+  if (nby_) *nby_ = nby;
+  return nbx * nby * nbz;
+}
+
+int nfs_lap_up_rms_parts(int D, int H, int W, int C, int nd) { return lap_up_cell_blocks(D, H, W, C, nd, nullptr, nullptr); }
+
+int nfs_lap_up_rms(const float* lo, const float* k, float scale, const float* addend, const float* addend_part,
+                   int addend_nparts, int64_t addend_n, float eps, float* out, float* out_part, int D, int H, int W, int C,
+                   int nd, nfs_stream_t stream) {
+  NFS_REQUIRE(lo && k && out, "nfs_lap_up_rms: null pointer");
+  NFS_REQUIRE(!addend_part || (addend && addend_nparts > 0 && addend_n > 0),
+              "nfs_lap_up_rms: addend partial sums without an addend, a count or a length");
+  int nbx = 0, nby = 0;
+  const int nb = lap_up_cell_blocks(D, H, W, C, nd, &nbx, &nby);
+  NFS_REQUIRE(nb > 0, "nfs_lap_up_rms: no cell-kernel instance for this shape (nfs_lap_up_rms_parts() == 0): use nfs_lap_up + "
+                      "nfs_normalize_mean");
+  if (C == 1)
+    hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale,
+                       nbx, nby, addend_part, addend_nparts, (double)addend_n, eps, out_part);
+  else
+    hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nb), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale,
+                       nbx, nby, addend_part, addend_nparts, (double)addend_n, eps, out_part);
+  return check_launch("nfs_lap_up_rms");
 }
 
 int nfs_normalize_mean(const float* x, float* out, int64_t n, int use_abs, float eps, float* workspace, int ws_floats,

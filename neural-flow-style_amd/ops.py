@@ -253,6 +253,27 @@ def lap_up(lo, k, out_shape, scale, addend=None):
     return out
 
 
+def lap_up_rms_parts(out_shape):
+    """partial sums ``lap_up_rms`` writes for an output of this shape; 0 where only ``lap_up`` applies"""
+    nd = 3 if len(out_shape) == 4 else 2
+    D, (H, W, Cn) = (out_shape[0] if nd == 3 else 1), tuple(out_shape)[-3:]
+    return int(_lib.lib().nfs_lap_up_rms_parts(int(D), int(H), int(W), int(Cn), nd))
+
+
+def lap_up_rms(lo, k, out_shape, scale, addend=None, addend_part=None, eps=1e-10, want_part=False):
+    """``lap_up`` with the RMS normalisation of pyramid levels riding in it (nfs_hip.h: nfs_lap_up_rms): ``addend_part``
+    (the partial sums of addend^2 an earlier call returned): the addend enters divided by max(rms(addend), eps);
+    ``want_part``: also return the partial sums of out^2.  -> out, or (out, part)"""
+    nd = 3 if lo.dim() == 4 else 2
+    out = _empty(tuple(out_shape), lo)
+    D, (H, W, Cn) = (out_shape[0] if nd == 3 else 1), tuple(out_shape)[-3:]
+    part = _empty((lap_up_rms_parts(out_shape),), lo) if want_part else None
+    _lib.call("nfs_lap_up_rms", _ptr(lo), _ptr(k), float(scale), _ptr(addend), _ptr(addend_part),
+              0 if addend_part is None else addend_part.numel(), 0 if addend is None else addend.numel(), float(eps),
+              _ptr(out), _ptr(part), D, H, W, Cn, nd, _stream())
+    return (out, part) if want_part else out
+
+
 def normalize_mean(x, use_abs=False, eps=1e-10):
     """x / max(sqrt(mean(x^2)), eps)  (normalize_std, util.py:86-90)  or  x / max(mean|x|, eps)"""
     out = _empty(x.shape, x)

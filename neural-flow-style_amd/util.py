@@ -179,17 +179,25 @@ def lap_normalize(img, scale_n=3, is_3d=False, c=1):
         _LAP_K[key] = torch.as_tensor(lap_kernel(is_3d)).to(img.device).contiguous()
     k = _LAP_K[key]
     s = 5.0 if is_3d else 4.0
-    levels = []
+    # A level of the 200^3 x 3 pyramid is 96 MB: where the cell kernel applies, the sum of squares of a high-pass level is
+    # formed by the kernel that writes it and its 1 / RMS is applied by the merge kernel that reads it (no normalisation
+    # pass of its own: two reads and a write of the level less)
+    fuse = os.environ.get("NFS_LAP_FUSE", "1") != "0"
+    his = []
     cur = img
     for _ in range(scale_n):                                   # lap_split_n (util.py:68-75)
         lo = ops.lap_down(cur, k)
-        levels.append(ops.lap_up(lo, k, cur.shape, -s, addend=cur))   # hi = img - conv_transpose(lo, k * s)
+        if fuse and ops.lap_up_rms_parts(cur.shape) > 0:       # hi = img - conv_transpose(lo, k * s), + its sum of squares
+            his.append(ops.lap_up_rms(lo, k, cur.shape, -s, addend=cur, want_part=True))
+        else:
+            his.append((ops.lap_up(lo, k, cur.shape, -s, addend=cur), None))
         cur = lo
-    levels.append(cur)
-    levels = [ops.normalize_mean(l_, use_abs=False, eps=1e-10) for l_ in levels[::-1]]
-    out = levels[0]
-    for hi in levels[1:]:                                       # lap_merge (util.py:77-84)
-        out = ops.lap_up(out, k, hi.shape, s, addend=hi)
+    out = ops.normalize_mean(cur, use_abs=False, eps=1e-10)     # the low-pass rest (normalize_std, util.py:86-90)
+    for hi, part in his[::-1]:                                  # lap_merge (util.py:77-84) of the normalised levels
+        if part is not None:
+            out = ops.lap_up_rms(out, k, hi.shape, s, addend=hi, addend_part=part, eps=1e-10)
+        else:
+            out = ops.lap_up(out, k, hi.shape, s, addend=ops.normalize_mean(hi, use_abs=False, eps=1e-10))
     return out
 
 

@@ -156,6 +156,23 @@ def test_laplacian_pyramid_normalisation_matches_the_oracle():
             got = util.lap_normalize(torch.tensor(g).cuda(), scale_n=scale_n, is_3d=is_3d, c=shape[-1]).cpu().numpy()
             assert got.shape == g.shape
             assert rel(got, want) < 2e-5, (shape, scale_n)
+    # volumes of >= 2^21 cells: the RMS normalisation of the high-pass levels rides in the kernels that write and merge
+    # them (nfs_lap_up_rms) -- against the three-pass form of the same library and against the oracle
+    import os
+    for shape in ((130, 128, 129, 3), (128, 132, 128, 1)):
+        g = (rng.randn(*shape) * np.linspace(0.1, 30, shape[2])[None, None, :, None]).astype(np.float32)
+        gd = torch.tensor(g).cuda()
+        fused = util.lap_normalize(gd, scale_n=3, is_3d=True, c=shape[-1])
+        os.environ["NFS_LAP_FUSE"] = "0"
+        try:
+            plain = util.lap_normalize(gd, scale_n=3, is_3d=True, c=shape[-1])
+        finally:
+            del os.environ["NFS_LAP_FUSE"]
+        assert rel(fused.cpu(), plain.cpu()) < 1e-6 and not torch.equal(fused, plain)       # (the fused form did run)
+        assert torch.equal(fused, util.lap_normalize(gd, scale_n=3, is_3d=True, c=shape[-1]))      # deterministic
+        if shape[-1] == 1:
+            want = O.lap_normalize(torch.tensor(g, dtype=torch.float64), util.lap_kernel(True).astype(np.float64), 3).numpy()
+            assert rel(fused.cpu().numpy(), want) < 2e-5
     # what it is for: every frequency band of the result has unit RMS before the merge, so a gradient dominated by one
     # scale is flattened -- the normalised field of a smooth + noisy mix has a higher noise-to-smooth ratio than the input
     zz, yy, xx = np.meshgrid(*[np.linspace(0, 1, 32)] * 3, indexing="ij")
