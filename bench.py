@@ -1091,7 +1091,8 @@ def main():
             gs.step(rot_local, loss_view=True)
         torch.cuda.synchronize()
         s_ms, s_fl, s_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-        L.nfs_gemm_timer_read_kind(1, ctypes.byref(s_ms), ctypes.byref(s_fl), ctypes.byref(s_n))    # split-limb launches
+        s_by = ctypes.c_double()
+        L.nfs_gemm_timer_read_kind(1, ctypes.byref(s_ms), ctypes.byref(s_fl), ctypes.byref(s_n), ctypes.byref(s_by))
         g_ms, g_fl, g_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
         L.nfs_gemm_timer_read(ctypes.byref(g_ms), ctypes.byref(g_fl), ctypes.byref(g_n))             # the f32-input rest
         L.nfs_gemm_timer(0)
@@ -1145,6 +1146,13 @@ def main():
                         "durations, HIP events on the launch stream around every launch (nfs_gemm_timer) in the headline "
                         "configuration; peak = the dense bf16 MFMA rate.  f32_equivalent_tflops = 2*Z*T*K*N / time, the "
                         "figure comparable with rounds 1-4 (f32-input MFMA, peak %.1f)" % MFMA_F32_PEAK_TF,
+                # the same launches against HBM: each reads V and the packed float32 filters and writes M exactly once when
+                # nothing is re-fetched (tools/pmc_rb16s_traffic.sh: 98 MB fetched for 71 MB of operands at conv4_2)
+                "hbm_side": {"algorithmic_bytes_per_launch": s_by.value / max(s_n.value, 1),
+                             "achieved_gbs": s_by.value / (s_ms.value * 1e-3) / 1e9, "peak_gbs": HBM_PEAK_GBS,
+                             "frac_hbm": s_by.value / (s_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "4 Z (T K + K N + T N) bytes per launch: at the bf16 rate these products are bound as "
+                                     "much by their compulsory traffic as by the matrix pipe (DESIGN.md section 3, K7s16)"},
                 "f32_input_launches": f32_roof}
         else:
             out["roofline"] = {}

@@ -59,8 +59,10 @@ int nfs_gemm_timer(int enable);
 int nfs_gemm_mode(int mode);
 int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
 /* the same for one kind of launch only (split_limb != 0: the bf16-MFMA split-limb launches; 0: the f32-input ones);
- * records of the other kind stay for a later read */
-int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches);
+ * records of the other kind stay for a later read.  bytes_total (nullable): the summed algorithmic operand bytes of the
+ * split-limb launches, 4 Z (T K + K N + T N) each -- V read, packed filters read, M written */
+int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches,
+                             double* bytes_total);
 
 /* ---- A2: batch_warp3d / _interpolate3d (transform.py:238-269, 343-433) -------------
  * imgs [B,X,Y,Z,C], coords [B,3,X,Y,Z] normalised [-1,1] (axis order = array order),
@@ -576,6 +578,22 @@ int nfs_adam_tf_step(float* x, float* m, float* v, const float* g, int64_t n,
 /* small helpers used by the host loop */
 int nfs_fill(float* x, float value, int64_t n, nfs_stream_t stream);
 int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream); /* y += a*x */
+
+/* ---- 2-D colour stylizer: the elementwise links of its chain (styler_2p.py:68-102, 259-262) -------------------
+ * The reference's graph for one frame is c_ = clip(c, 0, 1) -> p2g(p, pc = c_, pd = r) -> clip(., 0, 1) -> loss net, and
+ * per iteration g_opt += nan_to_num(c_new) - g_opt.  As TF ops (or torch autograd nodes) these are a dozen launches of a
+ * few thousand elements around the splat; here:
+ *   nfs_colour_clamp_gather       out[i] = clip(var[order[i]], 0, 1)  ([N,C]; order nullable = identity: the frame's grid
+ *                                 order, a permutation held as int64)
+ *   nfs_clamp01_bwd               out = g where 0 <= x <= 1, else 0   (adjoint of the clip of the splatted image)
+ *   nfs_colour_clamp_scatter_bwd  g_var[order[i]] = g_cc[i] where 0 <= var[order[i]] <= 1, else 0
+ *   nfs_iterate_update            r = g_opt + (nan_to_num(x) - g_opt) (the reference's two roundings); g_opt <- r, x <- r
+ *                                 (x: the variable ApplyAdam has just updated: the next iteration's start) */
+int nfs_colour_clamp_gather(const float* var, const long long* order, float* out, int64_t N, int C, nfs_stream_t stream);
+int nfs_clamp01_bwd(const float* g, const float* x, float* out, int64_t n, nfs_stream_t stream);
+int nfs_colour_clamp_scatter_bwd(const float* g_cc, const long long* order, const float* var, float* g_var, int64_t N,
+                                 int C, nfs_stream_t stream);
+int nfs_iterate_update(float* x, float* g_opt, int64_t n, nfs_stream_t stream);
 
 /* ---- (e) multi-GPU: send buffer of the D-slab reduce-scatter ----------------------------------
  * The reference has no collective; the view-sharded step exchanges the density-field gradient as a

@@ -62,7 +62,7 @@ SIGNATURES = {
     "nfs_gemm_timer": [_I],
     "nfs_gemm_mode": [_I],
     "nfs_gemm_timer_read": [_P, _P, _P],
-    "nfs_gemm_timer_read_kind": [_I, _P, _P, _P],
+    "nfs_gemm_timer_read_kind": [_I, _P, _P, _P, _P],
     "nfs_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nfs_rotate_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -157,6 +157,10 @@ SIGNATURES = {
     "nfs_fill": [_P, _F, _L, _P],
     "nfs_axpy": [_P, _P, _F, _L, _P],
     "nfs_slab_pack": [_P, _P, _I, _L, _I, _I, _P],
+    "nfs_colour_clamp_gather": [_P, _P, _P, _L, _I, _P],
+    "nfs_clamp01_bwd": [_P, _P, _P, _L, _P],
+    "nfs_colour_clamp_scatter_bwd": [_P, _P, _P, _P, _L, _I, _P],
+    "nfs_iterate_update": [_P, _P, _L, _P],
 }
 _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64,
             "nfs_conv3x3_workspace_floats": C.c_int64, "nfs_gram_workspace_floats": C.c_int64,

@@ -235,6 +235,44 @@ __global__ void __launch_bounds__(256) slab_pack_kernel(const float4* __restrict
     dst[i] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : src[i];
 }
 
+// ---- 2-D colour stylizer: the elementwise links of its chain (styler_2p.py:68-102, 259-262) -----------------------------
+// clip(c, 0, 1) read through the frame's grid order; the adjoints of the two clips (tf.clip_by_value passes the gradient
+// where min <= x <= max); the iterate update g_opt += nan_to_num(x) - g_opt with the next step's variable in the same pass
+__global__ void __launch_bounds__(256) colour_clamp_gather_kernel(const float* __restrict__ var,
+                                                                  const long long* __restrict__ order,
+                                                                  float* __restrict__ out, int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = i / C, src = order ? (int64_t)order[row] * C + (i - row * C) : i;
+  out[i] = fminf(fmaxf(var[src], 0.f), 1.f);
+}
+__global__ void __launch_bounds__(256) clamp01_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                          float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (x[i] >= 0.f && x[i] <= 1.f) ? g[i] : 0.f;
+}
+__global__ void __launch_bounds__(256) colour_clamp_scatter_bwd_kernel(const float* __restrict__ g_cc,
+                                                                       const long long* __restrict__ order,
+                                                                       const float* __restrict__ var,
+                                                                       float* __restrict__ g_var, int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = i / C, dst = order ? (int64_t)order[row] * C + (i - row * C) : i;
+  const float v = var[dst];
+  g_var[dst] = (v >= 0.f && v <= 1.f) ? g_cc[i] : 0.f;
+}
+__global__ void __launch_bounds__(256) iterate_update_kernel(float* __restrict__ x, float* __restrict__ g_opt, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  v = v != v ? 0.f : fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);      // np.nan_to_num
+  const float g = g_opt[i];
+  const float d = v - g;
+  const float r = g + d;                     // (the reference's two roundings: g_tmp = new - old, g_opt += g_tmp)
+  g_opt[i] = r;
+  x[i] = r;
+}
+
 // ---- A5 ------------------------------------------------------------------------------
 __constant__ float kVggMean[3] = {0.485f * 255.f, 0.456f * 255.f, 0.406f * 255.f};  // vgg.py:18-20
 
@@ -423,6 +461,33 @@ int nfs_axpy(float* y, const float* x, float a, int64_t n, nfs_stream_t stream) 
   NFS_REQUIRE(x && y && n > 0, "nfs_axpy: bad argument");
   hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), y, x, a, n);
   return check_launch("nfs_axpy");
+}
+
+int nfs_colour_clamp_gather(const float* var, const long long* order, float* out, int64_t N, int C, nfs_stream_t stream) {
+  NFS_REQUIRE(var && out && N > 0 && C > 0, "nfs_colour_clamp_gather: bad argument");
+  hipLaunchKernelGGL(colour_clamp_gather_kernel, dim3(blocks_for(N * C, 256)), dim3(256), 0, as_stream(stream), var, order,
+                     out, N * C, C);
+  return check_launch("nfs_colour_clamp_gather");
+}
+
+int nfs_clamp01_bwd(const float* g, const float* x, float* out, int64_t n, nfs_stream_t stream) {
+  NFS_REQUIRE(g && x && out && n > 0, "nfs_clamp01_bwd: bad argument");
+  hipLaunchKernelGGL(clamp01_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), g, x, out, n);
+  return check_launch("nfs_clamp01_bwd");
+}
+
+int nfs_colour_clamp_scatter_bwd(const float* g_cc, const long long* order, const float* var, float* g_var, int64_t N,
+                                 int C, nfs_stream_t stream) {
+  NFS_REQUIRE(g_cc && var && g_var && N > 0 && C > 0, "nfs_colour_clamp_scatter_bwd: bad argument");
+  hipLaunchKernelGGL(colour_clamp_scatter_bwd_kernel, dim3(blocks_for(N * C, 256)), dim3(256), 0, as_stream(stream), g_cc,
+                     order, var, g_var, N * C, C);
+  return check_launch("nfs_colour_clamp_scatter_bwd");
+}
+
+int nfs_iterate_update(float* x, float* g_opt, int64_t n, nfs_stream_t stream) {
+  NFS_REQUIRE(x && g_opt && n > 0, "nfs_iterate_update: bad argument");
+  hipLaunchKernelGGL(iterate_update_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, g_opt, n);
+  return check_launch("nfs_iterate_update");
 }
 
 int nfs_slab_pack(const float* gpad, float* pack, int D, int64_t plane, int world, int cs, nfs_stream_t stream) {

@@ -1384,7 +1384,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 
 // ---- host side -----------------------------------------------------------------------------------------------
 // ---- optional per-launch event timing of the GEMM kernel (nfs_gemm_timer) ---------------------------------
-struct GemmTimerRec { hipEvent_t e0, e1; double flops; int split = 0; };   // split: a split-limb (bf16 MFMA) launch
+struct GemmTimerRec { hipEvent_t e0, e1; double flops; int split = 0; double bytes = 0.0; };   // split: a split-limb (bf16 MFMA) launch; bytes: V + U + M
 static std::atomic<bool> g_timer_on{false};
 static std::vector<GemmTimerRec> g_timer_recs;
 static std::mutex g_timer_mu;
@@ -1522,6 +1522,7 @@ static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
     rec.split = 1;
+    rec.bytes = 4.0 * a.Z * ((double)a.T * a.K + (double)a.K * a.N + (double)a.T * a.N * a.ksplit);
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
@@ -1942,20 +1943,21 @@ int nfs_gemm_timer(int enable) {
 }
 
 // which: 0 every record, 1 only the split-limb launches, 2 only the f32-input launches; the records read are removed
-static int gemm_timer_read(double* ms_total, double* flops_total, long long* launches, int which, const char* who) {
+static int gemm_timer_read(double* ms_total, double* flops_total, long long* launches, int which, const char* who,
+                           double* bytes_total = nullptr) {
   if (!ms_total || !flops_total || !launches) { nfs::set_error("%s: null pointer", who); return NFS_EINVAL; }
   if (hipDeviceSynchronize() != hipSuccess) {
     nfs::set_error("%s: device synchronise failed", who);
     return NFS_ELAUNCH;
   }
   std::lock_guard<std::mutex> lk(nfs::g_timer_mu);
-  double ms = 0.0, fl = 0.0;
+  double ms = 0.0, fl = 0.0, by = 0.0;
   long long n = 0;
   std::vector<nfs::GemmTimerRec> keep;
   for (auto& r : nfs::g_timer_recs) {
     if ((which == 1 && !r.split) || (which == 2 && r.split)) { keep.push_back(r); continue; }
     float t = 0.f;
-    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; }
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; fl += r.flops; by += r.bytes; }
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
     ++n;
@@ -1963,6 +1965,7 @@ static int gemm_timer_read(double* ms_total, double* flops_total, long long* lau
   *ms_total = ms;
   *flops_total = fl;
   *launches = n;
+  if (bytes_total) *bytes_total = by;
   nfs::g_timer_recs.swap(keep);
   return NFS_OK;
 }
@@ -1971,8 +1974,9 @@ int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launch
   return gemm_timer_read(ms_total, flops_total, launches, 0, "nfs_gemm_timer_read");
 }
 
-int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches) {
-  return gemm_timer_read(ms_total, flops_total, launches, split_limb ? 1 : 2, "nfs_gemm_timer_read_kind");
+int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches,
+                             double* bytes_total) {
+  return gemm_timer_read(ms_total, flops_total, launches, split_limb ? 1 : 2, "nfs_gemm_timer_read_kind", bytes_total);
 }
 }
 

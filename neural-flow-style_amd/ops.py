@@ -857,6 +857,42 @@ def slab_pack(gpad, pack, D, world, cs):
     return pack
 
 
+def _iptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
+    return t.data_ptr()
+
+
+def colour_clamp_gather(var, order=None):
+    """clip(var, 0, 1) read through a permutation (int64 [N], None = identity): var [N,C] -> [N,C]"""
+    out = _empty(var.shape, var)
+    _lib.call("nfs_colour_clamp_gather", _ptr(var), _iptr(order), _ptr(out), var.shape[0], var.shape[1], _stream())
+    return out
+
+
+def clamp01_bwd(g, x):
+    """adjoint of clip(x, 0, 1): g where 0 <= x <= 1, else 0"""
+    out = _empty(g.shape, g)
+    _lib.call("nfs_clamp01_bwd", _ptr(g), _ptr(x), _ptr(out), g.numel(), _stream())
+    return out
+
+
+def colour_clamp_scatter_bwd(g_cc, var, order=None):
+    """adjoint of colour_clamp_gather: g_var[order[i]] = g_cc[i] where 0 <= var[order[i]] <= 1, else 0"""
+    g_var = _empty(var.shape, var)
+    _lib.call("nfs_colour_clamp_scatter_bwd", _ptr(g_cc), _iptr(order), _ptr(var), _ptr(g_var), var.shape[0], var.shape[1],
+              _stream())
+    return g_var
+
+
+def iterate_update(x, g_opt):
+    """g_opt += nan_to_num(x) - g_opt (styler_2p.py:259-262) in place, and x <- the new g_opt"""
+    assert x.shape == g_opt.shape
+    _lib.call("nfs_iterate_update", _ptr(x), _ptr(g_opt), x.numel(), _stream())
+    _written(x, g_opt)
+
+
 def fill(x, value):
     _lib.call("nfs_fill", _ptr(x), float(value), x.numel(), _stream())
 

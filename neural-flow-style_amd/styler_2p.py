@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import engine
+from . import ops
 from . import transform as T
 from . import vgg as vggmod
 from .styler_base import StylerBase
@@ -141,6 +142,16 @@ class Styler(StylerBase):
             # the per-step losses stay on the device until the octave is done: reading one back per step is a host
             # synchronisation per step, and the whole iteration is ~0.3 ms of kernels
             loss_dev = torch.zeros(self.iter * max(nb, 1), dtype=torch.float32, device=self.device)
+            # The chain of one frame is clip -> (permutation) -> splat -> clip -> loss net: five small launches either side
+            # of the loss chain.  With torch autograd each of them is a node (the two clips' adjoints alone are eight
+            # elementwise kernels) and the iteration is host-bound; written out by hand on the C-ABI operators
+            # (nfs_colour_clamp_gather / nfs_p2g_fwd / nfs_clamp01_bwd / nfs_p2g_bwd / nfs_colour_clamp_scatter_bwd /
+            # nfs_iterate_update) it is the same arithmetic in a third of the launches (NFS_2P_AUTOGRAD=1: the autograd form)
+            explicit = os.environ.get("NFS_2P_AUTOGRAD", "0") != "1"
+            cfg = ops.make_splat_cfg(2, list(res), list(self.domain), self.radius, self.support, self.rest_density,
+                                     self.nsize, self.clip, 1)
+            filt = self.window_sigma > 0 and self.num_frames > 1
+            vars_dev = [g.clone() for g in g_opt] if explicit else None      # the variables ApplyAdam updates in place
             for step in range(self.iter):
                 g_tmp = [None] * self.num_frames
                 B = self.batch_size
@@ -149,12 +160,19 @@ class Styler(StylerBase):
                     # B frames share one sess.run (styler_2p.py:42-98: batch_size towers): one image batch through the
                     # loss network -- style summed over the images, TV averaged (styler_base.py:181, 212) -- and ONE
                     # optimiser step on the B colour variables (Adam slots per batch position, one step count)
-                    vars_ = [g_opt[t + i].clone().requires_grad_(True) for i in range(B)]
                     opt_id = engine.optimizer_slot(getattr(self, "optimizer", "adam"), t, self.frames_per_opt)
                     if opt_id not in opt_:
                         opt_[opt_id] = engine.make_optimizer(getattr(self, "optimizer", "adam"))
-                    imgs = [self._colour_ordered(frames[t + i], vars_[i], res) for i in range(B)]
-                    d = imgs[0] if B == 1 else torch.cat(imgs, 0)
+                    if explicit:
+                        ccs = [ops.colour_clamp_gather(vars_dev[t + i], frames[t + i][0]) for i in range(B)]
+                        raws = [ops.p2g_fwd(frames[t + i][1][0], cfg, attr=ccs[i], pd=frames[t + i][2].reshape(-1))
+                                for i in range(B)]
+                        d_raw = raws[0].unsqueeze(0) if B == 1 else torch.stack(raws)
+                        d = torch.clamp(d_raw, 0, 1)
+                    else:
+                        vars_ = [g_opt[t + i].clone().requires_grad_(True) for i in range(B)]
+                        imgs = [self._colour_ordered(frames[t + i], vars_[i], res) for i in range(B)]
+                        d = imgs[0] if B == 1 else torch.cat(imgs, 0)
                     d_gray = frames[t][3] if B == 1 else torch.cat([frames[t + i][3] for i in range(B)], 0)
                     if self._graph_loss is None:
                         # the loss chain of one colour image is ~40 small launches: hipGraph replay where a measured
@@ -168,24 +186,44 @@ class Styler(StylerBase):
                         losses, g_d = self.loss.loss_and_grad(d.detach().contiguous(), d_gray)
                     k = step * nb + t // B
                     torch.sum(losses, dim=0, keepdim=True, out=loss_dev[k:k + 1])    # (before the next call overwrites them)
-                    d.backward(g_d)
-                    if B == 1:                                                       # (views: nothing to stack)
-                        x, gx = vars_[0].detach().unsqueeze(0), vars_[0].grad.unsqueeze(0)
+                    if explicit:
+                        g_raw = ops.clamp01_bwd(g_d.contiguous(), d_raw)
+                        gxs = []
+                        for i in range(B):
+                            _, g_cc, _ = ops.p2g_bwd(frames[t + i][1][0], cfg, g_raw[i], attr=ccs[i],
+                                                     pd=frames[t + i][2].reshape(-1), need_p=False, need_attr=True)
+                            gxs.append(ops.colour_clamp_scatter_bwd(g_cc, vars_dev[t + i], frames[t + i][0]))
+                        if B == 1:
+                            x, gx = vars_dev[t].unsqueeze(0), gxs[0].unsqueeze(0)
+                        else:
+                            x, gx = torch.stack(vars_dev[t:t + B]), torch.stack(gxs)
                     else:
-                        x = torch.stack([v.detach() for v in vars_])                # [B,N,3]
-                        gx = torch.stack([v.grad for v in vars_])
+                        d.backward(g_d)
+                        if B == 1:                                                   # (views: nothing to stack)
+                            x, gx = vars_[0].detach().unsqueeze(0), vars_[0].grad.unsqueeze(0)
+                        else:
+                            x = torch.stack([v.detach() for v in vars_])            # [B,N,3]
+                            gx = torch.stack([v.grad for v in vars_])
                     opt_[opt_id].step(x, gx.contiguous(), lr)
                     for i in range(B):
-                        g_tmp[t + i] = torch.nan_to_num(x[i]) - g_opt[t + i]
+                        if explicit and not filt and B == 1:
+                            # g_opt += nan_to_num(x) - g_opt, and the variable restarts from it: one launch
+                            ops.iterate_update(vars_dev[t + i], g_opt[t + i])
+                        else:
+                            g_tmp[t + i] = torch.nan_to_num(x[i]) - g_opt[t + i]
                     if step == self.iter - 1 and octave < self.octave_n - 1:
                         with torch.no_grad():
-                            dd = torch.cat([self._colour(p[t + i], r[t + i], x[i], res)[0] for i in range(B)], 0)
+                            xs = [g_opt[t + i] if g_tmp[t + i] is None else x[i] for i in range(B)]
+                            dd = torch.cat([self._colour(p[t + i], r[t + i], xs[i], res)[0] for i in range(B)], 0)
                             d_intm_o.append(((dd * d_gray) * 255).cpu().numpy().astype(np.uint8))
-                if self.window_sigma > 0 and self.num_frames > 1:
+                if filt:
                     stack = denoise(np.stack([g.cpu().numpy() for g in g_tmp]), sigma=(self.window_sigma, 0, 0))
                     g_tmp = [self._dev(s) for s in stack]
                 for t in range(self.num_frames):
-                    g_opt[t] = g_opt[t] + g_tmp[t]
+                    if g_tmp[t] is not None:
+                        g_opt[t] = g_opt[t] + g_tmp[t]
+                        if explicit:
+                            vars_dev[t].copy_(g_opt[t])
             loss_history_o = [float(v) for v in loss_dev.cpu().numpy()]
             loss_history.append(loss_history_o)
             if octave < self.octave_n - 1:

@@ -161,6 +161,42 @@ def test_styler2p_colour_runs_and_decreases_loss():
     assert l[-1] < l[0]
 
 
+@pytest.mark.parametrize("F,B,sigma", [(1, 1, 3.0), (2, 1, 1.0), (4, 2, 1.0)])
+def test_styler2p_chain_written_out_on_the_operators_equals_the_autograd_form(F, B, sigma):
+    """the colour chain of a frame (clip -> grid order -> splat -> clip -> loss net, and back) on the C-ABI operators
+    directly (the default) against the same chain as torch autograd nodes (NFS_2P_AUTOGRAD=1): the same arithmetic -- loss
+    history to the last bits of an atomic sum, colours and images bit for bit; one frame (the iterate update in the Adam step's wake), two frames under the
+    temporal filter, batches of two"""
+    import os
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_2p import Styler
+    rng = np.random.RandomState(21)
+    ps = [S.dambreak_particles(24, rng) for _ in range(F)]
+    rs = [rng.uniform(900, 1100, (ps[0].shape[0], 1)).astype(np.float32) for _ in range(F)]
+    H = W = 32
+    simg = S.style_image(H, W, rng)
+    out = []
+    for autograd in ("0", "1"):
+        cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.05, nsize=2, support=4, rest_density=1000, clip=False,
+                      target_field="c", num_frames=F, batch_size=B, frames_per_opt=200, window_sigma=sigma, lr=0.01, iter=4,
+                      octave_n=2, octave_scale=1.6, style_layer=["conv2_1", "conv3_1"], w_style_layer=[0.5, 0.5],
+                      w_style=1.0, w_content=0, style_mask=True, w_tv=0.01, style_target=simg, resize_scale=1.0)
+        os.environ["NFS_2P_AUTOGRAD"] = autograd
+        try:
+            st = Styler(cfg)
+            st.load_img([H, W])
+            out.append(st.run({"p": ps, "r": rs}))
+        finally:
+            del os.environ["NFS_2P_AUTOGRAD"]
+    a, b = out
+    for la, lb in zip(a["l"], b["l"]):       # (the loss VALUE is a float-atomic sum of block partials: last-bit order effects)
+        np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for t in range(F):
+        assert np.array_equal(a["opt"][t], b["opt"][t]) and np.array_equal(a["d"][t], b["d"][t])
+    if len(a["d_intm"]):
+        assert np.abs(a["d_intm"][0].astype(np.int32) - b["d_intm"][0].astype(np.int32)).max() <= 1
+
+
 def test_styler2p_matches_oracle_loop():
     """BASELINE config 0 in miniature (dambreak2d: 2-D SPH colour splat, style mask, TV, two octaves, two frames
     with temporal smoothing): the whole Styler.run against the oracle's restatement of styler_2p.py:165-315"""
