@@ -1116,207 +1116,17 @@ __global__ void __launch_bounds__(256) winograd_pack_frag_kernel(const float* __
   uq[((((int64_t)z * (N / 32) + n / 32) * (K / 8) + kk) * 64 + hh * 32 + (n & 31)) * 4 + jj] = u;
 }
 
-// ---- the batched GEMM in float32-equivalent arithmetic on the bf16 matrix pipe ("split-limb" form) --------------------
+// ---- split-limb arithmetic (float32-equivalent products on the bf16 matrix pipe) --------------------------------------
 // Every float32 operand is written EXACTLY as the sum of three bf16 limbs, x = hi + mid + lo (round-to-nearest at each
 // level: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; 3 x 8 significand bits cover float32's 24, the remainders x - hi and
-// x - hi - mid are exact in float32).  A product of two limbs has a 16-bit significand, i.e. is exact in float32, and
-// v_mfma_f32_32x32x16_bf16 accumulates in float32.  So
+// x - hi - mid are exact in float32).  A product of two limbs has a 16-bit significand, i.e. is exact in float32, and the
+// bf16 MFMA accumulates in float32.  So
 //     a * b = hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi) + [mid lo + lo mid + lo lo]
 // and the six leading limb products carry a*b to within 2^-26 |a b| (the dropped bracket) -- below float32's own
-// rounding unit 2^-24: the same accuracy class as the float32 FMA chain of v_mfma_f32_32x32x2_f32 (measured against a
-// float64 GEMM: tests/test_ops_gpu.py::test_split_limb_gemm_is_float32_accurate), at 6 x 32 cycles per 32x32x16 block
-// instead of 8 x 64 on the f32-input MFMA (2.67x).  Inputs, outputs and accumulation are float32; nothing is stored in
-// reduced precision.  A (the transformed activations) is split while it is staged into LDS; B (the Winograd-domain
-// filters) is split once at pack time into limb planes [Z][K/32][N][3][32].
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int WB_RB = 80;            // bytes per LDS row of one limb plane: 32 bf16 + 16 pad (conflict-free b128 reads)
-
-__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
-  const __bf16 bh = (__bf16)x;
-  const float r1 = x - (float)bh;
-  const __bf16 bm = (__bf16)r1;
-  const float r2 = r1 - (float)bm;
-  const __bf16 bl = (__bf16)r2;
-  h = __builtin_bit_cast(unsigned short, bh);
-  m = __builtin_bit_cast(unsigned short, bm);
-  l = __builtin_bit_cast(unsigned short, bl);
-}
-
-// f32 U [Z][K/32][N][32] -> limb planes [Z][K/32][N][3][32]
-__global__ void __launch_bounds__(256) winograd_split_planes_kernel(const float* __restrict__ U,
-                                                                    unsigned short* __restrict__ Ub, int64_t n) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n) return;
-  const int64_t row = gid >> 5;
-  const int k = (int)(gid & 31);
-  unsigned short h, m, l;
-  split3(U[gid], h, m, l);
-  unsigned short* o = Ub + row * 96 + k;
-  o[0] = h; o[32] = m; o[64] = l;
-}
-
-template <int BM, int BN, int NBUF>
-__global__ void __launch_bounds__(256, 2) winograd_gemm_split_kernel(WgGemmArgs a) {
-  constexpr int MT = BM / 64, NT = BN / 64;
-  constexpr int AJ = BM / 32;                         // float4 of A per thread and chunk
-  constexpr int BP = BN * 12 / 256;                   // 16-byte pieces of the B limb planes per thread and chunk
-  constexpr int A_PLANE = BM * WB_RB, B_PLANE = BN * WB_RB;   // bytes
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm = wid >> 1, wn = wid & 1, i = lane & 31, h = lane >> 5;
-  const int per_xcd = gridDim.x / WG_XCDS;
-  const int logical = (blockIdx.x % WG_XCDS) * per_xcd + blockIdx.x / WG_XCDS;
-  if (logical >= a.mt * a.nt * a.Z) return;
-  const int comp = logical / (a.mt * a.nt);
-  const int rem = logical - comp * (a.mt * a.nt);
-  const int64_t m0 = (int64_t)(rem % a.mt) * BM;
-  const int n0 = (rem / a.mt) * BN;
-  const float* Vc = a.V + (int64_t)comp * a.T * a.K;
-  const int nchunks = a.K / WG_KC;
-  // B limb planes of this component: chunk c, rows n0.. : contiguous BN x 192 bytes
-  const uint4* Bg = reinterpret_cast<const uint4*>(a.Ub + ((int64_t)comp * nchunks * a.N + n0) * 96);
-  const int64_t bchunk16 = (int64_t)a.N * 12;          // uint4 per chunk
-
-  const int q4 = 4 * (t & 7), r0 = t >> 3;
-  const int64_t last = a.T - 1;
-#define NFS_SP_ROW(j) (Vc + ((m0 + r0 + 32 * (j)) < a.T ? (m0 + r0 + 32 * (j)) : last) * a.K + q4)
-  const float* ap0 = NFS_SP_ROW(0); const float* ap1 = NFS_SP_ROW(1);
-  const float* ap2 = NFS_SP_ROW(AJ > 2 ? 2 : 0); const float* ap3 = NFS_SP_ROW(AJ > 2 ? 3 : 0);
-#undef NFS_SP_ROW
-  // Two register sets, two chunks in flight: while chunk c is multiplied, the loads of chunks c+1 (issued one
-  // iteration earlier) and c+2 (issued right after chunk c was staged) are outstanding.  At the split-limb MFMA rate a
-  // CU consumes ~65 GB/s of operands; one 40 KB chunk per block in flight (80 KB per CU) against ~2 us of loaded
-  // latency sustains less than half of that (Little's law) -- measured 56 us -> see DESIGN.md.
-  float4 a0, a1, a2, a3, c0, c1, c2, c3;
-  uint4 b0, b1, b2, b3, b4, b5, d0, d1, d2, d3, d4, d5;
-#define NFS_SP_LD4(p) (*reinterpret_cast<const float4*>(p))
-#define NFS_SP_LOAD(A0, A1, A2, A3, B0, B1, B2, B3, B4, B5, c_)                         \
-  {                                                                                     \
-    const int cc_ = (c_) < nchunks ? (c_) : nchunks - 1;                                \
-    const int ko_ = cc_ * WG_KC;                                                        \
-    A0 = NFS_SP_LD4(ap0 + ko_); A1 = NFS_SP_LD4(ap1 + ko_);                             \
-    if (AJ > 2) { A2 = NFS_SP_LD4(ap2 + ko_); A3 = NFS_SP_LD4(ap3 + ko_); }             \
-    const uint4* bq_ = Bg + (int64_t)cc_ * bchunk16 + t;                                \
-    B0 = bq_[0]; B1 = bq_[256]; B2 = bq_[512];                                          \
-    if (BP > 3) { B3 = bq_[768]; B4 = bq_[1024]; B5 = bq_[1280]; }                      \
-  }
-  NFS_SP_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, 0)
-  NFS_SP_LOAD(c0, c1, c2, c3, d0, d1, d2, d3, d4, d5, 1)
-
-  // LDS byte offsets.  A: plane p, row r, k: p*A_PLANE + r*80 + 2k.  B: 3*A_PLANE + p*B_PLANE + n*80 + 2k.
-  const int a_st = r0 * WB_RB + q4 * 2;               // + 32*j rows, + plane
-  int b_st[6];
-#pragma unroll
-  for (int e = 0; e < 6; ++e) {
-    const int pi = t + 256 * e;                        // piece index: row = pi / 12, plane = (pi % 12) / 4, part = pi % 4
-    const int row = pi / 12, w12 = pi - row * 12;
-    b_st[e] = 3 * A_PLANE + (w12 >> 2) * B_PLANE + row * WB_RB + (w12 & 3) * 16;
-  }
-  int abase[MT], bbase[NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * (BM / 2) + mt * 32 + i) * WB_RB + 16 * h;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = 3 * A_PLANE + (wn * (BN / 2) + nt * 32 + i) * WB_RB + 16 * h;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  unsigned char* const stage = smem_b;
-#define NFS_SP_STA(v, j)                                                                                   \
-  {                                                                                                        \
-    unsigned short h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;                                        \
-    split3(v.x, h0, m0_, l0); split3(v.y, h1, m1, l1); split3(v.z, h2, m2, l2); split3(v.w, h3, m3, l3);   \
-    unsigned char* d_ = stage + a_st + 32 * (j) * WB_RB;                                                   \
-    *reinterpret_cast<uint2*>(d_) = make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));      \
-    *reinterpret_cast<uint2*>(d_ + A_PLANE) = make_uint2(m0_ | ((unsigned)m1 << 16), m2 | ((unsigned)m3 << 16)); \
-    *reinterpret_cast<uint2*>(d_ + 2 * A_PLANE) = make_uint2(l0 | ((unsigned)l1 << 16), l2 | ((unsigned)l3 << 16)); \
-  }
-#define NFS_SP_STAGE(A0, A1, A2, A3, B0, B1, B2, B3, B4, B5)                            \
-  {                                                                                     \
-    NFS_SP_STA(A0, 0) NFS_SP_STA(A1, 1)                                                 \
-    if (AJ > 2) { NFS_SP_STA(A2, 2) NFS_SP_STA(A3, 3) }                                 \
-    *reinterpret_cast<uint4*>(stage + b_st[0]) = B0;                                    \
-    *reinterpret_cast<uint4*>(stage + b_st[1]) = B1;                                    \
-    *reinterpret_cast<uint4*>(stage + b_st[2]) = B2;                                    \
-    if (BP > 3) {                                                                       \
-      *reinterpret_cast<uint4*>(stage + b_st[3]) = B3;                                  \
-      *reinterpret_cast<uint4*>(stage + b_st[4]) = B4;                                  \
-      *reinterpret_cast<uint4*>(stage + b_st[5]) = B5;                                  \
-    }                                                                                   \
-  }
-#define NFS_SP_MMA()                                                                                          \
-  _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) {                                                          \
-    bf16x8 af[MT][3], bf[NT][3];                                                                              \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                           \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
-        af[mt][p] = *reinterpret_cast<const bf16x8*>(stage + p * A_PLANE + abase[mt] + 32 * sl);              \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                       \
-        bf[nt][p] = *reinterpret_cast<const bf16x8*>(stage + p * B_PLANE + bbase[nt] + 32 * sl);              \
-    }                                                                                                         \
-    /* limb product outermost (smallest terms first: hi lo, lo hi, mid mid | hi mid, mid hi | hi hi), tiles inner: \
-       consecutive MFMAs go to different accumulators */                                                      \
-    _Pragma("unroll") for (int lp = 0; lp < 6; ++lp) {                                                        \
-      const int pa = lp == 0 ? 0 : lp == 1 ? 2 : lp == 2 ? 1 : lp == 3 ? 0 : lp == 4 ? 1 : 0;                 \
-      const int pb = lp == 0 ? 2 : lp == 1 ? 0 : lp == 2 ? 1 : lp == 3 ? 1 : lp == 4 ? 0 : 0;                 \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                       \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                     \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt], 0, 0, 0); \
-    }                                                                                                         \
-  }
-
-  // nchunks is even (K % 64 == 0, checked by the launcher); loads past the end re-request the last chunk
-  for (int c = 0; c < nchunks; c += 2) {
-    if (c > 0 && !NFS_DBG(a, 16)) __syncthreads();     // everyone is done reading the previous chunk
-    if (!NFS_DBG(a, 8)) NFS_SP_STAGE(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5)
-    if (!NFS_DBG(a, 16)) __syncthreads();
-    if (!NFS_DBG(a, 4)) NFS_SP_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, c + 2)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!NFS_DBG(a, 1)) NFS_SP_MMA()
-    __builtin_amdgcn_sched_barrier(0);
-    if (!NFS_DBG(a, 16)) __syncthreads();
-    if (!NFS_DBG(a, 8)) NFS_SP_STAGE(c0, c1, c2, c3, d0, d1, d2, d3, d4, d5)
-    if (!NFS_DBG(a, 16)) __syncthreads();
-    if (!NFS_DBG(a, 4)) NFS_SP_LOAD(c0, c1, c2, c3, d0, d1, d2, d3, d4, d5, c + 3)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!NFS_DBG(a, 1)) NFS_SP_MMA()
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef NFS_SP_LD4
-#undef NFS_SP_LOAD
-#undef NFS_SP_STA
-#undef NFS_SP_STAGE
-#undef NFS_SP_MMA
-
-  // epilogue: transpose the tile through LDS, leave as float4 rows
-  constexpr int OS = BN + 4;
-  float* otile = reinterpret_cast<float*>(smem_b);
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) otile[row * OS + wn * (BN / 2) + nt * 32 + i] = acc[mt][nt][r];
-    }
-  __syncthreads();
-  float* Mc = a.M + (int64_t)comp * a.T * a.N;
-  constexpr int Q = BN / 4;
-#pragma unroll
-  for (int e = 0; e < (BM * Q) / 256; ++e) {
-    const int f = t + 256 * e;
-    const int row = f / Q, q = f - row * Q;
-    const int64_t m = m0 + row;
-    if (m >= a.T) continue;
-    const float4 v = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
-    if (!NFS_DBG(a, 2) || v.x == 12345.f) *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = v;
-  }
-}
+// rounding unit 2^-24: the accuracy class of the float32 FMA chain of the f32-input MFMA (measured against a float64
+// GEMM: tests/test_ops_gpu.py::test_split_limb_gemm_is_float32_accurate).  The kernel is winograd_gemm_rb16s_kernel
+// above.  (Round 2's form -- both operands through LDS, filters as limb planes from memory, 32x32x16 tiles of 64 rows --
+// was slower than the f32-input kernels it was meant to beat and left the tree in round 5: DESIGN_HISTORY.md.)
 
 // ---- output transform + layer epilogue: one thread = one tile x 4 channels -----------------------------
 template <int MODE>  // 0: y = relu?(Y + bias); 1: y = Y * (x_in > 0) + addend
@@ -1442,27 +1252,6 @@ static void pick_gemm_tile(int64_t T, int N, int Z, int cus, int* bm_out, int* b
 // winograd_gemm_split_kernel).  Process-wide setting (nfs_gemm_mode); NFS_GEMM_MODE presets it.
 static std::atomic<int> g_gemm_mode{[] { const char* e = getenv("NFS_GEMM_MODE"); return e ? (atoi(e) == 0 ? 0 : 1) : 1; }()};
 
-template <int BM, int BN, int NBUF>
-static void launch_gemm_split(const WgGemmArgs& a, hipStream_t s) {
-  const size_t oper = (size_t)NBUF * 3 * WB_RB * (BM + BN), tile = (size_t)BM * (BN + 4) * sizeof(float);
-  const size_t lds = oper > tile ? oper : tile;
-  static std::once_flag attr_once;   // (one set per kernel instance, safe from several host threads)
-  if (lds > 65536) std::call_once(attr_once, [&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_split_kernel<BM, BN, NBUF>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-  const int total = a.mt * a.nt * a.Z, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
-  GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
-  const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
-  if (timed) (void)hipEventRecord(rec.e0, s);
-  hipLaunchKernelGGL((winograd_gemm_split_kernel<BM, BN, NBUF>), dim3(grid), dim3(256), lds, s, a);
-  if (timed) {
-    rec.split = 1;
-    (void)hipEventRecord(rec.e1, s);
-    std::lock_guard<std::mutex> lk(g_timer_mu);
-    g_timer_recs.push_back(rec);
-  }
-}
-
 template <int BM, int BN>
 static void launch_gemm_rb(const WgGemmArgs& a, hipStream_t s) {
   const size_t oper = 2 * BM * WG_LS, tile = (BM / 2) * (BN + 4);
@@ -1575,13 +1364,6 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   static const int dbg = getenv("NFS_GEMM_DBG") ? atoi(getenv("NFS_GEMM_DBG")) : 0;
   a.dbg = dbg;
 #endif
-  if (variant != 3 && g_gemm_mode == 1 && a.Ub && !a.mask && !a.alpha_dev && a.alpha == 1.f && a.K % 64 == 0) {
-    if (bm == 128 && bn == 128) launch_gemm_split<128, 128, 1>(a, s);
-    else if (bm == 128) launch_gemm_split<128, 64, 1>(a, s);
-    else if (bn == 128) launch_gemm_split<64, 128, 1>(a, s);
-    else launch_gemm_split<64, 64, 1>(a, s);
-    return;
-  }
   if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0 && !a.mask && !a.alpha_dev &&
       a.alpha == 1.f && !a.symb) {
     // the 16-row register-B form in split-limb arithmetic (mode 1): 64- or 128-column tiles
@@ -1669,13 +1451,12 @@ static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
   int bm16 = 80;
   const int64_t pad32 = (a.T + 63) / 64 * 64, pad16 = rb16_best_rows(a.T, &bm16);
   static const bool bm_forced = getenv("NFS_GEMM_BM") != nullptr;
-  // mode 1: a plain product takes the split-limb instance of the 16-row form (variant 3; NFS_GEMM_SPLIT16=0: the
-  // round-2 kernel on 64-row tiles instead); the Gram gradient (mask / scale / symmetric B) stays on the f32-input MFMA
-  static const bool split16 = [] { const char* e = getenv("NFS_GEMM_SPLIT16"); return !(e && atoi(e) == 0); }();
+  // mode 1: a plain product takes the split-limb instance of the 16-row form (variant 3); the Gram gradient (mask /
+  // scale / symmetric B) stays on the f32-input MFMA
   const bool plain = !a.mask && !a.alpha_dev && a.alpha == 1.f && !a.symb;
   const int mode = g_gemm_mode;
   const int v16 = (mode == 1 && plain) ? 3 : 2;
-  const bool rows16 = (mode == 0 || !plain || split16) && gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
+  const bool rows16 = gemm_rb16_applies(a) && force_rb != 1 && !bm_forced &&
                       pad16 * 100 <= pad32 * rows16_pct;
   // K parts (winograd_ksplit: by shape alone) only on the 16-row register-B form of a plain product (no mask / scale in
   // the epilogue: those apply to the complete sum)
@@ -1824,29 +1605,27 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
   return f4 > f5 ? f4 : f5;
 }
 
-// 36 floats per (ci, co): room for either tile size
-// plus, for the F(4x4) filters, their three bf16 limb planes (6 bytes per element = 54 floats per (ci, co))
+// 36 floats per (ci, co): room for either tile size,
+// the filters twice more in MFMA fragment order (register-B GEMM kernels, 32x32x2 and 16x16x4 forms -- the 16x16x4 pack
+// also feeds the split-limb kernel, which splits it in registers),
 // and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
-// and the filters twice more in MFMA fragment order (register-B GEMM kernels, 32x32x2 and 16x16x4 forms)
 int64_t winograd_packed_floats(int Ci, int Co) {
-  return (int64_t)(36 + 54 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co);
+  return (int64_t)(36 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co);
 }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
   const int64_t n = (int64_t)Ci * Co;
   if (winograd_tile() == 4) {
     hipLaunchKernelGGL(winograd_pack4_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
-    hipLaunchKernelGGL(winograd_split_planes_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up,
-                       reinterpret_cast<unsigned short*>(up + 36 * n), 36 * n);
     const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
-    hipLaunchKernelGGL(winograd_pack_frag_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 90 * n, Kc, Nc,
+    hipLaunchKernelGGL(winograd_pack_frag_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 36 * n, Kc, Nc,
                        36 * n);
-    hipLaunchKernelGGL(winograd_pack_frag16_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 126 * n, Kc,
+    hipLaunchKernelGGL(winograd_pack_frag16_kernel, dim3(blocks_for(36 * n, 256)), dim3(256), 0, s, up, up + 72 * n, Kc,
                        Nc, 36 * n);
     if (winograd_fusable(Kc, Nc))
-      if (int e = winograd_pack_fused(up, up + 162 * n, Kc, Nc, s)) return e;
+      if (int e = winograd_pack_fused(up, up + 108 * n, Kc, Nc, s)) return e;
     if (winograd5_channels(Kc, Nc))       // the F(5x5) filters and their fragment order, behind everything else
-      if (int e = winograd5_pack(w_hwio, up + 162 * n + winograd_fused_packed_floats(Ci, Co), Ci, Co, kind, s)) return e;
+      if (int e = winograd5_pack(w_hwio, up + 108 * n + winograd_fused_packed_floats(Ci, Co), Ci, Co, kind, s)) return e;
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1863,12 +1642,12 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   const int m = winograd_tile(), comps = (m + 2) * (m + 2);
   // narrow layers: one kernel, no V / M round trip
   if (m == 4 && winograd_fusable(K, N) && winograd_fused_takes(B, H, W, K, N) && (!pooled_grad || mode == 1))
-    return winograd_fused_conv(x, U + (int64_t)162 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
+    return winograd_fused_conv(x, U + (int64_t)108 * K * N, aux0, aux1, y, B, H, W, K, N, mode, relu, s, ypool, xmask,
                                in_bits, out_bits, pooled_grad);
   // deep layers with heavily padded F(4x4) tilings: F(5x5) (no pooling fused there; its ReLU bit cache has its own
   // layout, sized by nfs_conv3x3_relu_bits_words for exactly the layers that come here)
   if (m == 4 && !pooled_grad && !ypool && !out_bits && y && winograd5_takes(H, W, K, N))
-    return winograd5_conv(x, U + (int64_t)162 * K * N + winograd_fused_packed_floats(K, N), aux0, aux1, y, ws, B, H, W, K, N,
+    return winograd5_conv(x, U + (int64_t)108 * K * N + winograd_fused_packed_floats(K, N), aux0, aux1, y, ws, B, H, W, K, N,
                           mode, relu, cus, s, in_bits);
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const int64_t T = (int64_t)B * TH * TW;
@@ -1888,9 +1667,8 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
                        TW);
   WgGemmArgs a{V, U, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   if (m == 4) {
-    a.Ub = reinterpret_cast<const unsigned short*>(U + (int64_t)36 * K * N);
-    a.Uq = U + (int64_t)90 * K * N;
-    a.Uq16 = U + (int64_t)126 * K * N;
+    a.Uq = U + (int64_t)36 * K * N;
+    a.Uq16 = U + (int64_t)72 * K * N;
   }
   const int nsplit = launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {

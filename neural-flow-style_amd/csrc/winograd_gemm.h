@@ -18,9 +18,8 @@ struct WgGemmArgs {
   const float* alpha_dev;    // optional per-batch scale (device)
   const float* mask;         // optional [Z][T][N]: C = mask > 0 ? C : 0
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
-  const unsigned short* Ub = nullptr;   // B as three bf16 limb planes [Z][K/32][N][3][32] (split-limb kernel)
   const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
-  const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 kernel)
+  const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 / rb16s kernels)
   int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations

@@ -34,12 +34,13 @@ def test_argument_errors_do_not_need_a_gpu():
     with pytest.raises(RuntimeError, match="null pointer"):
         _lib.call("nfs_render_fwd", None, None, None, 1, 1, 1, 1, 0.1, 0, None)
     assert _lib.lib().nfs_conv3x3_packed_floats(3, 64, 0) == 9 * 3 * 64              # conv1_1: direct only
-    # + Winograd F(4x4,3x3) filters (36 floats per (ci, co)) + their three bf16 limb planes (6 bytes x 36 = 54 floats)
-    # + the same filters in MFMA fragment order, for the 32x32x2 and the 16x16x4 instruction (36 + 36)
+    # + Winograd F(4x4,3x3) filters (36 floats per (ci, co))
+    # + the same filters in MFMA fragment order, for the 32x32x2 and the 16x16x4 instruction (36 + 36; the split-limb GEMM
+    #   splits the 16x16x4 pack in registers: no limb planes are stored)
     # + where both channel counts are >= 128: the F(5x5,3x3) filters and their fragment order (49 + 49)
-    assert _lib.lib().nfs_conv3x3_packed_floats(256, 512, 0) == (9 + 36 + 54 + 36 + 36 + 98) * 256 * 512
+    assert _lib.lib().nfs_conv3x3_packed_floats(256, 512, 0) == (9 + 36 + 36 + 36 + 98) * 256 * 512
     # narrow layers (64 / 128 channels both sides): + the filters in the fragment order of the single-kernel path
-    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36 + 54 + 36 + 36 + 36) * 64 * 128
+    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36 + 36 + 36 + 36) * 64 * 128
 
 
 def test_no_cpu_fallback():
