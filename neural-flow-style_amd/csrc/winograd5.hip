@@ -221,6 +221,127 @@ __global__ void __launch_bounds__(256) winograd5_output_kernel(const float* __re
   }
 }
 
+// ---- the same two transforms with seven waves per (tile, 64 channels) ---------------------------------------------------
+// The one-thread-per-(tile, channel) kernels above put 1.5-3 waves on a SIMD at 8 views (200-800 tiles) and a fraction of
+// one at one view, each wave a chain of 49 loads -> 14 seven-point transforms -> 49 stores.  Here a block of 7 waves takes
+// one tile x 64 channels: wave s transforms patch column s (7 loads, one transform) into LDS, then wave r transforms row r
+// of the result (7 LDS reads, one transform, 7 stores): seven times the waves, a seventh of the chain.  Same sums per value.
+__global__ void __launch_bounds__(448) winograd5_input7_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
+                                                               int H, int W, int K, int TH, int TW,
+                                                               uint32_t* __restrict__ bits) {
+  __shared__ float tl[7][7][64];                 // [column s][row r][channel lane] after the vertical pass
+  __shared__ unsigned long long mk[5][64];       // the mask bits of patch columns 1..5
+  const int64_t T = (int64_t)B * TH * TW;
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;       // a contiguous range of tiles per XCD
+  const int kg = K / 64;
+  if ((int64_t)lb >= T * kg) return;
+  const int64_t tile = lb / kg;
+  const int lane = threadIdx.x, w = threadIdx.y, c = (int)(lb % kg) * 64 + lane;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int y0 = 5 * ty - 1, x0 = 5 * tx - 1;
+  {
+    const int xx = x0 + w, xc = min(max(xx, 0), W - 1);
+    float d[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int yc = min(max(y0 + r, 0), H - 1);
+      d[r] = x[(((int64_t)b * H + yc) * W + xc) * K + c];
+    }
+    unsigned long long mask = 0ull;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int yy = y0 + r;
+      d[r] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? d[r] : 0.f;
+      if (r >= 1 && r <= 5) mask |= (unsigned long long)(d[r] > 0.f ? 1u : 0u) << (2 * ((r - 1) * 5));
+    }
+    if (bits && w >= 1 && w <= 5) mk[w - 1][lane] = mask << (2 * (w - 1));
+    float t[7];
+    w5_bt(d, t);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) tl[w][r][lane] = t[r];
+  }
+  __syncthreads();
+  const int64_t gid = tile * K + c;
+  if (bits && w == 6) {
+    const unsigned long long mask = mk[0][lane] | mk[1][lane] | mk[2][lane] | mk[3][lane] | mk[4][lane];
+    const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+    const uint32_t plo = __shfl_xor(lo, 1, 64), phi = __shfl_xor(hi, 1, 64);
+    if (!(c & 1)) *reinterpret_cast<uint2*>(bits + gid) = make_uint2(lo | (plo << 1), hi | (phi << 1));
+  }
+  const float row[7] = {tl[0][w][lane], tl[1][w][lane], tl[2][w][lane], tl[3][w][lane], tl[4][w][lane], tl[5][w][lane], tl[6][w][lane]};
+  float o[7];
+  w5_bt(row, o);
+  const int64_t comp_stride = T * K;
+  float* vo = V + gid + (int64_t)(w * 7) * comp_stride;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) vo[(int64_t)q * comp_stride] = o[q];
+}
+
+template <int MODE, int NSPLIT>
+__global__ void __launch_bounds__(448) winograd5_output7_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
+                                                                const float* __restrict__ aux1, float* __restrict__ y,
+                                                                int B, int H, int W, int N, int TH, int TW, int relu,
+                                                                const uint32_t* __restrict__ bits) {
+  __shared__ float tl[7][5][64];                 // [column s][output row a][channel lane]
+  const int64_t T = (int64_t)B * TH * TW;
+  const int ng = N / 64;
+  const int64_t tile = blockIdx.x / ng;
+  const int lane = threadIdx.x, w = threadIdx.y, c = (int)(blockIdx.x % ng) * 64 + lane;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int64_t comp_stride = T * N, gid = tile * N + c;
+  // the operands of the second pass go out first (row a = min(w, 4) of the addend: no branch around a load)
+  const int a = min(w, 4), yy = 5 * ty + a;
+  float ad[5];
+  uint2 mw = make_uint2(0u, 0u);
+  if (MODE == 1) {
+    const float* ap = aux1 ? aux1 : M;
+    const int yc = min(yy, H - 1);
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) ad[cc] = ap[(((int64_t)b * H + yc) * W + min(5 * tx + cc, W - 1)) * N + c];
+    if (bits) mw = *reinterpret_cast<const uint2*>(bits + (gid & ~(int64_t)1));
+  }
+  {
+    const float* mi = M + gid + (int64_t)w * comp_stride;         // column s = w: components 7 r + s
+    float m[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      m[r] = mi[(int64_t)(r * 7) * comp_stride];
+#pragma unroll
+      for (int p = 1; p < NSPLIT; ++p) m[r] += mi[((int64_t)p * 49 + r * 7) * comp_stride];
+    }
+    float t[5];
+    w5_at(m, t);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) tl[w][q][lane] = t[q];
+  }
+  __syncthreads();
+  if (w >= 5 || yy >= H) return;
+  const float row[7] = {tl[0][a][lane], tl[1][a][lane], tl[2][a][lane], tl[3][a][lane], tl[4][a][lane], tl[5][a][lane], tl[6][a][lane]};
+  float o[5];
+  w5_at(row, o);
+  const float bias = (MODE == 0 && aux0) ? aux0[c] : 0.f;
+  const unsigned long long mask = ((((unsigned long long)mw.y << 32) | mw.x) >> (c & 1)) >> (2 * (a * 5));
+#pragma unroll
+  for (int cc = 0; cc < 5; ++cc) {
+    const int xx = 5 * tx + cc;
+    if (xx >= W) continue;
+    float v = o[cc];
+    const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + c;
+    if (MODE == 0) {
+      v += bias;
+      if (relu) v = fmaxf(v, 0.f);
+    } else {
+      const float adv = aux1 ? ad[cc] : 0.f;
+      if (relu) v += adv;
+      if (bits) v = ((mask >> (2 * cc)) & 1ull) ? v : 0.f;
+      else if (aux0) v = aux0[idx] > 0.f ? v : 0.f;
+      if (!relu) v += adv;
+    }
+    y[idx] = v;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 // F(5x5) where it executes at most 0.9 x the GEMM rows of F(4x4) (49 tiles5 vs 36 tiles4) and both channel counts are
 // >= 128 (the narrower layers have their own single-kernel path, and their images are large: the padding saved is small)
@@ -260,10 +381,17 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
   const int64_t T = (int64_t)B * TH * TW;
   float* V = ws;
   float* M = ws + 49 * T * K;
-  const dim3 ig((blocks_for(T * K, 256) + 7) / 8 * 8);
+  // the seven-wave transforms where a launch has at most this many (tile, channel) items (NFS_W5_WAVES7_MAX; 0: never)
+  static const int64_t waves7_max = [] { const char* e = getenv("NFS_W5_WAVES7_MAX"); return e ? atoll(e) : (int64_t)65536; }();
   // forward: record the mask of x (the layer's own data gradient reads it); data gradient: read the mask of x_in
-  hipLaunchKernelGGL(winograd5_input_kernel, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
-                     mode == 0 ? in_bits : nullptr);
+  if (T * K <= waves7_max) {
+    const dim3 ig((unsigned)((T * (K / 64) + 7) / 8 * 8));
+    hipLaunchKernelGGL(winograd5_input7_kernel, ig, dim3(64, 7), 0, s, x, V, B, H, W, K, TH, TW, mode == 0 ? in_bits : nullptr);
+  } else {
+    const dim3 ig((blocks_for(T * K, 256) + 7) / 8 * 8);
+    hipLaunchKernelGGL(winograd5_input_kernel, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW,
+                       mode == 0 ? in_bits : nullptr);
+  }
   WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   a.Uq16 = U5 + (int64_t)49 * K * N;
   const int nsplit = winograd_launch_batched_gemm(a, 49, cus, s);
@@ -273,6 +401,18 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
     return NFS_EINVAL;
   }
   const uint32_t* ib = aux0 ? in_bits : nullptr;
+  if (T * N <= waves7_max) {
+    const dim3 og((unsigned)(T * (N / 64)));
+#define NFS_W5_OUT7(MODE_, NS_, BITS_)                                                                                \
+    hipLaunchKernelGGL((winograd5_output7_kernel<MODE_, NS_>), og, dim3(64, 7), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW,  \
+                       relu, BITS_)
+    if (mode == 0 && nsplit == 1) NFS_W5_OUT7(0, 1, (const uint32_t*)nullptr);
+    else if (mode == 0) NFS_W5_OUT7(0, 2, (const uint32_t*)nullptr);
+    else if (nsplit == 1) NFS_W5_OUT7(1, 1, ib);
+    else NFS_W5_OUT7(1, 2, ib);
+#undef NFS_W5_OUT7
+    return check_launch("winograd5_conv");
+  }
   if (mode == 0 && nsplit == 1)
     hipLaunchKernelGGL((winograd5_output_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                        (const uint32_t*)nullptr);

@@ -726,6 +726,35 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     assert torch.equal(q3, q3_ref)
 
 
+@pytest.mark.parametrize("H,W,Ci,Co", [(25, 25, 256, 512), (24, 29, 512, 256), (50, 50, 256, 256)])
+def test_f5_transforms_of_few_and_of_many_tiles_agree(ops, H, W, Ci, Co):
+    """the F(5x5) transforms run as seven waves per (tile, 64 channels) up to 65536 (tile, channel) items and as one
+    thread per (tile, channel) beyond (NFS_W5_WAVES7_MAX): the same image alone and stacked 12 times -- outputs and data
+    gradients per image agree to rounding (the GEMM between them may split K differently), the ReLU bit caches exactly"""
+    torch.manual_seed(H + Ci)
+    reps = 12 if H < 50 else 4
+    assert H // 5 * (W // 5) * max(Ci, Co) <= 65536 < reps * ((H + 4) // 5) * ((W + 4) // 5) * min(Ci, Co)
+    x1 = torch.relu(torch.randn(1, H, W, Ci, device="cuda"))
+    w = torch.randn(3, 3, Ci, Co) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, device="cuda") * 0.1
+    wf, wd = ops.conv3x3_pack(dev(w), 0), ops.conv3x3_pack(dev(w), 1)
+    gy1 = torch.randn(1, H, W, Co, device="cuda")
+    add1 = torch.randn(1, H, W, Ci, device="cuda")
+    res = []
+    for B in (1, reps):
+        x, gy, add = (t.repeat(B, 1, 1, 1).contiguous() for t in (x1, gy1, add1))
+        rb = ops.conv3x3_relu_bits(B, H, W, Ci, Co, False, x.device)
+        y = ops.conv3x3_fwd(x, wf, b, Co, True, relu_bits=rb)
+        g = ops.conv3x3_dgrad(gy, wd, Ci, x_in=x, addend=add, relu_bits=rb)
+        res.append((y, g, rb.view(B, -1).clone()))
+    (y1, g1, r1), (yb, gb, rbb) = res
+    for i in (0, reps - 1):
+        assert torch.equal(r1[0].view(torch.int32), rbb[i].view(torch.int32))
+        for a, c in ((y1[0], yb[i]), (g1[0], gb[i])):
+            assert float((a - c).norm()) <= 1e-5 * float(a.norm())            # (F(5x5) against float64: ~5e-6, budget 2e-5)
+            assert float((a - c).abs().max()) <= 1e-4 * float(a.abs().max())
+
+
 @pytest.mark.parametrize("shape", [(2, 18, 22, 64, 128), (2, 20, 24, 64, 128)])     # three-kernel / single-kernel path
 def test_pooled_layer_without_full_resolution_output(ops, shape):
     """with the bit cache a pooled layer need not write its full-resolution output: forward (pool only) and data
