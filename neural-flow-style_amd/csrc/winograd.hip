@@ -380,6 +380,188 @@ __global__ void __launch_bounds__(256) winograd_output4_kernel(const float* __re
   }
 }
 
+// ---- the F(4x4) transforms with six waves per (tile, 128 channels) -------------------------------------------------------
+// One view per GPU leaves the deep layers with 9-169 tiles: the one-thread-per-(tile, channel pair) kernels above are then a
+// fraction of a wave per SIMD, each a chain of 36 loads -> 12 six-point transforms -> 36 stores.  Here a block of 6 waves
+// takes one tile x 128 channels: wave s transforms patch column s into LDS, wave r then row r of the result (the scheme of
+// winograd5_input7_kernel).  Same sums per value, same bit cache, same pooled output (summed in the same order).
+template <int POOLED>   // 0 / 1 as in winograd_input4_kernel (2, the float mask, stays there)
+__global__ void __launch_bounds__(384) winograd_input4w_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
+                                                               int H, int W, int K, int TH, int TW,
+                                                               uint32_t* __restrict__ bits) {
+  __shared__ float2 tl[6][6][64];                // [column s][row r][channel-pair lane] after the vertical pass
+  __shared__ uint32_t wk[4][64];                 // the mask bits of patch columns 1..4
+  const int K2 = K >> 1, kg = K >> 7;
+  const int64_t T = (int64_t)B * TH * TW;
+  const unsigned per_xcd = gridDim.x / 8;
+  const unsigned lb = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if ((int64_t)lb >= T * kg) return;
+  const int64_t tile = lb / kg;
+  const int lane = threadIdx.x, w = threadIdx.y, c2 = (int)(lb % kg) * 64 + lane;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+  const int PH = H >> 1, PW = W >> 1;
+  const int64_t gid = tile * K2 + c2;
+  {
+    const int s = w, xx = x0 + s;
+    [[maybe_unused]] uint32_t nb[3];             // POOLED 1: the words of the three tiles this patch column reaches into
+    const int dx = s == 0 ? 0 : (s == 5 ? 2 : 1), is = s == 0 ? 3 : (s == 5 ? 0 : s - 1);
+    if (POOLED == 1) {
+      const int nx = min(max(tx + dx - 1, 0), TW - 1);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int ny = min(max(ty + dy - 1, 0), TH - 1);
+        nb[dy] = bits[(((int64_t)b * TH + ny) * TW + nx) * K2 + c2];
+      }
+    }
+    float2 d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = y0 + r;
+      if (!POOLED) {
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * H + yc) * W + xc) * K + 2 * c2);
+      } else {
+        const int yc = min(max(yy, 0) >> 1, PH - 1), xc = min(max(xx, 0) >> 1, PW - 1);
+        d[r] = *reinterpret_cast<const float2*>(x + (((int64_t)b * PH + yc) * PW + xc) * K + 2 * c2);
+      }
+    }
+    uint32_t word = 0u;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = y0 + r;
+      float2 v = d[r];
+      if (!POOLED) {
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        v = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+        if (r >= 1 && r <= 4) word |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u)) << (((r - 1) * 4) * 2);
+      } else {
+        const bool ok = yy >= 0 && xx >= 0 && (yy >> 1) < PH && (xx >> 1) < PW;
+        const int dy = r == 0 ? 0 : (r == 5 ? 2 : 1), ir = r == 0 ? 3 : (r == 5 ? 0 : r - 1);
+        const uint32_t wv = nb[dy] >> ((ir * 4 + is) * 2);
+        v = make_float2((ok && (wv & 1u)) ? 0.25f * v.x : 0.f, (ok && (wv & 2u)) ? 0.25f * v.y : 0.f);
+      }
+      d[r] = v;
+    }
+    if (!POOLED && bits && s >= 1 && s <= 4) wk[s - 1][lane] = word << ((s - 1) * 2);
+    float2 t[6];
+    wg4_bt(d, t);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) tl[s][r][lane] = t[r];
+  }
+  __syncthreads();
+  if (!POOLED && bits && w == 5) bits[gid] = wk[0][lane] | wk[1][lane] | wk[2][lane] | wk[3][lane];
+  const float2 row[6] = {tl[0][w][lane], tl[1][w][lane], tl[2][w][lane], tl[3][w][lane], tl[4][w][lane], tl[5][w][lane]};
+  float2 o[6];
+  wg4_bt(row, o);
+  const int64_t comp_stride = T * K;
+  float* vo = V + tile * K + 2 * c2 + (int64_t)(w * 6) * comp_stride;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) *reinterpret_cast<float2*>(vo + (int64_t)q * comp_stride) = o[q];
+}
+
+template <int MODE, int NSPLIT>
+__global__ void __launch_bounds__(384) winograd_output4w_kernel(const float* __restrict__ M, const float* __restrict__ aux0,
+                                                                const float* __restrict__ aux1, float* __restrict__ y,
+                                                                int B, int H, int W, int N, int TH, int TW, int relu,
+                                                                float* __restrict__ ypool, uint32_t* __restrict__ bits) {
+  __shared__ float2 tl[6][4][64];                // [column s][output row a][channel-pair lane]
+  __shared__ float2 vs[4][4][64];                // MODE 0: the tile's outputs, for the pooled sums
+  __shared__ uint32_t wk[4][64];
+  const int N2 = N >> 1, ng = N >> 7;
+  const int64_t T = (int64_t)B * TH * TW;
+  const int64_t tile = blockIdx.x / ng;
+  const int lane = threadIdx.x, w = threadIdx.y, c2 = (int)(blockIdx.x % ng) * 64 + lane;
+  const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((int64_t)TW * TH));
+  const int64_t comp_stride = T * N, gid = tile * N2 + c2;
+  const int a = min(w, 3), yy = 4 * ty + a;
+  // the second pass's operands first: row a of the addend and the mask word (clamped addresses, no branch around a load)
+  float2 adq[4];
+  uint32_t word = 0u;
+  if (MODE == 1) {
+    const float* ap = aux1 ? aux1 : M;
+    const int yc = min(yy, H - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      adq[c] = *reinterpret_cast<const float2*>(ap + (((int64_t)b * H + yc) * W + min(4 * tx + c, W - 1)) * N + 2 * c2);
+    if (bits) word = bits[gid];
+  }
+  {
+    const float* mi = M + tile * N + 2 * c2 + (int64_t)w * comp_stride;       // column s = w: components 6 r + s
+    float2 m[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      m[r] = *reinterpret_cast<const float2*>(mi + (int64_t)(r * 6) * comp_stride);
+#pragma unroll
+      for (int p = 1; p < NSPLIT; ++p) {
+        const float2 q = *reinterpret_cast<const float2*>(mi + ((int64_t)p * 36 + r * 6) * comp_stride);
+        m[r].x += q.x; m[r].y += q.y;
+      }
+    }
+    float2 t[4];
+    wg4_at(m, t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tl[w][q][lane] = t[q];
+  }
+  __syncthreads();
+  if (w < 4) {
+    uint32_t wout = 0u;
+    if (yy < H) {
+      const float2 row[6] = {tl[0][a][lane], tl[1][a][lane], tl[2][a][lane], tl[3][a][lane], tl[4][a][lane], tl[5][a][lane]};
+      float2 o[4];
+      wg4_at(row, o);
+      float2 bias = make_float2(0.f, 0.f);
+      if (MODE == 0 && aux0) bias = *reinterpret_cast<const float2*>(aux0 + 2 * c2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int xx = 4 * tx + c;
+        float2 v = o[c];
+        if (xx < W) {
+          const int64_t idx = (((int64_t)b * H + yy) * W + xx) * N + 2 * c2;
+          if (MODE == 0) {
+            v.x += bias.x; v.y += bias.y;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+            wout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u)) << ((a * 4 + c) * 2);
+          } else {
+            const float2 ad = aux1 ? adq[c] : make_float2(0.f, 0.f);
+            if (relu) { v.x += ad.x; v.y += ad.y; }
+            if (bits) {
+              const uint32_t wv = word >> ((a * 4 + c) * 2);
+              v.x = (wv & 1u) ? v.x : 0.f; v.y = (wv & 2u) ? v.y : 0.f;
+            } else if (aux0) {
+              const float2 xin = *reinterpret_cast<const float2*>(aux0 + idx);
+              v.x = xin.x > 0.f ? v.x : 0.f; v.y = xin.y > 0.f ? v.y : 0.f;
+            }
+            if (!relu) { v.x += ad.x; v.y += ad.y; }
+          }
+          if (MODE != 0 || y) *reinterpret_cast<float2*>(y + idx) = v;
+        }
+        if (MODE == 0) vs[a][c][lane] = v;        // (outside the image: never part of a complete pooling window)
+      }
+    }
+    if (MODE == 0) wk[a][lane] = wout;
+  }
+  if (MODE != 0) return;
+  __syncthreads();
+  if (bits && w == 5) bits[gid] = wk[0][lane] | wk[1][lane] | wk[2][lane] | wk[3][lane];
+  if (ypool && w < 2) {                           // pooled row w of the tile: rows 2 w, 2 w + 1, summed in the order above
+    const int PH = H >> 1, PW = W >> 1, py = 2 * ty + w;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const int px = 2 * tx + pc;
+      if (py < PH && px < PW) {
+        float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 v = vs[2 * w + (i >> 1)][2 * pc + (i & 1)][lane];
+          p.x += v.x; p.y += v.y;
+        }
+        *reinterpret_cast<float2*>(ypool + (((int64_t)b * PH + py) * PW + px) * N + 2 * c2) = make_float2(0.25f * p.x, 0.25f * p.y);
+      }
+    }
+  }
+}
+
 // ---- batched GEMMs on the f32 MFMA ------------------------------------------------------------------
 // block = 4 waves (2 M x 2 N), tile 128 rows x BN columns, K in 32-wide chunks; both operand tiles are
 // prefetched into registers one chunk ahead and double-buffered in LDS (36-float padded rows, b128 fragment
@@ -1654,6 +1836,16 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   float* V = ws;
   float* M = ws + comps * T * K;
   const dim3 ig((blocks_for(T * (K / 2), 256) + 7) / 8 * 8);
+  // few tiles: the six-wave transforms (NFS_W4_WAVES6_MAX (tile, channel) items per launch; 0: never)
+  static const int64_t waves6_max = [] { const char* e = getenv("NFS_W4_WAVES6_MAX"); return e ? atoll(e) : (int64_t)65536; }();
+  const bool in6 = m == 4 && K % 128 == 0 && T * K <= waves6_max, out6 = m == 4 && N % 128 == 0 && T * N <= waves6_max;
+  const dim3 ig6((unsigned)((T * (K / 128) + 7) / 8 * 8));
+  if (in6 && pooled_grad && mode == 1 && out_bits)
+    hipLaunchKernelGGL(winograd_input4w_kernel<1>, ig6, dim3(64, 6), 0, s, x, V, B, H, W, K, TH, TW, out_bits);
+  else if (in6 && !pooled_grad)
+    hipLaunchKernelGGL(winograd_input4w_kernel<0>, ig6, dim3(64, 6), 0, s, x, V, B, H, W, K, TH, TW,
+                       mode == 0 ? in_bits : (uint32_t*)nullptr);
+  else
   if (m == 4 && pooled_grad && mode == 1 && out_bits)   // pooled data gradient: the mask of the layer's own output from the bit cache ...
     hipLaunchKernelGGL(winograd_input4_kernel<1>, ig, dim3(256), 0, s, x, V, B, H, W, K, TH, TW, xmask, out_bits);
   else if (m == 4 && pooled_grad)                       // ... or from the float output
@@ -1678,6 +1870,17 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
       set_error("winograd_conv: unsupported number of K parts");
       return NFS_EINVAL;
     }
+    if (out6) {
+      const dim3 og6((unsigned)(T * (N / 128)));
+#define NFS_W4_OUT6(MODE_, NS_, POOL_, BITS_)                                                                         \
+      hipLaunchKernelGGL((winograd_output4w_kernel<MODE_, NS_>), og6, dim3(64, 6), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, \
+                         relu, POOL_, BITS_)
+      if (mode == 0 && nsplit == 1) NFS_W4_OUT6(0, 1, ypool, out_bits);
+      else if (mode == 0) NFS_W4_OUT6(0, 2, ypool, out_bits);
+      else if (nsplit == 1) NFS_W4_OUT6(1, 1, (float*)nullptr, ib);
+      else NFS_W4_OUT6(1, 2, (float*)nullptr, ib);
+#undef NFS_W4_OUT6
+    } else
     if (mode == 0 && nsplit == 1)
       hipLaunchKernelGGL((winograd_output4_kernel<0, 1>), dim3(ob), dim3(256), 0, s, M, aux0, aux1, y, B, H, W, N, TH, TW, relu,
                          ypool, out_bits);

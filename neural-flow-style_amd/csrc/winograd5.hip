@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(256) winograd5_pack_kernel(const float* __rest
 // A^T (5 x 7) = {1,1,1,1,1,1,0} {0,1,-1,2,-2,1/2,0} {0,1,1,4,4,1/4,0} {0,1,-1,8,-8,1/8,0} {0,1,1,16,16,1/16,1}
 // (written for one float; a thread owns ONE channel of a tile: the deep layers have few tiles -- 200 at 25 x 25 and 8 views --
 // and two channels per thread, as in the F(4x4) transforms, leave the chip with less than one wave per SIMD)
+// (no FMA contraction in the two transforms, as in wg4_bt / wg4_at: every kernel that inlines them rounds alike)
 __device__ __forceinline__ void w5_bt(const float* d, float* o) {
+#pragma clang fp contract(off)
   o[0] = -2.f * d[0] + 4.f * d[1] + 2.5f * d[2] - 5.f * d[3] - 0.5f * d[4] + d[5];
   o[1] = 2.f * d[1] - 2.f * d[2] - 4.5f * d[3] + 0.5f * d[4] + d[5];
   o[2] = -2.f * d[1] + 6.f * d[2] - 3.5f * d[3] - 1.5f * d[4] + d[5];
@@ -81,6 +83,7 @@ __device__ __forceinline__ void w5_bt(const float* d, float* o) {
   o[6] = -2.f * d[1] + 4.f * d[2] + 2.5f * d[3] - 5.f * d[4] - 0.5f * d[5] + d[6];
 }
 __device__ __forceinline__ void w5_at(const float* m, float* o) {
+#pragma clang fp contract(off)
   const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
   o[0] = m[0] + s12 + s34 + m[5];
   o[1] = d12 + 2.f * d34 + 0.5f * m[5];

@@ -6,8 +6,14 @@
 namespace nfs {
 
 // B^T (6x6) applied to a column / row of float2 channel pairs
-__device__ __forceinline__ float2 wg_lin(float a, float2 x, float b, float2 y) { return make_float2(a * x.x + b * y.x, a * x.y + b * y.y); }
+__device__ __forceinline__ float2 wg_lin(float a, float2 x, float b, float2 y) {
+#pragma clang fp contract(off)
+  return make_float2(a * x.x + b * y.x, a * x.y + b * y.y);
+}
+// (no FMA contraction inside the transforms: which products get fused depends on the code around an inlined copy, and
+// the kernels that share them -- one thread per tile or six waves per tile, float masks or the bit cache -- must round alike)
 __device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
+#pragma clang fp contract(off)
   // [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0] [0,-2,-1,2,1,0] [0,2,-1,-2,1,0] [0,4,0,-5,0,1]
   const float2 p = wg_lin(-4.f, d[2], 1.f, d[4]);     // d4 - 4 d2
   const float2 q = wg_lin(-4.f, d[1], 1.f, d[3]);     // d3 - 4 d1
@@ -23,6 +29,7 @@ __device__ __forceinline__ void wg4_bt(const float2* d, float2* o) {
 
 // A^T (4x6) = [1,1,1,1,1,0] [0,1,-1,2,-2,0] [0,1,1,4,4,0] [0,1,-1,8,-8,1]
 __device__ __forceinline__ void wg4_at(const float2* m, float2* o) {
+#pragma clang fp contract(off)
   const float2 s12 = make_float2(m[1].x + m[2].x, m[1].y + m[2].y), d12 = make_float2(m[1].x - m[2].x, m[1].y - m[2].y);
   const float2 s34 = make_float2(m[3].x + m[4].x, m[3].y + m[4].y), d34 = make_float2(m[3].x - m[4].x, m[3].y - m[4].y);
   o[0] = make_float2(m[0].x + s12.x + s34.x, m[0].y + s12.y + s34.y);

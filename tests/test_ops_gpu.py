@@ -726,11 +726,13 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     assert torch.equal(q3, q3_ref)
 
 
-@pytest.mark.parametrize("H,W,Ci,Co", [(25, 25, 256, 512), (24, 29, 512, 256), (50, 50, 256, 256)])
-def test_f5_transforms_of_few_and_of_many_tiles_agree(ops, H, W, Ci, Co):
-    """the F(5x5) transforms run as seven waves per (tile, 64 channels) up to 65536 (tile, channel) items and as one
-    thread per (tile, channel) beyond (NFS_W5_WAVES7_MAX): the same image alone and stacked 12 times -- outputs and data
-    gradients per image agree to rounding (the GEMM between them may split K differently), the ReLU bit caches exactly"""
+@pytest.mark.parametrize("H,W,Ci,Co", [(25, 25, 256, 512), (24, 29, 512, 256), (50, 50, 256, 256),
+                                       (24, 24, 512, 512), (22, 27, 256, 256)])             # the last two: F(4x4)
+def test_transforms_of_few_and_of_many_tiles_agree(ops, H, W, Ci, Co):
+    """the F(5x5) / F(4x4) transforms run as seven / six waves per (tile, 64 / 128 channels) up to 65536 (tile, channel)
+    items and as one thread per (tile, channel / channel pair) beyond (NFS_W5_WAVES7_MAX, NFS_W4_WAVES6_MAX): the same
+    image alone and stacked 12 times -- outputs and data gradients per image agree to rounding (the GEMM between them may
+    split K differently), the ReLU bit caches exactly"""
     torch.manual_seed(H + Ci)
     reps = 12 if H < 50 else 4
     assert H // 5 * (W // 5) * max(Ci, Co) <= 65536 < reps * ((H + 4) // 5) * ((W + 4) // 5) * min(Ci, Co)
