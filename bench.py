@@ -1151,7 +1151,7 @@ def main():
                 "hbm_side": {"algorithmic_bytes_per_launch": s_by.value / max(s_n.value, 1),
                              "achieved_gbs": s_by.value / (s_ms.value * 1e-3) / 1e9, "peak_gbs": HBM_PEAK_GBS,
                              "frac_hbm": s_by.value / (s_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "4 Z (T K + K N + T N) bytes per launch: at the bf16 rate these products are bound as "
+                             "note": "Z (4 T K + 6 K N + 4 T N) bytes per launch (V read, the filters' bf16 limb planes read, M written): at the bf16 rate these products are bound as "
                                      "much by their compulsory traffic as by the matrix pipe (DESIGN.md section 3, K7s16)"},
                 "f32_input_launches": f32_roof}
         else:

@@ -52,7 +52,7 @@ int nfs_gemm_timer(int enable);
  *      accuracy: measured against float64 it is no worse than mode 0 at every tested shape and at the 200^3 headline
  *      size, tests/test_ops_gpu.py::test_split_limb_gemm_is_float32_accurate, bench.py parity.full_size), at 2.67x the
  *      matrix-pipe rate of the f32-input MFMA.  A (transformed activations) is split while a block stages it into LDS,
- *      B (the packed float32 filters: 4 bytes per element from HBM) in registers by the wave that loaded it;
+ *      B (the filters) once, by nfs_conv3x3_pack: the packed buffer holds its limb planes (6 bytes per value);
  *   0  float32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2).
  * The Gram gradient (mask / scale / symmetric operand) runs on the f32-input MFMA in both modes.
  * NFS_GEMM_MODE=0 presets 0. */
@@ -60,7 +60,7 @@ int nfs_gemm_mode(int mode);
 int nfs_gemm_timer_read(double* ms_total, double* flops_total, long long* launches);
 /* the same for one kind of launch only (split_limb != 0: the bf16-MFMA split-limb launches; 0: the f32-input ones);
  * records of the other kind stay for a later read.  bytes_total (nullable): the summed algorithmic operand bytes of the
- * split-limb launches, 4 Z (T K + K N + T N) each -- V read, packed filters read, M written */
+ * split-limb launches, Z (4 T K + 6 K N + 4 T N) each -- V read, the filters' limb planes read, M written */
 int nfs_gemm_timer_read_kind(int split_limb, double* ms_total, double* flops_total, long long* launches,
                              double* bytes_total);
 

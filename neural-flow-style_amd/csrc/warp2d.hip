@@ -7,6 +7,7 @@
 // Images are small (128^2 ... 512 x 1024) next to the volumes: one thread per output element, exact reference stencil
 // (x0 = floor, x1 = x0 + 1, both clipped to [0, n-1], weight dx = x - float(clipped x0)).
 #include "common.h"
+#include <cstring>
 
 namespace nfs {
 
@@ -353,22 +354,32 @@ __global__ void __launch_bounds__(256) lap_down3_tiled_kernel(const float* __res
                                                               float* __restrict__ out, int D, int H, int W, int ntx,
                                                               int nty) {
   __shared__ float tile[LD_IZ * LD_IY * LD_IX * C];
-  __shared__ float ks[125];
   const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int bx = blockIdx.x % ntx, by = (blockIdx.x / ntx) % nty, bz = blockIdx.x / (ntx * nty);
   const int zo0 = bz * LD_TZ, yo0 = by * LD_TY, xo0 = bx * LD_TX;
   const int zi0 = 2 * zo0 - same_pad_before(D), yi0 = 2 * yo0 - same_pad_before(H), xi0 = 2 * xo0 - same_pad_before(W);
-  if (threadIdx.x < 125) ks[threadIdx.x] = k[threadIdx.x];
-  constexpr int ROW = LD_IX * C;
-  for (int i = threadIdx.x; i < LD_IZ * LD_IY * ROW; i += 256) {
-    const int xc = i % ROW, iy = (i / ROW) % LD_IY, iz = i / (ROW * LD_IY);
-    const int gz = zi0 + iz, gy = yi0 + iy, gx = xi0 + xc / C;
-    float v = 0.f;
-    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-      v = x[(((int64_t)gz * H + gy) * W + gx) * C + xc % C];
-    tile[i] = v;
+  constexpr int ROW = LD_IX * C, NEL = LD_IZ * LD_IY * ROW, BATCH = 10;
+  // staging in batches of BATCH loads per thread, all requested before the first is written (clamped addresses, the value
+  // outside the volume dropped by a select: as a loop of guarded loads every element was a round trip of its own --
+  // 0.159 ms for a 96 MB level)
+  for (int i0 = threadIdx.x; i0 < NEL; i0 += 256 * BATCH) {
+    float v[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = min(i0 + 256 * j, NEL - 1);
+      const int xc = i % ROW, iy = (i / ROW) % LD_IY, iz = i / (ROW * LD_IY);
+      const int gz = zi0 + iz, gy = yi0 + iy, gx = xi0 + xc / C;
+      const bool in = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      const float t = x[(((int64_t)cz * H + cy) * W + cx) * C + xc % C];
+      v[j] = in ? t : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j)
+      if (i0 + 256 * j < NEL) tile[i0 + 256 * j] = v[j];
   }
   __syncthreads();
+  // (the 125 weights: uniform addresses with compile-time offsets = scalar loads, not a second LDS read per tap)
   for (int o = threadIdx.x; o < LD_TZ * LD_TY * LD_TX * C; o += 256) {
     const int c = o % C, xo = (o / C) % LD_TX, yo = (o / (C * LD_TX)) % LD_TY, zo = o / (C * LD_TX * LD_TY);
     if (zo0 + zo >= Do || yo0 + yo >= Ho || xo0 + xo >= Wo) continue;
@@ -379,7 +390,7 @@ __global__ void __launch_bounds__(256) lap_down3_tiled_kernel(const float* __res
 #pragma unroll
       for (int b = 0; b < 5; ++b)
 #pragma unroll
-        for (int e = 0; e < 5; ++e) s += ks[(a * 5 + b) * 5 + e] * t0[(a * LD_IY + b) * ROW + e * C];
+        for (int e = 0; e < 5; ++e) s += k[(a * 5 + b) * 5 + e] * t0[(a * LD_IY + b) * ROW + e * C];
     out[(((int64_t)(zo0 + zo) * Ho + yo0 + yo) * Wo + xo0 + xo) * C + c] = s;
   }
 }
@@ -522,6 +533,134 @@ __global__ void __launch_bounds__(256) lap_up3_cell_kernel(const float* __restri
   }
 }
 
+// The 3-D form of lap_up by ROWS: a block owns one coarse cell row of y (two fine rows), all of x and LR_CZ cells of z
+// (2 LR_CZ fine planes); a lane is one float (x, c) of a fine row, so the addend loads and the output stores of a wave are
+// 256 contiguous bytes (the cell form's lanes sit 6 floats apart: six partial stores per 384-byte span).  The
+// 3 x (LR_CZ + 2) coarse rows the block reaches are staged in LDS once (whole rows: contiguous loads, all requested before
+// the first is written); a lane reads its 3 x 3 x (LR_CZ + 2) coarse values from there and forms 2 x 2 LR_CZ outputs.  The
+// parity of (y, x) picks one of four weight sets -- taps b = ey + 2 j, e = ex + 2 i, zero where b or e would be 5 -- from an
+// LDS table; the z parity is compile-time (taps 0, 2, 4 / 1, 3).  Same taps as the gather form (an out-of-range coarse
+// voxel adds k * 0); addend_part / out_part as in the cell form.
+constexpr int LR_CZ = 2, LR_T = 320, LR_ROWS = 3 * (LR_CZ + 2), LR_BATCH = 6;
+template <int C>
+__global__ void __launch_bounds__(LR_T) lap_up3_row_kernel(const float* __restrict__ lo, const float* __restrict__ k,
+                                                           const float* __restrict__ addend, float* __restrict__ out,
+                                                           int D, int H, int W, float scale, int ncy,
+                                                           const float* __restrict__ addend_part, int addend_nparts,
+                                                           double addend_n, float eps, float* __restrict__ out_part) {
+  extern __shared__ __attribute__((aligned(16))) float cs[];      // [q = coarse plane mz0 - 2 + q][j = coarse row my - j][Wo C]
+  __shared__ float wt[2][2][45];
+  __shared__ double tot[LR_T];
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  float amul = 1.f;
+  if (addend_part) {
+    double t = 0.0;
+    for (int i = tid; i < addend_nparts; i += LR_T) t += (double)addend_part[i];
+    tot[tid] = t;
+    __syncthreads();
+    if (tid < 64) tot[tid] += tot[tid + 256];                       // 320 = 256 + 64 slots, then the tree over 256
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) tot[tid] += tot[tid + w];
+      __syncthreads();
+    }
+    amul = 1.f / fmaxf(sqrtf((float)(tot[0] / addend_n)), eps);
+  }
+  if (tid < 180) {
+    const int r = tid % 45, a = r / 9, j = (r / 3) % 3, ii = r % 3, b = tid / 90 + 2 * j, e = (tid / 45) % 2 + 2 * ii;
+    (&wt[0][0][0])[tid] = (b < 5 && e < 5) ? k[(a * 5 + b) * 5 + e] : 0.f;
+  }
+  const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
+  const int RW = Wo * C, NS = LR_ROWS * RW;
+  const int by = blockIdx.x % ncy, bz = blockIdx.x / ncy;
+  const int my = (py >> 1) + by, mz0 = (pz >> 1) + bz * LR_CZ;
+  for (int i0 = tid; i0 < NS; i0 += LR_T * LR_BATCH) {
+    float v[LR_BATCH];
+#pragma unroll
+    for (int b = 0; b < LR_BATCH; ++b) {
+      const int i = min(i0 + LR_T * b, NS - 1);
+      const int xc = i % RW, row = i / RW, j = row % 3, q = row / 3;
+      const int gz = mz0 - 2 + q, gy = my - j;
+      const bool in = gz >= 0 && gz < Do && gy >= 0 && gy < Ho;
+      const int cz = min(max(gz, 0), Do - 1), cy = min(max(gy, 0), Ho - 1);
+      const float t = lo[((int64_t)cz * Ho + cy) * RW + xc];
+      v[b] = in ? t : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < LR_BATCH; ++b)
+      if (i0 + LR_T * b < NS) cs[i0 + LR_T * b] = v[b];
+  }
+  __syncthreads();
+  float sq = 0.f;
+  const int64_t plane = (int64_t)H * W * C;
+  for (int xc = tid; xc < W * C; xc += LR_T) {
+    const int x = xc / C, c = xc % C;
+    const int ex = (x + px) & 1, xo0 = (x + px - ex) >> 1;           // coarse voxel of tap i = 0; tap i: xo0 - i
+    // the 4 LR_CZ addend values first (clamped addresses, no branch around a load): one round trip, not one per output
+    float ad[2][LR_CZ][2];
+#pragma unroll
+    for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+      for (int t = 0; t < LR_CZ; ++t)
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez) {
+          const int yc = min(max(2 * my - py + ey, 0), H - 1), zc = min(max(2 * (mz0 + t) - pz + ez, 0), D - 1);
+          ad[ey][t][ez] = addend ? addend[(int64_t)zc * plane + (int64_t)yc * W * C + xc] : 0.f;
+        }
+    float cq[LR_CZ + 2][3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int gx = xo0 - i;
+      const bool in = gx >= 0 && gx < Wo;
+      const int off = min(max(gx, 0), Wo - 1) * C + c;
+#pragma unroll
+      for (int q = 0; q < LR_CZ + 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float t = cs[(q * 3 + j) * RW + off];
+          cq[q][j][i] = in ? t : 0.f;
+        }
+    }
+#pragma unroll
+    for (int ey = 0; ey < 2; ++ey) {
+      const int y = 2 * my - py + ey;
+      if (y < 0 || y >= H) continue;
+      float w[5][3][3];
+#pragma unroll
+      for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) w[a][j][i] = wt[ey][ex][(a * 3 + j) * 3 + i];
+#pragma unroll
+      for (int t = 0; t < LR_CZ; ++t)
+#pragma unroll
+        for (int ez = 0; ez < 2; ++ez) {
+          const int z = 2 * (mz0 + t) - pz + ez;
+          if (z < 0 || z >= D) continue;
+          float s = 0.f;
+#pragma unroll
+          for (int tz = 0; tz < 3 - ez; ++tz)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) s += w[ez + 2 * tz][j][i] * cq[t + 2 - tz][j][i];
+          s *= scale;
+          const int64_t gid = (int64_t)z * plane + (int64_t)y * W * C + xc;
+          if (addend) s += amul * ad[ey][t][ez];
+          out[gid] = s;
+          sq += s * s;
+        }
+    }
+  }
+  if (out_part) {
+    sq = block_sum(sq, red);
+    if (tid == 0) out_part[blockIdx.x] = sq;
+  }
+}
+
 // normalize_std / mean-abs normalisation: partial sums (fixed block order => deterministic) then scale
 __global__ void __launch_bounds__(256) norm_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part,
                                                            int use_abs) {
@@ -590,19 +729,49 @@ int nfs_lap_down(const float* x, const float* k, float* out, int D, int H, int W
   return check_launch("nfs_lap_down");
 }
 
+// the 3-D kernels of lap_up (C = 1 or 3): the row form from 4096 voxels on (NFS_LAP_UP=cell: the 2 x 2 x 2 cell form, from
+// 2^21 voxels on, as before round 5); returns the number of blocks (= partial sums), 0 where neither applies
+struct LapUpPlan { int kind, blocks, a, b; };          // kind 1: cells (a, b = nbx, nby); 2: rows (a = cell rows of y)
+static LapUpPlan lap_up3_plan(int D, int H, int W, int C, int nd) {
+  static const bool cell = [] { const char* e = getenv("NFS_LAP_UP"); return e && !strcmp(e, "cell"); }();
+  LapUpPlan pl{0, 0, 0, 0};
+  if (!(nd == 3 && (C == 1 || C == 3))) return pl;
+  const int64_t vox = (int64_t)D * H * W;
+  const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
+  // cells m = (p >> 1) ... floor((n - 1 + p) / 2) per axis
+  const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
+  if (cell) {
+    if (vox < ((int64_t)1 << 21)) return pl;           // (small volumes: too few blocks)
+    const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
+    return LapUpPlan{1, nbx * nby * nbz, nbx, nby};
+  }
+  const int Wo = (W + 1) / 2;
+  if (vox < 4096 || (int64_t)LR_ROWS * Wo * C * (int64_t)sizeof(float) > 64 * 1024) return pl;    // (the staged rows fit LDS)
+  const int nbz = (ncz + LR_CZ - 1) / LR_CZ;
+  return LapUpPlan{2, ncy * nbz, ncy, 0};
+}
+static void lap_up3_launch(const LapUpPlan& pl, const float* lo, const float* k, float scale, const float* addend, float* out,
+                           int D, int H, int W, int C, const float* addend_part, int addend_nparts, double addend_n,
+                           float eps, float* out_part, hipStream_t s) {
+  if (pl.kind == 1) {
+    if (C == 1) hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(pl.blocks), dim3(256), 0, s, lo, k, addend, out, D, H, W, scale, pl.a, pl.b, addend_part, addend_nparts, addend_n, eps, out_part);
+    else hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(pl.blocks), dim3(256), 0, s, lo, k, addend, out, D, H, W, scale, pl.a, pl.b, addend_part, addend_nparts, addend_n, eps, out_part);
+  } else {
+    const size_t lds = (size_t)LR_ROWS * ((W + 1) / 2) * C * sizeof(float);
+    if (C == 1) hipLaunchKernelGGL(lap_up3_row_kernel<1>, dim3(pl.blocks), dim3(LR_T), lds, s, lo, k, addend, out, D, H, W, scale, pl.a, addend_part, addend_nparts, addend_n, eps, out_part);
+    else hipLaunchKernelGGL(lap_up3_row_kernel<3>, dim3(pl.blocks), dim3(LR_T), lds, s, lo, k, addend, out, D, H, W, scale, pl.a, addend_part, addend_nparts, addend_n, eps, out_part);
+  }
+}
+
 int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend, float* out, int D, int H, int W, int C,
                int nd, nfs_stream_t stream) {
   NFS_REQUIRE(lo && k && out, "nfs_lap_up: null pointer");
   NFS_REQUIRE((nd == 2 && D == 1) || nd == 3, "nfs_lap_up: nd must be 2 (D == 1) or 3");
   if (int e = check_dims2(D, H, W, C)) return e;
   const int64_t n = (int64_t)D * H * W * C;
-  if (nd == 3 && (C == 1 || C == 3) && (int64_t)D * H * W >= ((int64_t)1 << 21)) {   // (small volumes: too few blocks)
-    const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
-    // cells m = (p >> 1) ... floor((n - 1 + p) / 2) per axis
-    const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
-    const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
-    if (C == 1) hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby, (const float*)nullptr, 0, 1.0, 0.f, (float*)nullptr);
-    else hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nbx * nby * nbz), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale, nbx, nby, (const float*)nullptr, 0, 1.0, 0.f, (float*)nullptr);
+  const LapUpPlan pl = lap_up3_plan(D, H, W, C, nd);
+  if (pl.kind) {
+    lap_up3_launch(pl, lo, k, scale, addend, out, D, H, W, C, nullptr, 0, 1.0, 0.f, nullptr, as_stream(stream));
     return check_launch("nfs_lap_up");
   }
   hipLaunchKernelGGL(lap_up_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W,
@@ -610,18 +779,7 @@ int nfs_lap_up(const float* lo, const float* k, float scale, const float* addend
   return check_launch("nfs_lap_up");
 }
 
-// blocks (= partial sums) of the cell kernel for an output volume; 0 where nfs_lap_up takes another kernel
-static int lap_up_cell_blocks(int D, int H, int W, int C, int nd, int* nbx_, int* nby_) {
-  if (!(nd == 3 && (C == 1 || C == 3) && (int64_t)D * H * W >= ((int64_t)1 << 21))) return 0;
-  const int pz = same_pad_before(D), py = same_pad_before(H), px = same_pad_before(W);
-  const int ncz = (D - 1 + pz) / 2 - (pz >> 1) + 1, ncy = (H - 1 + py) / 2 - (py >> 1) + 1, ncx = (W - 1 + px) / 2 - (px >> 1) + 1;
-  const int nbx = (ncx + LU_CX - 1) / LU_CX, nby = (ncy + LU_CY - 1) / LU_CY, nbz = (ncz + LU_CZ - 1) / LU_CZ;
-  if (nbx_) *nbx_ = nbx;
-  if (nby_) *nby_ = nby;
-  return nbx * nby * nbz;
-}
-
-int nfs_lap_up_rms_parts(int D, int H, int W, int C, int nd) { return lap_up_cell_blocks(D, H, W, C, nd, nullptr, nullptr); }
+int nfs_lap_up_rms_parts(int D, int H, int W, int C, int nd) { return lap_up3_plan(D, H, W, C, nd).blocks; }
 
 int nfs_lap_up_rms(const float* lo, const float* k, float scale, const float* addend, const float* addend_part,
                    int addend_nparts, int64_t addend_n, float eps, float* out, float* out_part, int D, int H, int W, int C,
@@ -629,16 +787,11 @@ int nfs_lap_up_rms(const float* lo, const float* k, float scale, const float* ad
   NFS_REQUIRE(lo && k && out, "nfs_lap_up_rms: null pointer");
   NFS_REQUIRE(!addend_part || (addend && addend_nparts > 0 && addend_n > 0),
               "nfs_lap_up_rms: addend partial sums without an addend, a count or a length");
-  int nbx = 0, nby = 0;
-  const int nb = lap_up_cell_blocks(D, H, W, C, nd, &nbx, &nby);
-  NFS_REQUIRE(nb > 0, "nfs_lap_up_rms: no cell-kernel instance for this shape (nfs_lap_up_rms_parts() == 0): use nfs_lap_up + "
-                      "nfs_normalize_mean");
-  if (C == 1)
-    hipLaunchKernelGGL(lap_up3_cell_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale,
-                       nbx, nby, addend_part, addend_nparts, (double)addend_n, eps, out_part);
-  else
-    hipLaunchKernelGGL(lap_up3_cell_kernel<3>, dim3(nb), dim3(256), 0, as_stream(stream), lo, k, addend, out, D, H, W, scale,
-                       nbx, nby, addend_part, addend_nparts, (double)addend_n, eps, out_part);
+  const LapUpPlan pl = lap_up3_plan(D, H, W, C, nd);
+  NFS_REQUIRE(pl.kind, "nfs_lap_up_rms: no 3-D kernel instance for this shape (nfs_lap_up_rms_parts() == 0): use nfs_lap_up + "
+                       "nfs_normalize_mean");
+  lap_up3_launch(pl, lo, k, scale, addend, out, D, H, W, C, addend_part, addend_nparts, (double)addend_n, eps, out_part,
+                 as_stream(stream));
   return check_launch("nfs_lap_up_rms");
 }
 

@@ -1109,6 +1109,27 @@ __device__ __forceinline__ void rb16s_split8(const float4& a, const float4& b, b
   H = __builtin_bit_cast(bf16x8s, hv); M = __builtin_bit_cast(bf16x8s, mv); L = __builtin_bit_cast(bf16x8s, lv);
 }
 
+// B once and for all: the fragment pack split at PACK time into three limb planes, [Z][N/16][K/32][3][64 lanes][8 bf16]
+// (6 bytes per filter value instead of 4).  Splitting B in registers costs every block ~44 VALU instructions per chunk
+// and 64 columns, repeated by each of the T / BM row blocks that share the columns (10 times at conv3_x and 8 views):
+// 4-5 us of a 40-us launch (profiles/r05_rb16s_ablation.txt, mask 2).  NFS_RB16S_PRE=0 builds the in-register form.
+#ifndef NFS_RB16S_PRE
+#define NFS_RB16S_PRE 1
+#endif
+__global__ void __launch_bounds__(256) winograd_pack_limbs16_kernel(const float4* __restrict__ uq16, uint4* __restrict__ ub,
+                                                                    int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (z, n tile, 32-deep chunk) x lane
+  if (gid >= total) return;
+  const int64_t grp = gid >> 6;
+  const int lane = (int)(gid & 63);
+  const float4 a = uq16[(2 * grp) * 64 + lane], b = uq16[(2 * grp + 1) * 64 + lane];
+  bf16x8s H, M, L;
+  rb16s_split8(a, b, H, M, L);
+  ub[(3 * grp) * 64 + lane] = __builtin_bit_cast(uint4, H);
+  ub[(3 * grp + 1) * 64 + lane] = __builtin_bit_cast(uint4, M);
+  ub[(3 * grp + 2) * 64 + lane] = __builtin_bit_cast(uint4, L);
+}
+
 template <int MT16, int NW16>
 __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, unsigned char* smem, int comp, int64_t m0,
                                                           int n0, int split) {
@@ -1121,8 +1142,14 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   const int nchunks = a.K / WG_KC / a.ksplit, c0 = split * nchunks;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
+#if NFS_RB16S_PRE
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(static_cast<const unsigned char*>(a.Ub16)) + (int64_t)comp * a.K * a.N * 6, 0,
+      (uint32_t)((int64_t)a.K * a.N * 6), 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.Uq16 + (int64_t)comp * a.K * a.N), 0, (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
+#endif
   // A staging: thread t moves float4 #(t & 7) (k = 4 (t & 7) ...) of rows (t >> 3) + 32 j; in fragment order those four
   // values are positions 8 q + 4 half .. + 3 with q = (t & 3), half = (t >> 2) & 1: 8 bytes at 16 q + 8 half
   const int q4 = 4 * (t & 7), r0 = t >> 3;
@@ -1135,13 +1162,14 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
     ao[j] = (r < BM && m < a.T) ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
   }
   const uint32_t bo = (uint32_t)lane * 16u;
-  const uint32_t kgs = (uint32_t)(a.K / 16) * 1024u;
+  constexpr int NB = NFS_RB16S_PRE ? 3 : 2;                       // 16-byte loads per lane, chunk and 16 columns
+  const uint32_t kgs = (uint32_t)(a.K / 16) * (NFS_RB16S_PRE ? 1536u : 1024u);
   const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
   // Two register sets, two chunks in flight per wave: at the split-limb rate a chunk's MFMAs take ~0.4 us, a round trip
   // to HBM 1-2 us, and the accumulators leave room for two blocks per CU only -- with one chunk ahead (the rb16 kernel's
   // distance) every chunk waited for its operands (measured: 40 us where the MFMAs need 12)
   constexpr int PF = NFS_RB16S_PF;                // register sets = chunks in flight per wave
-  float4 av[PF][AJ], bq[PF][NW16][2];
+  float4 av[PF][AJ], bq[PF][NW16][NB];
 #pragma unroll
   for (int st = 0; st < PF; ++st) {
     const int cc = c0 + (st < nchunks ? st : nchunks - 1);
@@ -1150,7 +1178,7 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
 #pragma unroll
     for (int nt = 0; nt < NW16; ++nt)
 #pragma unroll
-      for (int g = 0; g < 2; ++g) bq[st][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cc + g) * 1024u);
+      for (int g = 0; g < NB; ++g) bq[st][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(NB * cc + g) * 1024u);
   }
 
   const int afrag = (lane & 15) * WS_RB + 16 * (lane >> 4);     // + 16 mt rows, + plane
@@ -1186,12 +1214,14 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
       if (NFS_RB16S_ABL & 2) {                                                                                     \
         bf[nt][0] = __builtin_bit_cast(bf16x8s, bq[ST][nt][0]); bf[nt][1] = __builtin_bit_cast(bf16x8s, bq[ST][nt][1]); \
         bf[nt][2] = bf[nt][0];                                                                                     \
+      } else if (NFS_RB16S_PRE) {                                                                                  \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[nt][p] = __builtin_bit_cast(bf16x8s, bq[ST][nt][p % NB]);  \
       } else rb16s_split8(bq[ST][nt][0], bq[ST][nt][1], bf[nt][0], bf[nt][1], bf[nt][2]);                          \
     }                                                                                                              \
     if (!(NFS_RB16S_ABL & 8))                                                                                      \
       _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                          \
-        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                              \
-          bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(2 * cn + g) * 1024u);                     \
+        _Pragma("unroll") for (int g = 0; g < NB; ++g)                                                             \
+          bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(NB * cn + g) * 1024u);                    \
     _Pragma("unroll") for (int mg = 0; mg < MT16; mg += G) {                                                       \
       bf16x8s af[G][3];                                                                                            \
       _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
@@ -1493,7 +1523,7 @@ static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
     rec.split = 1;
-    rec.bytes = 4.0 * a.Z * ((double)a.T * a.K + (double)a.K * a.N + (double)a.T * a.N * a.ksplit);
+    rec.bytes = a.Z * (4.0 * a.T * a.K + (NFS_RB16S_PRE ? 6.0 : 4.0) * a.K * a.N + 4.0 * a.T * a.N * a.ksplit);   // V, limb planes, M
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
@@ -1531,6 +1561,12 @@ void winograd_pack_frag16(const float* up, float* uq, int K, int N, int64_t tota
   hipLaunchKernelGGL(winograd_pack_frag16_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, up, uq, K, N, total);
 }
 
+void winograd_pack_limbs16(const float* uq16, float* ub16, int K, int N, int Z, hipStream_t s) {
+  const int64_t total = (int64_t)Z * (N / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(winograd_pack_limbs16_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(uq16), reinterpret_cast<uint4*>(ub16), total);
+}
+
 static unsigned long long* g_gemm_prof = nullptr;        // NFS_ABLATE builds only (nfs_gemm_prof)
 
 static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s, int variant = 0) {
@@ -1547,7 +1583,7 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   a.dbg = dbg;
 #endif
   if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0 && !a.mask && !a.alpha_dev &&
-      a.alpha == 1.f && !a.symb) {
+      a.alpha == 1.f && !a.symb && (!NFS_RB16S_PRE || a.Ub16)) {
     // the 16-row register-B form in split-limb arithmetic (mode 1): 64- or 128-column tiles
     a.mt = (int)((a.T + bm - 1) / bm);
     if (bn > 128 && bm == 208) { bn = 128; a.nt = a.N / 128; }
@@ -1792,7 +1828,7 @@ int64_t winograd_workspace_floats(int B, int H, int W, int K, int N) {
 // also feeds the split-limb kernel, which splits it in registers),
 // and, for the layers the single-kernel path takes (winograd_fused.hip), the filters in its fragment order
 int64_t winograd_packed_floats(int Ci, int Co) {
-  return (int64_t)(36 + 36 + 36) * Ci * Co + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co);
+  return (int64_t)(36 + 36 + 36 + 54) * Ci * Co + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co);
 }
 
 int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipStream_t s) {
@@ -1806,8 +1842,11 @@ int winograd_pack(const float* w_hwio, float* up, int Ci, int Co, int kind, hipS
                        Nc, 36 * n);
     if (winograd_fusable(Kc, Nc))
       if (int e = winograd_pack_fused(up, up + 108 * n, Kc, Nc, s)) return e;
-    if (winograd5_channels(Kc, Nc))       // the F(5x5) filters and their fragment order, behind everything else
+    if (winograd5_channels(Kc, Nc))       // the F(5x5) filters, their fragment order and its limb planes
       if (int e = winograd5_pack(w_hwio, up + 108 * n + winograd_fused_packed_floats(Ci, Co), Ci, Co, kind, s)) return e;
+    // the limb planes of the 16 x 16 fragment pack (split-limb GEMM), behind everything else
+    winograd_pack_limbs16(up + 72 * n, up + 108 * n + winograd_fused_packed_floats(Ci, Co) + winograd5_packed_floats(Ci, Co),
+                          Kc, Nc, 36, s);
   } else
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up, Ci, Co, kind);
   return check_launch("winograd_pack");
@@ -1861,6 +1900,7 @@ int winograd_conv(const float* x, const float* U, const float* aux0, const float
   if (m == 4) {
     a.Uq = U + (int64_t)36 * K * N;
     a.Uq16 = U + (int64_t)72 * K * N;
+    a.Ub16 = U + (int64_t)108 * K * N + winograd_fused_packed_floats(K, N) + winograd5_packed_floats(K, N);
   }
   const int nsplit = launch_batched_gemm(a, comps, cus, s);
   if (m == 4) {

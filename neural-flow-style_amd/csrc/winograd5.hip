@@ -358,7 +358,8 @@ bool winograd5_takes(int H, int W, int K, int N) {
   return r5 * 10 <= r4 * 9;
 }
 
-int64_t winograd5_packed_floats(int Ci, int Co) { return winograd5_channels(Ci, Co) ? (int64_t)98 * Ci * Co : 0; }
+// 49 + 49 floats per (ci, co) and the limb planes of the second 49 (1.5 x: 73.5)
+int64_t winograd5_packed_floats(int Ci, int Co) { return winograd5_channels(Ci, Co) ? (int64_t)98 * Ci * Co + (int64_t)147 * Ci * Co / 2 : 0; }
 
 int64_t winograd5_workspace_floats(int B, int H, int W, int K, int N) {
   if (!winograd5_takes(H, W, K, N)) return 0;
@@ -372,6 +373,7 @@ int winograd5_pack(const float* w_hwio, float* up5, int Ci, int Co, int kind, hi
   const int Kc = kind == 0 ? Ci : Co, Nc = kind == 0 ? Co : Ci;
   hipLaunchKernelGGL(winograd5_pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, w_hwio, up5, Ci, Co, kind);
   winograd_pack_frag16(up5, up5 + 49 * n, Kc, Nc, 49 * n, s);
+  winograd_pack_limbs16(up5 + 49 * n, up5 + 98 * n, Kc, Nc, 49, s);
   return check_launch("winograd5_pack");
 }
 
@@ -397,6 +399,7 @@ int winograd5_conv(const float* x, const float* U5, const float* aux0, const flo
   }
   WgGemmArgs a{V, U5, M, T, K, N, (int64_t)K * N, (int64_t)N * 32, 32, 1.f, nullptr, nullptr};
   a.Uq16 = U5 + (int64_t)49 * K * N;
+  a.Ub16 = U5 + (int64_t)98 * K * N;
   const int nsplit = winograd_launch_batched_gemm(a, 49, cus, s);
   const unsigned ob = blocks_for(T * N, 256);
   if (nsplit != 1 && nsplit != 2) {

@@ -20,6 +20,7 @@ struct WgGemmArgs {
   int mt, nt, Z;             // tile counts (filled by launch_batched_gemm)
   const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
   const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 / rb16s kernels)
+  const void* Ub16 = nullptr;           // rb16s: the same pack as three bf16 limb planes [Z][N/16][K/32][3][64 lanes][8 bf16]
   int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
@@ -36,5 +37,7 @@ int winograd_launch_batched_gemm(const WgGemmArgs& a, int Z, int cus, hipStream_
 int winograd_ksplit(int64_t T, int K);
 // filters U [Z][K/32][N][32] -> the 16x16x4 fragment order [Z][N/16][K/16][64][4] (total = Z*K*N elements)
 void winograd_pack_frag16(const float* up, float* uq, int K, int N, int64_t total, hipStream_t s);
+// Uq16 [Z][N/16][K/16][64][4] floats -> the limb planes [Z][N/16][K/32][3][64][8 bf16] (1.5 x the floats); Z K N / 8 threads
+void winograd_pack_limbs16(const float* uq16, float* ub16, int K, int N, int Z, hipStream_t s);
 
 }  // namespace nfs

@@ -35,12 +35,12 @@ def test_argument_errors_do_not_need_a_gpu():
         _lib.call("nfs_render_fwd", None, None, None, 1, 1, 1, 1, 0.1, 0, None)
     assert _lib.lib().nfs_conv3x3_packed_floats(3, 64, 0) == 9 * 3 * 64              # conv1_1: direct only
     # + Winograd F(4x4,3x3) filters (36 floats per (ci, co))
-    # + the same filters in MFMA fragment order, for the 32x32x2 and the 16x16x4 instruction (36 + 36; the split-limb GEMM
-    #   splits the 16x16x4 pack in registers: no limb planes are stored)
-    # + where both channel counts are >= 128: the F(5x5,3x3) filters and their fragment order (49 + 49)
-    assert _lib.lib().nfs_conv3x3_packed_floats(256, 512, 0) == (9 + 36 + 36 + 36 + 98) * 256 * 512
+    # + the same filters in MFMA fragment order, for the 32x32x2 and the 16x16x4 instruction (36 + 36)
+    # + the 16x16x4 pack as three bf16 limb planes for the split-limb GEMM (6 bytes per value: 54)
+    # + where both channel counts are >= 128: the F(5x5,3x3) filters, their fragment order (49 + 49) and its limb planes (73.5)
+    assert _lib.lib().nfs_conv3x3_packed_floats(256, 512, 0) == (9 + 36 + 36 + 36 + 54 + 98) * 256 * 512 + 147 * 256 * 512 // 2
     # narrow layers (64 / 128 channels both sides): + the filters in the fragment order of the single-kernel path
-    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36 + 36 + 36 + 36) * 64 * 128
+    assert _lib.lib().nfs_conv3x3_packed_floats(64, 128, 0) == (9 + 36 + 36 + 36 + 54 + 36) * 64 * 128
 
 
 def test_no_cpu_fallback():

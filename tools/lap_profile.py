@@ -22,3 +22,7 @@ for lvl in range(3):
         t(lambda: ops.lap_up(lo, k, cur.shape, -5.0, addend=cur)), t(lambda: ops.normalize_mean(cur, use_abs=False, eps=1e-10))))
     cur = lo
 print("whole lap_normalize(scale_n=3): %.3f ms" % t(lambda: U.lap_normalize(g, scale_n=3, is_3d=True, c=3), 5))
+# reference points for level 0: a plain 96 MB -> 96 MB elementwise pass, and the transpose without its addend
+lo0 = ops.lap_down(g, k)
+print("torch.add 96 MB -> 96 MB: %.3f ms; lap_up without addend: %.3f ms; with: %.3f ms" % (
+    t(lambda: torch.add(g, 1.0)), t(lambda: ops.lap_up(lo0, k, g.shape, -5.0)), t(lambda: ops.lap_up(lo0, k, g.shape, -5.0, addend=g))))
