@@ -1278,8 +1278,16 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   }
 }
 
+// Blocks per CU the register allocation aims at for the instances of up to 10 accumulator tiles per wave: with 3 the
+// 80 x 128 tile drops from 196 to 144 VGPRs without a spill (48 x 128: 144 -> 112) and a third block sits in another phase
+// while one is in its MFMAs -- the VALU / load / barrier phases of a chunk hide under a neighbour's matrix work instead of
+// queueing behind the block's own (fixed tiles: 515.5 -> 488.1 us for the 14 launches of tools/split_gemm_bench.py; the
+// 8-view step 2.487 -> 2.450 ms; 4 spills the 80 x 128 instance: 763 us)
+#ifndef NFS_RB16S_OCC
+#define NFS_RB16S_OCC 3
+#endif
 template <int MT16, int NW16>
-__global__ void __launch_bounds__(256) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
+__global__ void __launch_bounds__(256, (MT16 * NW16 <= 10 ? NFS_RB16S_OCC : 1)) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
   const int nblocks = (int)gridDim.x, block = (int)blockIdx.x;
   const int per_xcd = nblocks / WG_XCDS;
