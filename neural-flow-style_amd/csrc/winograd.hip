@@ -1169,6 +1169,7 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   // to HBM 1-2 us, and the accumulators leave room for two blocks per CU only -- with one chunk ahead (the rb16 kernel's
   // distance) every chunk waited for its operands (measured: 40 us where the MFMAs need 12)
   constexpr int PF = NFS_RB16S_PF;                // register sets = chunks in flight per wave
+  static_assert(PF >= 2 && PF <= 4, "the K loop below is written for 2-4 register sets");
   float4 av[PF][AJ], bq[PF][NW16][NB];
 #pragma unroll
   for (int st = 0; st < PF; ++st) {
@@ -1278,7 +1279,7 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   }
 }
 
-// Blocks per CU the register allocation aims at for the instances of up to 10 accumulator tiles per wave: with 3 the
+// Blocks per CU the register allocation aims at for the instances of up to NFS_RB16S_OCC_TILES accumulator tiles per wave: with 3 the
 // 80 x 128 tile drops from 196 to 144 VGPRs without a spill (48 x 128: 144 -> 112) and a third block sits in another phase
 // while one is in its MFMAs -- the VALU / load / barrier phases of a chunk hide under a neighbour's matrix work instead of
 // queueing behind the block's own (fixed tiles: 515.5 -> 488.1 us for the 14 launches of tools/split_gemm_bench.py; the
@@ -1286,8 +1287,11 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
 #ifndef NFS_RB16S_OCC
 #define NFS_RB16S_OCC 3
 #endif
+#ifndef NFS_RB16S_OCC_TILES
+#define NFS_RB16S_OCC_TILES 14        // (10 -> 14, i.e. the 112 x 128 tile too: 486 -> 482 us)
+#endif
 template <int MT16, int NW16>
-__global__ void __launch_bounds__(256, (MT16 * NW16 <= 10 ? NFS_RB16S_OCC : 1)) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
+__global__ void __launch_bounds__(256, (MT16 * NW16 <= NFS_RB16S_OCC_TILES ? NFS_RB16S_OCC : 1)) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
   const int nblocks = (int)gridDim.x, block = (int)blockIdx.x;
   const int per_xcd = nblocks / WG_XCDS;
