@@ -1130,7 +1130,7 @@ __global__ void __launch_bounds__(256) winograd_pack_limbs16_kernel(const float4
   ub[(3 * grp + 2) * 64 + lane] = __builtin_bit_cast(uint4, L);
 }
 
-template <int MT16, int NW16>
+template <int MT16, int NW16, bool PRE>
 __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, unsigned char* smem, int comp, int64_t m0,
                                                           int n0, int split) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16;
@@ -1142,14 +1142,12 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
   const int nchunks = a.K / WG_KC / a.ksplit, c0 = split * nchunks;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.V + (int64_t)comp * a.T * a.K), 0, (uint32_t)(a.T * a.K * 4), 0x00020000);
-#if NFS_RB16S_PRE
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(static_cast<const unsigned char*>(a.Ub16)) + (int64_t)comp * a.K * a.N * 6, 0,
-      (uint32_t)((int64_t)a.K * a.N * 6), 0x00020000);
-#else
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.Uq16 + (int64_t)comp * a.K * a.N), 0, (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
-#endif
+  const __amdgpu_buffer_rsrc_t b_rsrc =
+      PRE ? __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned char*>(static_cast<const unsigned char*>(a.Ub16)) + (int64_t)comp * a.K * a.N * 6, 0,
+                (uint32_t)((int64_t)a.K * a.N * 6), 0x00020000)
+          : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Uq16 + (int64_t)comp * a.K * a.N), 0,
+                                              (uint32_t)((int64_t)a.K * a.N * 4), 0x00020000);
   // A staging: thread t moves float4 #(t & 7) (k = 4 (t & 7) ...) of rows (t >> 3) + 32 j; in fragment order those four
   // values are positions 8 q + 4 half .. + 3 with q = (t & 3), half = (t >> 2) & 1: 8 bytes at 16 q + 8 half
   const int q4 = 4 * (t & 7), r0 = t >> 3;
@@ -1162,8 +1160,8 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
     ao[j] = (r < BM && m < a.T) ? (uint32_t)((m * a.K + q4) * 4) : 0x80000000u;
   }
   const uint32_t bo = (uint32_t)lane * 16u;
-  constexpr int NB = NFS_RB16S_PRE ? 3 : 2;                       // 16-byte loads per lane, chunk and 16 columns
-  const uint32_t kgs = (uint32_t)(a.K / 16) * (NFS_RB16S_PRE ? 1536u : 1024u);
+  constexpr int NB = PRE ? 3 : 2;                                 // 16-byte loads per lane, chunk and 16 columns
+  const uint32_t kgs = (uint32_t)(a.K / 16) * (PRE ? 1536u : 1024u);
   const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
   // Two register sets, two chunks in flight per wave: at the split-limb rate a chunk's MFMAs take ~0.4 us, a round trip
   // to HBM 1-2 us, and the accumulators leave room for two blocks per CU only -- with one chunk ahead (the rb16 kernel's
@@ -1215,7 +1213,7 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
       if (NFS_RB16S_ABL & 2) {                                                                                     \
         bf[nt][0] = __builtin_bit_cast(bf16x8s, bq[ST][nt][0]); bf[nt][1] = __builtin_bit_cast(bf16x8s, bq[ST][nt][1]); \
         bf[nt][2] = bf[nt][0];                                                                                     \
-      } else if (NFS_RB16S_PRE) {                                                                                  \
+      } else if (PRE) {                                                                                            \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[nt][p] = __builtin_bit_cast(bf16x8s, bq[ST][nt][p % NB]);  \
       } else rb16s_split8(bq[ST][nt][0], bq[ST][nt][1], bf[nt][0], bf[nt][1], bf[nt][2]);                          \
     }                                                                                                              \
@@ -1290,7 +1288,7 @@ __device__ __forceinline__ void winograd_gemm_rb16s_block(const WgGemmArgs& a, u
 #ifndef NFS_RB16S_OCC_TILES
 #define NFS_RB16S_OCC_TILES 14        // (10 -> 14, i.e. the 112 x 128 tile too: 486 -> 482 us)
 #endif
-template <int MT16, int NW16>
+template <int MT16, int NW16, bool PRE>
 __global__ void __launch_bounds__(256, (MT16 * NW16 <= NFS_RB16S_OCC_TILES ? NFS_RB16S_OCC : 1)) winograd_gemm_rb16s_kernel(WgGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
   const int nblocks = (int)gridDim.x, block = (int)blockIdx.x;
@@ -1307,13 +1305,13 @@ __global__ void __launch_bounds__(256, (MT16 * NW16 <= NFS_RB16S_OCC_TILES ? NFS
   if constexpr (MT16 <= 5) {
     const int64_t left = (a.T - m0 + 15) / 16;
     const int live = left < MT16 ? (int)left : MT16;
-    if (live == MT16) winograd_gemm_rb16s_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
-    else if (live == 1) winograd_gemm_rb16s_block<1, NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 2 && live == 2) winograd_gemm_rb16s_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 3 && live == 3) winograd_gemm_rb16s_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 4 && live == 4) winograd_gemm_rb16s_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem_s, comp, m0, n0, split);
+    if (live == MT16) winograd_gemm_rb16s_block<MT16, NW16, PRE>(a, smem_s, comp, m0, n0, split);
+    else if (live == 1) winograd_gemm_rb16s_block<1, NW16, PRE>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 2 && live == 2) winograd_gemm_rb16s_block<(MT16 > 2 ? 2 : 1), NW16, PRE>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 3 && live == 3) winograd_gemm_rb16s_block<(MT16 > 3 ? 3 : 1), NW16, PRE>(a, smem_s, comp, m0, n0, split);
+    else if (MT16 > 4 && live == 4) winograd_gemm_rb16s_block<(MT16 > 4 ? 4 : 1), NW16, PRE>(a, smem_s, comp, m0, n0, split);
   } else {
-    winograd_gemm_rb16s_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
+    winograd_gemm_rb16s_block<MT16, NW16, PRE>(a, smem_s, comp, m0, n0, split);
   }
 }
 
@@ -1518,28 +1516,41 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
   }
 }
 
-template <int MT16, int NW16>
-static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
+// Which form of B a launch reads: the limb planes (6 bytes per filter value, no split in the kernel) from NFS_RB16S_PRE_ROWS
+// rows on, the float32 fragment pack split in registers (4 bytes per value) below -- a launch of a few dozen rows (one or
+// two views per GPU) is bound by its filter stream, 51 MB at conv4_x, and the planes would make that 77 (one view 0.958 ->
+// 0.997 ms, configs[1] 0.604 -> 0.654 with planes everywhere).  The limbs are the same numbers either way: bit-identical
+// results, so the choice may depend on T.  NFS_RB16S_PRE=0 builds: never the planes.
+#ifndef NFS_RB16S_PRE_ROWS
+#define NFS_RB16S_PRE_ROWS 128
+#endif
+template <int MT16, int NW16, bool PRE>
+static void launch_gemm_rb16s_pre(const WgGemmArgs& a, hipStream_t s) {
   constexpr int BM = 16 * MT16, BN = 64 * NW16, BMP = (BM + 31) / 32 * 32;
   constexpr int EPMAX = NW16 >= 4 ? 2 : 5;
   const size_t oper = (size_t)2 * 3 * BMP * WS_RB, tile = (size_t)16 * (MT16 < EPMAX ? MT16 : EPMAX) * (BN + 4) * sizeof(float);
   const size_t lds = oper > tile ? oper : tile;
   static std::once_flag attr_once;
   if (lds > 65536) std::call_once(attr_once, [&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16s_kernel<MT16, NW16>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16s_kernel<MT16, NW16, PRE>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int total = a.mt * a.nt * a.Z * a.ksplit, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
   if (timed) (void)hipEventRecord(rec.e0, s);
-  hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16, PRE>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
     rec.split = 1;
-    rec.bytes = a.Z * (4.0 * a.T * a.K + (NFS_RB16S_PRE ? 6.0 : 4.0) * a.K * a.N + 4.0 * a.T * a.N * a.ksplit);   // V, limb planes, M
+    rec.bytes = a.Z * (4.0 * a.T * a.K + (PRE ? 6.0 : 4.0) * a.K * a.N + 4.0 * a.T * a.N * a.ksplit);   // V, filters, M
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer_recs.push_back(rec);
   }
+}
+template <int MT16, int NW16>
+static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
+  if (NFS_RB16S_PRE && a.Ub16 && a.T >= NFS_RB16S_PRE_ROWS) launch_gemm_rb16s_pre<MT16, NW16, true>(a, s);
+  else launch_gemm_rb16s_pre<MT16, NW16, false>(a, s);
 }
 
 // the register-B kernel takes the plain Winograd GEMMs (packed filters, no mask / scale) with 32-bit operand offsets
@@ -1595,7 +1606,7 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   a.dbg = dbg;
 #endif
   if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0 && !a.mask && !a.alpha_dev &&
-      a.alpha == 1.f && !a.symb && (!NFS_RB16S_PRE || a.Ub16)) {
+      a.alpha == 1.f && !a.symb) {
     // the 16-row register-B form in split-limb arithmetic (mode 1): 64- or 128-column tiles
     a.mt = (int)((a.T + bm - 1) / bm);
     if (bn > 128 && bm == 208) { bn = 128; a.nt = a.N / 128; }
