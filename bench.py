@@ -1131,7 +1131,8 @@ def main():
                 "kernel": "nfs::winograd_gemm_rb16s_kernel: the 49 Winograd F(5x5,3x3) / 36 F(4x4,3x3) products of every conv "
                           "layer from conv3_1 on (forward and data gradient) as batched GEMMs in split-limb arithmetic on "
                           "v_mfma_f32_16x16x32_bf16 (A split into three bf16 limb planes while staged into LDS, B = the "
-                          "float32 fragment pack, split in registers; six limb products per 16 x 16 x 32 block): %d "
+                          "filters' limb planes made at pack time -- launches of fewer than 128 rows split the float32 "
+                          "pack in registers instead; six limb products per 16 x 16 x 32 block): %d "
                           "launches/step, %.2f ms/step = the largest share of the step"
                           % (s_n.value // psteps, s_ms.value / psteps),
                 "bound": "mfma", "achieved": 6.0 * tfe, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -1146,7 +1147,7 @@ def main():
                         "durations, HIP events on the launch stream around every launch (nfs_gemm_timer) in the headline "
                         "configuration; peak = the dense bf16 MFMA rate.  f32_equivalent_tflops = 2*Z*T*K*N / time, the "
                         "figure comparable with rounds 1-4 (f32-input MFMA, peak %.1f)" % MFMA_F32_PEAK_TF,
-                # the same launches against HBM: each reads V and the packed float32 filters and writes M exactly once when
+                # the same launches against HBM: each reads V and the packed filters and writes M exactly once when
                 # nothing is re-fetched (tools/pmc_rb16s_traffic.sh: 98 MB fetched for 71 MB of operands at conv4_2)
                 "hbm_side": {"algorithmic_bytes_per_launch": s_by.value / max(s_n.value, 1),
                              "achieved_gbs": s_by.value / (s_ms.value * 1e-3) / 1e9, "peak_gbs": HBM_PEAK_GBS,
