@@ -726,6 +726,35 @@ def test_conv_relu_bit_cache_equals_float_masks(ops, shape):
     assert torch.equal(q3, q3_ref)
 
 
+def test_limb_planes_of_the_packed_filters_are_the_round_to_nearest_split_of_the_float_pack(ops):
+    """nfs_conv3x3_pack writes the 16 x 16 fragment order of the transformed filters twice: as float32 (read and split in
+    registers by split-limb GEMM launches of fewer than 128 rows) and as three bf16 limb planes (read ready-made by the
+    larger launches).  The planes must be exactly hi = rne_bf16(x), mid = rne_bf16(x - hi), lo = rne_bf16(x - hi - mid) of the
+    float pack -- then both forms feed the MFMAs the same numbers and the row threshold cannot change a result.
+    Layout for Ci = Co = 64 (no F(5x5) pack): direct 9 | U 36 | Uq 36 | Uq16 36 | fused 36 | limb planes 54 floats per (ci, co)"""
+    Ci = Co = 64
+    n = Ci * Co
+    torch.manual_seed(5)
+    w = torch.randn(3, 3, Ci, Co) * torch.logspace(-6, 3, Co)[None, None, None, :]          # ten orders of magnitude
+    pk = ops.conv3x3_pack(dev(w), 0).cpu().numpy()
+    assert pk.size == (9 + 36 + 36 + 36 + 36 + 54) * n
+    uq16 = pk[(9 + 72) * n:(9 + 108) * n]
+    planes = pk[(9 + 144) * n:].view(np.uint16)
+    G = 36 * (Co // 16) * (Ci // 32)
+    vals = uq16.reshape(G, 2, 64, 4).transpose(0, 2, 1, 3).reshape(G, 64, 8)               # a lane's eight k of a chunk
+    got = planes.reshape(G, 3, 64, 8)
+
+    def rne_bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+        return r, (r.astype(np.uint32) << 16).view(np.float32)
+
+    h16, h = rne_bf16(vals)
+    m16, m = rne_bf16(vals - h)
+    l16, _ = rne_bf16(vals - h - m)
+    assert np.array_equal(got[:, 0], h16) and np.array_equal(got[:, 1], m16) and np.array_equal(got[:, 2], l16)
+
+
 @pytest.mark.parametrize("H,W,Ci,Co", [(25, 25, 256, 512), (24, 29, 512, 256), (50, 50, 256, 256),
                                        (24, 24, 512, 512), (22, 27, 256, 256)])             # the last two: F(4x4)
 def test_transforms_of_few_and_of_many_tiles_agree(ops, H, W, Ci, Co):
