@@ -1520,7 +1520,8 @@ static void launch_gemm_rb16(const WgGemmArgs& a, hipStream_t s) {
 // rows on, the float32 fragment pack split in registers (4 bytes per value) below -- a launch of a few dozen rows (one or
 // two views per GPU) is bound by its filter stream, 51 MB at conv4_x, and the planes would make that 77 (one view 0.958 ->
 // 0.997 ms, configs[1] 0.604 -> 0.654 with planes everywhere).  The limbs are the same numbers either way: bit-identical
-// results, so the choice may depend on T.  NFS_RB16S_PRE=0 builds: never the planes.
+// results, so the choice may depend on T (the environment variable of the same name moves the threshold, read once:
+// tests/test_ops_gpu.py runs both forms on one input in two processes).  NFS_RB16S_PRE=0 builds: never the planes.
 #ifndef NFS_RB16S_PRE_ROWS
 #define NFS_RB16S_PRE_ROWS 128
 #endif
@@ -1549,7 +1550,8 @@ static void launch_gemm_rb16s_pre(const WgGemmArgs& a, hipStream_t s) {
 }
 template <int MT16, int NW16>
 static void launch_gemm_rb16s(const WgGemmArgs& a, hipStream_t s) {
-  if (NFS_RB16S_PRE && a.Ub16 && a.T >= NFS_RB16S_PRE_ROWS) launch_gemm_rb16s_pre<MT16, NW16, true>(a, s);
+  static const int64_t pre_rows = [] { const char* e = getenv("NFS_RB16S_PRE_ROWS"); return e ? atoll(e) : (int64_t)NFS_RB16S_PRE_ROWS; }();
+  if (NFS_RB16S_PRE && a.Ub16 && a.T >= pre_rows) launch_gemm_rb16s_pre<MT16, NW16, true>(a, s);
   else launch_gemm_rb16s_pre<MT16, NW16, false>(a, s);
 }
 

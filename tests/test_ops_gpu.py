@@ -755,6 +755,36 @@ def test_limb_planes_of_the_packed_filters_are_the_round_to_nearest_split_of_the
     assert np.array_equal(got[:, 0], h16) and np.array_equal(got[:, 1], m16) and np.array_equal(got[:, 2], l16)
 
 
+def test_split_limb_gemm_from_limb_planes_and_from_the_float_pack_is_bit_identical(tmp_path):
+    """the same deep layers (F(5x5) and F(4x4), forward and data gradient, 8 views) in two processes: NFS_RB16S_PRE_ROWS=0
+    (every split-limb launch reads the filters' limb planes) and a threshold no launch reaches (every launch splits the
+    float pack in registers) -- outputs bit for bit the same"""
+    import subprocess, sys, os
+    code = (
+        "import sys, numpy as np, torch\n"
+        "import neural_flow_style_amd.ops as ops\n"
+        "torch.manual_seed(3)\n"
+        "outs = {}\n"
+        "for name, (B, H, W, Ci, Co) in {'f5': (8, 25, 25, 256, 512), 'f4': (8, 24, 24, 256, 256)}.items():\n"
+        "    x = torch.relu(torch.randn(B, H, W, Ci, device='cuda'))\n"
+        "    w = torch.randn(3, 3, Ci, Co, device='cuda') * 0.03\n"
+        "    b = torch.randn(Co, device='cuda') * 0.1\n"
+        "    wf, wd = ops.conv3x3_pack(w, 0), ops.conv3x3_pack(w, 1)\n"
+        "    y = ops.conv3x3_fwd(x, wf, b, Co, True)\n"
+        "    g = ops.conv3x3_dgrad(torch.randn(B, H, W, Co, device='cuda'), wd, Ci, x_in=x)\n"
+        "    outs[name + '_y'] = y.cpu().numpy(); outs[name + '_g'] = g.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **outs)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for tag, rows in (("planes", "0"), ("registers", "1000000000")):
+        out = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ, NFS_RB16S_PRE_ROWS=rows, NFS_GEMM_TUNE="0", PYTHONPATH=root)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=root, timeout=600)
+        res.append(np.load(out))
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 @pytest.mark.parametrize("H,W,Ci,Co", [(25, 25, 256, 512), (24, 29, 512, 256), (50, 50, 256, 256),
                                        (24, 24, 512, 512), (22, 27, 256, 256)])             # the last two: F(4x4)
 def test_transforms_of_few_and_of_many_tiles_agree(ops, H, W, Ci, Co):
