@@ -94,12 +94,45 @@ def relaunch(args):
     os.execv(sys.executable, cmd)
 
 
-def build_problem(G, V, device, rank, world):
+LIVE_BOX_FRAC = 1.0       # share of the volume inside the boxes the rotate adjoint accumulates (set from the mask in main())
+
+
+def live_box_fraction(gs):
+    """what nfs_rotate_bwd_coef_live works on, from the stylizer's current mask: (live voxels / all, volume of the per-tile
+    boxes / all, tiles skipped / all) -- the host-side restatement of the kernel's per-tile box (14 x 14 x 34 tiles)"""
+    D, H, W = gs.d0.shape
+    dil = 1 if gs.k > 0 else 0
+    words = gs._live_buf.view(torch.int64).cpu().numpy().view(np.uint64)
+    m = np.unpackbits(words.view(np.uint8), bitorder="little")[:D * H * W].reshape(D, H, W).astype(bool)
+    TZ, TY, TX = 14, 14, 34
+    vol = skipped = tiles = 0
+    for z0 in range(0, D, TZ):
+        for y0 in range(0, H, TY):
+            for x0 in range(0, W, TX):
+                tiles += 1
+                z1, y1, x1 = min(z0 + TZ, D), min(y0 + TY, H), min(x0 + TX, W)
+                sub = m[max(z0 - dil, 0):min(z1 + dil, D), max(y0 - dil, 0):min(y1 + dil, H), max(x0 - dil, 0):min(x1 + dil, W)]
+                if not sub.any():
+                    skipped += 1
+                    continue
+                ext = []
+                for ax, (lo, hi, n) in enumerate(((z0, z1, D), (y0, y1, H), (x0, x1, W))):
+                    idx = np.nonzero(sub.any(axis=tuple(a for a in range(3) if a != ax)))[0] + max(lo - dil, 0)
+                    ext.append(min(hi - 1, idx.max() + dil) - max(lo, idx.min() - dil) + 1)
+                vol += ext[0] * ext[1] * ext[2]
+    return float(m.mean()), vol / float(D * H * W), skipped / float(tiles)
+
+
+def build_problem(G, V, device, rank, world, dense=False):
     from neural_flow_style_amd import engine, vgg
     from neural_flow_style_amd import synthetic as S
     from neural_flow_style_amd import transform as T
     rng = np.random.RandomState(123)
     d0 = S.blob_density(G, rng)
+    if dense:
+        # the control for the data-dependent part of the step: a density that varies everywhere (no empty space, no
+        # plateau), so that no voxel's velocity gradient vanishes and nothing is skipped
+        d0 = (0.05 + 0.1 * np.random.RandomState(321).rand(G, G, G)).astype(np.float32)
     vel = S.curl_velocity(G, rng, max_cells=2.0)
     simg = S.style_image(G, G, rng)
     mats = S.uniform_views(V)
@@ -168,6 +201,11 @@ def work_of(name, a):
         V, D, H, W = a[4:8]
         # read u once + the (A, B) planes + write g_d (the adjoint reads no render-adjoint volume any more)
         return "B", 4.0 * V * D * H * W + 32.0 * V * H * W + 4.0 * D * H * W
+    if name == "nfs_rotate_bwd_coef_live":
+        V, D, H, W = a[4:8]
+        # only the boxes the live mask leaves are accumulated: u and the (A, B) planes are read for that fraction of the
+        # volume (LIVE_BOX_FRAC, measured from the mask in main()); g_d is written everywhere
+        return "B", LIVE_BOX_FRAC * (4.0 * V * D * H * W + 32.0 * V * H * W) + 4.0 * D * H * W
     if name == "nfs_rotate_bwd":
         V, D, H, W, C = a[3:8]
         return "B", 4.0 * V * D * H * W * C + 8.0 * D * H * W * C
@@ -177,6 +215,9 @@ def work_of(name, a):
     if name == "nfs_advect_fwd":
         D, H, W, C = a[3:7]
         return "B", (8.0 * C + 12.0) * D * H * W
+    if name == "nfs_advect_fwd_live":
+        D, H, W = a[4:7]
+        return "B", 20.125 * D * H * W
     if name == "nfs_advect_bwd":
         D, H, W, C = a[5:9]
         return "B", ((12.0 if a[3] else 8.0) * C + 24.0) * D * H * W
@@ -188,6 +229,9 @@ def work_of(name, a):
         D, H, W = a[6:9]
         # the same + the next iteration's forward sample written (4 bytes; its gathers hit the lines the adjoint just read)
         return "B", 84.0 * D * H * W
+    if name == "nfs_advect_bwd_adam_fwd_live":
+        D, H, W = a[7:10]
+        return "B", 84.125 * D * H * W             # + one mask bit per voxel
     if name in ("nfs_smooth3d_relu_fwd",):
         D, H, W = a[2:5]
         return "B", 8.0 * D * H * W
@@ -1035,6 +1079,36 @@ def main():
                              if gs.slab is not None else
                              ("replicated on every rank behind one all-reduce(sum)" if world > 1 else "one rank"))
         step_fn, units = views_step, 1
+        if gs._live_kw():
+            # data dependence of the headline, made visible: the rotate adjoint skips what only feeds voxels whose
+            # velocity gradient is an exact zero (empty space, plateaus).  (a) the same problem with skipping off,
+            # (b) a dense density on which nothing can be skipped -- both NOT the headline
+            global LIVE_BOX_FRAC
+            lf, bf, sk = live_box_fraction(gs)
+            LIVE_BOX_FRAC = bf
+            ctl = {"live_voxel_fraction": lf, "accumulated_box_fraction": bf, "tiles_skipped_fraction": sk,
+                   "note": "velocity variable: dL/dv(x) = g(x) * grad d0(x - v) is an exact zero where the eight "
+                           "back-traced density corners are equal, whatever g(x) is; the rotate adjoint therefore sums "
+                           "only the per-tile bounding boxes of the voxels within the smoothing stencil of a live voxel "
+                           "(nfs_rotate_bwd_coef_live).  The Adam update is BIT-identical with and without it "
+                           "(tests/test_dead_skip_gpu.py); the synthetic smoke of SURVEY 8(d) is %.0f %% live" % (100 * lf)}
+            gs.dead_skip = False
+            settle(views_step, 3)
+            dto, _ = time_steps(views_step, barrier, args.warmup, args.steps, device, world)
+            ctl["skipping_off"] = {"value": args.steps / dto, "unit": "iters/s", "ms_per_step": 1e3 * dto / args.steps}
+            gs.dead_skip = True
+            settle(views_step, 3)
+            if world == 1 and not args.no_other_configs:
+                gsd, rotd, _ = build_problem(G, V, device, rank, world, dense=True)
+                dstep = lambda: gsd.step(rotd, loss_view=True)
+                settle(dstep)
+                dtd, _ = time_steps(dstep, barrier, args.warmup, args.steps, device, world)
+                ctl["dense_density"] = {"value": args.steps / dtd, "unit": "iters/s", "ms_per_step": 1e3 * dtd / args.steps,
+                                        "live_voxel_fraction": live_box_fraction(gsd)[0],
+                                        "density": "0.05 + 0.1 U[0,1) per voxel: every stencil has differing corners"}
+                del gsd, rotd
+                torch.cuda.empty_cache()
+            out["dead_region_skipping"] = ctl
         if world > 1 and not args.no_other_configs:
             # the same box, the other sharding: a sequence with one frame per rank (weak scaling)
             res, cfg_, _, _ = frames_run()
@@ -1195,8 +1269,9 @@ def main():
         # and SURVEY 8(d)'s fully fused counts (rotate+render fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + 4VG^2)
         fam = [r for r in rows if r["kernel"] in ("nfs_rotate_render_fwd", "nfs_render_bwd", "nfs_rotate_bwd",
                                                   "nfs_rotate_render_fwd_coef", "nfs_render_ray_coef", "nfs_rotate_bwd_coef",
-                                                  "nfs_advect_fwd", "nfs_advect_bwd_adam", "nfs_advect_bwd",
-                                                  "nfs_advect_bwd_adam_fwd")]
+                                                  "nfs_rotate_bwd_coef_live", "nfs_advect_fwd", "nfs_advect_fwd_live",
+                                                  "nfs_advect_bwd_adam", "nfs_advect_bwd", "nfs_advect_bwd_adam_fwd",
+                                                  "nfs_advect_bwd_adam_fwd_live")]
         if fam:
             fms = sum(r["ms_per_step"] for r in fam)
             built = sum(r["achieved"] * r["ms_per_step"] for r in fam)        # GB/s * ms = MB

@@ -293,6 +293,29 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
                         int V, int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds,
                         int overwrite, nfs_stream_t stream);
 
+/* Dead-region skipping for the velocity variable (the adjoint of transform.py:557-569 is g(x) * grad d(x - v), an exact
+ * zero wherever the eight density corners the back-traced point interpolates are equal -- empty space and plateaus --
+ * WHATEVER g(x) is; so the chain above it need not produce g there).
+ *   live [nfs_live_mask_words(D,H,W)] 64-bit words, bit (z H + y) W + x = "the corners of voxel (z,y,x)'s back-traced
+ *   stencil differ".  nfs_advect_fwd_live = nfs_advect_fwd (C = 1; D,H,W >= 2, D*H*W % 4 == 0, else NFS_EINVAL) + the
+ *   mask; nfs_advect_bwd_adam_fwd_live = nfs_advect_bwd_adam_fwd + the mask of the UPDATED velocity (the one the next
+ *   iteration's adjoint needs).
+ *   nfs_rotate_bwd_coef_live = nfs_rotate_bwd_coef restricted to the voxels within `dilate` cells of a live voxel
+ *   (`dilate` = reach of the linear stencil between g_d and the advect adjoint: 1 for the 3x3x3 smoothing of
+ *   styler_3p.py:112-125, 0 without it; RT tile + 2 dilate <= 63): a tile without such voxels returns before its sample
+ *   loop, the others accumulate only the bounding box of theirs.  g_d there is bit-identical to nfs_rotate_bwd_coef;
+ *   elsewhere it holds zeros or partial sums, finite values that only ever meet the zero factor.  The resulting
+ *   velocity gradient / Adam update is bit-identical with and without the mask. */
+int nfs_live_mask_words(int D, int H, int W);
+int nfs_advect_fwd_live(const float* d, const float* vel, float* out, unsigned long long* live,
+                        int D, int H, int W, nfs_stream_t stream);
+int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                                 unsigned long long* live_next, int D, int H, int W, float lr_t, float beta1,
+                                 float beta2, float eps, nfs_stream_t stream);
+int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc,
+                             int V, int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds,
+                             int overwrite, const unsigned long long* live, int dilate, nfs_stream_t stream);
+
 /* d /= reduce_max(d) (styler_3p.py:158): G groups of n contiguous floats, one max per
  * group (v_batch views form one group; v_batch=1 => per view).  gmax [G] is written by
  * fwd and read by bwd; the max gradient is split equally among ties like TF's.  bwd `workspace`

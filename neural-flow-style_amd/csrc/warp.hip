@@ -149,7 +149,18 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
 // while the new velocity is still in registers (advect reads the velocity of its own voxel only; the gathered density is
 // constant): the forward advect launch of the next iteration and its 96 MB velocity read disappear.  Same arithmetic
 // as MODE 0 on the stored velocity: bit-identical to running nfs_advect_fwd afterwards.
-struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; float* adv_next = nullptr; };
+struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; float* adv_next = nullptr;
+                   unsigned long long* live = nullptr; };
+
+// live mask (nullable; whole-volume launches only): bit i of the mask = "the eight density corners the back-traced point
+// of voxel i interpolates are NOT all equal".  Where they are equal the sample does not depend on the coordinate and the
+// velocity gradient of that voxel is g * 0 whatever g is, so the adjoint chain above it (rotate, smooth) need not
+// produce g there (rotate_bwd_tiled_kernel skips the tiles / clips to the box that matter).  A wave's lanes hold 64
+// consecutive voxels per j: one ballot = one 64-bit word of the mask.
+__device__ __forceinline__ bool corners_differ(const F2u (&p)[4]) {
+  const float a = p[0].x;
+  return !(p[0].y == a && p[1].x == a && p[1].y == a && p[2].x == a && p[2].y == a && p[3].x == a && p[3].y == a);
+}
 
 // MODE 0: forward; 1: velocity gradient -> out; 2: velocity gradient consumed on the spot by the TF-Adam update of
 // the velocity itself (vel, m, v updated in place: every thread reads and writes only its own 4 voxels of them;
@@ -237,6 +248,10 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
       const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
       if (ok[j]) out[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
+      if (ad.live) {
+        const unsigned long long lv = __ballot(ok[j] && corners_differ(p[j]));
+        if (lane == 0 && first + 64 * j < n) ad.live[(first + 64 * j) >> 6] = lv;
+      }
     }
   } else {
 #pragma unroll
@@ -306,6 +321,10 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
         const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
         const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
         if (ok[j]) ad.adv_next[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
+        if (ad.live) {
+          const unsigned long long lv = __ballot(ok[j] && corners_differ(p[j]));
+          if (lane == 0 && first + 64 * j < n) ad.live[(first + 64 * j) >> 6] = lv;
+        }
       }
     }
   }
@@ -546,8 +565,11 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
                                                                          float bound_factor, int V, int D, int H,
                                                                          int W, int tiles_y, int tiles_x, int overwrite,
                                                                          int order, const float2* __restrict__ ab,
-                                                                         int nseg, int seg_len, int nbounds) {
+                                                                         int nseg, int seg_len, int nbounds,
+                                                                         const unsigned long long* __restrict__ live,
+                                                                         int dil) {
   __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
+  __shared__ int lbox[6];
   __shared__ ViewRows vrows[RT_VMAX];
   [[maybe_unused]] __shared__ float gred[RT_THREADS / 64];
   const int t = threadIdx.x;
@@ -577,12 +599,53 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
     bx = ox_ == 0 ? 0 : (ox_ == 1 ? tiles_x - 1 : ox_ - 1);
     if (order == 1) { bz = col / tiles_y; by = col % tiles_y; } else { by = col / tiles_z; bz = col % tiles_z; }
   }
-  const int z0 = bz * RT_TZ, y0 = by * RT_TY, x0 = bx * RT_TX;
-  const int z1 = min(z0 + RT_TZ, D) - 1, y1 = min(y0 + RT_TY, H) - 1, x1 = min(x0 + RT_TX, W) - 1;  // inclusive
-  for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
+  // the tile (T*) and the box of it this block accumulates (z0 ... x1, inclusive): the whole tile, or -- with a live
+  // mask -- the bounding box of the voxels whose gradient anything downstream reads
+  const int Tz0 = bz * RT_TZ, Ty0 = by * RT_TY, Tx0 = bx * RT_TX;
+  const int Tz1 = min(Tz0 + RT_TZ, D) - 1, Ty1 = min(Ty0 + RT_TY, H) - 1, Tx1 = min(Tx0 + RT_TX, W) - 1;
+  int z0 = Tz0, y0 = Ty0, x0 = Tx0, z1 = Tz1, y1 = Ty1, x1 = Tx1;
+  bool dead = false;
+  if (live) {
+    // live (nfs_advect_*_live): bit (z H + y) W + x set = the velocity gradient of voxel (z, y, x) can be non-zero.  The
+    // smooth adjoint between this kernel and the advect adjoint reads g_d within `dil` cells of such a voxel and nothing
+    // else of g_d is ever multiplied by a non-zero: only the box of the tile's voxels within `dil` of a live voxel needs
+    // its sums.  What is written outside that box (zeros) meets an exact zero factor downstream; inside it every sample
+    // that touches a voxel is still visited and the integer sums do not depend on the order: the velocity gradient is
+    // bit-identical to the unmasked launch (tests/test_dead_skip_gpu.py).
+    if (t < 6) lbox[t] = (t & 1) ? -1 : 0x7fffffff;
+    __syncthreads();
+    const int ez0 = max(Tz0 - dil, 0), ez1 = min(Tz1 + dil, D - 1), ey0 = max(Ty0 - dil, 0), ey1 = min(Ty1 + dil, H - 1);
+    const int ex0 = max(Tx0 - dil, 0), ex1 = min(Tx1 + dil, W - 1);
+    const int nry = ey1 - ey0 + 1, len = ex1 - ex0 + 1;                // len <= RT_TX + 2 dil <= 63
+    for (int r = t; r < (ez1 - ez0 + 1) * nry; r += RT_THREADS) {
+      const int rz = ez0 + r / nry, ry = ey0 + r % nry;
+      const int64_t bit0 = ((int64_t)rz * H + ry) * W + ex0;
+      const int sh = (int)(bit0 & 63);
+      unsigned long long bits = live[bit0 >> 6] >> sh;
+      if (sh + len > 64) bits |= live[(bit0 >> 6) + 1] << (64 - sh);
+      bits &= (1ull << len) - 1ull;
+      if (bits) {
+        atomicMin(&lbox[0], rz); atomicMax(&lbox[1], rz);
+        atomicMin(&lbox[2], ry); atomicMax(&lbox[3], ry);
+        atomicMin(&lbox[4], ex0 + (int)__builtin_ctzll(bits)); atomicMax(&lbox[5], ex0 + 63 - (int)__builtin_clzll(bits));
+      }
+    }
+    __syncthreads();
+    // (the box is the same for every lane: through readfirstlane it lives in scalar registers like the tile's corners)
+    int lb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lb[i] = __builtin_amdgcn_readfirstlane(lbox[i]);
+    dead = lb[1] < 0;
+    z0 = max(Tz0, lb[0] - dil); z1 = min(Tz1, lb[1] + dil);
+    y0 = max(Ty0, lb[2] - dil); y1 = min(Ty1, lb[3] + dil);
+    x0 = max(Tx0, lb[4] - dil); x1 = min(Tx1, lb[5] + dil);
+  }
+  if (!dead)
+    for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
   // fixed-point scale 2^k: |any voxel sum| <= bound_factor * max|g_out| must stay below 2^62
-  float gmax;
-  if (COEF) {                                     // the maximum of the coefficient kernel's per-block bounds
+  float gmax = 0.f;
+  if (dead) {                                     // (uniform over the block)
+  } else if (COEF) {                              // the maximum of the coefficient kernel's per-block bounds
     const float* bounds = reinterpret_cast<const float*>(gmax_bits);
     float m = 0.f;
     for (int i = t; i < nbounds; i += RT_THREADS) m = fmaxf(m, bounds[i]);
@@ -595,11 +658,11 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   } else {
     gmax = __uint_as_float(*gmax_bits);
   }
-  if (!(gmax > 0.f)) {                            // all-zero gradient: nothing to add
+  if (dead || !(gmax > 0.f)) {                    // nothing downstream reads this tile / all-zero gradient
     if (overwrite)
       for (int i = t; i < RT_TZ * RT_TY * RT_TX; i += RT_THREADS) {
         const int lx_ = i % RT_TX, ly_ = (i / RT_TX) % RT_TY, lz_ = i / (RT_TX * RT_TY);
-        const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
+        const int z = Tz0 + lz_, y = Ty0 + ly_, x = Tx0 + lx_;
         if (z < D && y < H && x < W) g_d[((int64_t)z * H + y) * W + x] = 0.f;
       }
     return;
@@ -735,9 +798,11 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   __syncthreads();
   for (int i = t; i < RT_TZ * RT_TY * RT_TX; i += RT_THREADS) {
     const int lx_ = i % RT_TX, ly_ = (i / RT_TX) % RT_TY, lz_ = i / (RT_TX * RT_TY);
-    const int z = z0 + lz_, y = y0 + ly_, x = x0 + lx_;
+    const int z = Tz0 + lz_, y = Ty0 + ly_, x = Tx0 + lx_;
     if (z < D && y < H && x < W) {
-      const long long q = (long long)acc[((lz_ + 1) * RT_LY + ly_ + 1) * RT_LX + lx_ + 1];
+      // (the accumulators are indexed from the box's origin; the tile's voxels outside the box hold no sum)
+      const bool in = z >= z0 && z <= z1 && y >= y0 && y <= y1 && x >= x0 && x <= x1;
+      const long long q = in ? (long long)acc[((z - z0 + 1) * RT_LY + (y - y0) + 1) * RT_LX + (x - x0) + 1] : 0ll;
       // the tiles partition the volume: with `overwrite` every voxel is written exactly once (no zero fill before)
       if (overwrite) g_d[((int64_t)z * H + y) * W + x] = q != 0 ? (float)ldexp((double)q, -kexp) : 0.f;
       else if (q != 0) g_d[((int64_t)z * H + y) * W + x] += (float)ldexp((double)q, -kexp);
@@ -813,7 +878,8 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
       const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
       hipLaunchKernelGGL(rotate_bwd_tiled_kernel<false>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                          g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
-                         ty, tx, (overwrite && v0 == 0) ? 1 : 0, order, (const float2*)nullptr, 1, D, 0);
+                         ty, tx, (overwrite && v0 == 0) ? 1 : 0, order, (const float2*)nullptr, 1, D, 0,
+                         (const unsigned long long*)nullptr, 0);
     }
     return check_launch("nfs_rotate_bwd(tiled)");
   }
@@ -828,12 +894,14 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
 // the tiled adjoint on the render's u volume and per-(view, segment, ray) coefficients: sample gradient = A u - B
 // (nfs_rotate_render_fwd_coef / nfs_render_ray_coef); bounds [nbounds]: per-block bounds on max |sample gradient|, whose
 // maximum sets the fixed-point scale
-int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H, int W,
-                        int nseg, int seg_len, const float* bounds, int nbounds, int overwrite, nfs_stream_t stream) {
+static int rotate_bwd_coef_impl(const char* who, const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V,
+                                int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds, int overwrite,
+                                const unsigned long long* live, int dilate, nfs_stream_t stream) {
   NFS_REQUIRE(u_rot && ab && rot && g_d_acc && bounds, "nfs_rotate_bwd_coef: null pointer");
   NFS_REQUIRE(nbounds > 0, "nfs_rotate_bwd_coef: no bounds");
   if (int e = check_dims(V, D, H, W, 1)) return e;
   NFS_REQUIRE(nseg > 0 && seg_len > 0 && (int64_t)nseg * seg_len >= D, "nfs_rotate_bwd_coef: the segments do not cover D");
+  NFS_REQUIRE(!live || (dilate >= 0 && RT_TX + 2 * dilate <= 63), "nfs_rotate_bwd_coef_live: dilate out of range");
   const int tz = (D + RT_TZ - 1) / RT_TZ, ty = (H + RT_TY - 1) / RT_TY, tx = (W + RT_TX - 1) / RT_TX;
   const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
   const float bound_factor = 4.f * (float)nmax * (float)V + 8.f;
@@ -844,9 +912,35 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
     hipLaunchKernelGGL(rotate_bwd_tiled_kernel<true>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                        u_rot + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, reinterpret_cast<const unsigned*>(bounds),
                        bound_factor, vn, D, H, W, ty, tx, (overwrite && v0 == 0) ? 1 : 0, order,
-                       reinterpret_cast<const float2*>(ab) + (int64_t)v0 * nseg * H * W, nseg, seg_len, nbounds);
+                       reinterpret_cast<const float2*>(ab) + (int64_t)v0 * nseg * H * W, nseg, seg_len, nbounds, live,
+                       dilate);
   }
-  return check_launch("nfs_rotate_bwd_coef");
+  return check_launch(who);
+}
+
+int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H, int W,
+                        int nseg, int seg_len, const float* bounds, int nbounds, int overwrite, nfs_stream_t stream) {
+  return rotate_bwd_coef_impl("nfs_rotate_bwd_coef", u_rot, ab, rot, g_d_acc, V, D, H, W, nseg, seg_len, bounds, nbounds,
+                              overwrite, nullptr, 0, stream);
+}
+
+// ... restricted to what a velocity variable can use: `live` is the mask nfs_advect_fwd_live / nfs_advect_bwd_adam_fwd_live
+// wrote for the CURRENT velocity ([nfs_live_mask_words] 64-bit words, bit = linear voxel index), `dilate` the reach of
+// the linear stencil between g_d and the advect adjoint (1 for the 3x3x3 smoothing, 0 without it).  Voxels of g_d further
+// than `dilate` from every live voxel are written as zeros or as partial sums -- values that only ever meet a zero
+// factor; all others are bit-identical to nfs_rotate_bwd_coef.  A tile without such voxels returns before its sample loop.
+int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H,
+                             int W, int nseg, int seg_len, const float* bounds, int nbounds, int overwrite,
+                             const unsigned long long* live, int dilate, nfs_stream_t stream) {
+  NFS_REQUIRE(live, "nfs_rotate_bwd_coef_live: null mask");
+  return rotate_bwd_coef_impl("nfs_rotate_bwd_coef_live", u_rot, ab, rot, g_d_acc, V, D, H, W, nseg, seg_len, bounds,
+                              nbounds, overwrite, live, dilate, stream);
+}
+
+// 64-bit words of the live mask of a [D,H,W] volume (one bit per voxel, rounded up to whole waves of 256 voxels)
+int nfs_live_mask_words(int D, int H, int W) {
+  const int64_t n = (int64_t)D * H * W;
+  return (D > 0 && H > 0 && W > 0 && n < ((int64_t)1 << 30)) ? (int)((n + 255) / 256 * 4) : 0;
 }
 
 int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, int W, int C, nfs_stream_t stream) {
@@ -861,6 +955,22 @@ int nfs_advect_fwd(const float* d, const float* vel, float* out, int D, int H, i
   }
   hipLaunchKernelGGL(warp_fwd_kernel<COORD_ADVECT>, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), a, out);
   return check_launch("nfs_advect_fwd");
+}
+
+// nfs_advect_fwd for a scalar field + the live mask of the back-traced stencils (see AdamFused::live): refuses the shapes
+// the four-voxel kernel does not take (NFS_EINVAL; callers then run without a mask)
+int nfs_advect_fwd_live(const float* d, const float* vel, float* out, unsigned long long* live, int D, int H, int W,
+                        nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && out && live, "nfs_advect_fwd_live: null pointer");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
+              "nfs_advect_fwd_live: needs D, H, W >= 2 and D*H*W %% 4 == 0");
+  AdamFused ad{};
+  ad.live = live;
+  hipLaunchKernelGGL(advect1_kernel<0>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
+                     (const float*)nullptr, out, D, H, W, ad, 0, D);
+  return check_launch("nfs_advect_fwd_live");
 }
 
 int nfs_advect_bwd(const float* d, const float* vel, const float* g_out, float* g_d_acc, float* g_vel, int D, int H,
@@ -906,6 +1016,21 @@ int nfs_advect_bwd_adam_fwd(const float* d, float* vel, const float* g_out, floa
   hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next}, 0, D);
   return check_launch("nfs_advect_bwd_adam_fwd");
+}
+
+// ... and the live mask of that next forward sample (for the next iteration's nfs_rotate_bwd_coef_live)
+int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                                 unsigned long long* live_next, int D, int H, int W, float lr_t, float beta1, float beta2,
+                                 float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v && adv_next && live_next, "nfs_advect_bwd_adam_fwd_live: null pointer");
+  NFS_REQUIRE(adv_next != d && adv_next != g_out, "nfs_advect_bwd_adam_fwd_live: adv_next must not alias d or g_out");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam_fwd_live: needs D, H, W >= 2 and D*H*W %% 4 == 0");
+  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live_next}, 0, D);
+  return check_launch("nfs_advect_bwd_adam_fwd_live");
 }
 
 // Slab forms (view-sharded runs shard the replicated field work over D-slabs, engine.GridStylizer): d is the whole

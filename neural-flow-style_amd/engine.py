@@ -392,7 +392,9 @@ class RenderStyleLoss(object):
             _add_logical(sg, self.content_layer, acts[self.content_layer], g)
 
     # -- the hot step -----------------------------------------------------------------------
-    def _chain(self, d, rot, g_d, overwrite=False, total_out=None):
+    accepts_live = True       # loss_and_grad(..., live=, dilate=): see ops.rotate_bwd_coef
+
+    def _chain(self, d, rot, g_d, overwrite=False, total_out=None, live=None, dilate=1):
         """render -> loss net -> Gram losses -> full adjoint for the views ``rot`` on the CURRENT stream;
         g_d [D,H,W] += dL/dd (= with ``overwrite``, two-pass rotate adjoint only); returns the per-view losses"""
         D, H, W = d.shape
@@ -431,7 +433,7 @@ class RenderStyleLoss(object):
         if self.rotate and d_rot is not None and seg is not None:
             # u form: per-(ray, segment) coefficients from the image gradient, then the rotate adjoint alone
             ab, bounds = ops.render_ray_coef(g_img, seg, self.tau)
-            ops.rotate_bwd_coef(d_rot, ab, rot, bounds, g_d_acc=g_d, overwrite=overwrite)
+            ops.rotate_bwd_coef(d_rot, ab, rot, bounds, g_d_acc=g_d, overwrite=overwrite, live=live, dilate=dilate)
         elif self.rotate and d_rot is not None:
             # two-pass adjoint: streaming render adjoint on the kept rotated volume (re-using its
             # buffer for the per-sample gradient) + LDS-tiled output-stationary rotate adjoint
@@ -465,9 +467,13 @@ class RenderStyleLoss(object):
         return bool(self.gram_grouped and self.layers and not self.w_tv and not self.hist_layers
                     and not self.content_layer and min(ngroups, V) <= 1)
 
-    def loss_and_grad(self, d, rot, g_d, overwrite=False, total_out=None):
+    def loss_and_grad(self, d, rot, g_d, overwrite=False, total_out=None, live=None, dilate=1):
         """d [D,H,W] (output of smooth3d_relu), rot [V,3,3] device tensor, g_d [D,H,W] += dL/dd.
         Returns loss per view [V] (device tensor).
+
+        ``live`` (``ops.live_mask`` written by the forward advect; velocity variable only): g_d is needed only within
+        ``dilate`` cells of a live voxel -- everywhere else the caller multiplies it by an exact zero -- and the rotate
+        adjoint of the coefficient form leaves it unsummed there (``ops.rotate_bwd_coef``).
 
         With >= 4 local views (and per-view normalisation, v_batch == 1) the views are split into groups
         whose whole chains run on separate HIP streams: the MFMA-bound conv launches of one group overlap
@@ -478,7 +484,8 @@ class RenderStyleLoss(object):
         ngroups = min(ngroups, V)
         if ngroups <= 1:
             return self._chain(d, rot, g_d, overwrite=overwrite and self.writes_gradient(V),
-                               total_out=total_out if (total_out is not None and self.sums_total(V)) else None)
+                               total_out=total_out if (total_out is not None and self.sums_total(V)) else None,
+                               live=live, dilate=dilate)
         assert not overwrite, "overwrite needs a single view batch (see writes_gradient)"
         assert total_out is None, "total_out needs a single view batch (see sums_total)"
         nst = min(self.vgg_streams, ngroups)
@@ -494,7 +501,7 @@ class RenderStyleLoss(object):
             si = gi % nst
             with torch.cuda.stream(self._streams[si]):
                 lo, hi = bounds[gi], bounds[gi + 1]
-                loss[lo:hi].copy_(self._chain(d, rot[lo:hi].contiguous(), g_parts[si]))
+                loss[lo:hi].copy_(self._chain(d, rot[lo:hi].contiguous(), g_parts[si], live=live, dilate=dilate))
         for si in range(nst):
             main.wait_stream(self._streams[si])
         for gp in g_parts:
@@ -630,7 +637,7 @@ class TFAdamState(object):
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.adam_tf_step(x, self.m, self.v, g, float(lr_t), float(self.b1), float(self.b2), float(self.eps))
 
-    def step_through_advect(self, vel, d0, g_adv, lr, adv_next=None):
+    def step_through_advect(self, vel, d0, g_adv, lr, adv_next=None, live_next=None):
         """the same update for the velocity variable of ``advect(d0, vel)`` given dL/d(advected density): the
         velocity gradient is formed and consumed inside one kernel (never written to HBM).  ``adv_next`` [D,H,W]
         (optional) receives advect(d0, updated vel) -- the next iteration's forward sample -- in the same pass"""
@@ -641,7 +648,7 @@ class TFAdamState(object):
         self.b2p = np.float32(self.b2p * self.b2)
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.advect_bwd_adam(d0, vel, g_adv, self.m, self.v, float(lr_t), float(self.b1), float(self.b2),
-                            float(self.eps), adv_next=adv_next)
+                            float(self.eps), adv_next=adv_next, live_next=live_next)
 
 
     def step_through_advect_slab(self, vel_slab, d0, g_adv_slab, z0, lr, adv_next=None):
@@ -778,6 +785,13 @@ class GridStylizer(object):
         self.fuse_advect = os.environ.get("NFS_FUSE_ADVECT", "1") != "0"
         self._adv_buf = None
         self._adv_src = None
+        # Dead-region skipping (velocity variable): the kernels that write the forward advect also write the mask of the
+        # voxels whose back-traced density corners differ; everywhere else the advect adjoint multiplies the incoming
+        # gradient by an exact zero, so step() / gradient() let the rotate adjoint skip what only feeds those voxels.
+        # The update is bit-identical with it on and off (tests/test_dead_skip_gpu.py); NFS_DEAD_SKIP=0 turns it off.
+        self.dead_skip = os.environ.get("NFS_DEAD_SKIP", "1") != "0"
+        self._live_buf = None
+        self._live_mark = None
         D, H, W = d0.shape
         if target == "v":
             self.var = torch.zeros(D, H, W, 3, dtype=torch.float32, device=d0.device)
@@ -945,8 +959,31 @@ class GridStylizer(object):
         D, H, W = self.d0.shape
         return self.target == "v" and self.fuse_adam and min(D, H, W) >= 2 and (D * H * W) % 4 == 0
 
-    def _adv_mark(self):
+    def _adv_mark(self, live=False):
         self._adv_src = (self.var, self.var._version, self.d0, self.d0._version)
+        self._live_mark = self._adv_src if live else None
+
+    def _live_target(self):
+        """the mask buffer the advect kernels fill beside the stored forward advect (None: skipping off / not applicable:
+        whole-volume velocity runs whose loss takes a mask; slab-sharded ranks hold only their planes' velocity)"""
+        if not (self.dead_skip and self.slab is None and getattr(self.loss, "accepts_live", False)
+                and self._adv_target() is not None):
+            return None
+        if self._live_buf is None or self._live_shape != tuple(self.d0.shape):
+            self._live_buf = ops.live_mask(*self.d0.shape, like=self.d0)
+            self._live_shape = tuple(self.d0.shape)
+            self._live_mark = None
+        return self._live_buf
+
+    def _live_valid(self):
+        return (self._live_buf is not None and self._live_mark is not None and self._live_mark is self._adv_src
+                and self._adv_valid())
+
+    def _live_kw(self):
+        """keyword arguments for loss_and_grad when the mask of the CURRENT forward advect exists"""
+        if self._live_target() is None or not self._live_valid():
+            return {}
+        return {"live": self._live_buf, "dilate": 1 if self.k > 0 else 0}
 
     def invalidate_forward(self):
         """forget the stored forward advect.  In-place torch ops on ``var`` / ``d0`` (also through ``detach()`` views, which
@@ -965,14 +1002,16 @@ class GridStylizer(object):
         (into the same buffer: a captured graph reads it by address)"""
         sl = self.slab
         buf = self._adv_target()
-        if buf is not None and self._adv_valid():
+        live = self._live_target()
+        if buf is not None and self._adv_valid() and (live is None or self._live_valid()):
             return buf
         if sl is None:
-            out = ops.advect_fwd(self.d0.unsqueeze(-1), self.var, out=None if buf is None else buf.unsqueeze(-1)).squeeze(-1)
+            out = ops.advect_fwd(self.d0.unsqueeze(-1), self.var, out=None if buf is None else buf.unsqueeze(-1),
+                                 live=live).squeeze(-1)
         else:
             out = ops.advect_fwd_slab(self.d0, self.var[sl.lo:sl.hi], sl.lo, out=buf)
         if buf is not None:
-            self._adv_mark()
+            self._adv_mark(live=live is not None)
         return out
 
     def forward_field(self):
@@ -986,12 +1025,14 @@ class GridStylizer(object):
         self.d_s = ops.smooth3d_relu_fwd(self.d_adv, self.k)
         return self.d_s
 
-    def field_gradient(self, rot_local, total=False):
+    def field_gradient(self, rot_local, total=False, for_variable=False):
         """forward + adjoint down to the smoothed density: (loss_per_view, dL/d d_s of the LOCAL views); ``total``: see
-        _loss_gradient"""
-        return self._loss_gradient(self.forward_field(), rot_local, total=total)
+        _loss_gradient.  ``for_variable``: the caller only takes the gradient on to the variable (step(), gradient()) --
+        with a velocity variable dL/d d_s is then left unsummed where the advect adjoint multiplies it by zero"""
+        d_s = self.forward_field()
+        return self._loss_gradient(d_s, rot_local, total=total, live_kw=self._live_kw() if for_variable else None)
 
-    def _loss_gradient(self, d_s, rot_local, total=False):
+    def _loss_gradient(self, d_s, rot_local, total=False, live_kw=None):
         """total: let the loss write the summed loss of the local views into the loss slot where it can (then None is
         returned instead of the per-view losses)"""
         V = rot_local.shape[0]
@@ -999,6 +1040,8 @@ class GridStylizer(object):
         if not fresh:
             self.g_ds.zero_()
         kw = {"overwrite": True} if fresh else {}
+        if live_kw:
+            kw.update(live_kw)
         if total and hasattr(self.loss, "sums_total") and self.loss.sums_total(V):
             kw["total_out"] = self._loss_slot
         losses = self.loss.loss_and_grad(d_s, rot_local, self.g_ds, **kw)
@@ -1016,7 +1059,7 @@ class GridStylizer(object):
 
     def gradient(self, rot_local):
         """one forward+backward over the local views; returns (loss_per_view, grad wrt variable)"""
-        losses, g_ds = self.field_gradient(rot_local)
+        losses, g_ds = self.field_gradient(rot_local, for_variable=self.target == "v")
         return losses, self.variable_gradient(g_ds)
 
     def _capture_key(self, rot_local):
@@ -1036,7 +1079,7 @@ class GridStylizer(object):
         (style / content targets, loss hyper-parameters, the addresses of d0 and the variable, the number of views):
         when any of that changes the graph is dropped and captured again.  The view matrices are copied into a
         static buffer."""
-        body = ((lambda r: self.field_gradient(r, total=True)) if with_field
+        body = ((lambda r: self.field_gradient(r, total=True, for_variable=self.target == "v")) if with_field
                 else (lambda r: self._loss_gradient(self.d_s, r, total=True)))
 
         def to_slot(losses):              # (None: the loss chain has written the total into the slot itself)
@@ -1047,7 +1090,8 @@ class GridStylizer(object):
             # the previous step's Adam kernel has not left it there (first step, a re-bound frame, a variable set by hand)
             self._apply_binding()
             self._advect_now()
-        key = self._capture_key(rot_local) + (with_field, self._adv_target() is not None)
+        key = self._capture_key(rot_local) + (with_field, self._adv_target() is not None,
+                                              with_field and bool(self._live_kw()))
         if self._graph is not None and key != self._graph_key:
             self._graph = None
             self._graph_warm = 0
@@ -1112,11 +1156,11 @@ class GridStylizer(object):
         if self.use_graph:
             total, g_ds = self._field_gradient_graphed(rot_local)
         elif self.pg is None:
-            losses, g_ds = self.field_gradient(rot_local, total=True)
+            losses, g_ds = self.field_gradient(rot_local, total=True, for_variable=self.target == "v")
             total = self._loss_slot if losses is None else None
             total_new = None if losses is None else losses.sum()             # (one kernel, a fresh tensor: no slot, no copy)
         else:
-            losses, g_ds = self.field_gradient(rot_local, total=True)
+            losses, g_ds = self.field_gradient(rot_local, total=True, for_variable=self.target == "v")
             if losses is not None:
                 torch.sum(losses, dim=0, keepdim=True, out=self._loss_slot)  # (one kernel: reduce straight into the slot)
             total = self._loss_slot
@@ -1132,9 +1176,11 @@ class GridStylizer(object):
         if self._fused_step_ok():
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
             adv = self._adv_target()
-            self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr, adv_next=adv)
+            live = self._live_target()
+            self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr, adv_next=adv,
+                                          live_next=live)
             if adv is not None:
-                self._adv_mark()
+                self._adv_mark(live=live is not None)
         else:
             self.adam.step(self.var, self.variable_gradient(g_ds), self.lr)
             self._adv_src = None          # (the variable moved and nothing wrote advect(d0, var) for it)

@@ -104,11 +104,24 @@ def rotate_bwd(g_out, rot, g_d_acc=None, tiled=True, g_max=None, overwrite=False
     return g_d_acc
 
 
-def advect_fwd(d, vel, out=None):
+def live_mask(D, H, W, like):
+    """buffer for the live mask of a [D,H,W] volume: nfs_live_mask_words 64-bit words, bit = linear voxel index, held as
+    float32 storage like every buffer that crosses the C-ABI here (``.view(torch.int64)`` to look at the words)"""
+    return torch.zeros(2 * int(_lib.lib().nfs_live_mask_words(D, H, W)), dtype=torch.float32, device=like.device)
+
+
+def advect_fwd(d, vel, out=None, live=None):
+    """``live`` (optional, ``live_mask``; scalar field only): also write the mask of the voxels whose back-traced density
+    corners differ, i.e. where the velocity gradient can be non-zero (see rotate_bwd_coef)"""
     D, H, W, Cn = d.shape
     if out is None:
         out = _empty(d.shape, d)
-    _lib.call("nfs_advect_fwd", _ptr(d), _ptr(vel), _ptr(out), D, H, W, Cn, _stream())
+    if live is not None:
+        assert Cn == 1
+        _lib.call("nfs_advect_fwd_live", _ptr(d), _ptr(vel), _ptr(out), _ptr(live), D, H, W, _stream())
+        _written(live)
+    else:
+        _lib.call("nfs_advect_fwd", _ptr(d), _ptr(vel), _ptr(out), D, H, W, Cn, _stream())
     return out
 
 
@@ -123,12 +136,18 @@ def advect_bwd(d, vel, g_out, need_d=True, need_vel=True, g_d_acc=None, g_vel=No
     return g_d_acc, g_vel
 
 
-def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None):
+def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None, live_next=None):
     """velocity gradient of advect consumed on the spot by the TF-Adam update of vel (vel, m, v in place);
-    ``adv_next`` [D,H,W] (optional): advect(d, updated vel), the next iteration's forward sample, written in the same pass"""
+    ``adv_next`` [D,H,W] (optional): advect(d, updated vel), the next iteration's forward sample, written in the same pass;
+    ``live_next`` (optional, with adv_next): the live mask of that sample (``advect_fwd``)"""
     D, H, W, Cn = d.shape
     assert Cn == 1
-    if adv_next is None:
+    if adv_next is not None and live_next is not None:
+        assert adv_next.is_contiguous() and adv_next.numel() == D * H * W
+        _lib.call("nfs_advect_bwd_adam_fwd_live", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), _ptr(adv_next),
+                  _ptr(live_next), D, H, W, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+        _written(live_next)
+    elif adv_next is None:
         _lib.call("nfs_advect_bwd_adam", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), D, H, W, float(lr_t),
                   float(beta1), float(beta2), float(eps), _stream())
     else:
@@ -395,15 +414,21 @@ def render_ray_coef(g_img, seg, tau, ab=None, bounds=None):
     return ab, bounds
 
 
-def rotate_bwd_coef(u_rot, ab, rot, bounds, g_d_acc=None, overwrite=False):
-    """the tiled rotate adjoint with the sample gradient A u - B formed on the fly; g_d_acc [D,H,W] (+=, or written)"""
+def rotate_bwd_coef(u_rot, ab, rot, bounds, g_d_acc=None, overwrite=False, live=None, dilate=1):
+    """the tiled rotate adjoint with the sample gradient A u - B formed on the fly; g_d_acc [D,H,W] (+=, or written).
+    ``live`` (``advect_fwd(live=...)``): only the voxels within ``dilate`` cells of a live voxel get their sums (the rest
+    of g_d is multiplied by an exact zero in the advect adjoint): tiles without any return at once"""
     V, D, H, W = u_rot.shape
     nseg, seg_len = render_coef_layout(V, D, H, W)
     if g_d_acc is None:
         overwrite = True
         g_d_acc = _empty((D, H, W), u_rot)
-    _lib.call("nfs_rotate_bwd_coef", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
-              _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _stream())
+    if live is not None:
+        _lib.call("nfs_rotate_bwd_coef_live", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
+                  _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _ptr(live), int(dilate), _stream())
+    else:
+        _lib.call("nfs_rotate_bwd_coef", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
+                  _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _stream())
     return g_d_acc
 
 
