@@ -303,9 +303,11 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
  *   nfs_rotate_bwd_coef_live = nfs_rotate_bwd_coef restricted to the voxels within `dilate` cells of a live voxel
  *   (`dilate` = reach of the linear stencil between g_d and the advect adjoint: 1 for the 3x3x3 smoothing of
  *   styler_3p.py:112-125, 0 without it; RT tile + 2 dilate <= 63): a tile without such voxels returns before its sample
- *   loop, the others accumulate only the bounding box of theirs.  g_d there is bit-identical to nfs_rotate_bwd_coef;
- *   elsewhere it holds zeros or partial sums, finite values that only ever meet the zero factor.  The resulting
- *   velocity gradient / Adam update is bit-identical with and without the mask. */
+ *   loop, the others accumulate only the bounding box of theirs, longest first (a small kernel ahead of the adjoint finds
+ *   the boxes and sorts the tiles by work into `workspace`, nfs_rotate_live_workspace_ints ints, zeroed ONCE by the
+ *   caller -- every launch leaves it ready for the next).  g_d there is bit-identical to nfs_rotate_bwd_coef;
+ *   elsewhere it holds zeros, which only ever meet the zero factor.  The resulting velocity gradient / Adam update is
+ *   bit-identical with and without the mask. */
 int nfs_live_mask_words(int D, int H, int W);
 int nfs_advect_fwd_live(const float* d, const float* vel, float* out, unsigned long long* live,
                         int D, int H, int W, nfs_stream_t stream);
@@ -314,7 +316,9 @@ int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out,
                                  float beta2, float eps, nfs_stream_t stream);
 int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc,
                              int V, int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds,
-                             int overwrite, const unsigned long long* live, int dilate, nfs_stream_t stream);
+                             int overwrite, const unsigned long long* live, int dilate, int* workspace,
+                             nfs_stream_t stream);
+int nfs_rotate_live_workspace_ints(int D, int H, int W);
 
 /* d /= reduce_max(d) (styler_3p.py:158): G groups of n contiguous floats, one max per
  * group (v_batch views form one group; v_batch=1 => per view).  gmax [G] is written by

@@ -100,7 +100,8 @@ SIGNATURES = {
     "nfs_live_mask_words": [_I, _I, _I],
     "nfs_advect_fwd_live": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nfs_advect_bwd_adam_fwd_live": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
-    "nfs_rotate_bwd_coef_live": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P],
+    "nfs_rotate_bwd_coef_live": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P],
+    "nfs_rotate_live_workspace_ints": [_I, _I, _I],
     "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "nfs_maxnorm_fwd": [_P, _P, _P, _I, _I, _P],
     "nfs_maxnorm_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],

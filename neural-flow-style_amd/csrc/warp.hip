@@ -554,6 +554,90 @@ __device__ __forceinline__ void rotate_tile_catchment(const float* r, int D, int
   out->my = ey > 1 ? 0xFFFFFFFFu / (unsigned)ey + 1u : 0u;     // ceil(2^32 / ey), ey >= 2
 }
 
+// ---- which tiles, and how much of each, a live-mask launch accumulates ------------------------------------------------
+// live (nfs_advect_*_live): bit (z H + y) W + x set = the velocity gradient of voxel (z, y, x) can be non-zero.  The
+// linear stencil between the rotate adjoint's g_d and the advect adjoint (the smoothing) reads g_d within `dil` cells of
+// such a voxel, and nothing else of g_d is ever multiplied by a non-zero: a tile needs the sums of the bounding box of
+// its voxels within `dil` of a live voxel, no more.  One block per tile finds that box; the block that finishes last
+// (a ticket) sorts the tiles by decreasing work into `order` -- the hardware starts blocks in index order, and with
+// boxes of very different sizes (and two fifths of the tiles empty on a smoke density) the long ones must not start last.
+// Workspace (ints): [0] ticket (zero before the first launch; the last block leaves it zero again), [LWS_BOXES + 8 t ...]
+// box of tile t = (z0, z1, y0, y1, x0, x1, work, -), [LWS_ORDER(ntiles) + i] the tile block i of the adjoint takes.
+constexpr int LWS_BOXES = 8;
+#define LWS_ORDER(ntiles) (nfs::LWS_BOXES + 8 * (ntiles))
+constexpr int LB_THREADS = 256, LB_CLASSES = 64;
+
+__global__ void __launch_bounds__(LB_THREADS) rotate_live_boxes_kernel(const unsigned long long* __restrict__ live, int D,
+                                                                       int H, int W, int tiles_y, int tiles_x, int dil,
+                                                                       int* __restrict__ ws) {
+  __shared__ int lbox[6];
+  __shared__ int hist[LB_CLASSES + 1];
+  __shared__ int last;
+  const int t = threadIdx.x, ntiles = gridDim.x, tile = blockIdx.x;
+  const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, bz = tile / (tiles_x * tiles_y);
+  const int Tz0 = bz * RT_TZ, Ty0 = by * RT_TY, Tx0 = bx * RT_TX;
+  const int Tz1 = min(Tz0 + RT_TZ, D) - 1, Ty1 = min(Ty0 + RT_TY, H) - 1, Tx1 = min(Tx0 + RT_TX, W) - 1;
+  if (t < 6) lbox[t] = (t & 1) ? -1 : 0x7fffffff;
+  __syncthreads();
+  const int ez0 = max(Tz0 - dil, 0), ez1 = min(Tz1 + dil, D - 1), ey0 = max(Ty0 - dil, 0), ey1 = min(Ty1 + dil, H - 1);
+  const int ex0 = max(Tx0 - dil, 0), ex1 = min(Tx1 + dil, W - 1);
+  const int nry = ey1 - ey0 + 1, len = ex1 - ex0 + 1;                // len <= RT_TX + 2 dil <= 63
+  for (int r = t; r < (ez1 - ez0 + 1) * nry; r += LB_THREADS) {
+    const int rz = ez0 + r / nry, ry = ey0 + r % nry;
+    const int64_t bit0 = ((int64_t)rz * H + ry) * W + ex0;
+    const int sh = (int)(bit0 & 63);
+    unsigned long long bits = live[bit0 >> 6] >> sh;
+    if (sh + len > 64) bits |= live[(bit0 >> 6) + 1] << (64 - sh);
+    bits &= (1ull << len) - 1ull;
+    if (bits) {
+      atomicMin(&lbox[0], rz); atomicMax(&lbox[1], rz);
+      atomicMin(&lbox[2], ry); atomicMax(&lbox[3], ry);
+      atomicMin(&lbox[4], ex0 + (int)__builtin_ctzll(bits)); atomicMax(&lbox[5], ex0 + 63 - (int)__builtin_clzll(bits));
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    int* b = ws + LWS_BOXES + tile * 8;
+    int work = 0;
+    int z0 = Tz0, z1 = Tz1, y0 = Ty0, y1 = Ty1, x0 = Tx0, x1 = Tx1;
+    if (lbox[1] >= 0) {
+      z0 = max(Tz0, lbox[0] - dil); z1 = min(Tz1, lbox[1] + dil);
+      y0 = max(Ty0, lbox[2] - dil); y1 = min(Ty1, lbox[3] + dil);
+      x0 = max(Tx0, lbox[4] - dil); x1 = min(Tx1, lbox[5] + dil);
+      // samples whose base cell lies in [lo - 1, hi] per axis; a box on the volume's border also catches the samples
+      // clamped onto it (a few cells' worth at these view angles)
+      const int cz = z1 - z0 + 2 + (z0 == 0 ? 6 : 0) + (z1 == D - 1 ? 6 : 0);
+      const int cy = y1 - y0 + 2 + (y0 == 0 ? 6 : 0) + (y1 == H - 1 ? 6 : 0);
+      const int cx = x1 - x0 + 2 + (x0 == 0 ? 6 : 0) + (x1 == W - 1 ? 6 : 0);
+      work = cz * cy * cx;
+    }
+    b[0] = z0; b[1] = z1; b[2] = y0; b[3] = y1; b[4] = x0; b[5] = x1; b[6] = work; b[7] = 0;
+    __threadfence();
+    last = atomicAdd(ws, 1) == ntiles - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  // ---- the last block: counting sort of the tiles by work class, largest first ----
+  __threadfence();
+  const volatile int* boxes = ws + LWS_BOXES;
+  constexpr int WMAX = (RT_TZ + 13) * (RT_TY + 13) * (RT_TX + 13);
+  for (int i = t; i <= LB_CLASSES; i += LB_THREADS) hist[i] = 0;
+  __syncthreads();
+  auto cls = [](int work) {   // 0 = most work ... LB_CLASSES - 1 = least, LB_CLASSES = none
+    return work == 0 ? LB_CLASSES : LB_CLASSES - 1 - min((int)(((int64_t)work * LB_CLASSES) / (WMAX + 1)), LB_CLASSES - 1);
+  };
+  for (int i = t; i < ntiles; i += LB_THREADS) atomicAdd(&hist[cls(boxes[i * 8 + 6])], 1);
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int c = 0; c <= LB_CLASSES; ++c) { const int n = hist[c]; hist[c] = run; run += n; }
+    ws[0] = 0;                                           // the ticket for the next launch
+  }
+  __syncthreads();
+  int* order = ws + LWS_ORDER(ntiles);
+  for (int i = t; i < ntiles; i += LB_THREADS) order[atomicAdd(&hist[cls(boxes[i * 8 + 6])], 1)] = i;
+}
+
 // COEF: g_out holds, per sample, the render's u (nfs_rotate_render_fwd with u_rot) and `ab` the per-(view, depth
 // segment, ray) pair (A, B) of nfs_render_ray_coef: the sample's gradient is A u - B, formed here instead of by a
 // render-adjoint pass over the whole rotated volume (K4a: 512 MB of traffic and a launch at eight views)
@@ -566,10 +650,8 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
                                                                          int W, int tiles_y, int tiles_x, int overwrite,
                                                                          int order, const float2* __restrict__ ab,
                                                                          int nseg, int seg_len, int nbounds,
-                                                                         const unsigned long long* __restrict__ live,
-                                                                         int dil) {
+                                                                         const int* __restrict__ lws) {
   __shared__ unsigned long long acc[RT_LZ * RT_LY * RT_LX];
-  __shared__ int lbox[6];
   __shared__ ViewRows vrows[RT_VMAX];
   [[maybe_unused]] __shared__ float gred[RT_THREADS / 64];
   const int t = threadIdx.x;
@@ -582,7 +664,17 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
   // shared catchment rows are L2 hits: FETCH_SIZE 340 -> 308 / 290 MB (raw counter) but 0.297 -> 0.308 ms -- the kernel is
   // bound by its VALU + LDS-atomic stream, not by the fetch, and the round-robin deal balances the slow border tiles better.
   int bz, by, bx;
-  if (order == 0) {
+  const int* lbox = nullptr;
+  if (lws) {
+    // live-mask launch: rotate_live_boxes_kernel has left, per tile, the box to accumulate and, in `order`, the tiles by
+    // decreasing work -- the longest blocks start first, the tiles nothing reads come last and return at once
+    const int ntiles = gridDim.x;
+    const int tile = lws[LWS_ORDER(ntiles) + blockIdx.x];
+    lbox = lws + LWS_BOXES + tile * 8;
+    bx = tile % tiles_x;
+    by = (tile / tiles_x) % tiles_y;
+    bz = tile / (tiles_x * tiles_y);
+  } else if (order == 0) {
     const int tiles_z = gridDim.x / (tiles_x * tiles_y);
     by = blockIdx.x % tiles_y;
     const int oz_ = (blockIdx.x / tiles_y) % tiles_z;
@@ -600,45 +692,17 @@ __global__ void __launch_bounds__(RT_THREADS, 8) rotate_bwd_tiled_kernel(const f
     if (order == 1) { bz = col / tiles_y; by = col % tiles_y; } else { by = col / tiles_z; bz = col % tiles_z; }
   }
   // the tile (T*) and the box of it this block accumulates (z0 ... x1, inclusive): the whole tile, or -- with a live
-  // mask -- the bounding box of the voxels whose gradient anything downstream reads
+  // mask -- the bounding box of the voxels whose gradient anything downstream reads.  What is written outside that box
+  // (zeros) meets an exact zero factor downstream; inside it every sample that touches a voxel is still visited and the
+  // integer sums do not depend on the order: the velocity gradient is bit-identical to the unmasked launch
+  // (tests/test_dead_skip_gpu.py).
   const int Tz0 = bz * RT_TZ, Ty0 = by * RT_TY, Tx0 = bx * RT_TX;
   const int Tz1 = min(Tz0 + RT_TZ, D) - 1, Ty1 = min(Ty0 + RT_TY, H) - 1, Tx1 = min(Tx0 + RT_TX, W) - 1;
   int z0 = Tz0, y0 = Ty0, x0 = Tx0, z1 = Tz1, y1 = Ty1, x1 = Tx1;
   bool dead = false;
-  if (live) {
-    // live (nfs_advect_*_live): bit (z H + y) W + x set = the velocity gradient of voxel (z, y, x) can be non-zero.  The
-    // smooth adjoint between this kernel and the advect adjoint reads g_d within `dil` cells of such a voxel and nothing
-    // else of g_d is ever multiplied by a non-zero: only the box of the tile's voxels within `dil` of a live voxel needs
-    // its sums.  What is written outside that box (zeros) meets an exact zero factor downstream; inside it every sample
-    // that touches a voxel is still visited and the integer sums do not depend on the order: the velocity gradient is
-    // bit-identical to the unmasked launch (tests/test_dead_skip_gpu.py).
-    if (t < 6) lbox[t] = (t & 1) ? -1 : 0x7fffffff;
-    __syncthreads();
-    const int ez0 = max(Tz0 - dil, 0), ez1 = min(Tz1 + dil, D - 1), ey0 = max(Ty0 - dil, 0), ey1 = min(Ty1 + dil, H - 1);
-    const int ex0 = max(Tx0 - dil, 0), ex1 = min(Tx1 + dil, W - 1);
-    const int nry = ey1 - ey0 + 1, len = ex1 - ex0 + 1;                // len <= RT_TX + 2 dil <= 63
-    for (int r = t; r < (ez1 - ez0 + 1) * nry; r += RT_THREADS) {
-      const int rz = ez0 + r / nry, ry = ey0 + r % nry;
-      const int64_t bit0 = ((int64_t)rz * H + ry) * W + ex0;
-      const int sh = (int)(bit0 & 63);
-      unsigned long long bits = live[bit0 >> 6] >> sh;
-      if (sh + len > 64) bits |= live[(bit0 >> 6) + 1] << (64 - sh);
-      bits &= (1ull << len) - 1ull;
-      if (bits) {
-        atomicMin(&lbox[0], rz); atomicMax(&lbox[1], rz);
-        atomicMin(&lbox[2], ry); atomicMax(&lbox[3], ry);
-        atomicMin(&lbox[4], ex0 + (int)__builtin_ctzll(bits)); atomicMax(&lbox[5], ex0 + 63 - (int)__builtin_clzll(bits));
-      }
-    }
-    __syncthreads();
-    // (the box is the same for every lane: through readfirstlane it lives in scalar registers like the tile's corners)
-    int lb[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lb[i] = __builtin_amdgcn_readfirstlane(lbox[i]);
-    dead = lb[1] < 0;
-    z0 = max(Tz0, lb[0] - dil); z1 = min(Tz1, lb[1] + dil);
-    y0 = max(Ty0, lb[2] - dil); y1 = min(Ty1, lb[3] + dil);
-    x0 = max(Tx0, lb[4] - dil); x1 = min(Tx1, lb[5] + dil);
+  if (lbox) {
+    z0 = lbox[0]; z1 = lbox[1]; y0 = lbox[2]; y1 = lbox[3]; x0 = lbox[4]; x1 = lbox[5];   // (scalar loads: uniform address)
+    dead = lbox[6] == 0;
   }
   if (!dead)
     for (int i = t; i < RT_LZ * RT_LY * RT_LX; i += RT_THREADS) acc[i] = 0ull;
@@ -879,7 +943,7 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
       hipLaunchKernelGGL(rotate_bwd_tiled_kernel<false>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                          g_out + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, gmax_bits, bound_factor, vn, D, H, W,
                          ty, tx, (overwrite && v0 == 0) ? 1 : 0, order, (const float2*)nullptr, 1, D, 0,
-                         (const unsigned long long*)nullptr, 0);
+                         (const int*)nullptr);
     }
     return check_launch("nfs_rotate_bwd(tiled)");
   }
@@ -896,7 +960,7 @@ int nfs_rotate_bwd(const float* g_out, const float* rot, float* g_d_acc, int V, 
 // maximum sets the fixed-point scale
 static int rotate_bwd_coef_impl(const char* who, const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V,
                                 int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds, int overwrite,
-                                const unsigned long long* live, int dilate, nfs_stream_t stream) {
+                                const unsigned long long* live, int dilate, int* lws, nfs_stream_t stream) {
   NFS_REQUIRE(u_rot && ab && rot && g_d_acc && bounds, "nfs_rotate_bwd_coef: null pointer");
   NFS_REQUIRE(nbounds > 0, "nfs_rotate_bwd_coef: no bounds");
   if (int e = check_dims(V, D, H, W, 1)) return e;
@@ -906,14 +970,17 @@ static int rotate_bwd_coef_impl(const char* who, const float* u_rot, const float
   const int nmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
   const float bound_factor = 4.f * (float)nmax * (float)V + 8.f;
   static const int order = [] { const char* e = getenv("NFS_RT_XCD"); return e ? atoi(e) : 0; }();
-  const int grid = order == 0 ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
+  const int grid = (live || order == 0) ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
+  if (live)
+    hipLaunchKernelGGL(rotate_live_boxes_kernel, dim3(tz * ty * tx), dim3(LB_THREADS), 0, as_stream(stream), live, D, H, W,
+                       ty, tx, dilate, lws);
   for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
     const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
     hipLaunchKernelGGL(rotate_bwd_tiled_kernel<true>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
                        u_rot + (int64_t)v0 * D * H * W, rot + v0 * 9, g_d_acc, reinterpret_cast<const unsigned*>(bounds),
                        bound_factor, vn, D, H, W, ty, tx, (overwrite && v0 == 0) ? 1 : 0, order,
-                       reinterpret_cast<const float2*>(ab) + (int64_t)v0 * nseg * H * W, nseg, seg_len, nbounds, live,
-                       dilate);
+                       reinterpret_cast<const float2*>(ab) + (int64_t)v0 * nseg * H * W, nseg, seg_len, nbounds,
+                       live ? (const int*)lws : (const int*)nullptr);
   }
   return check_launch(who);
 }
@@ -921,7 +988,7 @@ static int rotate_bwd_coef_impl(const char* who, const float* u_rot, const float
 int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H, int W,
                         int nseg, int seg_len, const float* bounds, int nbounds, int overwrite, nfs_stream_t stream) {
   return rotate_bwd_coef_impl("nfs_rotate_bwd_coef", u_rot, ab, rot, g_d_acc, V, D, H, W, nseg, seg_len, bounds, nbounds,
-                              overwrite, nullptr, 0, stream);
+                              overwrite, nullptr, 0, nullptr, stream);
 }
 
 // ... restricted to what a velocity variable can use: `live` is the mask nfs_advect_fwd_live / nfs_advect_bwd_adam_fwd_live
@@ -931,10 +998,18 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
 // factor; all others are bit-identical to nfs_rotate_bwd_coef.  A tile without such voxels returns before its sample loop.
 int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H,
                              int W, int nseg, int seg_len, const float* bounds, int nbounds, int overwrite,
-                             const unsigned long long* live, int dilate, nfs_stream_t stream) {
-  NFS_REQUIRE(live, "nfs_rotate_bwd_coef_live: null mask");
+                             const unsigned long long* live, int dilate, int* workspace, nfs_stream_t stream) {
+  NFS_REQUIRE(live && workspace, "nfs_rotate_bwd_coef_live: null mask / workspace");
   return rotate_bwd_coef_impl("nfs_rotate_bwd_coef_live", u_rot, ab, rot, g_d_acc, V, D, H, W, nseg, seg_len, bounds,
-                              nbounds, overwrite, live, dilate, stream);
+                              nbounds, overwrite, live, dilate, workspace, stream);
+}
+
+// ints of that workspace: a ticket, a box per tile, the tiles in the order the adjoint's blocks take them.  Zero it once;
+// every launch leaves the ticket zero again.
+int nfs_rotate_live_workspace_ints(int D, int H, int W) {
+  if (D <= 0 || H <= 0 || W <= 0) return 0;
+  const int nt = ((D + RT_TZ - 1) / RT_TZ) * ((H + RT_TY - 1) / RT_TY) * ((W + RT_TX - 1) / RT_TX);
+  return LWS_ORDER(nt) + nt;
 }
 
 // 64-bit words of the live mask of a [D,H,W] volume (one bit per voxel, rounded up to whole waves of 256 voxels)

@@ -414,6 +414,9 @@ def render_ray_coef(g_img, seg, tau, ab=None, bounds=None):
     return ab, bounds
 
 
+_LIVE_WS = {}      # (device, D, H, W, stream) -> workspace of nfs_rotate_bwd_coef_live
+
+
 def rotate_bwd_coef(u_rot, ab, rot, bounds, g_d_acc=None, overwrite=False, live=None, dilate=1):
     """the tiled rotate adjoint with the sample gradient A u - B formed on the fly; g_d_acc [D,H,W] (+=, or written).
     ``live`` (``advect_fwd(live=...)``): only the voxels within ``dilate`` cells of a live voxel get their sums (the rest
@@ -424,8 +427,13 @@ def rotate_bwd_coef(u_rot, ab, rot, bounds, g_d_acc=None, overwrite=False, live=
         overwrite = True
         g_d_acc = _empty((D, H, W), u_rot)
     if live is not None:
+        # (one per stream: view groups on side streams run this adjoint concurrently, and a launch owns its ticket)
+        key = (u_rot.device, D, H, W, int(_stream(u_rot.device) or 0))
+        ws = _LIVE_WS.get(key)
+        if ws is None:      # zeroed once: every launch leaves its ticket zero again (and a captured graph keeps the address)
+            ws = _LIVE_WS[key] = _zeros((int(_lib.lib().nfs_rotate_live_workspace_ints(D, H, W)),), u_rot)
         _lib.call("nfs_rotate_bwd_coef_live", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
-                  _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _ptr(live), int(dilate), _stream())
+                  _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _ptr(live), int(dilate), _ptr(ws), _stream())
     else:
         _lib.call("nfs_rotate_bwd_coef", _ptr(u_rot), _ptr(ab), _ptr(rot), _ptr(g_d_acc), V, D, H, W, nseg, seg_len,
                   _ptr(bounds), int(bounds.numel()), int(bool(overwrite)), _stream())
