@@ -591,40 +591,45 @@ def other_configs(device, base):
         out.append({"config": "configs[0]", "error": repr(e)})
 
     # configs[0] end to end: Styler(config).run of the 2-D colour stylizer (particle colours -> splat -> masked style + TV ->
-    # adjoint -> TF-Adam), 50 iterations at 128 x 128 (tools/dambreak_bench.py)
-    try:
-        from neural_flow_style_amd.config import get_config as _gc
-        from neural_flow_style_amd.styler_2p import Styler as Styler2
-        rng = np.random.RandomState(7)
-        pp2 = S.dambreak_particles(80, rng)
-        rr2 = rng.uniform(900, 1100, (pp2.shape[0], 1)).astype(np.float32)
-        c2, _ = _gc([])
-        for k_, v_ in dict(network="vgg_19.ckpt", data_dir="/nonexistent", synthetic_weights=True, resolution=[128, 128],
-                           domain=[3.2, 3.2], radius=0.0125, nsize=2, support=4, rest_density=1000, clip=False,
-                           target_field="c", num_frames=1, batch_size=1, frames_per_opt=200, window_sigma=3, lr=0.01,
-                           iter=50, octave_n=1, octave_scale=1.7, style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0,
-                           w_content=0, style_mask=True, w_tv=0.01, style_target=S.style_image(128, 128, rng),
-                           resize_scale=1.0).items():
-            setattr(c2, k_, v_)
-        c2.rng = np.random.RandomState(c2.seed)
-        import contextlib, io as _io
-        with contextlib.redirect_stdout(_io.StringIO()):           # (the stylizer prints its octave sizes)
-            st2 = Styler2(c2)
-            st2.load_img([128, 128])
-            st2.run({"p": [pp2], "r": [rr2]})                       # warm-up (weight packing, workspaces)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            res2 = st2.run({"p": [pp2], "r": [rr2]})
-            torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t0) / c2.iter
-        out.append({"config": "configs[0] dambreak2d 128x128 END TO END: Styler(config).run of the 2-D colour stylizer, %d "
-                              "particles, conv3_1, style mask + TV, 50 Adam iterations" % pp2.shape[0],
-                    "value": 1.0 / dt2, "unit": "iters/s", "ms_per_step": 1e3 * dt2,
-                    "loss_first_last": [float(res2["l"][0][0]), float(res2["l"][0][-1])],
-                    "loss_chain_mode": getattr(st2._graph_loss, "mode", None) if st2._graph_loss else "eager"})
-        del st2
-    except Exception as e:  # pragma: no cover
-        out.append({"config": "configs[0] end to end", "error": repr(e)})
+    # adjoint -> TF-Adam), 50 iterations at 128 x 128 -- on SURVEY 8(d)'s workload (16 384 particles: two per cell and
+    # dimension on the dam-break lattice, scene/dambreak2d.py:96-103) and, beside it, on the 1 344 particles rounds 3-5
+    # quoted (tools/dambreak_bench.py)
+    for n_side, n_keep in ((280, 16384), (80, None)):
+        try:
+            from neural_flow_style_amd.config import get_config as _gc
+            from neural_flow_style_amd.styler_2p import Styler as Styler2
+            rng = np.random.RandomState(7)
+            pp2 = S.dambreak_particles(n_side, rng, n_keep)
+            rr2 = rng.uniform(900, 1100, (pp2.shape[0], 1)).astype(np.float32)
+            c2, _ = _gc([])
+            for k_, v_ in dict(network="vgg_19.ckpt", data_dir="/nonexistent", synthetic_weights=True, resolution=[128, 128],
+                               domain=[3.2, 3.2], radius=0.0125, nsize=2, support=4, rest_density=1000, clip=False,
+                               target_field="c", num_frames=1, batch_size=1, frames_per_opt=200, window_sigma=3, lr=0.01,
+                               iter=50, octave_n=1, octave_scale=1.7, style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0,
+                               w_content=0, style_mask=True, w_tv=0.01, style_target=S.style_image(128, 128, rng),
+                               resize_scale=1.0).items():
+                setattr(c2, k_, v_)
+            c2.rng = np.random.RandomState(c2.seed)
+            import contextlib, io as _io
+            with contextlib.redirect_stdout(_io.StringIO()):           # (the stylizer prints its octave sizes)
+                st2 = Styler2(c2)
+                st2.load_img([128, 128])
+                st2.run({"p": [pp2], "r": [rr2]})                       # warm-up (weight packing, workspaces)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res2 = st2.run({"p": [pp2], "r": [rr2]})
+                torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / c2.iter
+            out.append({"config": "configs[0] dambreak2d 128x128 END TO END: Styler(config).run of the 2-D colour stylizer, %d "
+                                  "particles%s, conv3_1, style mask + TV, 50 Adam iterations"
+                                  % (pp2.shape[0], " (SURVEY 8(d)'s workload)" if n_keep else " (the sparse lattice of rounds 3-5)"),
+                        "particles": int(pp2.shape[0]),
+                        "value": 1.0 / dt2, "unit": "iters/s", "ms_per_step": 1e3 * dt2,
+                        "loss_first_last": [float(res2["l"][0][0]), float(res2["l"][0][-1])],
+                        "loss_chain_mode": getattr(st2._graph_loss, "mode", None) if st2._graph_loss else "eager"})
+            del st2
+        except Exception as e:  # pragma: no cover
+            out.append({"config": "configs[0] end to end (%d-lattice)" % n_side, "error": repr(e)})
 
     # configs[4]: chocolate-scale splat, 5e5 particles -> 200^3 (grid-cell order as Styler.run processes them)
     try:
@@ -1127,8 +1132,30 @@ def main():
                                                  % (4 * G ** 3 // 2 ** 20)}
     if world > 1:
         import torch.distributed as dist
+        from neural_flow_style_amd import parallel as _par
         out["collective_backend"] = dist.get_backend()
         out["world_size_seen"] = dist.get_world_size()
+        # what every rank saw: the backend (nccl = RCCL), the group size, its device, and the collectives of a step timed
+        # on the device (event pair on the stream that waits for the collective) -- a SCALE run then shows that RCCL had N
+        # ranks on N devices and how far the exchange is from the 0.05-0.37 ms DESIGN section 7 estimates for it
+        tsteps = max(2, min(args.steps, 5))
+        barrier()
+        _par.TIMER = {}
+        for _ in range(tsteps):
+            step_fn()
+        barrier()
+        coll = _par.timer_summary(tsteps)
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "backend": dist.get_backend(),
+                "world_size": dist.get_world_size(), "device_index": int(device.index), "device_name": props.name,
+                "device_uuid": str(getattr(props, "uuid", "")), "views_local": None if rot_local is None else int(rot_local.shape[0]),
+                "hipgraph": None if gs is None else bool(gs.use_graph), "collectives": coll,
+                "collective_device_ms_per_step": sum(c["device_ms_per_step"] for c in coll.values())}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        out["ranks"] = allr
+        out["collective_ms_per_step_max_over_ranks"] = max(r["collective_device_ms_per_step"] for r in allr)
+        out["distinct_devices"] = len(set((r["device_uuid"] or r["device_index"]) for r in allr))
 
     if not args.no_sustained:
         out["sustained"] = dict(sustained(step_fn, barrier, units, device, world), unit=out["unit"])

@@ -25,12 +25,46 @@ def shard(items, rank=None, world=None, group=None):
     return list(items[rank::world])
 
 
+# Optional timing of the collectives (bench.py --gpus N): when TIMER is a dict every collective below is bracketed by an
+# event pair on the current stream (the stream the collective's result is waited on) and a host clock; entries are
+# name -> [(start_event, end_event, payload_bytes, host_seconds)].  Off by default: two event records per call.
+TIMER = None
+
+
+def _timed(name, t, fn):
+    if TIMER is None or not t.is_cuda:
+        return fn()
+    import time
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    h0 = time.perf_counter()
+    r = fn()
+    h1 = time.perf_counter()
+    e1.record()
+    TIMER.setdefault(name, []).append((e0, e1, int(t.numel() * t.element_size()), h1 - h0))
+    return r
+
+
+def timer_summary(steps):
+    """per collective: calls and milliseconds per step (device: between the event pairs; host: inside the call), payload
+    bytes per call.  Call after a device synchronisation; empties the timer."""
+    global TIMER
+    out = {}
+    for name, recs in (TIMER or {}).items():
+        out[name] = {"calls_per_step": len(recs) / float(steps),
+                     "device_ms_per_step": sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs) / float(steps),
+                     "host_ms_per_step": 1e3 * sum(h for _, _, _, h in recs) / float(steps),
+                     "payload_bytes_per_call": recs[0][2]}
+    TIMER = None
+    return out
+
+
 def all_reduce_sum_(tensors, group=None):
     """in-place sum over ranks of a list of tensors (field gradient, loss); no-op for world 1"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return tensors
     for t in tensors:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _timed("all_reduce", t, lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
     return tensors
 
 
@@ -39,14 +73,15 @@ def reduce_scatter_sum(out, inp, group=None):
     every rank keeps only its own chunk"""
     assert out.is_contiguous() and inp.is_contiguous() and inp.numel() == out.numel() * dist.get_world_size(group)
     # (flat views: gloo wants input.shape[0] == world * output.shape[0])
-    dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=dist.ReduceOp.SUM, group=group)
+    _timed("reduce_scatter", inp,
+           lambda: dist.reduce_scatter_tensor(out.view(-1), inp.view(-1), op=dist.ReduceOp.SUM, group=group))
     return out
 
 
 def all_gather_into(out, inp, group=None):
     """out [world, chunk...] <- every rank's inp [chunk...]: the second half of an all-reduce"""
     assert out.is_contiguous() and inp.is_contiguous() and out.numel() == inp.numel() * dist.get_world_size(group)
-    dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
+    _timed("all_gather", out, lambda: dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group))
     return out
 
 

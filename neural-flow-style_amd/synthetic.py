@@ -65,10 +65,15 @@ def blob_particles(N, rng, n_blobs=16):
     return np.clip(p, 0.05, 0.95).astype(np.float32)
 
 
-def dambreak_particles(n_side, rng):
-    """2-D jittered lattice filling the lower-left 35% x 60% box, [N,2] ordered (y,x) in [0,1]"""
+def dambreak_particles(n_side, rng, n=None):
+    """2-D jittered lattice filling the lower-left 35% x 60% box, [N,2] ordered (y,x) in [0,1].  ``n``: keep the first n
+    particles (row-major from the floor up): SURVEY 8(d)'s configs[0] workload is ``dambreak_particles(280, rng, 16384)``
+    (scene/dambreak2d.py:96-103 at two particles per cell and dimension on the 128 x 128 grid)"""
     ny, nx = int(n_side * 0.60), int(n_side * 0.35)
     yy, xx = np.meshgrid((np.arange(ny) + 0.5) / n_side, (np.arange(nx) + 0.5) / n_side, indexing="ij")
     p = np.stack([yy.ravel(), xx.ravel()], -1)
     p += rng.uniform(-0.25, 0.25, p.shape) / n_side
+    if n is not None:
+        assert n <= p.shape[0], (n, p.shape[0])
+        p = p[:n]
     return p.astype(np.float32)

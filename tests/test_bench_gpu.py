@@ -49,7 +49,13 @@ def test_bench_line_and_sharded_ranks_reproduce_the_single_rank_trajectory():
     assert 0 < one["render_advect_family"]["survey_fused"]["frac_hbm"] < one["render_advect_family"]["as_built"]["frac_hbm"]
     assert one["parity"]["grad_rel_l2"] < one["parity"]["tolerance"]
     assert "64^3" in one["metric"] and one["sustained"]["windows"] >= 3
-    assert len(one["other_configs"]) == 10 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
+    assert len(one["other_configs"]) == 11 and not any("error" in c for c in one["other_configs"]), one["other_configs"]
+    # configs[0] end to end on SURVEY 8(d)'s particle count, the sparse lattice of earlier rounds beside it
+    assert sorted(c["particles"] for c in one["other_configs"] if "particles" in c) == [1344, 16384]
+    # the data-dependent part of the headline is visible: the same step without skipping, and a density with nothing to skip
+    skip = one["dead_region_skipping"]
+    assert 0 < skip["live_voxel_fraction"] < 1 and 0 < skip["accumulated_box_fraction"] <= 1
+    assert skip["skipping_off"]["value"] > 0 and skip["dense_density"]["live_voxel_fraction"] > 0.99
     widened = one["other_configs"][-1]["ops"]                         # SURVEY 8(f) operators: one timed call each
     assert len(widened) == 10 and all(o["ms"] > 0 and 0 < o["frac_hbm"] < 1 for o in widened), widened
     fast = args + ["--no-kernel-profile", "--no-other-configs", "--no-sustained"]
@@ -98,6 +104,13 @@ def test_bench_gpus_4_and_8_over_gloo():
         assert r["metric"] == one["metric"] and r["config"]["workload"] == one["config"]["workload"]
         assert abs(r["final_loss"] - one["final_loss"]) <= 1e-5 * abs(one["final_loss"]), (n, r["final_loss"])
         assert r["config"]["field_work"].startswith("D-slab sharded"), r["config"]
+        # every rank's own record: backend, group size, device, the step's collectives timed on the device
+        assert len(r["ranks"]) == n and sorted(x["rank"] for x in r["ranks"]) == list(range(n))
+        for x in r["ranks"]:
+            assert x["backend"] == "gloo" and x["world_size"] == n and x["views_local"] == 8 // n
+            assert set(x["collectives"]) == {"reduce_scatter", "all_gather"}, x["collectives"]
+            assert all(c["calls_per_step"] == 1.0 and c["device_ms_per_step"] > 0 for c in x["collectives"].values())
+        assert r["collective_ms_per_step_max_over_ranks"] > 0 and r["distinct_devices"] == 1      # (one GPU shared here)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

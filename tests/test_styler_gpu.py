@@ -228,6 +228,35 @@ def test_styler2p_matches_oracle_loop():
         assert np.abs(res["d"][t].astype(np.int32) - imgs[t].astype(np.int32)).max() <= 1     # uint8 rounding
 
 
+def test_styler2p_config0_workload_matches_oracle_loop():
+    """BASELINE configs[0] on SURVEY 8(d)'s stated workload: 16 384 particles on the jittered dam-break lattice, 128 x 128,
+    VGG-19 conv3_1, style mask + TV, 50 Adam iterations at lr 0.01 (test_dambreak2d.py:142-192 with one octave and one
+    style layer) -- the whole Styler.run against the oracle's loop"""
+    from neural_flow_style_amd import synthetic as S
+    from neural_flow_style_amd.styler_2p import Styler
+    rng = np.random.RandomState(7)
+    ps = [S.dambreak_particles(280, rng, 16384)]
+    assert ps[0].shape == (16384, 2)
+    rs = [rng.uniform(900, 1100, (16384, 1)).astype(np.float32)]
+    H = W = 128
+    simg = S.style_image(H, W, rng)
+    cfg = _config(resolution=[H, W], domain=[3.2, 3.2], radius=0.0125, nsize=2, support=4, rest_density=1000, clip=False,
+                  target_field="c", num_frames=1, batch_size=1, frames_per_opt=200, window_sigma=3, lr=0.01, iter=50,
+                  octave_n=1, octave_scale=1.7, style_layer=["conv3_1"], w_style_layer=[1.0], w_style=1.0, w_content=0,
+                  style_mask=True, w_tv=0.01, style_target=simg, resize_scale=1.0)
+    st = Styler(cfg)
+    st.load_img([H, W])
+    params = {"p": ps, "r": rs}
+    res = st.run(params)
+    w = O.synthetic_vgg19_weights(123, upto="conv3_1")
+    hist, c_opt, imgs = O.styler2p_run(dict(vars(cfg)), params, w, res["style_per_octave"], res["c_init"])
+    assert len(res["l"][0]) == 50
+    np.testing.assert_allclose(res["l"][0], hist[0], rtol=2e-3)
+    assert res["l"][0][-1] < res["l"][0][0]
+    assert rel(res["opt"][0], c_opt[0]) < 1e-3
+    assert np.abs(res["d"][0].astype(np.int32) - imgs[0].astype(np.int32)).max() <= 1     # uint8 rounding
+
+
 @pytest.mark.parametrize("frames_per_opt,w_content", [(200, 0), (2, 0), (200, 1e3)])
 def test_styler2p_batches_of_two_frames_match_oracle_loop(frames_per_opt, w_content):
     """run.bat's last line (``test_dambreak2d.py ... --num_frames 20 --batch_size 4``): batch_size consecutive frames
