@@ -174,6 +174,7 @@ _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64
             "nfs_conv2d_workspace_floats": C.c_int64, "nfs_conv2d_group_workspace_floats": C.c_int64}
 
 _lib = None
+ABI_VERSION = 150          # nfs_version() this table was written against (include/nfs_hip.h)
 
 
 def build(verbose=False):
@@ -209,6 +210,11 @@ def lib():
                 raise NfsLibraryError("libnfs_hip.so does not export %s (stale build?)" % name)
             f.argtypes = argt
             f.restype = _RESTYPE.get(name, C.c_int)
+        # the binding and the library move together (entry points, packed-filter sizes, the default GEMM arithmetic): a
+        # stale .so with every symbol of an older minor present must not be driven by this table
+        if L.nfs_version() < ABI_VERSION:
+            raise NfsLibraryError("libnfs_hip.so reports ABI %d, this binding needs >= %d: rebuild (make -C %s)"
+                                  % (L.nfs_version(), ABI_VERSION, CSRC_DIR))
         _lib = L
     return _lib
 

@@ -735,7 +735,9 @@ static LapUpPlan lap_up3_plan(int D, int H, int W, int C, int nd) {
     return LapUpPlan{1, nbx * nby * nbz, nbx, nby};
   }
   const int Wo = (W + 1) / 2;
-  if (vox < 4096 || (int64_t)LR_ROWS * Wo * C * (int64_t)sizeof(float) > 64 * 1024) return pl;    // (the staged rows fit LDS)
+  // (the staged rows fit LDS: 64 KB is what a launch gets without an opt-in, and the kernel holds ~3.3 KB of static LDS
+  // beside them -- weights, the double partial sums, the reduction slots)
+  if (vox < 4096 || (int64_t)LR_ROWS * Wo * C * (int64_t)sizeof(float) > 60 * 1024) return pl;
   const int nbz = (ncz + LR_CZ - 1) / LR_CZ;
   return LapUpPlan{2, ncy * nbz, ncy, 0};
 }

@@ -1607,8 +1607,10 @@ static void launch_gemm_tile(WgGemmArgs a, int Z, int bm, int bn, hipStream_t s,
   static const int dbg = getenv("NFS_GEMM_DBG") ? atoi(getenv("NFS_GEMM_DBG")) : 0;
   a.dbg = dbg;
 #endif
-  if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0 && !a.mask && !a.alpha_dev &&
-      a.alpha == 1.f && !a.symb) {
+  // (a split-limb choice that meets a launch with a mask / scale / symmetric operand runs the same tile on the f32-input
+  // MFMA: never the generic kernel with the 16-row form's tile height)
+  if (variant == 3 && (a.mask || a.alpha_dev || a.alpha != 1.f || a.symb)) variant = 2;
+  if (variant == 3 && gemm_rb16_applies(a) && rb16_rows_ok(bm) && a.N % bn == 0) {
     // the 16-row register-B form in split-limb arithmetic (mode 1): 64- or 128-column tiles
     a.mt = (int)((a.T + bm - 1) / bm);
     if (bn > 128 && bm == 208) { bn = 128; a.nt = a.N / 128; }
@@ -1711,7 +1713,9 @@ static int launch_batched_gemm(WgGemmArgs a, int Z, int cus, hipStream_t s) {
     if (rb16_rows_ok(fbm) && a.N % fbn == 0 && gemm_rb16_applies(a)) { bm = fbm; bn = fbn; } else variant = 0;
   }
   if (tune) {
-    const GemmKey key{a.T, a.K, a.N, Z, mode * 2 + (a.mask ? 1 : 0)};
+    // (the arithmetic of a cached choice is part of the key: in mode 1 a plain product runs variant 3, a Gram gradient of
+    // the same (T, K, N, Z) variant 2 -- one must never inherit the other's entry)
+    const GemmKey key{a.T, a.K, a.N, Z, mode * 4 + (plain ? 2 : 0) + (a.mask ? 1 : 0)};
     if (rows16) { variant = v16; bm = bm16; bn = a.N % 128 == 0 ? 128 : 64; }   // (capture / timer: no trial)
     std::unique_lock<std::mutex> lk(g_tile_mu);
     auto it = g_tile_cache.find(key);

@@ -840,9 +840,10 @@ def p2g_wavg_bwd(p, cfg, xsum, wsum, g_out, attr, eps=1e-6, need_p=True, need_at
         _lib.call("nfs_p2g_wavg_bwd", _ptr(p), _ptr(attr), _ptr(xsum), _ptr(wsum), _ptr(g_out), _ptr(g_p), _ptr(g_attr), N,
                   Cn, float(eps), C.byref(cfg), _stream())
     except _lib.NfsError as e:
-        # the library's own predicate (launch_p2g_bwd: cells < 2^31, its reading of NFS_SPLAT_LDS) is the authority: an
-        # argument it refuses (nothing was launched) sends the caller down the two-launch adjoint
-        if e.code != _lib.NFS_EINVAL:
+        # the library's own predicate (launch_p2g_bwd: cells < 2^31, its reading of NFS_SPLAT_LDS) is the authority: the
+        # ONE refusal it documents -- no compile-time instance, nothing launched -- sends the caller down the two-launch
+        # adjoint; any other NFS_EINVAL (a null pointer, a bad N or mode) is an error, not a slow path
+        if e.code != _lib.NFS_EINVAL or "no compile-time instance" not in str(e):
             raise
         return None
     return g_p, g_attr

@@ -205,17 +205,19 @@ class Styler(StylerBase):
                             x = torch.stack([v.detach() for v in vars_])            # [B,N,3]
                             gx = torch.stack([v.grad for v in vars_])
                     opt_[opt_id].step(x, gx.contiguous(), lr)
+                    if step == self.iter - 1 and octave < self.octave_n - 1:
+                        # the octave's intermediate image is d_out of the sess.run that applied the step
+                        # (styler_2p.py:264-266): rendered from the RAW Adam-updated variable, before the iterate
+                        # update below sanitises it (x is a view of the variable on the explicit path)
+                        with torch.no_grad():
+                            dd = torch.cat([self._colour(p[t + i], r[t + i], x[i], res)[0] for i in range(B)], 0)
+                            d_intm_o.append(((dd * d_gray) * 255).cpu().numpy().astype(np.uint8))
                     for i in range(B):
                         if explicit and not filt and B == 1:
                             # g_opt += nan_to_num(x) - g_opt, and the variable restarts from it: one launch
                             ops.iterate_update(vars_dev[t + i], g_opt[t + i])
                         else:
                             g_tmp[t + i] = torch.nan_to_num(x[i]) - g_opt[t + i]
-                    if step == self.iter - 1 and octave < self.octave_n - 1:
-                        with torch.no_grad():
-                            xs = [g_opt[t + i] if g_tmp[t + i] is None else x[i] for i in range(B)]
-                            dd = torch.cat([self._colour(p[t + i], r[t + i], xs[i], res)[0] for i in range(B)], 0)
-                            d_intm_o.append(((dd * d_gray) * 255).cpu().numpy().astype(np.uint8))
                 if filt:
                     stack = denoise(np.stack([g.cpu().numpy() for g in g_tmp]), sigma=(self.window_sigma, 0, 0))
                     g_tmp = [self._dev(s) for s in stack]

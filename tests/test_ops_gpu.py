@@ -885,6 +885,38 @@ def test_split_limb_gemm_is_float32_accurate(B, H, W, Ci, Co, floor):
     assert errs[1] < 1.5 * errs[0] + 1e-7, errs
 
 
+@pytest.mark.parametrize("magnitude", [1e28, 1e-28])
+def test_split_limb_gemm_at_the_ends_of_the_float_range(magnitude):
+    """bf16 shares float32's exponent range, so the three-limb split is exact wherever all three limbs are normal
+    numbers: activations of uniform magnitude 1e28 (products ~1e27, far from overflow through the Winograd transforms'
+    constants) and 1e-28 (the lowest limb ~1e-33, still normal) must come out as accurately as at unit scale -- no inf - inf
+    from a rounded-up leading limb, no flushed low limb.  (Beyond ~3e38 / 2^8 the leading limb can round to inf and below
+    ~1e-33 the low limbs flush: both outside anything a loss network sees; stated in INTEGRATION.md.)"""
+    from neural_flow_style_amd import ops
+    rng = np.random.RandomState(14)
+    B, H, W, Ci, Co = 2, 25, 25, 256, 256
+    x = (np.abs(rng.randn(B, H, W, Ci)) * magnitude).astype(np.float32)
+    w = (rng.randn(3, 3, Ci, Co) * 0.05).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.tensor(x).double().permute(0, 3, 1, 2),
+                                     torch.tensor(w).double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    scale = torch.nn.functional.conv2d(torch.tensor(x).double().abs().permute(0, 3, 1, 2),
+                                       torch.tensor(w).double().abs().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    xd, wd = torch.tensor(x).cuda(), torch.tensor(w).cuda()
+    pk = ops.conv3x3_pack(wd, 0)
+    errs = {}
+    prev = ops.gemm_mode(None)
+    try:
+        for mode in (0, 1):
+            ops.gemm_mode(mode)
+            y = ops.conv3x3_fwd(xd, pk, None, Co, relu=False)
+            assert torch.isfinite(y).all()
+            errs[mode] = float(((y.double().cpu() - ref).abs() / scale).max())
+    finally:
+        ops.gemm_mode(prev)
+    assert errs[0] < 2e-5 and errs[1] < 2e-5, errs
+    assert errs[1] < 1.5 * errs[0] + 1e-7, errs
+
+
 def test_gradient_chain_identical_in_both_gemm_modes():
     """VGG forward + data-gradient chain with the Winograd GEMMs in split-limb mode vs float32-input MFMA mode: the
     two float32-equivalent arithmetics agree to float32 rounding (1e-5), far inside the 1e-3 bar"""
