@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the small HIP-vs-oracle gradient check")
+    ap.add_argument("--no-skip-control", action="store_true",
+                    help="skip the dead-region-skipping controls (the same step with skipping off / on a dense density)")
     ap.add_argument("--no-split-limb", action="store_true", help="skip the secondary split-limb GEMM measurement")
     ap.add_argument("--cpu-views", type=int, default=1,
                     help="views 0..n-1 in the bounded CPU sample, besides view V-1 (so the default times two views)")
@@ -1084,7 +1086,7 @@ def main():
                              if gs.slab is not None else
                              ("replicated on every rank behind one all-reduce(sum)" if world > 1 else "one rank"))
         step_fn, units = views_step, 1
-        if gs._live_kw():
+        if gs._live_kw() and not args.no_skip_control:
             # data dependence of the headline, made visible: the rotate adjoint skips what only feeds voxels whose
             # velocity gradient is an exact zero (empty space, plateaus).  (a) the same problem with skipping off,
             # (b) a dense density on which nothing can be skipped -- both NOT the headline

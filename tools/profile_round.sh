@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-parity --no-sustained --no-other-configs --no-split-limb"
+BENCH="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-parity --no-sustained --no-other-configs --no-split-limb --no-skip-control"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o b -- $BENCH > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -o b -- $BENCH > /dev/null 2> $out/${tag}_pmc_fetch.err
