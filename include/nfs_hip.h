@@ -303,9 +303,9 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
  *   nfs_rotate_bwd_coef_live = nfs_rotate_bwd_coef restricted to the voxels within `dilate` cells of a live voxel
  *   (`dilate` = reach of the linear stencil between g_d and the advect adjoint: 1 for the 3x3x3 smoothing of
  *   styler_3p.py:112-125, 0 without it; RT tile + 2 dilate <= 63): a tile without such voxels returns before its sample
- *   loop, the others accumulate only the bounding box of theirs, longest first (a small kernel ahead of the adjoint finds
- *   the boxes and sorts the tiles by work into `workspace`, nfs_rotate_live_workspace_ints ints, zeroed ONCE by the
- *   caller -- every launch leaves it ready for the next).  g_d there is bit-identical to nfs_rotate_bwd_coef;
+ *   loop, the others accumulate only the bounding box of theirs, longest first (two small launches ahead of the adjoint
+ *   find the boxes and sort the tiles by work into `workspace`, nfs_rotate_live_workspace_ints ints, no initialisation
+ *   needed; one workspace per stream that runs this concurrently).  g_d there is bit-identical to nfs_rotate_bwd_coef;
  *   elsewhere it holds zeros, which only ever meet the zero factor.  The resulting velocity gradient / Adam update is
  *   bit-identical with and without the mask. */
 int nfs_live_mask_words(int D, int H, int W);

@@ -558,84 +558,105 @@ __device__ __forceinline__ void rotate_tile_catchment(const float* r, int D, int
 // live (nfs_advect_*_live): bit (z H + y) W + x set = the velocity gradient of voxel (z, y, x) can be non-zero.  The
 // linear stencil between the rotate adjoint's g_d and the advect adjoint (the smoothing) reads g_d within `dil` cells of
 // such a voxel, and nothing else of g_d is ever multiplied by a non-zero: a tile needs the sums of the bounding box of
-// its voxels within `dil` of a live voxel, no more.  One block per tile finds that box; the block that finishes last
-// (a ticket) sorts the tiles by decreasing work into `order` -- the hardware starts blocks in index order, and with
-// boxes of very different sizes (and two fifths of the tiles empty on a smoke density) the long ones must not start last.
-// Workspace (ints): [0] ticket (zero before the first launch; the last block leaves it zero again), [LWS_BOXES + 8 t ...]
-// box of tile t = (z0, z1, y0, y1, x0, x1, work, -), [LWS_ORDER(ntiles) + i] the tile block i of the adjoint takes.
+// its voxels within `dil` of a live voxel, no more.  One wave per tile finds that box; a second, one-block launch sorts
+// the tiles by decreasing work into `order` -- the hardware starts blocks in index order, and with boxes of very
+// different sizes (and two fifths of the tiles empty on a smoke density) the long ones must not start last.
+// Workspace (ints): [LWS_BOXES + 8 t ...] box of tile t = (z0, z1, y0, y1, x0, x1, work, -), [LWS_ORDER(ntiles) + i] the
+// tile block i of the adjoint takes.
 constexpr int LWS_BOXES = 8;
 #define LWS_ORDER(ntiles) (nfs::LWS_BOXES + 8 * (ntiles))
-constexpr int LB_THREADS = 256, LB_CLASSES = 64;
+constexpr int LB_THREADS = 1024, LB_WAVES = LB_THREADS / 64, LB_CLASSES = 64;
 
+// a WAVE per tile, four (z, y) rows of the tile's dilated box per lane
 __global__ void __launch_bounds__(LB_THREADS) rotate_live_boxes_kernel(const unsigned long long* __restrict__ live, int D,
                                                                        int H, int W, int tiles_y, int tiles_x, int dil,
-                                                                       int* __restrict__ ws) {
-  __shared__ int lbox[6];
+                                                                       int ntiles, int* __restrict__ ws) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int tile = blockIdx.x * LB_WAVES + (t >> 6);
+  if (tile < ntiles) {
+    const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, bz = tile / (tiles_x * tiles_y);
+    const int Tz0 = bz * RT_TZ, Ty0 = by * RT_TY, Tx0 = bx * RT_TX;
+    const int Tz1 = min(Tz0 + RT_TZ, D) - 1, Ty1 = min(Ty0 + RT_TY, H) - 1, Tx1 = min(Tx0 + RT_TX, W) - 1;
+    const int ez0 = max(Tz0 - dil, 0), ez1 = min(Tz1 + dil, D - 1), ey0 = max(Ty0 - dil, 0), ey1 = min(Ty1 + dil, H - 1);
+    const int ex0 = max(Tx0 - dil, 0), ex1 = min(Tx1 + dil, W - 1);
+    const int nry = ey1 - ey0 + 1, len = ex1 - ex0 + 1, nrows = (ez1 - ez0 + 1) * nry;   // len <= RT_TX + 2 dil <= 63
+    int b0 = 0x7fffffff, b1 = -1, b2 = 0x7fffffff, b3 = -1, b4 = 0x7fffffff, b5 = -1;
+    for (int r = lane; r < nrows; r += 64) {
+      const int rz = ez0 + r / nry, ry = ey0 + r % nry;
+      const int64_t bit0 = ((int64_t)rz * H + ry) * W + ex0;
+      const int sh = (int)(bit0 & 63);
+      unsigned long long bits = live[bit0 >> 6] >> sh;
+      if (sh + len > 64) bits |= live[(bit0 >> 6) + 1] << (64 - sh);
+      bits &= (1ull << len) - 1ull;
+      if (bits) {
+        b0 = min(b0, rz); b1 = max(b1, rz); b2 = min(b2, ry); b3 = max(b3, ry);
+        b4 = min(b4, ex0 + (int)__builtin_ctzll(bits)); b5 = max(b5, ex0 + 63 - (int)__builtin_clzll(bits));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      b0 = min(b0, __shfl_xor(b0, o, 64)); b1 = max(b1, __shfl_xor(b1, o, 64));
+      b2 = min(b2, __shfl_xor(b2, o, 64)); b3 = max(b3, __shfl_xor(b3, o, 64));
+      b4 = min(b4, __shfl_xor(b4, o, 64)); b5 = max(b5, __shfl_xor(b5, o, 64));
+    }
+    if (lane == 0) {
+      int* b = ws + LWS_BOXES + tile * 8;
+      int work = 0;
+      int z0 = Tz0, z1 = Tz1, y0 = Ty0, y1 = Ty1, x0 = Tx0, x1 = Tx1;
+      if (b1 >= 0) {
+        z0 = max(Tz0, b0 - dil); z1 = min(Tz1, b1 + dil);
+        y0 = max(Ty0, b2 - dil); y1 = min(Ty1, b3 + dil);
+        x0 = max(Tx0, b4 - dil); x1 = min(Tx1, b5 + dil);
+        // samples whose base cell lies in [lo - 1, hi] per axis; a box on the volume's border also catches the samples
+        // clamped onto it (a few cells' worth at these view angles)
+        const int cz = z1 - z0 + 2 + (z0 == 0 ? 6 : 0) + (z1 == D - 1 ? 6 : 0);
+        const int cy = y1 - y0 + 2 + (y0 == 0 ? 6 : 0) + (y1 == H - 1 ? 6 : 0);
+        const int cx = x1 - x0 + 2 + (x0 == 0 ? 6 : 0) + (x1 == W - 1 ? 6 : 0);
+        work = cz * cy * cx;
+      }
+      b[0] = z0; b[1] = z1; b[2] = y0; b[3] = y1; b[4] = x0; b[5] = x1; b[6] = work; b[7] = 0;
+    }
+  }
+}
+
+// ... and the tiles by decreasing work: one block, counting sort by work class (a launch of its own: the boxes come from
+// 85 blocks on all XCDs, and a ticket + __threadfence() in their kernel -- the "last block sorts" form this replaced --
+// cost 30 us of cache maintenance; a kernel boundary costs 3)
+__global__ void __launch_bounds__(LB_THREADS) rotate_live_order_kernel(int ntiles, int* __restrict__ ws) {
   __shared__ int hist[LB_CLASSES + 1];
-  __shared__ int last;
-  const int t = threadIdx.x, ntiles = gridDim.x, tile = blockIdx.x;
-  const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, bz = tile / (tiles_x * tiles_y);
-  const int Tz0 = bz * RT_TZ, Ty0 = by * RT_TY, Tx0 = bx * RT_TX;
-  const int Tz1 = min(Tz0 + RT_TZ, D) - 1, Ty1 = min(Ty0 + RT_TY, H) - 1, Tx1 = min(Tx0 + RT_TX, W) - 1;
-  if (t < 6) lbox[t] = (t & 1) ? -1 : 0x7fffffff;
-  __syncthreads();
-  const int ez0 = max(Tz0 - dil, 0), ez1 = min(Tz1 + dil, D - 1), ey0 = max(Ty0 - dil, 0), ey1 = min(Ty1 + dil, H - 1);
-  const int ex0 = max(Tx0 - dil, 0), ex1 = min(Tx1 + dil, W - 1);
-  const int nry = ey1 - ey0 + 1, len = ex1 - ex0 + 1;                // len <= RT_TX + 2 dil <= 63
-  for (int r = t; r < (ez1 - ez0 + 1) * nry; r += LB_THREADS) {
-    const int rz = ez0 + r / nry, ry = ey0 + r % nry;
-    const int64_t bit0 = ((int64_t)rz * H + ry) * W + ex0;
-    const int sh = (int)(bit0 & 63);
-    unsigned long long bits = live[bit0 >> 6] >> sh;
-    if (sh + len > 64) bits |= live[(bit0 >> 6) + 1] << (64 - sh);
-    bits &= (1ull << len) - 1ull;
-    if (bits) {
-      atomicMin(&lbox[0], rz); atomicMax(&lbox[1], rz);
-      atomicMin(&lbox[2], ry); atomicMax(&lbox[3], ry);
-      atomicMin(&lbox[4], ex0 + (int)__builtin_ctzll(bits)); atomicMax(&lbox[5], ex0 + 63 - (int)__builtin_clzll(bits));
-    }
-  }
-  __syncthreads();
-  if (t == 0) {
-    int* b = ws + LWS_BOXES + tile * 8;
-    int work = 0;
-    int z0 = Tz0, z1 = Tz1, y0 = Ty0, y1 = Ty1, x0 = Tx0, x1 = Tx1;
-    if (lbox[1] >= 0) {
-      z0 = max(Tz0, lbox[0] - dil); z1 = min(Tz1, lbox[1] + dil);
-      y0 = max(Ty0, lbox[2] - dil); y1 = min(Ty1, lbox[3] + dil);
-      x0 = max(Tx0, lbox[4] - dil); x1 = min(Tx1, lbox[5] + dil);
-      // samples whose base cell lies in [lo - 1, hi] per axis; a box on the volume's border also catches the samples
-      // clamped onto it (a few cells' worth at these view angles)
-      const int cz = z1 - z0 + 2 + (z0 == 0 ? 6 : 0) + (z1 == D - 1 ? 6 : 0);
-      const int cy = y1 - y0 + 2 + (y0 == 0 ? 6 : 0) + (y1 == H - 1 ? 6 : 0);
-      const int cx = x1 - x0 + 2 + (x0 == 0 ? 6 : 0) + (x1 == W - 1 ? 6 : 0);
-      work = cz * cy * cx;
-    }
-    b[0] = z0; b[1] = z1; b[2] = y0; b[3] = y1; b[4] = x0; b[5] = x1; b[6] = work; b[7] = 0;
-    __threadfence();
-    last = atomicAdd(ws, 1) == ntiles - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  // ---- the last block: counting sort of the tiles by work class, largest first ----
-  __threadfence();
-  const volatile int* boxes = ws + LWS_BOXES;
+  const int t = threadIdx.x;
+  const int* boxes = ws + LWS_BOXES;
   constexpr int WMAX = (RT_TZ + 13) * (RT_TY + 13) * (RT_TX + 13);
   for (int i = t; i <= LB_CLASSES; i += LB_THREADS) hist[i] = 0;
   __syncthreads();
   auto cls = [](int work) {   // 0 = most work ... LB_CLASSES - 1 = least, LB_CLASSES = none
     return work == 0 ? LB_CLASSES : LB_CLASSES - 1 - min((int)(((int64_t)work * LB_CLASSES) / (WMAX + 1)), LB_CLASSES - 1);
   };
-  for (int i = t; i < ntiles; i += LB_THREADS) atomicAdd(&hist[cls(boxes[i * 8 + 6])], 1);
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int c = 0; c <= LB_CLASSES; ++c) { const int n = hist[c]; hist[c] = run; run += n; }
-    ws[0] = 0;                                           // the ticket for the next launch
-  }
-  __syncthreads();
+  constexpr int PER = 4;                                   // tiles per thread and round (4096 per round)
   int* order = ws + LWS_ORDER(ntiles);
-  for (int i = t; i < ntiles; i += LB_THREADS) order[atomicAdd(&hist[cls(boxes[i * 8 + 6])], 1)] = i;
+  int done = 0;                                            // tiles placed by earlier rounds (volumes of > 4096 tiles)
+  for (int base = 0; base < ntiles; base += PER * LB_THREADS) {
+    int c[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = base + j * LB_THREADS + t;
+      c[j] = i < ntiles ? cls(boxes[i * 8 + 6]) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (c[j] >= 0) atomicAdd(&hist[c[j]], 1);
+    __syncthreads();
+    if (t == 0) {
+      int run = done;
+      for (int k = 0; k <= LB_CLASSES; ++k) { const int n = hist[k]; hist[k] = run; run += n; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (c[j] >= 0) order[atomicAdd(&hist[c[j]], 1)] = base + j * LB_THREADS + t;
+    __syncthreads();
+    done = min(base + PER * LB_THREADS, ntiles);
+    for (int i = t; i <= LB_CLASSES; i += LB_THREADS) hist[i] = 0;
+  }
 }
 
 // COEF: g_out holds, per sample, the render's u (nfs_rotate_render_fwd with u_rot) and `ab` the per-(view, depth
@@ -972,8 +993,10 @@ static int rotate_bwd_coef_impl(const char* who, const float* u_rot, const float
   static const int order = [] { const char* e = getenv("NFS_RT_XCD"); return e ? atoi(e) : 0; }();
   const int grid = (live || order == 0) ? tz * ty * tx : 8 * ((tz * ty + 7) / 8) * tx;
   if (live)
-    hipLaunchKernelGGL(rotate_live_boxes_kernel, dim3(tz * ty * tx), dim3(LB_THREADS), 0, as_stream(stream), live, D, H, W,
-                       ty, tx, dilate, lws);
+    hipLaunchKernelGGL(rotate_live_boxes_kernel, dim3((tz * ty * tx + LB_WAVES - 1) / LB_WAVES), dim3(LB_THREADS), 0,
+                       as_stream(stream), live, D, H, W, ty, tx, dilate, tz * ty * tx, lws);
+  if (live)
+    hipLaunchKernelGGL(rotate_live_order_kernel, dim3(1), dim3(LB_THREADS), 0, as_stream(stream), tz * ty * tx, lws);
   for (int v0 = 0; v0 < V; v0 += RT_VMAX) {
     const int vn = V - v0 < RT_VMAX ? V - v0 : RT_VMAX;
     hipLaunchKernelGGL(rotate_bwd_tiled_kernel<true>, dim3(grid), dim3(RT_THREADS), 0, as_stream(stream),
@@ -1004,8 +1027,8 @@ int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* r
                               nbounds, overwrite, live, dilate, workspace, stream);
 }
 
-// ints of that workspace: a ticket, a box per tile, the tiles in the order the adjoint's blocks take them.  Zero it once;
-// every launch leaves the ticket zero again.
+// ints of that workspace: a box per tile, the tiles in the order the adjoint's blocks take them (written by every launch
+// before it is read: no initialisation needed)
 int nfs_rotate_live_workspace_ints(int D, int H, int W) {
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int nt = ((D + RT_TZ - 1) / RT_TZ) * ((H + RT_TY - 1) / RT_TY) * ((W + RT_TX - 1) / RT_TX);
