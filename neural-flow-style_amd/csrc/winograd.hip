@@ -1315,195 +1315,15 @@ __global__ void __launch_bounds__(256, (MT16 * NW16 <= NFS_RB16S_OCC_TILES ? NFS
   }
 }
 
-// ---- rb16s with A as limb planes moved global -> LDS without passing registers ("rb16d", round 6) -------------------------
-// The verdict's untried variant of the split-limb GEMM: V arrives already split (three bf16 planes per 32-deep chunk, in
-// fragment order: Vb [Z][K/32][3][T][32 bf16]), and a block moves its rows into LDS with `buffer_load_dwordx4 ... lds`:
-// no VALU split, no ds_write, three LDS buffers so that the transfer of chunk c + 2 is in flight while chunk c is
-// multiplied.  An instruction moves 16 rows x 64 bytes of one plane (1 KB, contiguous in memory and in LDS); the 16-byte
-// pieces of a row are XOR-swizzled by (row >> 2) & 3 on the global side so that the fragment reads (lane = row + 16 q
-// reads piece q of its row) are conflict-free without padding.  Same limbs, same products, same order as rb16s: bit-
-// identical results.  NFS_RB16D=1 routes the PRE launches here through a conversion pass (measurement only: see
-// profiles/r06_rb16d_*.txt for what it is worth before the transforms are taught to write the planes).
-__global__ void __launch_bounds__(256) winograd_v_limb_planes_kernel(const float* __restrict__ V, uint4* __restrict__ Vb,
-                                                                     int64_t T, int K, int64_t total) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (z, chunk, row, piece q)
-  if (gid >= total) return;
-  const int q = (int)(gid & 3);
-  const int64_t m = (gid >> 2) % T;
-  const int64_t zc = (gid >> 2) / T;                                      // z * NC + c
-  const int NC = K / 32;
-  const int64_t z = zc / NC;
-  const int c = (int)(zc - z * NC);
-  const float* row = V + (z * T + m) * K + 32 * c;
-  const float4 a = *reinterpret_cast<const float4*>(row + 4 * q), b = *reinterpret_cast<const float4*>(row + 16 + 4 * q);
-  bf16x8s H, M, L;
-  rb16s_split8(a, b, H, M, L);
-  uint4* dst = Vb + (zc * 3 * T + m) * 4 + q;                              // plane stride T * 4 uint4
-  dst[0] = __builtin_bit_cast(uint4, H);
-  dst[T * 4] = __builtin_bit_cast(uint4, M);
-  dst[2 * T * 4] = __builtin_bit_cast(uint4, L);
-}
-
-#define NFS_LDSP(p_) ((__attribute__((address_space(3))) void*)(p_))
-template <int MT16, int NW16>
-__device__ __forceinline__ void winograd_gemm_rb16d_block(const WgGemmArgs& a, unsigned char* smem, int comp, int64_t m0,
-                                                          int n0, int split) {
-  constexpr int BM = 16 * MT16, BN = 64 * NW16;
-  constexpr int PLANE = BM * 64, BUF = 3 * PLANE;             // bytes: [3 buffers][3 limbs][BM rows][64]
-  constexpr int G = MT16 <= 5 ? MT16 : (MT16 == 7 ? 4 : 5);
-  constexpr int ND = 3 * MT16, ND_W = (ND + 3) / 4;           // transfer instructions per chunk: of the block / of each wave
-  const int t = threadIdx.x, lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int NC = a.K / WG_KC;
-  const int nchunks = NC / a.ksplit, c0 = split * nchunks;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(static_cast<const unsigned char*>(a.Vb16)) + (int64_t)comp * NC * 3 * a.T * 64, 0,
-      (uint32_t)((int64_t)NC * 3 * a.T * 64), 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char*>(static_cast<const unsigned char*>(a.Ub16)) + (int64_t)comp * a.K * a.N * 6, 0,
-      (uint32_t)((int64_t)a.K * a.N * 6), 0x00020000);
-  // transfer role: lane = (row r = lane >> 2 of a 16-row group, LDS slot sl = lane & 3); it fetches piece sl ^ swz(r)
-  const int tr = lane >> 2, tq = (lane & 3) ^ ((tr >> 2) & 3);
-  const uint32_t plane_b = (uint32_t)(a.T * 64);              // bytes of one (chunk, limb) plane
-  // every wave issues the SAME number of transfers per chunk (instruction ii = wid + 4 j; one past the end goes, with an
-  // out-of-range offset = zeros, to a spare KB behind the buffers): straight-line code, and the waits below can count
-  auto issue = [&](int cc, int buf) {
-#pragma unroll
-    for (int j = 0; j < ND_W; ++j) {
-      const int ii = wid + 4 * j;                              // (wave-uniform: scalar arithmetic)
-      const bool on = ii < ND;
-      const int p = on ? ii / MT16 : 0, g = on ? ii - p * MT16 : 0;
-      const int64_t m = m0 + 16 * g + tr;
-      const uint32_t vo = (on && m < a.T) ? (uint32_t)(m * 64 + 16 * tq) : 0x80000000u;
-      unsigned char* dst = on ? smem + buf * BUF + p * PLANE + g * 1024 : smem + 3 * BUF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, NFS_LDSP(dst), 16, vo, (uint32_t)(cc * 3 + p) * plane_b, 0, 0);
-    }
-  };
-  const uint32_t bo = (uint32_t)lane * 16u;
-  constexpr int NB = 3;
-  const uint32_t kgs = (uint32_t)(a.K / 16) * 1536u;
-  const uint32_t bt0 = (uint32_t)((n0 + wid * 16 * NW16) / 16) * kgs;
-  float4 bq[2][NW16][NB];
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const int cc = c0 + (st < nchunks ? st : nchunks - 1);
-    issue(cc, st);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nt = 0; nt < NW16; ++nt)
-#pragma unroll
-      for (int g = 0; g < NB; ++g) bq[st][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(NB * cc + g) * 1024u);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const int arow = lane & 15;
-  const int afrag = arow * 64 + 16 * ((lane >> 4) ^ ((arow >> 2) & 3));   // + 16 mt rows, + plane
-  f32x4 acc[MT16][NW16];
-#pragma unroll
-  for (int mt = 0; mt < MT16; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NW16; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // per chunk: own transfers of chunk c landed (what this wave issued after them and after the filters of chunk c may
-  // still fly: the ND_W transfers and the NW16 * NB filter loads of chunk c + 1; the filters of chunk c are needed now) -> barrier (every wave's part is in LDS; buffer (c + 2) % 3 was last
-  // read in chunk c - 1) -> start the transfer of chunk c + 2 -> fragments, MFMAs
-#define NFS_RB16D_STEP(ST, C)                                                                                      \
-  {                                                                                                                \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND_W + NW16 * NB) : "memory");                                        \
-    __syncthreads();                                                                                               \
-    const int cn = c0 + ((C) + 2 < nchunks ? (C) + 2 : nchunks - 1);   /* (past the end: a harmless re-fetch) */     \
-    issue(cn, ((C) + 2) % 3);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    const unsigned char* Ac = smem + ((C) % 3) * BUF;                                                              \
-    bf16x8s bf[NW16][3];                                                                                           \
-    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[nt][p] = __builtin_bit_cast(bf16x8s, bq[ST][nt][p]);         \
-    _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                            \
-      _Pragma("unroll") for (int g = 0; g < NB; ++g)                                                               \
-        bq[ST][nt][g] = wg_ld4(b_rsrc, bo, bt0 + nt * kgs + (uint32_t)(NB * cn + g) * 1024u);                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    _Pragma("unroll") for (int mg = 0; mg < MT16; mg += G) {                                                       \
-      bf16x8s af[G][3];                                                                                            \
-      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
-        if (mg + gi < MT16)                                                                                        \
-          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                            \
-            af[gi][p] = *reinterpret_cast<const bf16x8s*>(Ac + p * PLANE + afrag + (mg + gi) * 1024);              \
-      _Pragma("unroll") for (int lp = 0; lp < 6; ++lp) {                                                           \
-        const int pa = lp == 0 ? 0 : lp == 1 ? 2 : lp == 2 ? 1 : lp == 3 ? 0 : lp == 4 ? 1 : 0;                    \
-        const int pb = lp == 0 ? 2 : lp == 1 ? 0 : lp == 2 ? 1 : lp == 3 ? 1 : lp == 4 ? 0 : 0;                    \
-        _Pragma("unroll") for (int nt = 0; nt < NW16; ++nt)                                                        \
-          _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                         \
-            if (mg + gi < MT16)                                                                                    \
-              acc[mg + gi][nt] =                                                                                   \
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi][pa], bf[nt][pb], acc[mg + gi][nt], 0, 0, 0);      \
-      }                                                                                                            \
-    }                                                                                                              \
-  }
-  // (the buffer index (C) % 3 must be a compile-time constant inside the step: six steps per trip)
-#pragma unroll 1
-  for (int c = 0; c < nchunks; c += 6) {
-    NFS_RB16D_STEP(0, c)
-    if (c + 1 < nchunks) NFS_RB16D_STEP(1, c + 1)
-    if (c + 2 < nchunks) NFS_RB16D_STEP(0, c + 2)
-    if (c + 3 < nchunks) NFS_RB16D_STEP(1, c + 3)
-    if (c + 4 < nchunks) NFS_RB16D_STEP(0, c + 4)
-    if (c + 5 < nchunks) NFS_RB16D_STEP(1, c + 5)
-  }
-#undef NFS_RB16D_STEP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no transfer may land in the epilogue's tile buffer
-
-  constexpr int OS = BN + 4, EPMAX = NW16 >= 4 ? 2 : 5, EP = MT16 < EPMAX ? MT16 : EPMAX, NPASS = (MT16 + EP - 1) / EP;
-  float* otile = reinterpret_cast<float*>(smem);
-  float* Mc = a.M + ((int64_t)split * a.Z + comp) * a.T * a.N;
-  constexpr int Q = BN / 4;
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT16; ++mt)
-      if (mt / EP == pass)
-#pragma unroll
-        for (int nt = 0; nt < NW16; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            otile[(16 * (mt % EP) + 4 * (lane >> 4) + r) * OS + wid * 16 * NW16 + 16 * nt + (lane & 15)] = acc[mt][nt][r];
-    __syncthreads();
-    const int rows = 16 * ((pass + 1) * EP <= MT16 ? EP : MT16 - pass * EP);
-    for (int f = t; f < rows * Q; f += 256) {
-      const int row = f / Q, q = f - row * Q;
-      const int64_t m = m0 + 16 * EP * pass + row;
-      if (m >= a.T) continue;
-      *reinterpret_cast<float4*>(Mc + m * a.N + n0 + 4 * q) = *reinterpret_cast<const float4*>(otile + row * OS + 4 * q);
-    }
-  }
-}
-
-template <int MT16, int NW16>
-__global__ void __launch_bounds__(256, (MT16 * NW16 <= NFS_RB16S_OCC_TILES ? NFS_RB16S_OCC : 1)) winograd_gemm_rb16d_kernel(WgGemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-  const int nblocks = (int)gridDim.x, block = (int)blockIdx.x;
-  const int per_xcd = nblocks / WG_XCDS;
-  const int logical = (block % WG_XCDS) * per_xcd + block / WG_XCDS;
-  const int per_split = a.mt * a.nt * a.Z;
-  if (logical >= per_split * a.ksplit) return;
-  const int split = logical / per_split;
-  const int lg = logical - split * per_split;
-  const int comp = lg / (a.mt * a.nt);
-  const int rem = lg - comp * (a.mt * a.nt);
-  const int64_t m0 = (int64_t)(rem % a.mt) * (16 * MT16);
-  const int n0 = (rem / a.mt) * (64 * NW16);
-  if constexpr (MT16 <= 5) {
-    const int64_t left = (a.T - m0 + 15) / 16;
-    const int live = left < MT16 ? (int)left : MT16;
-    if (live == MT16) winograd_gemm_rb16d_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
-    else if (live == 1) winograd_gemm_rb16d_block<1, NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 2 && live == 2) winograd_gemm_rb16d_block<(MT16 > 2 ? 2 : 1), NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 3 && live == 3) winograd_gemm_rb16d_block<(MT16 > 3 ? 3 : 1), NW16>(a, smem_s, comp, m0, n0, split);
-    else if (MT16 > 4 && live == 4) winograd_gemm_rb16d_block<(MT16 > 4 ? 4 : 1), NW16>(a, smem_s, comp, m0, n0, split);
-  } else {
-    winograd_gemm_rb16d_block<MT16, NW16>(a, smem_s, comp, m0, n0, split);
-  }
-}
-
+// Round 6, built / measured / removed (profiles/r06_rb16d_ab.txt, the kernel text in profiles/r06_rb16d_kernel.hip.txt, commit
+// a7c1c05): A as three bf16 limb planes in fragment order moved global -> LDS by `buffer_load_dwordx4 ... lds` (no VALU split,
+// no ds_write, three LDS buffers, XOR-swizzled 64-byte rows).  Bit-identical to rb16s; the GEMM alone 1.4-4.9 us faster per
+// launch (conv3_x 41.6 -> 37.5, conv4_2 39.6 -> 37.9, conv5_1 +0.9), ~40 us per step -- against ~200 MB more V per step
+// (6 bytes per element written by 17 input transforms that run at the bandwidth already: ~50 us).  hipcc also waits for
+// EVERY transfer in flight before a fragment read that might alias it (it cannot tell the three buffers apart), so the
+// transfer of chunk c + 2 never overlaps the multiplies of chunk c; getting that needs the loads of the K loop in inline
+// asm with hand-counted waits on a fully unrolled loop.  Priced at 2-3 us more per launch: still not above the transforms'
+// extra bytes.
 // U [Z][K/32][N][32] -> Uq16 [Z][N/16][K/16][64][4]
 __global__ void __launch_bounds__(256) winograd_pack_frag16_kernel(const float* __restrict__ up, float* __restrict__ uq,
                                                                    int K, int N, int64_t total) {
@@ -1726,30 +1546,8 @@ static void launch_gemm_rb16s_pre(const WgGemmArgs& a, hipStream_t s) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   const int total = a.mt * a.nt * a.Z * a.ksplit, grid = (total + WG_XCDS - 1) / WG_XCDS * WG_XCDS;
   GemmTimerRec rec{nullptr, nullptr, 2.0 * a.Z * (double)a.T * a.K * a.N};
-  // NFS_RB16D=1 (measurement only, not capture-safe): the same product with A as limb planes moved global -> LDS by the
-  // transfer engine (winograd_gemm_rb16d_kernel); the planes come from a conversion pass OUTSIDE the timed region
-  static const bool rb16d = [] { const char* e = getenv("NFS_RB16D"); return e && atoi(e) != 0; }();
-  WgGemmArgs ad = a;
-  if (PRE && rb16d) {
-    static void* vb = nullptr; static size_t vb_bytes = 0;
-    const size_t need = (size_t)a.Z * a.T * a.K * 6;
-    if (need > vb_bytes) { if (vb) (void)hipFree(vb); (void)hipMalloc(&vb, need); vb_bytes = need; }
-    const int64_t tot = (int64_t)a.Z * (a.K / 32) * a.T * 4;
-    hipLaunchKernelGGL(winograd_v_limb_planes_kernel, dim3(blocks_for(tot, 256)), dim3(256), 0, s, a.V,
-                       reinterpret_cast<uint4*>(vb), a.T, a.K, tot);
-    ad.Vb16 = vb;
-  }
   const bool timed = g_timer_on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
   if (timed) (void)hipEventRecord(rec.e0, s);
-  if (PRE && rb16d) {
-    constexpr size_t lds_d = (size_t)3 * 3 * 16 * MT16 * 64 + 1024;
-    const size_t ldsd = lds_d > tile ? lds_d : tile;
-    static std::once_flag attr_d;
-    if (ldsd > 65536) std::call_once(attr_d, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_gemm_rb16d_kernel<MT16, NW16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd); });
-    hipLaunchKernelGGL((winograd_gemm_rb16d_kernel<MT16, NW16>), dim3(grid), dim3(256), ldsd, s, ad);
-  } else
   hipLaunchKernelGGL((winograd_gemm_rb16s_kernel<MT16, NW16, PRE>), dim3(grid), dim3(256), lds, s, a);
   if (timed) {
     rec.split = 1;

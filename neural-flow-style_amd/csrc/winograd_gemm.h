@@ -21,7 +21,6 @@ struct WgGemmArgs {
   const float* Uq = nullptr;            // B in MFMA fragment order [Z][N/32][K/8][64 lanes][4] (register-B kernel)
   const float* Uq16 = nullptr;          // ... for the 16x16x4 MFMA: [Z][N/16][K/16][64 lanes][4] (rb16 / rb16s kernels)
   const void* Ub16 = nullptr;           // rb16s: the same pack as three bf16 limb planes [Z][N/16][K/32][3][64 lanes][8 bf16]
-  const void* Vb16 = nullptr;           // rb16d: A as limb planes [Z][K/32][3][T][32 bf16, fragment order] (else V is read)
   int symb = 0;                         // rb16: Uq16 is instead a plain SYMMETRIC [Z][K][N] matrix (the Gram gradient's D)
   unsigned long long* prof = nullptr;   // -DNFS_ABLATE builds: per-wave phase cycle sums (nfs_gemm_prof)
   int dbg = 0;               // NFS_GEMM_DBG timing ablations
