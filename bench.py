@@ -1305,7 +1305,9 @@ def main():
             fms = sum(r["ms_per_step"] for r in fam)
             built = sum(r["achieved"] * r["ms_per_step"] for r in fam)        # GB/s * ms = MB
             Vl, G3 = int(rot_local.shape[0]), float(G) ** 3
-            fused = (4.0 * Vl * G3 + 4.0 * Vl * G * G) + (8.0 * Vl * G3 + 4.0 * Vl * G * G)
+            # (the adjoint's share scaled by what the live mask leaves of it: bytes not moved are not counted)
+            live_adj = LIVE_BOX_FRAC if any(r["kernel"] == "nfs_rotate_bwd_coef_live" for r in fam) else 1.0
+            fused = (4.0 * Vl * G3 + 4.0 * Vl * G * G) + live_adj * (8.0 * Vl * G3 + 4.0 * Vl * G * G)
             fused += sum(r["achieved"] * r["ms_per_step"] * 1e6 for r in fam if "advect" in r["kernel"])
             out["render_advect_family"] = {
                 "kernels": [r["kernel"] for r in fam], "ms_per_step": fms,
@@ -1314,6 +1316,7 @@ def main():
                                      "forward writes a kept volume (8VG^3) and the rotate adjoint reads it once (4VG^3 + "
                                      "4G^3) -- the render-adjoint pass (8VG^3) is gone; with NFS_RENDER_COEF=0: fwd 8VG^3, "
                                      "render adjoint 8VG^3, rotate adjoint 4VG^3 + 8G^3"},
+                "live_box_fraction": live_adj,
                 "survey_fused": {"bytes_per_step": fused, "frac_hbm": fused / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "note": "SURVEY 8(d) fully fused rotate+render (fwd 4VG^3 + 4VG^2, adjoint 8VG^3 + "
                                          "4VG^2) + the advect kernels as built, over the same measured time"}}

@@ -169,7 +169,7 @@ struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
 
 // Slab form (zoff, Dfull): vel / g_out / out / the moments hold only the D planes [zoff, zoff + D) of a volume of Dfull
 // planes, d is the WHOLE density (the back-traced points leave the slab); zoff = 0, Dfull = D is the whole volume.
-template <int MODE>
+template <int MODE, bool LIVE = false>   // LIVE: ad.live is set (a compile-time switch: the mask code out of the plain kernels)
 __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* vel,
                                                       const float* __restrict__ g_out, float* out,
                                                       int D, int H, int W, AdamFused ad, int zoff, int Dfull) {
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
       const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
       const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
       if (ok[j]) out[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
-      if (ad.live) {
+      if constexpr (LIVE) {
         const unsigned long long lv = __ballot(ok[j] && corners_differ(p[j]));
         if (lane == 0 && first + 64 * j < n) ad.live[(first + 64 * j) >> 6] = lv;
       }
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
         const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
         const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
         if (ok[j]) ad.adv_next[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
-        if (ad.live) {
+        if constexpr (LIVE) {
           const unsigned long long lv = __ballot(ok[j] && corners_differ(p[j]));
           if (lane == 0 && first + 64 * j < n) ad.live[(first + 64 * j) >> 6] = lv;
         }
@@ -1066,7 +1066,7 @@ int nfs_advect_fwd_live(const float* d, const float* vel, float* out, unsigned l
               "nfs_advect_fwd_live: needs D, H, W >= 2 and D*H*W %% 4 == 0");
   AdamFused ad{};
   ad.live = live;
-  hipLaunchKernelGGL(advect1_kernel<0>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
+  hipLaunchKernelGGL((advect1_kernel<0, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
                      (const float*)nullptr, out, D, H, W, ad, 0, D);
   return check_launch("nfs_advect_fwd_live");
 }
@@ -1126,7 +1126,7 @@ int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out,
   const int64_t n = (int64_t)D * H * W;
   NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
               "nfs_advect_bwd_adam_fwd_live: needs D, H, W >= 2 and D*H*W %% 4 == 0");
-  hipLaunchKernelGGL(advect1_kernel<2>, dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+  hipLaunchKernelGGL((advect1_kernel<2, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live_next}, 0, D);
   return check_launch("nfs_advect_bwd_adam_fwd_live");
 }
