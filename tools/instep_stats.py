@@ -26,7 +26,7 @@ def main():
         raise SystemExit("found %d step starts, expected >= %d" % (len(starts), steps))
     first = starts[-steps]
     # the step after the last timed one does not exist: the last step ends with the Adam update kernel
-    last = max(i for i, r in enumerate(rows) if "advect1_kernel<2>" in r[2] or "adam_kernel" in r[2])
+    last = max(i for i, r in enumerate(rows) if "advect1_kernel<2" in r[2] or "adam_kernel" in r[2])
     sel = rows[first:last + 1]
     agg = collections.defaultdict(lambda: [0, 0])
     for s, e, n in sel:
