@@ -447,7 +447,10 @@ __global__ void __launch_bounds__(256) transport_step_generic_kernel(const float
 #endif
 constexpr int RT_TZ = NFS_RT_TZ, RT_TY = NFS_RT_TY, RT_TX = NFS_RT_TX;
 constexpr int RT_LZ = RT_TZ + 2, RT_LY = RT_TY + 2, RT_LX = RT_TX + 2;
-constexpr int RT_THREADS = 1024;
+#ifndef NFS_RT_THREADS
+#define NFS_RT_THREADS 1024
+#endif
+constexpr int RT_THREADS = NFS_RT_THREADS;
 constexpr int RT_GROUP = NFS_RT_GROUP;   // lanes that share one lattice row
 constexpr int RT_VMAX = 32;   // views per launch (host loops over chunks)
 
