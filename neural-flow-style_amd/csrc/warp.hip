@@ -1019,9 +1019,10 @@ int nfs_rotate_bwd_coef(const float* u_rot, const float* ab, const float* rot, f
 
 // ... restricted to what a velocity variable can use: `live` is the mask nfs_advect_fwd_live / nfs_advect_bwd_adam_fwd_live
 // wrote for the CURRENT velocity ([nfs_live_mask_words] 64-bit words, bit = linear voxel index), `dilate` the reach of
-// the linear stencil between g_d and the advect adjoint (1 for the 3x3x3 smoothing, 0 without it).  Voxels of g_d further
-// than `dilate` from every live voxel are written as zeros or as partial sums -- values that only ever meet a zero
-// factor; all others are bit-identical to nfs_rotate_bwd_coef.  A tile without such voxels returns before its sample loop.
+// the linear stencil between g_d and the advect adjoint (1 for the 3x3x3 smoothing, 0 without it).  Inside a tile's box
+// (the bounding box of its voxels within `dilate` of a live voxel) g_d is bit-identical to nfs_rotate_bwd_coef; outside
+// the boxes it is written as zeros (overwrite) or left alone (accumulate) -- values that only ever meet a zero factor.
+// A tile without a box returns before its sample loop; the others run longest first.
 int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc, int V, int D, int H,
                              int W, int nseg, int seg_len, const float* bounds, int nbounds, int overwrite,
                              const unsigned long long* live, int dilate, int* workspace, nfs_stream_t stream) {
