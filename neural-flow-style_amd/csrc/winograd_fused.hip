@@ -168,6 +168,22 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
       const float row[6] = {tcol[0][r], tcol[1][r], tcol[2][r], tcol[3][r], tcol[4][r], tcol[5][r]};
       float o[6];
       wg4_bt1(row, o);
+#ifdef NFS_K7F_EMUL_BF16
+      // ... and the limb split of the transform's 36 outputs (three cvt_pk levels per pair), folded back so that it stays
+#pragma unroll
+      for (int q = 0; q < 6; q += 2) {
+        typedef float emu_f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 emu_b2 __attribute__((ext_vector_type(2)));
+        const emu_f2 x = {o[q], o[q + 1]};
+        const emu_b2 bh = __builtin_convertvector(x, emu_b2);
+        const emu_f2 r1 = x - __builtin_convertvector(bh, emu_f2);
+        const emu_b2 bm = __builtin_convertvector(r1, emu_b2);
+        const emu_f2 r2 = r1 - __builtin_convertvector(bm, emu_f2);
+        const emu_b2 bl = __builtin_convertvector(r2, emu_b2);
+        const emu_f2 back = __builtin_convertvector(bh, emu_f2) + __builtin_convertvector(bm, emu_f2) + __builtin_convertvector(bl, emu_f2);
+        o[q] = back.x; o[q + 1] = back.y;
+      }
+#endif
 #pragma unroll
       for (int q = 0; q < 6; ++q) V[(r * 6 + q) * WF_PXF + v_wr] = o[q];
     }
@@ -298,6 +314,22 @@ __global__ void __launch_bounds__(256, 2) winograd_fused_kernel(WfArgs a) {
       // (the two k-steps of a component are issued 6 MFMAs apart: back-to-back MFMAs on one accumulator wait for
       // each other)
       const int zb = 6 * (gi % 6);
+#ifdef NFS_K7F_EMUL_BF16
+      // TIMING-ONLY emulation (wrong results by construction; tools/k7f_bf16_emul.sh, never in the product build): what the
+      // slice loop would cost on the bf16 pipe -- a 16-deep slice of 36 components is 36 x 3 = 108 v_mfma_f32_16x16x32_bf16
+      // of 16 cycles (nine per group here) instead of 144 v_mfma_f32_16x16x4_f32 of 32 -- with everything else as it is
+      // (the filter stream of the f32 form: 2/3 of what limb planes at 16 tiles would need, 4/3 of the component-split
+      // form's; two blocks per CU)
+      {
+        typedef __bf16 emu_b8 __attribute__((ext_vector_type(8)));
+        const emu_b8 ea = __builtin_bit_cast(emu_b8, bq[gi % RING][0]), eb = __builtin_bit_cast(emu_b8, bq[gi % RING][1]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[zb + (i % 6)]) : "v"(ea), "v"(eb));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      continue;
+#endif
       // (inline asm: accumulate in place -- the builtin lets hipcc rotate the accumulators through two dozen spare
       // registers this kernel does not have)
 #pragma unroll
