@@ -183,3 +183,47 @@ def test_mask_follows_the_variable():
     gs.bind(d1); ref.bind(d1)
     gs.step(rot); ref.step(rot)
     assert torch.equal(gs.var, ref.var)
+
+
+def test_more_views_than_one_launch_takes():
+    """33 views = two launches of the adjoint (32 + 1) over ONE set of boxes: the first writes (overwrite), the second
+    accumulates inside the boxes only; needed voxels bit-equal to the unmasked pair of launches"""
+    import neural_flow_style_amd.ops as ops
+    import neural_flow_style_amd.transform as T
+    D, H, W, V = 16, 18, 40, 33
+    rng = np.random.RandomState(17)
+    d = torch.tensor(rng.rand(D, H, W).astype(np.float32)).cuda()
+    rot = T.rot_to_device(uniform_views(V), "cuda")
+    u_rot = torch.empty((V, D, H, W), dtype=torch.float32, device="cuda")
+    _, _, _, seg = ops.rotate_render_fwd_coef(d, rot, 0.05, u_rot=u_rot)
+    ab, bounds = ops.render_ray_coef(torch.tensor(rng.randn(V, H, W).astype(np.float32)).cuda(), seg, 0.05)
+    full = ops.rotate_bwd_coef(u_rot, ab, rot, bounds)
+    m = np.zeros((D, H, W), bool)
+    m[3:9, 10:15, 5:12] = True
+    words = np.zeros(int(ops._lib.lib().nfs_live_mask_words(D, H, W)) * 8, np.uint8)
+    packed = np.packbits(m.reshape(-1), bitorder="little")
+    words[:packed.size] = packed
+    live = torch.tensor(words.view(np.float32)).cuda()
+    got = ops.rotate_bwd_coef(u_rot, ab, rot, bounds, live=live, dilate=1)
+    need = torch.tensor(_dilate(m, 1)).cuda()
+    assert torch.equal(got[need], full[need]) and torch.isfinite(got).all()
+
+
+def test_view_groups_on_side_streams_and_no_smoothing():
+    """view groups whose chains run on separate streams use one box workspace per stream (the adjoints run concurrently);
+    k = 0 (no smoothing between the rotate and the advect adjoint) uses a reach of 0: both bit-equal to skipping off"""
+    import neural_flow_style_amd.engine as eng
+    for groups, k in ((2, 3.0), (1, 0.0)):
+        res = {}
+        for skip in (False, True):
+            gs, rot = _stylizer(44, 4, "smoke", skip, False)
+            gs.k = k
+            gs.loss.view_groups = groups
+            gs.loss.vgg_streams = groups
+            for _ in range(3):
+                gs.step(rot)
+            res[skip] = (gs.var.clone(), gs.adam.m.clone(), gs.adam.v.clone(), bool(gs._live_kw()),
+                         gs._live_kw().get("dilate"))
+        assert res[True][3] and res[True][4] == (1 if k > 0 else 0)
+        for x, y in zip(res[True][:3], res[False][:3]):
+            assert torch.equal(x, y), (groups, k)
