@@ -97,6 +97,21 @@ def relaunch(args):
 
 
 LIVE_BOX_FRAC = 1.0       # share of the volume inside the boxes the rotate adjoint accumulates (set from the mask in main())
+EVER_WAVE_FRAC = 1.0      # share of the 256-voxel waves of the advect + Adam kernel that hold an ever-live voxel (likewise)
+
+
+def ever_wave_fraction(gs):
+    """(ever-live voxels / all, 256-voxel waves with an ever-live voxel / all) from the Adam state's mask"""
+    ev = gs.adam.ever_mask()
+    if ev is None:
+        return 1.0, 1.0
+    n = gs.d0.numel()
+    words = ev.view(torch.int64).cpu().numpy().view(np.uint64)
+    nz = words != 0
+    pad = (-len(nz)) % 4
+    waves = np.concatenate([nz, np.zeros(pad, bool)]).reshape(-1, 4).any(1)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    return float(bits.mean()), float(waves[:(n + 255) // 256].mean())
 
 
 def live_box_fraction(gs):
@@ -234,6 +249,11 @@ def work_of(name, a):
     if name == "nfs_advect_bwd_adam_fwd_live":
         D, H, W = a[7:10]
         return "B", 84.125 * D * H * W             # + one mask bit per voxel
+    if name == "nfs_advect_bwd_adam_fwd_live_ever":
+        D, H, W = a[8:11]
+        # only the 256-voxel waves with a voxel that has ever been live move their 84 bytes per voxel (EVER_WAVE_FRAC,
+        # measured from the Adam state's mask in main()); every wave reads its four mask words twice
+        return "B", (84.125 * EVER_WAVE_FRAC + 0.25) * D * H * W
     if name in ("nfs_smooth3d_relu_fwd",):
         D, H, W = a[2:5]
         return "B", 8.0 * D * H * W
@@ -1095,14 +1115,18 @@ def main():
             # data dependence of the headline, made visible: the rotate adjoint skips what only feeds voxels whose
             # velocity gradient is an exact zero (empty space, plateaus).  (a) the same problem with skipping off,
             # (b) a dense density on which nothing can be skipped -- both NOT the headline
-            global LIVE_BOX_FRAC
+            global LIVE_BOX_FRAC, EVER_WAVE_FRAC
             lf, bf, sk = live_box_fraction(gs)
             LIVE_BOX_FRAC = bf
+            ef, EVER_WAVE_FRAC = ever_wave_fraction(gs)
             ctl = {"live_voxel_fraction": lf, "accumulated_box_fraction": bf, "tiles_skipped_fraction": sk,
+                   "ever_live_voxel_fraction": ef, "adam_waves_run_fraction": EVER_WAVE_FRAC,
                    "note": "velocity variable: dL/dv(x) = g(x) * grad d0(x - v) is an exact zero where the eight "
                            "back-traced density corners are equal, whatever g(x) is; the rotate adjoint therefore sums "
                            "only the per-tile bounding boxes of the voxels within the smoothing stencil of a live voxel "
-                           "(nfs_rotate_bwd_coef_live).  The Adam update is BIT-identical with and without it "
+                           "(nfs_rotate_bwd_coef_live), and the fused advect-adjoint + ApplyAdam kernel leaves out the 256-voxel "
+                           "waves none of whose voxels has ever been live (m = v = +0 there and the gradient is +-0: an exact "
+                           "no-op; nfs_advect_bwd_adam_fwd_live_ever).  The Adam update is BIT-identical with and without it "
                            "(tests/test_dead_skip_gpu.py); the synthetic smoke of SURVEY 8(d) is %.0f %% live" % (100 * lf)}
             gs.dead_skip = False
             settle(views_step, 3)
@@ -1305,7 +1329,7 @@ def main():
                                                   "nfs_rotate_render_fwd_coef", "nfs_render_ray_coef", "nfs_rotate_bwd_coef",
                                                   "nfs_rotate_bwd_coef_live", "nfs_advect_fwd", "nfs_advect_fwd_live",
                                                   "nfs_advect_bwd_adam", "nfs_advect_bwd", "nfs_advect_bwd_adam_fwd",
-                                                  "nfs_advect_bwd_adam_fwd_live")]
+                                                  "nfs_advect_bwd_adam_fwd_live", "nfs_advect_bwd_adam_fwd_live_ever")]
         if fam:
             fms = sum(r["ms_per_step"] for r in fam)
             built = sum(r["achieved"] * r["ms_per_step"] for r in fam)        # GB/s * ms = MB

@@ -314,6 +314,14 @@ int nfs_advect_fwd_live(const float* d, const float* vel, float* out, unsigned l
 int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
                                  unsigned long long* live_next, int D, int H, int W, float lr_t, float beta1,
                                  float beta2, float eps, nfs_stream_t stream);
+/* ... and without touching the voxels that have NEVER been live: `ever` [nfs_live_mask_words] = OR of every mask since the
+ * Adam moments were zeroed (zero it with them; do not use it once anything else has written m or v).  Where a voxel's bit
+ * is clear in `ever` and in the current mask (`live` on entry), m = v = +0 and this gradient is +-0: ApplyAdam is an
+ * exact no-op there and the next sample and mask bit are what they were, so a wave of 256 such voxels returns before its
+ * first load.  `live`: the current mask on entry, the next one on return.  Bit-identical to the call above. */
+int nfs_advect_bwd_adam_fwd_live_ever(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                                      unsigned long long* live, unsigned long long* ever, int D, int H, int W,
+                                      float lr_t, float beta1, float beta2, float eps, nfs_stream_t stream);
 int nfs_rotate_bwd_coef_live(const float* u_rot, const float* ab, const float* rot, float* g_d_acc,
                              int V, int D, int H, int W, int nseg, int seg_len, const float* bounds, int nbounds,
                              int overwrite, const unsigned long long* live, int dilate, int* workspace,

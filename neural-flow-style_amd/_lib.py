@@ -100,6 +100,7 @@ SIGNATURES = {
     "nfs_live_mask_words": [_I, _I, _I],
     "nfs_advect_fwd_live": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nfs_advect_bwd_adam_fwd_live": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "nfs_advect_bwd_adam_fwd_live_ever": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "nfs_rotate_bwd_coef_live": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P],
     "nfs_rotate_live_workspace_ints": [_I, _I, _I],
     "nfs_rotate_render_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
@@ -174,7 +175,7 @@ _RESTYPE = {"nfs_last_error": C.c_char_p, "nfs_conv3x3_packed_floats": C.c_int64
             "nfs_conv2d_workspace_floats": C.c_int64, "nfs_conv2d_group_workspace_floats": C.c_int64}
 
 _lib = None
-ABI_VERSION = 150          # nfs_version() this table was written against (include/nfs_hip.h)
+ABI_VERSION = 151          # nfs_version() this table was written against (include/nfs_hip.h)
 
 
 def build(verbose=False):

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpArgs a, const float* 
 // constant): the forward advect launch of the next iteration and its 96 MB velocity read disappear.  Same arithmetic
 // as MODE 0 on the stored velocity: bit-identical to running nfs_advect_fwd afterwards.
 struct AdamFused { float* m; float* v; float lr_t, b1, b2, eps; float* adv_next = nullptr;
-                   unsigned long long* live = nullptr; };
+                   unsigned long long* live = nullptr; unsigned long long* ever = nullptr; };
 
 // live mask (nullable; whole-volume launches only): bit i of the mask = "the eight density corners the back-traced point
 // of voxel i interpolates are NOT all equal".  Where they are equal the sample does not depend on the coordinate and the
@@ -188,6 +188,28 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   const unsigned lb = MODE == 2 ? blockIdx.x : (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const int first = (lb * blockDim.x + (threadIdx.x - lane)) * 4 + lane;
   if (first - lane >= n) return;
+  if constexpr (MODE == 2 && LIVE) {
+    // `ever` (nullable): bit i = voxel i has been live in SOME iteration since the Adam moments were zeroed.  Where it never
+    // was, every velocity gradient so far was an exact zero: m = v = +0, and this iteration's is zero again when the
+    // CURRENT mask (`live` on entry: the mask of the forward sample this gradient belongs to) has the bit clear too --
+    // ApplyAdam then leaves m, v and the velocity exactly as they are (b1 0 + (1 - b1) (+-0) = +0, x - lr 0 / (0 + eps) = x),
+    // so the next forward sample and its mask bit do not change either.  A wave whose 256 voxels are all like that has
+    // nothing to read and nothing to write: it returns here.  (Everything else runs the unchanged path: bit-identical.)
+    if (ad.ever) {
+      const int wbase = __builtin_amdgcn_readfirstlane(first - lane);
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = wbase + 64 * j;
+        if (b < n) {
+          const unsigned long long e0 = ad.ever[b >> 6], e = e0 | ad.live[b >> 6];
+          if (e != e0 && lane == 0) ad.ever[b >> 6] = e;
+          any |= e;
+        }
+      }
+      if (any == 0ull) return;
+    }
+  }
   const F3u* v3 = reinterpret_cast<const F3u*>(vel);
   const F3u* m3 = reinterpret_cast<const F3u*>(ad.m);
   const F3u* u3 = reinterpret_cast<const F3u*>(ad.v);
@@ -1133,6 +1155,24 @@ int nfs_advect_bwd_adam_fwd_live(const float* d, float* vel, const float* g_out,
   hipLaunchKernelGGL((advect1_kernel<2, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
                      D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live_next}, 0, D);
   return check_launch("nfs_advect_bwd_adam_fwd_live");
+}
+
+// ... skipping the waves whose voxels have never been live (see `ever` in advect1_kernel): `live` holds the mask of the
+// CURRENT forward sample on entry and that of the next one on return, `ever` [nfs_live_mask_words] is the OR of every mask
+// since m and v were zeroed (zero it with them; the caller must not use it once anything else has written m or v).
+// Bit-identical to nfs_advect_bwd_adam_fwd_live.
+int nfs_advect_bwd_adam_fwd_live_ever(const float* d, float* vel, const float* g_out, float* m, float* v, float* adv_next,
+                                      unsigned long long* live, unsigned long long* ever, int D, int H, int W, float lr_t,
+                                      float beta1, float beta2, float eps, nfs_stream_t stream) {
+  NFS_REQUIRE(d && vel && g_out && m && v && adv_next && live && ever, "nfs_advect_bwd_adam_fwd_live_ever: null pointer");
+  NFS_REQUIRE(adv_next != d && adv_next != g_out, "nfs_advect_bwd_adam_fwd_live_ever: adv_next must not alias d or g_out");
+  if (int e = check_dims(1, D, H, W, 1)) return e;
+  const int64_t n = (int64_t)D * H * W;
+  NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
+              "nfs_advect_bwd_adam_fwd_live_ever: needs D, H, W >= 2 and D*H*W %% 4 == 0");
+  hipLaunchKernelGGL((advect1_kernel<2, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
+                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live, ever}, 0, D);
+  return check_launch("nfs_advect_bwd_adam_fwd_live_ever");
 }
 
 // Slab forms (view-sharded runs shard the replicated field work over D-slabs, engine.GridStylizer): d is the whole

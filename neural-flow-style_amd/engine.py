@@ -626,6 +626,17 @@ class TFAdamState(object):
         self.b1p, self.b2p = np.float32(1.0), np.float32(1.0)
         self.m = None
         self.v = None
+        # OR of every live mask since m and v were zeroed (step_through_advect with a mask): voxels outside it still have
+        # m = v = +0.  Usable only while nothing but that kernel has written m or v (their version counters say)
+        self._ever = None
+        self._ever_key = None
+
+    def ever_mask(self):
+        """the mask above, or None when m or v have been written by anything else since they were zeroed"""
+        if self._ever is None or self.m is None or self._ever_key != (self.m._version, self.v._version):
+            self._ever = None
+            return None
+        return self._ever
 
     def step(self, x, g, lr):
         if self.m is None or self.m.shape != x.shape:
@@ -637,18 +648,31 @@ class TFAdamState(object):
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
         ops.adam_tf_step(x, self.m, self.v, g, float(lr_t), float(self.b1), float(self.b2), float(self.eps))
 
-    def step_through_advect(self, vel, d0, g_adv, lr, adv_next=None, live_next=None):
+    def step_through_advect(self, vel, d0, g_adv, lr, adv_next=None, live_next=None, live_current=False):
         """the same update for the velocity variable of ``advect(d0, vel)`` given dL/d(advected density): the
         velocity gradient is formed and consumed inside one kernel (never written to HBM).  ``adv_next`` [D,H,W]
-        (optional) receives advect(d0, updated vel) -- the next iteration's forward sample -- in the same pass"""
-        if self.m is None or self.m.shape != vel.shape:
+        (optional) receives advect(d0, updated vel) -- the next iteration's forward sample -- in the same pass, ``live_next``
+        its live mask.  ``live_current``: ``live_next`` holds the mask of the CURRENT sample on entry (and ``adv_next`` that
+        sample) -- the waves whose voxels never were live are then left out (``ever_mask``)"""
+        fresh = self.m is None or self.m.shape != vel.shape
+        if fresh:
             self.m = torch.zeros_like(vel)
             self.v = torch.zeros_like(vel)
+            self._ever = None
+        if fresh and live_next is not None:
+            self._ever = torch.zeros_like(live_next)
+            self._ever_key = (self.m._version, self.v._version)
+        ever = self.ever_mask() if (live_current and live_next is not None and adv_next is not None) else None
         self.b1p = np.float32(self.b1p * self.b1)
         self.b2p = np.float32(self.b2p * self.b2)
         lr_t = np.float32(lr) * np.sqrt(np.float32(1.0) - self.b2p) / (np.float32(1.0) - self.b1p)
+        tracked = self._ever is not None and self._ever_key == (self.m._version, self.v._version)
         ops.advect_bwd_adam(d0, vel, g_adv, self.m, self.v, float(lr_t), float(self.b1), float(self.b2),
-                            float(self.eps), adv_next=adv_next, live_next=live_next)
+                            float(self.eps), adv_next=adv_next, live_next=live_next, ever=ever)
+        if ever is not None:
+            self._ever_key = (self.m._version, self.v._version)      # (our own write: the mask stays usable)
+        elif tracked:
+            self._ever = None                                        # (a step without the mask update: it no longer covers m, v)
 
 
     def step_through_advect_slab(self, vel_slab, d0, g_adv_slab, z0, lr, adv_next=None):
@@ -1177,8 +1201,10 @@ class GridStylizer(object):
             g_adv = ops.smooth3d_relu_bwd(self.d_s, g_ds, self.k)
             adv = self._adv_target()
             live = self._live_target()
+            # (the mask buffer holds the CURRENT sample's mask when the adjoint above could use it: the Adam kernel may
+            # then leave out the voxels that never were live)
             self.adam.step_through_advect(self.var, self.d0.unsqueeze(-1), g_adv.unsqueeze(-1), self.lr, adv_next=adv,
-                                          live_next=live)
+                                          live_next=live, live_current=live is not None and self._live_valid())
             if adv is not None:
                 self._adv_mark(live=live is not None)
         else:

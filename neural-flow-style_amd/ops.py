@@ -136,13 +136,20 @@ def advect_bwd(d, vel, g_out, need_d=True, need_vel=True, g_d_acc=None, g_vel=No
     return g_d_acc, g_vel
 
 
-def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None, live_next=None):
+def advect_bwd_adam(d, vel, g_out, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, adv_next=None, live_next=None, ever=None):
     """velocity gradient of advect consumed on the spot by the TF-Adam update of vel (vel, m, v in place);
     ``adv_next`` [D,H,W] (optional): advect(d, updated vel), the next iteration's forward sample, written in the same pass;
-    ``live_next`` (optional, with adv_next): the live mask of that sample (``advect_fwd``)"""
+    ``live_next`` (optional, with adv_next): the live mask of that sample (``advect_fwd``);
+    ``ever`` (optional, with live_next, which must then hold the CURRENT mask on entry): the OR of every mask since m and v
+    were zeroed -- waves of voxels that never were live are left out altogether (ApplyAdam is an exact no-op there)"""
     D, H, W, Cn = d.shape
     assert Cn == 1
-    if adv_next is not None and live_next is not None:
+    if adv_next is not None and live_next is not None and ever is not None:
+        assert adv_next.is_contiguous() and adv_next.numel() == D * H * W and ever.numel() == live_next.numel()
+        _lib.call("nfs_advect_bwd_adam_fwd_live_ever", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), _ptr(adv_next),
+                  _ptr(live_next), _ptr(ever), D, H, W, float(lr_t), float(beta1), float(beta2), float(eps), _stream())
+        _written(live_next, ever)
+    elif adv_next is not None and live_next is not None:
         assert adv_next.is_contiguous() and adv_next.numel() == D * H * W
         _lib.call("nfs_advect_bwd_adam_fwd_live", _ptr(d), _ptr(vel), _ptr(g_out), _ptr(m), _ptr(v), _ptr(adv_next),
                   _ptr(live_next), D, H, W, float(lr_t), float(beta1), float(beta2), float(eps), _stream())

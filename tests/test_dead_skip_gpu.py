@@ -227,3 +227,37 @@ def test_view_groups_on_side_streams_and_no_smoothing():
         assert res[True][3] and res[True][4] == (1 if k > 0 else 0)
         for x, y in zip(res[True][:3], res[False][:3]):
             assert torch.equal(x, y), (groups, k)
+
+
+def test_never_live_waves_are_left_out_of_the_adam_kernel_only_while_the_moments_are_its_own():
+    """the fused advect-adjoint + ApplyAdam kernel skips the 256-voxel waves none of whose voxels has ever been live
+    (TFAdamState.ever_mask).  That rests on m = v = +0 there, so the mask is dropped as soon as anything else writes the
+    moments -- the plain Adam step, a copy into m -- and the steps stay bit-identical to skipping off throughout"""
+    G, V = 44, 2
+    gs, rot = _stylizer(G, V, "smoke", True, False)
+    ref, _ = _stylizer(G, V, "smoke", False, False)
+    for _ in range(2):
+        gs.step(rot); ref.step(rot)
+    ev = gs.adam.ever_mask()
+    assert ev is not None and ref.adam.ever_mask() is None
+    ever = _bits(ev, G ** 3)
+    live = _bits(gs._live_buf, G ** 3)
+    assert 0.05 < ever.mean() < 0.8                            # (the current mask is OR-ed in by the next step's kernel)
+    del live
+    # outside the mask the moments are exactly zero
+    m_nz = (gs.adam.m != 0).any(-1).reshape(-1).cpu().numpy() | (gs.adam.v != 0).any(-1).reshape(-1).cpu().numpy()
+    assert not (m_nz & ~ever).any()
+    # a foreign write to the moments (here: a no-op in value, but the version counter moves): the mask is dropped
+    gs.adam.m.mul_(1.0); ref.adam.m.mul_(1.0)
+    assert gs.adam.ever_mask() is None
+    for _ in range(2):
+        gs.step(rot); ref.step(rot)
+    assert gs.adam.ever_mask() is None                         # ... and does not come back for this state
+    assert torch.equal(gs.var, ref.var) and torch.equal(gs.adam.m, ref.adam.m) and torch.equal(gs.adam.v, ref.adam.v)
+    # a fresh state on the same stylizer starts a fresh mask
+    import neural_flow_style_amd.engine as eng
+    gs.adam = eng.TFAdamState(); ref.adam = eng.TFAdamState()
+    for _ in range(2):
+        gs.step(rot); ref.step(rot)
+    assert gs.adam.ever_mask() is not None
+    assert torch.equal(gs.var, ref.var) and torch.equal(gs.adam.m, ref.adam.m) and torch.equal(gs.adam.v, ref.adam.v)
