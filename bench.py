@@ -111,6 +111,12 @@ def ever_wave_fraction(gs):
     pad = (-len(nz)) % 4
     waves = np.concatenate([nz, np.zeros(pad, bool)]).reshape(-1, 4).any(1)
     bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    # the kernel predicates its streamed accesses per lane (unless NFS_EVER_LANES=0): memory then moves whole cache lines of
+    # ever-live voxels -- counted here in runs of 16 voxels (192 bytes of a 12-byte-per-voxel stream: a line and a half)
+    if os.environ.get("NFS_EVER_LANES", "1") != "0":
+        pad16 = (-n) % 16
+        runs = np.concatenate([bits, np.zeros(pad16, np.uint8)]).reshape(-1, 16).any(1)
+        return float(bits.mean()), float(runs.mean())
     return float(bits.mean()), float(waves[:(n + 255) // 256].mean())
 
 
@@ -251,8 +257,9 @@ def work_of(name, a):
         return "B", 84.125 * D * H * W             # + one mask bit per voxel
     if name == "nfs_advect_bwd_adam_fwd_live_ever":
         D, H, W = a[8:11]
-        # only the 256-voxel waves with a voxel that has ever been live move their 84 bytes per voxel (EVER_WAVE_FRAC,
-        # measured from the Adam state's mask in main()); every wave reads its four mask words twice
+        # only the ever-live part of the volume moves its 84 bytes per voxel (EVER_WAVE_FRAC, measured from the Adam state's
+        # mask in main(): 16-voxel runs with an ever-live voxel, or whole 256-voxel waves with NFS_EVER_LANES=0); every
+        # wave reads its four mask words twice
         return "B", (84.125 * EVER_WAVE_FRAC + 0.25) * D * H * W
     if name in ("nfs_smooth3d_relu_fwd",):
         D, H, W = a[2:5]
@@ -1120,7 +1127,7 @@ def main():
             LIVE_BOX_FRAC = bf
             ef, EVER_WAVE_FRAC = ever_wave_fraction(gs)
             ctl = {"live_voxel_fraction": lf, "accumulated_box_fraction": bf, "tiles_skipped_fraction": sk,
-                   "ever_live_voxel_fraction": ef, "adam_waves_run_fraction": EVER_WAVE_FRAC,
+                   "ever_live_voxel_fraction": ef, "adam_bytes_moved_fraction": EVER_WAVE_FRAC,
                    "note": "velocity variable: dL/dv(x) = g(x) * grad d0(x - v) is an exact zero where the eight "
                            "back-traced density corners are equal, whatever g(x) is; the rotate adjoint therefore sums "
                            "only the per-tile bounding boxes of the voxels within the smoothing stencil of a live voxel "
@@ -1128,12 +1135,15 @@ def main():
                            "waves none of whose voxels has ever been live (m = v = +0 there and the gradient is +-0: an exact "
                            "no-op; nfs_advect_bwd_adam_fwd_live_ever).  The Adam update is BIT-identical with and without it "
                            "(tests/test_dead_skip_gpu.py); the synthetic smoke of SURVEY 8(d) is %.0f %% live" % (100 * lf)}
-            gs.dead_skip = False
-            settle(views_step, 3)
-            dto, _ = time_steps(views_step, barrier, args.warmup, args.steps, device, world)
+            # (a stylizer of its own: a step without the masks ends the headline stylizer's ever-live bookkeeping for good)
+            gso, roto, _ = build_problem(G, V, device, rank, world)
+            gso.dead_skip = False
+            ostep = lambda: gso.step(roto, loss_view=True)
+            settle(ostep)
+            dto, _ = time_steps(ostep, barrier, args.warmup, args.steps, device, world)
             ctl["skipping_off"] = {"value": args.steps / dto, "unit": "iters/s", "ms_per_step": 1e3 * dto / args.steps}
-            gs.dead_skip = True
-            settle(views_step, 3)
+            del gso, roto
+            torch.cuda.empty_cache()
             if world == 1 and not args.no_other_configs:
                 gsd, rotd, _ = build_problem(G, V, device, rank, world, dense=True)
                 dstep = lambda: gsd.step(rotd, loss_view=True)

@@ -169,7 +169,8 @@ struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
 
 // Slab form (zoff, Dfull): vel / g_out / out / the moments hold only the D planes [zoff, zoff + D) of a volume of Dfull
 // planes, d is the WHOLE density (the back-traced points leave the slab); zoff = 0, Dfull = D is the whole volume.
-template <int MODE, bool LIVE = false>   // LIVE: ad.live is set (a compile-time switch: the mask code out of the plain kernels)
+// EVER (MODE 2 + LIVE, volumes below 2^31 / 12 voxels): ad.ever is set and the streamed accesses are predicated per lane
+template <int MODE, bool LIVE = false, bool EVER = false>   // LIVE: ad.live is set (a compile-time switch: the mask code out of the plain kernels)
 __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ d, const float* vel,
                                                       const float* __restrict__ g_out, float* out,
                                                       int D, int H, int W, AdamFused ad, int zoff, int Dfull) {
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
   const unsigned lb = MODE == 2 ? blockIdx.x : (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const int first = (lb * blockDim.x + (threadIdx.x - lane)) * 4 + lane;
   if (first - lane >= n) return;
+  [[maybe_unused]] unsigned long long ew[4] = {~0ull, ~0ull, ~0ull, ~0ull};
   if constexpr (MODE == 2 && LIVE) {
     // `ever` (nullable): bit i = voxel i has been live in SOME iteration since the Adam moments were zeroed.  Where it never
     // was, every velocity gradient so far was an exact zero: m = v = +0, and this iteration's is zero again when the
@@ -201,15 +203,36 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int b = wbase + 64 * j;
+        ew[j] = 0ull;
         if (b < n) {
           const unsigned long long e0 = ad.ever[b >> 6], e = e0 | ad.live[b >> 6];
           if (e != e0 && lane == 0) ad.ever[b >> 6] = e;
           any |= e;
+          ew[j] = e;
         }
       }
       if (any == 0ull) return;
     }
   }
+  // EVER: in a wave that runs, the lanes whose voxel never was live take part in nothing either -- their streamed loads
+  // get an offset beyond the buffer (the hardware answers zeros without touching memory: exactly what m and v hold
+  // there), their stores likewise, their mask bit stays clear.  Traffic then follows the ever-live cache lines, not the
+  // ever-live waves.
+  [[maybe_unused]] bool act[4] = {true, true, true, true};
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t vel_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vel), 0, EVER ? (uint32_t)n * 12u : 0u, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t m_rs = __builtin_amdgcn_make_buffer_rsrc(ad.m, 0, EVER ? (uint32_t)n * 12u : 0u, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(ad.v, 0, EVER ? (uint32_t)n * 12u : 0u, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_out), 0, EVER ? (uint32_t)n * 4u : 0u, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t adv_rs = __builtin_amdgcn_make_buffer_rsrc(ad.adv_next, 0, EVER ? (uint32_t)n * 4u : 0u, 0x00020000);
+  typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+  [[maybe_unused]] auto ld3 = [](__amdgpu_buffer_rsrc_t r, uint32_t o) {
+    const u32x3_t q = __builtin_amdgcn_raw_buffer_load_b96(r, o, 0, 0);
+    return F3u{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z)};
+  };
+  [[maybe_unused]] auto st3 = [](F3u f, __amdgpu_buffer_rsrc_t r, uint32_t o) {
+    const u32x3_t q = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z)};
+    __builtin_amdgcn_raw_buffer_store_b96(q, r, o, 0, 0);
+  };
   const F3u* v3 = reinterpret_cast<const F3u*>(vel);
   const F3u* m3 = reinterpret_cast<const F3u*>(ad.m);
   const F3u* u3 = reinterpret_cast<const F3u*>(ad.v);
@@ -221,6 +244,15 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
     const int idx = first + 64 * j;
     ok[j] = idx < n;
     const int ic = ok[j] ? idx : n - 1;
+    if constexpr (EVER) {
+      act[j] = ok[j] && ((ew[j] >> lane) & 1ull);
+      const uint32_t o12 = act[j] ? (uint32_t)idx * 12u : 0x80000000u, o4 = act[j] ? (uint32_t)idx * 4u : 0x80000000u;
+      vv[j] = ld3(vel_rs, o12);
+      gg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, o4, 0, 0));
+      mm[j] = ld3(m_rs, o12);
+      uu[j] = ld3(u_rs, o12);
+      continue;
+    }
     vv[j] = v3[ic];
     if (BWD) gg[j] = g_out[ic];
     if (MODE == 2) {   // the Adam moments are streamed: ask for them with the velocity, before the gather
@@ -305,7 +337,12 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
           xs[c] -= ad.lr_t * ms[c] / (sqrtf(us[c]) + ad.eps);
         }
         vv[j] = F3u{xs[0], xs[1], xs[2]};
-        if (ok[j]) {
+        if constexpr (EVER) {
+          const uint32_t o12 = act[j] ? (uint32_t)idx * 12u : 0x80000000u;
+          st3(vv[j], vel_rs, o12);
+          st3(F3u{ms[0], ms[1], ms[2]}, m_rs, o12);
+          st3(F3u{us[0], us[1], us[2]}, u_rs, o12);
+        } else if (ok[j]) {
           reinterpret_cast<F3u*>(out)[idx] = vv[j];
           reinterpret_cast<F3u*>(ad.m)[idx] = F3u{ms[0], ms[1], ms[2]};
           reinterpret_cast<F3u*>(ad.v)[idx] = F3u{us[0], us[1], us[2]};
@@ -342,9 +379,12 @@ __global__ void __launch_bounds__(256) advect1_kernel(const float* __restrict__ 
         const float a00 = fmaf(wx[j], p[j][0].y - p[j][0].x, p[j][0].x), a01 = fmaf(wx[j], p[j][1].y - p[j][1].x, p[j][1].x);
         const float a10 = fmaf(wx[j], p[j][2].y - p[j][2].x, p[j][2].x), a11 = fmaf(wx[j], p[j][3].y - p[j][3].x, p[j][3].x);
         const float b0 = fmaf(wy[j], a01 - a00, a00), b1 = fmaf(wy[j], a11 - a10, a10);
-        if (ok[j]) ad.adv_next[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
+        if constexpr (EVER)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, fmaf(wz[j], b1 - b0, b0)), adv_rs,
+                                                act[j] ? (uint32_t)(first + 64 * j) * 4u : 0x80000000u, 0, 0);
+        else if (ok[j]) ad.adv_next[first + 64 * j] = fmaf(wz[j], b1 - b0, b0);
         if constexpr (LIVE) {
-          const unsigned long long lv = __ballot(ok[j] && corners_differ(p[j]));
+          const unsigned long long lv = __ballot(ok[j] && (!EVER || act[j]) && corners_differ(p[j]));
           if (lane == 0 && first + 64 * j < n) ad.live[(first + 64 * j) >> 6] = lv;
         }
       }
@@ -1170,8 +1210,14 @@ int nfs_advect_bwd_adam_fwd_live_ever(const float* d, float* vel, const float* g
   const int64_t n = (int64_t)D * H * W;
   NFS_REQUIRE(W >= 2 && H >= 2 && D >= 2 && n % 4 == 0 && n < ((int64_t)1 << 30),
               "nfs_advect_bwd_adam_fwd_live_ever: needs D, H, W >= 2 and D*H*W %% 4 == 0");
-  hipLaunchKernelGGL((advect1_kernel<2, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out, vel,
-                     D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live, ever}, 0, D);
+  // (per-lane predication goes through buffer descriptors: 32-bit byte offsets, 12 n < 2^31; larger volumes skip by waves only)
+  static const bool lanes = [] { const char* e = getenv("NFS_EVER_LANES"); return !(e && atoi(e) == 0); }();
+  if (lanes && n * 12 < ((int64_t)1 << 31))
+    hipLaunchKernelGGL((advect1_kernel<2, true, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel,
+                       g_out, vel, D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live, ever}, 0, D);
+  else
+    hipLaunchKernelGGL((advect1_kernel<2, true>), dim3((blocks_for(n, 1024) + 7) / 8 * 8), dim3(256), 0, as_stream(stream), d, vel, g_out,
+                       vel, D, H, W, AdamFused{m, v, lr_t, beta1, beta2, eps, adv_next, live, ever}, 0, D);
   return check_launch("nfs_advect_bwd_adam_fwd_live_ever");
 }
 
