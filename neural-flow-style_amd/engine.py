@@ -632,7 +632,9 @@ class TFAdamState(object):
         self._ever_key = None
 
     def ever_mask(self):
-        """the mask above, or None when m or v have been written by anything else since they were zeroed"""
+        """the mask above, or None when m or v have been written by anything else since they were zeroed (as seen by their
+        torch version counters: a write that bypasses them -- through ``.data``, or a kernel on ``m.data_ptr()`` -- is not
+        seen; set ``_ever = None`` after one)"""
         if self._ever is None or self.m is None or self._ever_key != (self.m._version, self.v._version):
             self._ever = None
             return None
